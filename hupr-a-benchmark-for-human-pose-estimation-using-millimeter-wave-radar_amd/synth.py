@@ -1,0 +1,228 @@
+"""Build-owned, library-version-independent synthetic data generator.
+
+Everything synthetic in this repo (ADC cubes, model inputs, weights, labels)
+comes from one counter-based generator: ``u64 = splitmix64(key + index)`` so the
+GPU box, the CPU oracle and the golden-fixture script regenerate *identical*
+bits without shipping large files and without depending on NumPy/PyTorch RNG
+stream stability.  (SURVEY.md section 8(d) "Synthetic inputs".)
+"""
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    """Vectorised splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _key(*parts):
+    """Fold integers/strings into one 64-bit key (order-sensitive)."""
+    k = np.uint64(0x243F6A8885A308D3)
+    for p in parts:
+        if isinstance(p, str):
+            v = 0
+            for ch in p.encode():
+                v = (v * 131 + ch) & 0xFFFFFFFFFFFFFFFF
+        else:
+            v = int(p) & 0xFFFFFFFFFFFFFFFF
+        with np.errstate(over="ignore"):
+            k = _splitmix64(np.array([(int(k) ^ v) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+    return k
+
+
+def raw_u64(n, *key):
+    """n uint64 words for the stream identified by ``key``."""
+    base = _key(*key)
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return _splitmix64((idx * np.uint64(0xD1342543DE82EF95) + base) & _MASK)
+
+
+def uniform01(n, *key):
+    """float64 uniform in [0, 1) with 53 random bits."""
+    return (raw_u64(n, *key) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def uniform(shape, lo, hi, *key, dtype=np.float32):
+    n = int(np.prod(shape))
+    return (lo + (hi - lo) * uniform01(n, *key)).astype(dtype).reshape(shape)
+
+
+def normal(shape, *key, dtype=np.float32):
+    """Standard normal via Box-Muller on two independent streams."""
+    n = int(np.prod(shape))
+    u1 = uniform01(n, *key, "bm1")
+    u2 = uniform01(n, *key, "bm2")
+    z = np.sqrt(-2.0 * np.log1p(-u1)) * np.cos(2.0 * np.pi * u2)
+    return z.astype(dtype).reshape(shape)
+
+
+def randint(shape, lo, hi, *key):
+    """int64 uniform in [lo, hi)."""
+    n = int(np.prod(shape))
+    r = raw_u64(n, *key) % np.uint64(hi - lo)
+    return (r.astype(np.int64) + lo).reshape(shape)
+
+
+# ----------------------------------------------------------------------------
+# domain objects
+# ----------------------------------------------------------------------------
+NUM_RX, NUM_CHIRP, NUM_SAMPLE = 4, 192, 256
+
+
+def adc_cube_int16(seed, seq=0, frame=0, sensor=0, nframes=1):
+    """IWR1843 ADC cube(s): int16 I/Q uniform in [-2048, 2047] (12-bit ADC range).
+
+    Returns ``(nframes, 4 rx, 192 chirp, 256 sample, 2 [I,Q])`` int16 — the device
+    input layout of ``hupr_fft_chain_*`` (786 432 B per sensor-frame).
+    """
+    shape = (nframes, NUM_RX, NUM_CHIRP, NUM_SAMPLE, 2)
+    return randint(shape, -2048, 2048, "adc", seed, seq, frame, sensor).astype(np.int16)
+
+
+def adc_cube_complex(iq):
+    """int16 I/Q (..., 2) -> complex128 (what the reference's generateHeatmap consumes)."""
+    return iq[..., 0].astype(np.float64) + 1j * iq[..., 1].astype(np.float64)
+
+
+def point_target_cube(targets, noise=0.0, seed=0):
+    """Known-answer scene: sum of complex exponentials over (sample, chirp, virtual antenna).
+
+    ``targets`` = list of dict(range_bin, doppler_bin, az_bin, el_bin, amp).  Phase
+    progressions follow the reference's demux: chirp c = 3*cc + tx; tx0 -> az
+    antennas 0..3, tx2 -> az antennas 4..7, tx1 -> elevation row (az offset 2).
+    Returns int16 I/Q ``(1, 4, 192, 256, 2)``.
+    """
+    s = np.arange(NUM_SAMPLE)[None, None, :]
+    cc = np.arange(64)[None, :, None]
+    rx = np.arange(NUM_RX)[:, None, None]
+    out = np.zeros((NUM_RX, NUM_CHIRP, NUM_SAMPLE), dtype=np.complex128)
+    for t in targets:
+        fr, fd = t["range_bin"] / 256.0, t["doppler_bin"] / 64.0
+        fa, fe = t["az_bin"] / 64.0, t["el_bin"] / 8.0
+        base = t.get("amp", 400.0) * np.exp(2j * np.pi * (fr * s + fd * cc))
+        for tx in range(3):
+            if tx == 0:
+                ph = np.exp(2j * np.pi * fa * rx)
+            elif tx == 2:
+                ph = np.exp(2j * np.pi * fa * (rx + 4))
+            else:
+                ph = np.exp(2j * np.pi * (fa * (rx + 2) + fe))
+            out[:, tx::3, :] += base * ph
+    if noise > 0:
+        out += noise * (normal(out.shape, "ptn_r", seed, dtype=np.float64)
+                        + 1j * normal(out.shape, "ptn_i", seed, dtype=np.float64))
+    iq = np.stack([np.clip(np.rint(out.real), -32768, 32767),
+                   np.clip(np.rint(out.imag), -32768, 32767)], axis=-1).astype(np.int16)
+    return iq[None]
+
+
+def model_inputs(batch, seed, G=8, F=8, R=64, A=64, E=8):
+    """Two (B,G,F,2,R,A,E) fp32 standard-normal cubes (what Normalize emits statistically)."""
+    shape = (batch, G, F, 2, R, A, E)
+    return normal(shape, "hori", seed), normal(shape, "vert", seed)
+
+
+def keypoints(batch, seed, K=14, lo=40, hi=216):
+    """(B,K,2) int64 joints in 256-px image coordinates."""
+    return randint((batch, K, 2), lo, hi, "joints", seed)
+
+
+# ----------------------------------------------------------------------------
+# HuPRNet parameter inventory (reference state_dict contract)
+# ----------------------------------------------------------------------------
+def _bn_specs(pre, c):
+    return [(pre + ".weight", (c,), "bn_w"), (pre + ".bias", (c,), "bn_b"),
+            (pre + ".running_mean", (c,), "bn_rm"), (pre + ".running_var", (c,), "bn_rv"),
+            (pre + ".num_batches_tracked", (), "bn_nbt")]
+
+
+def hupr_param_specs(nf=32, G=8, K=14, H=64):
+    """[(state_dict key, shape, kind)] in the reference's registration order.
+
+    Mirrors models/networks.py:17-21, models/chirp_networks.py:15, models/layers.py:81-123,
+    190-210 and models/gcn_networks.py:41-43 (names/shapes only)."""
+    specs = []
+    for s in ("RA", "RE"):
+        specs += [(s + "chirpNet.temporalConvWx1x1.weight", (nf, 2, 2, 1, 1), "conv"),
+                  (s + "chirpNet.temporalConvWx1x1.bias", (nf,), "bias:4")]
+    for s in ("RA", "RE"):
+        pre = s + "radarEncoder."
+        specs += [(pre + "layer1.0.weight", (2 * nf, nf, 3, 3, 3), "conv"),
+                  (pre + "layer1.0.bias", (2 * nf,), "bias:%d" % (nf * 27))]
+        for blk, ci, co in (("layer1.1", 2 * nf, 2 * nf), ("layer2.1", 2 * nf, 4 * nf),
+                            ("layer2.2", 4 * nf, 4 * nf), ("layer3.1", 4 * nf, 8 * nf),
+                            ("layer3.2", 8 * nf, 8 * nf)):
+            b = pre + blk
+            specs += [(b + ".main.0.weight", (co, ci, 3, 3, 3), "conv")]
+            specs += _bn_specs(b + ".main.1", co)
+            specs += [(b + ".main.3.weight", (co, co, 3, 3, 3), "conv")]
+            specs += _bn_specs(b + ".main.4", co)
+            specs += [(b + ".downsample.0.weight", (co, ci, 3, 3, 3), "conv")]
+            specs += _bn_specs(b + ".downsample.1", co)
+        specs += [(pre + "l1temporalMerge.weight", (2 * nf, 2 * nf, G, 1, 1), "conv"),
+                  (pre + "l2temporalMerge.weight", (4 * nf, 4 * nf, G // 2, 1, 1), "conv"),
+                  (pre + "temporalMerge.weight", (8 * nf, 8 * nf, G // 4, 1, 1), "conv")]
+    pre = "radarDecoder."
+    for layer, blocks in (("decoderLayer3", ((32 * nf, 8 * nf), (8 * nf, 4 * nf))),
+                          ("decoderLayer2", ((20 * nf, 4 * nf), (4 * nf, 2 * nf))),
+                          ("decoderLayer1", ((10 * nf, 2 * nf), (2 * nf, nf)))):
+        for i, (ci, co) in enumerate(blocks):
+            b = "%s%s.%d" % (pre, layer, i)
+            specs += [(b + ".main.0.weight", (co, ci, 3, 3), "conv"),
+                      (b + ".main.1.weight", (1,), "prelu"),
+                      (b + ".main.2.weight", (co, co, 3, 3), "conv"),
+                      (b + ".downsample.0.weight", (co, ci, 3, 3), "conv"),
+                      (b + ".relu.weight", (1,), "prelu")]
+    specs += [(pre + "decoderLayer1.2.weight", (K, nf, 1, 1), "conv")]
+    feat = (H // 2) * (H // 2)
+    for l in ("L1", "L2", "L3"):
+        specs += [(pre + "gcn.%s.weight" % l, (feat, feat), "gcn"),
+                  (pre + "gcn.%s.bias" % l, (feat, K), "gcn")]
+    for name in ("phi_cross_hori", "theta_cross_hori", "phi_cross_vert", "theta_cross_vert",
+                 "phi_self_hori", "theta_self_hori", "phi_self_vert", "theta_self_vert"):
+        for i, c in enumerate((8 * nf, 4 * nf, 2 * nf)):
+            specs += [("%s%s.%d.weight" % (pre, name, i), (c, c, 1, 1), "conv")]
+    return specs
+
+
+def hupr_state(seed, gain=1.0, nontrivial_bn=True, **kw):
+    """Deterministic parameter dictionary {key: ndarray} with PyTorch-default bounds
+    (kaiming-uniform a=sqrt(5) => U(+-1/sqrt(fan_in)); GCN U(+-1/32); PReLU 0.25) times
+    ``gain``.  ``nontrivial_bn`` perturbs BN affine/running stats so eval mode is exercised."""
+    out = {}
+    for name, shape, kind in hupr_param_specs(**kw):
+        if kind == "conv":
+            fan_in = int(np.prod(shape[1:]))
+            b = gain / np.sqrt(fan_in)
+            out[name] = uniform(shape, -b, b, "w", seed, name)
+        elif kind.startswith("bias:"):
+            b = 1.0 / np.sqrt(int(kind.split(":")[1]))
+            out[name] = uniform(shape, -b, b, "w", seed, name)
+        elif kind == "gcn":
+            b = gain / np.sqrt(1024.0)
+            out[name] = uniform(shape, -b, b, "w", seed, name)
+        elif kind == "prelu":
+            out[name] = np.full(shape, 0.25, dtype=np.float32)
+        elif kind == "bn_w":
+            out[name] = uniform(shape, 0.6, 1.4, "w", seed, name) if nontrivial_bn \
+                else np.ones(shape, np.float32)
+        elif kind == "bn_b":
+            out[name] = uniform(shape, -0.2, 0.2, "w", seed, name) if nontrivial_bn \
+                else np.zeros(shape, np.float32)
+        elif kind == "bn_rm":
+            out[name] = uniform(shape, -0.1, 0.1, "w", seed, name) if nontrivial_bn \
+                else np.zeros(shape, np.float32)
+        elif kind == "bn_rv":
+            out[name] = uniform(shape, 0.5, 1.5, "w", seed, name) if nontrivial_bn \
+                else np.ones(shape, np.float32)
+        elif kind == "bn_nbt":
+            out[name] = np.zeros((), dtype=np.int64)
+    return out

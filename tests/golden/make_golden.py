@@ -1,0 +1,190 @@
+"""Generate the golden fixtures in this directory by running the IMPORTED REFERENCE
+(/root/reference, read-only, pure Python) on inputs from the build-owned generator
+(hupr_amd.synth).  Run in the build container only:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures are data (inputs are regenerable from seeds; expected outputs are stored):
+  fft_seed{0,1,2}.npz, fft_point.npz   RadarObject.generateHeatmap       (process_iwr1843.py:106-173)
+  loader_seed0.npz                     Normalize + Doppler select         (datasets/base.py:13-24, dataset.py:144-150)
+  model_eval.npz, model_train.npz      HuPRNet fwd (+ autograd bwd)        (models/*.py)
+  loss_seed0.npz                       LossComputer/generateTarget/argmax (misc/losses.py, utils.py, metrics.py)
+  contract.json                        state_dict keys/shapes, YAML dump, Runner helper outputs (tools/base.py)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from hupr_amd import synth            # noqa: E402
+from oracle import ref_import         # noqa: E402
+
+STRIDE = 61
+MODEL_SEED, INPUT_SEED, KP_SEED, GAIN = 1, 5, 7, 1.4
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_fft():
+    ro = ref_import.radar_object()
+    for seed in (0, 1, 2):
+        iq = synth.adc_cube_int16(seed)
+        out = ro.generateHeatmap(synth.adc_cube_complex(iq)[0])
+        np.savez_compressed(
+            os.path.join(HERE, "fft_seed%d.npz" % seed),
+            seed=seed, stride=STRIDE, sample=out.reshape(-1)[::STRIDE].copy(),
+            doppler_l2=np.sqrt((np.abs(out) ** 2).sum(axis=(1, 2, 3))),
+            sha256=sha(out), input_sha256=sha(iq))
+        print("fft seed", seed, out.shape, np.abs(out).max())
+    tg = [dict(range_bin=60, doppler_bin=3, az_bin=10, el_bin=2, amp=500.0),
+          dict(range_bin=40, doppler_bin=-5, az_bin=50, el_bin=5, amp=300.0)]
+    iq = synth.point_target_cube(tg)
+    out = ro.generateHeatmap(synth.adc_cube_complex(iq)[0])
+    mag = np.abs(out).sum(axis=3)
+    pk = np.unravel_index(mag.argmax(), mag.shape)
+    np.savez_compressed(os.path.join(HERE, "fft_point.npz"), stride=STRIDE,
+                        sample=out.reshape(-1)[::STRIDE].copy(), peak=np.array(pk),
+                        doppler_l2=np.sqrt((np.abs(out) ** 2).sum(axis=(1, 2, 3))),
+                        sha256=sha(out), input_sha256=sha(iq),
+                        targets=json.dumps(tg))
+    print("point peak (i, r, a) =", pk)
+    return ro
+
+
+def make_loader(ro):
+    _, _, _, Normalize = ref_import.misc_parts()
+    import torchvision.transforms as T      # the stub installed by ref_import
+    tf = T.Compose([T.ToTensor(), Normalize()])
+    iq = synth.adc_cube_int16(0)
+    cube = ro.generateHeatmap(synth.adc_cube_complex(iq)[0])
+    # reference dataset.py:144-150, one sensor
+    full = torch.zeros((8, 2, 64, 64, 8))
+    k = 0
+    for d in range(16 // 2 - 8 // 2, 16 // 2 + 8 // 2):
+        full[k, 0] = tf(cube[d].real).permute(1, 2, 0)
+        full[k, 1] = tf(cube[d].imag).permute(1, 2, 0)
+        k += 1
+    full = full.numpy()
+    slice_in = cube[5].real.copy()                       # a healthy Doppler bin
+    slice_out = tf(slice_in).permute(1, 2, 0).numpy()
+    zero_in = cube[8].imag.copy()                        # the clutter-nulled bin (hazard D.2)
+    np.savez_compressed(os.path.join(HERE, "loader_seed0.npz"),
+                        slice_in=slice_in, slice_out=slice_out.astype(np.float32),
+                        zero_doppler_absmax=np.abs(zero_in).max(), all_absmax=np.abs(cube).max(),
+                        stride=STRIDE, full_sample=full.reshape(-1)[::STRIDE].copy(),
+                        full_sha256=sha(full))
+    print("loader ok; zero-doppler absmax %.3e vs %.3e" % (np.abs(zero_in).max(), np.abs(cube).max()))
+
+
+def _sample(t, n=64):
+    f = t.reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].clone()
+
+
+def make_model():
+    cfg = ref_import.load_cfg()
+    models = ref_import.model_module()
+    LossComputer, generateTarget, get_max_preds, _ = ref_import.misc_parts()
+    net = models.HuPRNet(cfg)
+    st = synth.hupr_state(MODEL_SEED, gain=GAIN)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in st.items()}
+    hn, vn = synth.model_inputs(2, INPUT_SEED)
+    h, v = torch.from_numpy(hn), torch.from_numpy(vn)
+    gt = torch.from_numpy(synth.keypoints(2, KP_SEED))
+    lc = LossComputer(cfg, "cpu")
+
+    for mode in ("eval", "train"):
+        net.load_state_dict(sd)
+        net.train(mode == "train")
+        for p in net.parameters():
+            p.grad = None
+        p1, p2 = net(h, v)
+        loss, loss2, pred2d, gt2d = lc.computeLoss((p1, p2), gt)
+        loss.backward()
+        names, gnorm, gsamp = [], [], []
+        for n, p in net.named_parameters():
+            names.append(n)
+            gnorm.append(p.grad.double().norm().item())
+            s = _sample(p.grad)
+            gsamp.append(np.pad(s.numpy(), (0, 64 - s.numel())))
+        am1 = p1.detach().reshape(2, 14, -1).argmax(-1).numpy()
+        am2 = p2.detach().reshape(2, 14, -1).argmax(-1).numpy()
+        extra = {}
+        if mode == "train":   # BN running statistics after one train-mode forward
+            post = net.state_dict()
+            for k in post:
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    extra["stat:" + k] = post[k].numpy().copy()
+        np.savez_compressed(
+            os.path.join(HERE, "model_%s.npz" % mode),
+            model_seed=MODEL_SEED, input_seed=INPUT_SEED, kp_seed=KP_SEED, gain=GAIN,
+            heatmap=p1.detach().numpy(), gcn_heatmap=p2.detach().numpy(),
+            argmax1=am1, argmax2=am2, loss=loss.item(), loss2=loss2.item(),
+            pred2d=pred2d, gt2d=gt2d, grad_names=np.array(names), grad_l2=np.array(gnorm),
+            grad_sample=np.stack(gsamp), **extra)
+        print(mode, "loss", loss.item(), loss2.item(), "ranges",
+              p1.min().item(), p1.max().item(), p2.min().item(), p2.max().item())
+        print("   argmax2[0]", am2[0].tolist())
+
+    # loss / targets / argmax in isolation
+    tg = np.stack([generateTarget(g, 14, 64, 256)[0] for g in gt])
+    nz = np.argwhere(tg > 0)
+    np.savez_compressed(os.path.join(HERE, "loss_seed0.npz"), kp_seed=KP_SEED, gt=gt.numpy(),
+                        target_nz_index=nz.astype(np.int16), target_nz_value=tg[tg > 0],
+                        target_sha256=sha(tg))
+    return net, cfg
+
+
+def make_contract(net, cfg):
+    import yaml
+    sd = net.state_dict()
+    contract = {"state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()]}
+    with open(os.path.join(ref_import.REF, "config", "mscsa_prgcn.yaml")) as f:
+        contract["yaml"] = yaml.safe_load(f)
+
+    # Runner helpers (tools/base.py:49-72,124-147) exercised on a bare BaseRunner
+    def go():
+        import importlib
+        return importlib.import_module("tools.base")
+    base = ref_import._with_ref_path(go)
+
+    class Args:
+        gpuIDs, seed, dir, visDir, eval = [], 0, "x", "none", True
+    r = base.BaseRunner(Args(), cfg)
+    preds = synth.uniform((2, 14, 2), 0, 64, "preds").astype(np.float32) * 4.0
+    bbox = torch.tensor([[50.0, 60.0, 100.0, 150.0], [10.0, 20.0, 200.0, 90.0]])
+    recs = r.saveKeypoints([], preds, bbox, torch.tensor([100123, 1500042]))
+    contract["saveKeypoints"] = {"preds": preds.tolist(), "bbox": bbox.tolist(), "records": recs}
+    # LR schedule: adjustLR at idxBatch % 2000 == 0 for 3 epochs of 5790 iterations
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=cfg.TRAINING.lr)
+    r.optimizer = opt
+    lrs = []
+    for epoch in range(3):
+        for it in range(5790):
+            if it % cfg.TRAINING.lrDecayIter == 0:
+                r.adjustLR(epoch)
+            if it % 1000 == 0:
+                lrs.append(opt.param_groups[0]["lr"])
+    contract["lr_schedule"] = lrs
+    with open(os.path.join(HERE, "contract.json"), "w") as f:
+        json.dump(contract, f, indent=0)
+    print("contract ok", len(contract["state_dict"]), "keys")
+
+
+if __name__ == "__main__":
+    assert ref_import.available(), "reference tree not found"
+    ro = make_fft()
+    make_loader(ro)
+    net, cfg = make_model()
+    make_contract(net, cfg)

@@ -1,0 +1,143 @@
+"""CPU (-m "not gpu"): pin the oracle against the golden vectors that were produced by the
+imported reference (tests/golden/make_golden.py), and — when /root/reference is present —
+against the reference itself."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hupr_amd import synth
+from oracle import fft_chain, loader, loss as oloss, model as omodel, ref_import
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fft_chain_matches_reference_bits(seed):
+    g = np.load(os.path.join(G, "fft_seed%d.npz" % seed))
+    iq = synth.adc_cube_int16(seed)
+    assert sha(iq) == str(g["input_sha256"]), "synthetic generator drifted"
+    out = fft_chain.generate_heatmap(synth.adc_cube_complex(iq)[0])
+    assert out.shape == (16, 64, 64, 8) and out.dtype == np.complex128
+    assert sha(out) == str(g["sha256"])            # pocketfft is deterministic: bit-exact
+    np.testing.assert_array_equal(out.reshape(-1)[::int(g["stride"])], g["sample"])
+
+
+def test_fft_chain_point_target_known_answer():
+    g = np.load(os.path.join(G, "fft_point.npz"))
+    tg = json.loads(str(g["targets"]))
+    iq = synth.point_target_cube(tg)
+    assert sha(iq) == str(g["input_sha256"])
+    out = fft_chain.generate_heatmap(synth.adc_cube_complex(iq)[0])
+    np.testing.assert_allclose(out.reshape(-1)[::int(g["stride"])], g["sample"], rtol=0, atol=1e-6)
+    mag = np.abs(out).sum(axis=3)
+    pk = np.unravel_index(mag.argmax(), mag.shape)
+    # analytic location: i = 8 + doppler, r = 94 - range, a = (31 - az) % 64
+    assert pk == (8 + 3, 94 - 60, (31 - 10) % 64) == tuple(g["peak"])
+    # second target (weaker) at doppler -5, range 40, az 50
+    assert mag[8 - 5, 94 - 40, (31 - 50) % 64] > 0.2 * mag.max()
+
+
+def test_fft_percell_equals_vectorised_small():
+    # the per-cell loop form is slow; check it on one frame only
+    iq = synth.adc_cube_int16(3)
+    fr = synth.adc_cube_complex(iq)[0]
+    a = fft_chain.generate_heatmap(fr)
+    b = fft_chain.generate_heatmap_percell(fr)
+    assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max()
+
+
+def test_zero_doppler_bin_is_rounding_noise():
+    out = fft_chain.generate_heatmap(synth.adc_cube_complex(synth.adc_cube_int16(0))[0])
+    assert np.abs(out[8]).max() < 1e-12 * np.abs(out).max()
+
+
+def test_loader_normalize_matches_reference():
+    g = np.load(os.path.join(G, "loader_seed0.npz"))
+    got = loader.normalize_hwc(g["slice_in"]).astype(np.float32)
+    np.testing.assert_allclose(got, g["slice_out"], rtol=0, atol=2e-6)
+    # mean 0 / unbiased std 1 per elevation channel
+    flat = got.reshape(-1, 8).astype(np.float64)
+    assert np.abs(flat.mean(0)).max() < 1e-5 and np.abs(flat.std(0, ddof=1) - 1).max() < 1e-5
+    cube = fft_chain.generate_heatmap(synth.adc_cube_complex(synth.adc_cube_int16(0))[0])
+    full = loader.loader_transform(cube)
+    assert full.shape == (8, 2, 64, 64, 8) and full.dtype == np.float32
+    ref = g["full_sample"]
+    mine = full.reshape(-1)[::int(g["stride"])]
+    # slots fed by the clutter-nulled Doppler bin (index 8 -> f = 4) are normalised noise
+    f_idx = (np.arange(full.size)[::int(g["stride"])] // (2 * 64 * 64 * 8))
+    ok = f_idx != 4
+    np.testing.assert_allclose(mine[ok], ref[ok], rtol=0, atol=5e-6)
+
+
+def _state(seed, gain):
+    return {k: torch.from_numpy(np.array(v)) for k, v in synth.hupr_state(seed, gain=gain).items()}
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_model_oracle_matches_reference_golden(mode):
+    g = np.load(os.path.join(G, "model_%s.npz" % mode))
+    sd = _state(int(g["model_seed"]), float(g["gain"]))
+    h, v = synth.model_inputs(2, int(g["input_seed"]))
+    with torch.no_grad():
+        p1, p2 = omodel.forward(sd, torch.from_numpy(h), torch.from_numpy(v), train=(mode == "train"))
+    assert p1.shape == (2, 14, 1, 64, 64) and p2.shape == (2, 1, 14, 64, 64)
+    np.testing.assert_allclose(p1.numpy(), g["heatmap"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(p2.numpy(), g["gcn_heatmap"], rtol=0, atol=2e-5)
+    assert np.array_equal(p2.reshape(2, 14, -1).argmax(-1).numpy(), g["argmax2"])
+    gt = synth.keypoints(2, int(g["kp_seed"]))
+    loss, loss2, pred2d, gt2d = oloss.compute_loss((p1, p2), gt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 and abs(loss2.item() - float(g["loss2"])) < 1e-5
+    np.testing.assert_array_equal(pred2d, g["pred2d"])
+    np.testing.assert_array_equal(gt2d, g["gt2d"])
+
+
+def test_model_oracle_gradients_match_reference_golden():
+    g = np.load(os.path.join(G, "model_train.npz"))
+    sd = _state(int(g["model_seed"]), float(g["gain"]))
+    names = [str(n) for n in g["grad_names"]]
+    for n in names:
+        sd[n] = sd[n].clone().requires_grad_(True)
+    h, v = synth.model_inputs(2, int(g["input_seed"]))
+    p = omodel.forward(sd, torch.from_numpy(h), torch.from_numpy(v), train=True)
+    loss, *_ = oloss.compute_loss(p, synth.keypoints(2, int(g["kp_seed"])))
+    loss.backward()
+    for i, n in enumerate(names):
+        gn = sd[n].grad.double().norm().item()
+        assert abs(gn - g["grad_l2"][i]) <= 1e-3 * g["grad_l2"][i] + 1e-9, n
+
+
+def test_targets_and_argmax_match_reference():
+    g = np.load(os.path.join(G, "loss_seed0.npz"))
+    gt = synth.keypoints(2, int(g["kp_seed"]))
+    np.testing.assert_array_equal(gt, g["gt"])
+    tg, _ = oloss.batch_targets(gt)
+    assert sha(tg) == str(g["target_sha256"])
+    # edge cases: joints whose patch is clipped / fully outside
+    t, c = oloss.gaussian_targets(np.array([[0, 0], [255, 255], [-40, 100], [400, 400]] + [[128, 128]] * 10))
+    assert t[0, 0, 0] == 1.0 and abs(t[1, 63, 63] - np.exp(-0.25)) < 1e-6 and t[1].max() < 1   # mu=64 -> centre clipped
+    assert t[2].max() == 0.0 and t[3].max() == 0.0
+    hm = np.zeros((1, 2, 64, 64), np.float32)
+    hm[0, 0, 5, 7] = hm[0, 0, 9, 9] = 0.5           # tie -> lowest flat index
+    p, m = oloss.argmax_decode(hm)
+    assert p[0, 0].tolist() == [7.0, 5.0] and p[0, 1].tolist() == [0.0, 0.0] and m[0, 1, 0] == 0
+
+
+def test_param_specs_match_reference_contract():
+    c = json.load(open(os.path.join(G, "contract.json")))
+    specs = synth.hupr_param_specs()
+    assert [[k, list(s)] for k, s, _ in specs] == [[k, s] for k, s, _ in c["state_dict"]]
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not mounted")
+def test_oracle_vs_live_reference_fft():
+    ro = ref_import.radar_object()
+    fr = synth.adc_cube_complex(synth.adc_cube_int16(11))[0]
+    assert np.array_equal(ro.generateHeatmap(fr), fft_chain.generate_heatmap(fr))
