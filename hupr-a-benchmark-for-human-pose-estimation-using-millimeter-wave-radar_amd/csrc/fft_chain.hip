@@ -1,0 +1,446 @@
+// IWR1843 range -> Doppler -> elevation -> azimuth FFT chain for gfx950 (HBM-bound).
+//
+// What it computes is the reference's RadarObject.generateHeatmap
+// (preprocessing/process_iwr1843.py:106-173); how it computes it is not:
+//
+//   K1 hupr_k_range_doppler  one workgroup per (sensor-frame, virtual antenna)
+//        - coalesced int16 I/Q loads of the antenna's 64 chirps (TDM demux = index math)
+//        - 256-pt range FFT per chirp: LDS-staged radix-4 DIF, one wave per chirp
+//        - only the 64 kept range bins (94..31) are scattered into an LDS Doppler tile
+//        - clutter removal (chirp mean) + 64-pt Doppler FFT (radix-4, 16 lanes per FFT)
+//        - only the 16 kept Doppler bins are written: RD[sf][i][r][12 antennas]  (98 KB / sf)
+//   K2 hupr_k_angle           one workgroup per (sensor-frame, Doppler bin)
+//        - the zero-padded 8x64 angle FFT has <= 12 non-zero inputs, so it is evaluated as a
+//          pruned DFT:  out[e',a'] = P[a'] + w8^e' Q[a'] + [e'=0] R[a']
+//        - fftshift / flip / crop of the reference collapse into the output index map
+//          out[i,r,a,e] = M5[(3-e)%8, (31-a)%64, (56+i)%64, 94-r]      
+//        - each lane owns one azimuth bin and stores its 8 elevation bins as one 64-B run,
+//          so a wave writes 4 KB contiguous
+//        - LOADER variant: keeps Doppler 4..11, splits re/im and applies the per-elevation
+//          Normalize (datasets/base.py:13-24) == (x-mean)/std_unbiased of the (range,az) plane;
+//          statistics come from a first pass over the same LDS-resident inputs (recompute
+//          instead of a second trip through HBM)
+//
+// Algorithmic HBM bytes per sensor-frame: 786 432 read + 4 194 304 (c64) or 2 097 152 (loader)
+// written; the RD intermediate adds 2 x 98 304.
+#include "hupr_common.h"
+
+namespace hupr {
+
+constexpr int kRx = 4, kChirps = 192, kLoops = 64, kSamples = 256;
+constexpr int kVant = 12;            // 8 azimuth + 4 elevation virtual antennas
+constexpr int kRange = 64, kDop = 16, kAz = 64, kEl = 8;
+constexpr int kRangeHi = 94;         // kept range bins 94,93,...,31
+constexpr int kDopStride = 65;       // padded LDS row (float2) for the Doppler tile
+
+__device__ __forceinline__ int pad32(int p) { return p + (p >> 5); }
+
+// radix-4 DIF butterfly, forward transform (e^{-2 pi i / N})
+__device__ __forceinline__ void r4(float2& x0, float2& x1, float2& x2, float2& x3) {
+    float2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = csub(x1, x3);
+    float2 b3 = make_float2(a3.y, -a3.x);   // -i * a3
+    x0 = cadd(a0, a2);
+    x1 = cadd(a1, b3);
+    x2 = csub(a0, a2);
+    x3 = csub(a1, b3);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: range FFT + crop + clutter removal + Doppler FFT + crop
+// grid = n_sf * 12, block = 256
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __restrict__ iq,
+                                                            float2* __restrict__ rd) {
+    __shared__ float2 tw[256];                       // W_256^t
+    __shared__ float2 rbuf[4][256 + 8];              // one range-FFT scratch per wave
+    __shared__ float2 dop[kRange * kDopStride];      // [range bin][chirp loop]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sf = blockIdx.x / kVant, vant = blockIdx.x % kVant;
+    // TDM demux (reference :113-120): chirp%3==0 -> az rows 0..3, ==2 -> az rows 4..7, ==1 -> elevation
+    const int rx = vant & 3;
+    const int tx = (vant < 4) ? 0 : (vant < 8 ? 2 : 1);
+
+    {
+        double s, c;
+        sincospi(-2.0 * tid / 256.0, &s, &c);
+        tw[tid] = make_float2((float)c, (float)s);
+    }
+    __syncthreads();
+
+    // each int32 holds one (I,Q) sample
+    const int32_t* src = reinterpret_cast<const int32_t*>(iq) +
+                         ((size_t)(sf * kRx + rx) * kChirps) * kSamples;
+    float2* buf = rbuf[wave];
+
+    int32_t raw[4];
+    {
+        const int32_t* row = src + (size_t)(3 * (wave * 16) + tx) * kSamples;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[q] = row[lane + 64 * q];
+    }
+    for (int j = 0; j < 16; ++j) {
+        const int cc = wave * 16 + j;
+        float2 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            x[q] = make_float2((float)(int16_t)(raw[q] & 0xffff), (float)(raw[q] >> 16));
+        if (j + 1 < 16) {   // prefetch next chirp while this one is transformed
+            const int32_t* row = src + (size_t)(3 * (cc + 1) + tx) * kSamples;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw[q] = row[lane + 64 * q];
+        }
+        // stage 0 (span 64) straight from registers
+        r4(x[0], x[1], x[2], x[3]);
+        x[1] = cmul(x[1], tw[lane]);
+        x[2] = cmul(x[2], tw[(2 * lane) & 255]);
+        x[3] = cmul(x[3], tw[(3 * lane) & 255]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) buf[pad32(lane + 64 * q)] = x[q];
+        __syncthreads();
+        // stage 1 (span 16)
+        {
+            const int n = lane & 15, base = (lane >> 4) * 64 + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = buf[pad32(base + 16 * q)];
+            r4(x[0], x[1], x[2], x[3]);
+            x[1] = cmul(x[1], tw[(4 * n) & 255]);
+            x[2] = cmul(x[2], tw[(8 * n) & 255]);
+            x[3] = cmul(x[3], tw[(12 * n) & 255]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) buf[pad32(base + 16 * q)] = x[q];
+        }
+        __syncthreads();
+        // stage 2 (span 4)
+        {
+            const int n = lane & 3, base = (lane >> 2) * 16 + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = buf[pad32(base + 4 * q)];
+            r4(x[0], x[1], x[2], x[3]);
+            x[1] = cmul(x[1], tw[(16 * n) & 255]);
+            x[2] = cmul(x[2], tw[(32 * n) & 255]);
+            x[3] = cmul(x[3], tw[(48 * n) & 255]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) buf[pad32(base + 4 * q)] = x[q];
+        }
+        __syncthreads();
+        // stage 3 (span 1), results stay in registers; position p = 4*lane+q holds bin
+        // k = digit-reverse_4(p) = (lane>>4) + 4*((lane>>2)&3) + 16*(lane&3) + 64*q
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = buf[pad32(4 * lane + q)];
+            r4(x[0], x[1], x[2], x[3]);
+            const int kb = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = kRangeHi - (kb + 64 * q);
+                if (r >= 0 && r < kRange) dop[r * kDopStride + cc] = x[q];
+            }
+        }
+        __syncthreads();   // rbuf reuse + dop visibility
+    }
+
+    // Doppler: 64 FFTs of 64 points, 16 lanes each -> 16 FFTs per pass
+    const int n = tid & 15;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 16 + (tid >> 4);
+        float2* row = dop + r * kDopStride;
+        float2 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = row[n + 16 * q];
+        // static clutter removal (reference :122-128): subtract the mean over the 64 chirp loops
+        float sx = (x[0].x + x[1].x) + (x[2].x + x[3].x);
+        float sy = (x[0].y + x[1].y) + (x[2].y + x[3].y);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            sx += __shfl_xor(sx, o, 16);
+            sy += __shfl_xor(sy, o, 16);
+        }
+        sx *= (1.0f / 64.0f);
+        sy *= (1.0f / 64.0f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x[q].x -= sx; x[q].y -= sy; }
+        // stage 0 (span 16): W_64^{nq} = W_256^{4nq}
+        r4(x[0], x[1], x[2], x[3]);
+        x[1] = cmul(x[1], tw[(4 * n) & 255]);
+        x[2] = cmul(x[2], tw[(8 * n) & 255]);
+        x[3] = cmul(x[3], tw[(12 * n) & 255]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[n + 16 * q] = x[q];
+        __syncthreads();
+        {   // stage 1 (span 4)
+            const int m = n & 3, base = (n >> 2) * 16 + m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = row[base + 4 * q];
+            r4(x[0], x[1], x[2], x[3]);
+            x[1] = cmul(x[1], tw[(16 * m) & 255]);
+            x[2] = cmul(x[2], tw[(32 * m) & 255]);
+            x[3] = cmul(x[3], tw[(48 * m) & 255]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) row[base + 4 * q] = x[q];
+        }
+        __syncthreads();
+        {   // stage 2 (span 1); position 4n+q holds Doppler bin d = (n>>2) + 4*(n&3) + 16*q
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = row[4 * n + q];
+            r4(x[0], x[1], x[2], x[3]);
+            const int db = (n >> 2) + 4 * (n & 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = (db + 16 * q + 8) & 63;   // fftshift + keep 24..39 -> i = 0..15
+                if (i < kDop) rd[((size_t)(sf * kDop + i) * kRange + r) * kVant + vant] = x[q];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: pruned angle DFT + index map (+ optional loader epilogue)
+// grid = n_sf * (LOADER ? 8 : 16), block = 256 (4 waves x 16 range cells each)
+// ------------------------------------------------------------------------------------------
+struct AngleOut {
+    float2 o[kEl];   // indexed by OUTPUT elevation bin e
+};
+
+__device__ __forceinline__ AngleOut angle_cell(const float2* __restrict__ cell, const float2* twl) {
+    // cell[0..7] azimuth antennas, cell[8..11] elevated antennas (at azimuth offsets 2..5)
+    float2 P = make_float2(0.f, 0.f), Q = P, R = cell[0];
+#pragma unroll
+    for (int a = 2; a < 6; ++a) {
+        cfma(P, cell[a], twl[a]);
+        cfma(Q, cell[8 + a - 2], twl[a]);
+    }
+    cfma(R, cell[1], twl[1]);
+    cfma(R, cell[6], twl[6]);
+    cfma(R, cell[7], twl[7]);
+    constexpr float c = 0.70710678118654752440f;
+    // w8^{e'} = exp(-2 pi i e'/8)
+    const float2 w8[8] = {{1.f, 0.f}, {c, -c}, {0.f, -1.f}, {-c, -c},
+                          {-1.f, 0.f}, {-c, c}, {0.f, 1.f}, {c, c}};
+    AngleOut r;
+#pragma unroll
+    for (int e = 0; e < kEl; ++e) {
+        const int ep = (3 - e) & 7;                // source elevation-FFT bin for output bin e
+        float2 v = cadd(P, cmul(w8[ep], Q));
+        if (ep == 0) v = cadd(v, R);
+        r.o[e] = v;
+    }
+    return r;
+}
+
+template <bool LOADER>
+__global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ rd, void* __restrict__ out_) {
+    __shared__ float2 cells[kRange * kVant];   // RD for this (sf, i): 64 range bins x 12 antennas
+    __shared__ float2 tw64[64];
+    __shared__ float red[4][32];
+    __shared__ float s_mean[16], s_rstd[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kPlanes = LOADER ? 8 : 16;
+    const int sf = blockIdx.x / kPlanes, pl = blockIdx.x % kPlanes;
+    const int i = LOADER ? pl + 4 : pl;         // loader keeps Doppler indices 4..11 (dataset.py:145)
+
+    const float2* src = rd + (size_t)(sf * kDop + i) * kRange * kVant;
+    for (int t = tid; t < kRange * kVant; t += 256) cells[t] = src[t];
+    if (tid < 64) {
+        double s, c;
+        sincospi(-2.0 * tid / 64.0, &s, &c);
+        tw64[tid] = make_float2((float)c, (float)s);
+    }
+    __syncthreads();
+
+    // lane == azimuth-FFT output bin a'; twl[a] = W_64^{a a'}
+    float2 twl[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) twl[a] = tw64[(a * lane) & 63];
+    const int a_out = (31 - lane) & 63;
+
+    if (LOADER) {
+        // pass 1: per (re/im, elevation) plane statistics over the 64x64 (range, azimuth) plane
+        float sum[16], ssq[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum[k] = ssq[k] = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            const int r = wave * 16 + j;
+            AngleOut v = angle_cell(cells + r * kVant, twl);
+#pragma unroll
+            for (int e = 0; e < kEl; ++e) {
+                sum[e] += v.o[e].x;          ssq[e] = fmaf(v.o[e].x, v.o[e].x, ssq[e]);
+                sum[8 + e] += v.o[e].y;      ssq[8 + e] = fmaf(v.o[e].y, v.o[e].y, ssq[8 + e]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { sum[k] = wave_sum(sum[k]); ssq[k] = wave_sum(ssq[k]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { red[wave][k] = sum[k]; red[wave][16 + k] = ssq[k]; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const double n = 4096.0;
+            double S = (double)red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            double SS = (double)red[0][16 + tid] + red[1][16 + tid] + red[2][16 + tid] + red[3][16 + tid];
+            double mean = S / n;
+            double var = (SS - S * mean) / (n - 1.0);   // unbiased, like torch.std_mean
+            s_mean[tid] = (float)mean;
+            s_rstd[tid] = (float)(1.0 / sqrt(var));
+        }
+        __syncthreads();
+        float mean[16], rstd[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { mean[k] = s_mean[k]; rstd[k] = s_rstd[k]; }
+        float* out = reinterpret_cast<float*>(out_);
+        // out[sf][f=pl][c][r][a][e]
+        float* base_re = out + ((size_t)((sf * 8 + pl) * 2 + 0) * kRange) * kAz * kEl;
+        float* base_im = base_re + (size_t)kRange * kAz * kEl;
+        for (int j = 0; j < 16; ++j) {
+            const int r = wave * 16 + j;
+            AngleOut v = angle_cell(cells + r * kVant, twl);
+            float re[8], im[8];
+#pragma unroll
+            for (int e = 0; e < kEl; ++e) {
+                re[e] = (v.o[e].x - mean[e]) * rstd[e];
+                im[e] = (v.o[e].y - mean[8 + e]) * rstd[8 + e];
+            }
+            float4* pr = reinterpret_cast<float4*>(base_re + ((size_t)r * kAz + a_out) * kEl);
+            float4* pi = reinterpret_cast<float4*>(base_im + ((size_t)r * kAz + a_out) * kEl);
+            pr[0] = make_float4(re[0], re[1], re[2], re[3]);
+            pr[1] = make_float4(re[4], re[5], re[6], re[7]);
+            pi[0] = make_float4(im[0], im[1], im[2], im[3]);
+            pi[1] = make_float4(im[4], im[5], im[6], im[7]);
+        }
+    } else {
+        float2* out = reinterpret_cast<float2*>(out_) + ((size_t)(sf * kDop + i) * kRange) * kAz * kEl;
+        for (int j = 0; j < 16; ++j) {
+            const int r = wave * 16 + j;
+            AngleOut v = angle_cell(cells + r * kVant, twl);
+            float4* p = reinterpret_cast<float4*>(out + ((size_t)r * kAz + a_out) * kEl);
+#pragma unroll
+            for (int e = 0; e < kEl; e += 2)
+                p[e >> 1] = make_float4(v.o[e].x, v.o[e].y, v.o[e + 1].x, v.o[e + 1].y);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// (a2) loader glue on a precomputed complex cube: Doppler select + re/im split + Normalize
+// grid = n_sf * 8, block = 256; each block owns the 16 planes of one (sf, f)
+// cube[sf][16][64][64][8] float2 -> out[sf][8][2][64][64][8] float
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hupr_k_loader_normalize(const float2* __restrict__ cube,
+                                                               float* __restrict__ out) {
+    __shared__ float red[4][32];
+    __shared__ float s_mean[16], s_rstd[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sf = blockIdx.x >> 3, f = blockIdx.x & 7, i = f + 4;
+    // view the (64,64,8) complex slab as float4 = 2 complex (elevation pair)
+    const float4* src = reinterpret_cast<const float4*>(cube + ((size_t)(sf * kDop + i)) * kRange * kAz * kEl);
+    constexpr int kVec = kRange * kAz * kEl / 2;     // 16384 float4
+    const int epair = tid & 3;                        // which elevation pair this thread always sees
+    float sum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};   // (e0.re, e0.im, e1.re, e1.im)
+    for (int t = tid; t < kVec; t += 256) {
+        float4 v = src[t];
+        sum[0] += v.x; ssq[0] = fmaf(v.x, v.x, ssq[0]);
+        sum[1] += v.y; ssq[1] = fmaf(v.y, v.y, ssq[1]);
+        sum[2] += v.z; ssq[2] = fmaf(v.z, v.z, ssq[2]);
+        sum[3] += v.w; ssq[3] = fmaf(v.w, v.w, ssq[3]);
+    }
+    // reduce across lanes that share the same elevation pair (lane & 3): xor 4,8,16,32
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) {
+            sum[k] += __shfl_xor(sum[k], o, 64);
+            ssq[k] += __shfl_xor(ssq[k], o, 64);
+        }
+    }
+    if (lane < 4) {
+        // plane index k16 = c*8 + e, with e = 2*epair + {0,1}
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = 2 * epair + (k >> 1), c = k & 1;
+            red[wave][c * 8 + e] = sum[k];
+            red[wave][16 + c * 8 + e] = ssq[k];
+        }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const double n = 4096.0;
+        double S = (double)red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        double SS = (double)red[0][16 + tid] + red[1][16 + tid] + red[2][16 + tid] + red[3][16 + tid];
+        double mean = S / n;
+        double var = (SS - S * mean) / (n - 1.0);
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var));
+    }
+    __syncthreads();
+    const int e0 = 2 * epair;
+    const float m0r = s_mean[e0], m1r = s_mean[e0 + 1], m0i = s_mean[8 + e0], m1i = s_mean[8 + e0 + 1];
+    const float r0r = s_rstd[e0], r1r = s_rstd[e0 + 1], r0i = s_rstd[8 + e0], r1i = s_rstd[8 + e0 + 1];
+    float* ore = out + ((size_t)((sf * 8 + f) * 2 + 0)) * kRange * kAz * kEl;
+    float* oim = ore + (size_t)kRange * kAz * kEl;
+    for (int t = tid; t < kVec; t += 256) {
+        float4 v = src[t];                       // second read is L2-resident (256 KB slab)
+        float2 re = make_float2((v.x - m0r) * r0r, (v.z - m1r) * r1r);
+        float2 im = make_float2((v.y - m0i) * r0i, (v.w - m1i) * r1i);
+        reinterpret_cast<float2*>(ore)[t] = re;
+        reinterpret_cast<float2*>(oim)[t] = im;
+    }
+}
+
+}  // namespace hupr
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace hupr;
+
+extern "C" size_t hupr_fft_chain_ws_bytes(int n_sf) {
+    if (n_sf <= 0) return 0;
+    return (size_t)n_sf * kDop * kRange * kVant * sizeof(float2);
+}
+
+static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws, size_t ws_bytes,
+                            hupr_stream_t stream, bool loader) {
+    HUPR_REQUIRE(n_sf >= 0, "hupr_fft_chain: n_sf=%d", n_sf);
+    if (n_sf == 0) return HUPR_OK;                      // empty batch is a no-op
+    HUPR_REQUIRE(adc_iq && out && ws, "hupr_fft_chain: null pointer");
+    HUPR_REQUIRE(((uintptr_t)adc_iq & 3) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)ws & 15) == 0,
+                 "hupr_fft_chain: misaligned buffer");
+    HUPR_REQUIRE(n_sf <= (1 << 20), "hupr_fft_chain: n_sf=%d too large", n_sf);
+    if (ws_bytes < hupr_fft_chain_ws_bytes(n_sf))
+        return fail(HUPR_ERR_WORKSPACE, "hupr_fft_chain: workspace %zu < %zu", ws_bytes,
+                    hupr_fft_chain_ws_bytes(n_sf));
+    hipStream_t s = as_stream(stream);
+    float2* rd = reinterpret_cast<float2*>(ws);
+    hipLaunchKernelGGL(hupr_k_range_doppler, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd);
+    HUPR_LAUNCH_OK("hupr_k_range_doppler");
+    if (loader)
+        hipLaunchKernelGGL(hupr_k_angle<true>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
+    else
+        hipLaunchKernelGGL(hupr_k_angle<false>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
+    HUPR_LAUNCH_OK("hupr_k_angle");
+    return HUPR_OK;
+}
+
+extern "C" int hupr_fft_chain_c64(const int16_t* adc_iq, int n_sf, void* out_c64, void* ws,
+                                  size_t ws_bytes, hupr_stream_t stream) {
+    return fft_chain_common(adc_iq, n_sf, out_c64, ws, ws_bytes, stream, false);
+}
+
+extern "C" int hupr_fft_chain_loader_f32(const int16_t* adc_iq, int n_sf, float* out, void* ws,
+                                         size_t ws_bytes, hupr_stream_t stream) {
+    return fft_chain_common(adc_iq, n_sf, out, ws, ws_bytes, stream, true);
+}
+
+extern "C" int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* out, hupr_stream_t stream) {
+    HUPR_REQUIRE(n_sf >= 0, "hupr_loader_normalize_c64: n_sf=%d", n_sf);
+    if (n_sf == 0) return HUPR_OK;
+    HUPR_REQUIRE(cube_c64 && out, "hupr_loader_normalize_c64: null pointer");
+    HUPR_REQUIRE(((uintptr_t)cube_c64 & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                 "hupr_loader_normalize_c64: misaligned buffer");
+    hipLaunchKernelGGL(hupr_k_loader_normalize, dim3(n_sf * 8), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2*>(cube_c64), out);
+    HUPR_LAUNCH_OK("hupr_k_loader_normalize");
+    return HUPR_OK;
+}

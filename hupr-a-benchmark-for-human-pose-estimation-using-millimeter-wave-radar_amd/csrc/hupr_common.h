@@ -1,0 +1,60 @@
+// Shared host/device helpers for the gfx950 kernels behind include/hupr.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "hupr.h"
+
+namespace hupr {
+
+// thread-local error text returned by hupr_last_error()
+char* error_buffer();
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HUPR_REQUIRE(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) return ::hupr::fail(HUPR_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define HUPR_LAUNCH_OK(name)                                                            \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess)                                                          \
+            return ::hupr::fail(HUPR_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- device helpers -------------------------------------------------------------------
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// acc += a*b
+__device__ __forceinline__ void cfma(float2& acc, float2 a, float2 b) {
+    acc.x = fmaf(a.x, b.x, fmaf(-a.y, b.y, acc.x));
+    acc.y = fmaf(a.x, b.y, fmaf(a.y, b.x, acc.y));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline hipStream_t as_stream(hupr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace hupr

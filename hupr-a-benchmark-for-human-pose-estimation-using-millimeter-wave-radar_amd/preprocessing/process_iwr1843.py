@@ -1,0 +1,98 @@
+"""Host-side mirror of the reference's preprocessing operator.
+
+``RadarObject().generateHeatmap(frame)`` keeps the reference contract
+(preprocessing/process_iwr1843.py:106,173): ``frame`` complex ndarray (4,192,256) ->
+complex ndarray (16,64,64,8); the arithmetic runs in the gfx950 FFT-chain kernels
+(csrc/fft_chain.hip) in complex64 and is widened to complex128 on return.
+
+The batched device entry points (`fft_chain`, `fft_chain_loader`) are what the training
+loader uses: int16 I/Q cubes resident in HBM in, complex64 cubes or normalised fp32 network
+input out.
+"""
+import numpy as np
+import torch
+
+from .. import runtime as rt
+
+NUM_RX, NUM_CHIRP, NUM_SAMPLE = 4, 192, 256
+
+
+def _workspace(n_sf, device):
+    nbytes = rt.lib().hupr_fft_chain_ws_bytes(n_sf)
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device), nbytes
+
+
+def _check_adc(adc_iq):
+    if adc_iq.dtype != torch.int16 or tuple(adc_iq.shape[1:]) != (NUM_RX, NUM_CHIRP, NUM_SAMPLE, 2):
+        raise ValueError("adc_iq must be int16 (n,4,192,256,2), got %s %r" % (adc_iq.dtype, tuple(adc_iq.shape)))
+
+
+def fft_chain(adc_iq, ws=None):
+    """adc_iq: int16 GPU tensor (n,4,192,256,2) -> complex64 GPU tensor (n,16,64,64,8)."""
+    _check_adc(adc_iq)
+    n = adc_iq.shape[0]
+    out = torch.empty((n, 16, 64, 64, 8), dtype=torch.complex64, device=adc_iq.device)
+    if ws is None:
+        ws, nbytes = _workspace(n, adc_iq.device)
+    else:
+        nbytes = ws.numel() * ws.element_size()
+    rt.check(rt.lib().hupr_fft_chain_c64(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
+    return out
+
+
+def fft_chain_loader(adc_iq, ws=None, out=None):
+    """adc_iq: int16 GPU tensor (n,4,192,256,2) -> fp32 GPU tensor (n, 8, 2, 64, 64, 8):
+    Doppler bins 4..11, re/im split, per-elevation Normalize (datasets glue fused in)."""
+    _check_adc(adc_iq)
+    n = adc_iq.shape[0]
+    if out is None:
+        out = torch.empty((n, 8, 2, 64, 64, 8), dtype=torch.float32, device=adc_iq.device)
+    if ws is None:
+        ws, nbytes = _workspace(n, adc_iq.device)
+    else:
+        nbytes = ws.numel() * ws.element_size()
+    rt.check(rt.lib().hupr_fft_chain_loader_f32(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes,
+                                               rt.stream()))
+    return out
+
+
+def loader_normalize(cube):
+    """cube: complex64 GPU tensor (n,16,64,64,8) -> fp32 (n,8,2,64,64,8) (dataset.py:144-150)."""
+    if cube.dtype != torch.complex64 or tuple(cube.shape[1:]) != (16, 64, 64, 8):
+        raise ValueError("cube must be complex64 (n,16,64,64,8)")
+    n = cube.shape[0]
+    out = torch.empty((n, 8, 2, 64, 64, 8), dtype=torch.float32, device=cube.device)
+    rt.check(rt.lib().hupr_loader_normalize_c64(rt.ptr(cube), n, rt.ptr(out), rt.stream()))
+    return out
+
+
+class RadarObject:
+    """Same constants and operator surface as the reference class (process_iwr1843.py:8-34)."""
+
+    def __init__(self, device="cuda"):
+        self.numADCSamples = 256
+        self.adcRatio = 4
+        self.numAngleBins = self.numADCSamples // self.adcRatio
+        self.numEleBins = 8
+        self.numRX = 4
+        self.numLanes = 2
+        self.framePerSecond = 10
+        self.duration = 60
+        self.numFrame = self.framePerSecond * self.duration
+        self.numChirp = 64 * 3
+        self.idxProcChirp = 64
+        self.numGroupChirp = 4
+        self.numKeypoints = 14
+        self.device = device
+
+    def generateHeatmap(self, frame):
+        """frame: complex ndarray (4,192,256) -> complex128 ndarray (16,64,64,8)."""
+        frame = np.asarray(frame)
+        if frame.shape != (self.numRX, self.numChirp, self.numADCSamples):
+            raise ValueError("frame must be (4,192,256), got %r" % (frame.shape,))
+        iq = np.stack([frame.real, frame.imag], axis=-1)
+        if not np.all(np.abs(iq) <= 32767) or not np.array_equal(iq, np.rint(iq)):
+            raise ValueError("generateHeatmap expects integer-valued 16-bit ADC samples")
+        dev = torch.from_numpy(iq.astype(np.int16)[None]).to(self.device)
+        out = fft_chain(dev)
+        return out[0].cpu().numpy().astype(np.complex128)

@@ -1,0 +1,71 @@
+"""ctypes binding of the C ABI (include/hupr.h) — the only door to compute in this package.
+
+There is deliberately no fallback: if ``lib/libhupr_hip.so`` is missing, or a kernel is asked
+to run on a non-GPU tensor, this raises.  PyTorch is used for device memory, streams and
+``torch.distributed`` only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhupr_hip.so")
+
+c_void_p, c_int, c_size_t, c_float, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
+                                                ctypes.c_float, ctypes.c_char_p)
+c_i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol declared in include/hupr.h
+SIGNATURES = {
+    "hupr_version": (c_int, []),
+    "hupr_last_error": (c_char_p, []),
+    "hupr_fft_chain_ws_bytes": (c_size_t, [c_int]),
+    "hupr_fft_chain_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_fft_chain_loader_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_loader_normalize_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class HuprError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HuprError(
+                "HIP extension %s not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HuprError("hupr error %d: %s" % (rc, lib().hupr_last_error().decode()))
+
+
+def stream():
+    """Current torch HIP stream as a raw hipStream_t."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous GPU tensor (loud failure otherwise)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HuprError("tensor is on %s; the HIP path needs a GPU tensor (no CPU fallback)" % t.device)
+    if not t.is_contiguous():
+        raise HuprError("tensor must be contiguous")
+    return t.data_ptr()

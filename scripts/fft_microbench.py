@@ -1,0 +1,35 @@
+"""Times the FFT-chain kernels with HIP events (inputs resident in HBM) and prints GB/s against
+the algorithmic byte counts of SURVEY.md 8(d).  Usage: python scripts/fft_microbench.py [n_sf]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hupr_amd import preprocessing, runtime as rt, synth  # noqa: E402
+
+n_sf = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+base = torch.from_numpy(synth.adc_cube_int16(0, nframes=16)).cuda()
+iq = base.repeat((n_sf + 15) // 16, 1, 1, 1, 1)[:n_sf].contiguous()
+ws = torch.empty(rt.lib().hupr_fft_chain_ws_bytes(n_sf), dtype=torch.uint8, device="cuda")
+out_l = torch.empty((n_sf, 8, 2, 64, 64, 8), dtype=torch.float32, device="cuda")
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+t_c = timeit(lambda: preprocessing.fft_chain(iq, ws=ws))
+t_l = timeit(lambda: preprocessing.fft_chain_loader(iq, ws=ws, out=out_l))
+b_c, b_l = n_sf * 4980736, n_sf * 2883584
+print("n_sf=%d  c64: %.1f us  %.0f GB/s (%.3f of 8 TB/s) | loader: %.1f us  %.0f GB/s (%.3f)  | %.0f sensor-frames/s"
+      % (n_sf, t_c * 1e6, b_c / t_c / 1e9, b_c / t_c / 8e12, t_l * 1e6, b_l / t_l / 1e9, b_l / t_l / 8e12, n_sf / t_l))

@@ -1,0 +1,131 @@
+"""GPU (-m gpu): FFT-chain HIP kernels vs the oracle and the reference-derived golden vectors.
+Gates: rel-L2 <= 1e-5 on Doppler bins != 8, |bin 8| <= 1e-6 * max|all|."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hupr_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _run(iq):
+    from hupr_amd import preprocessing
+    return preprocessing.fft_chain(torch.from_numpy(iq).cuda()).cpu().numpy()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fft_chain_vs_golden_and_oracle(seed):
+    from oracle import fft_chain as offt
+    iq = synth.adc_cube_int16(seed)
+    got = _run(iq)[0]
+    assert got.shape == (16, 64, 64, 8) and got.dtype == np.complex64
+    ref = offt.generate_heatmap(synth.adc_cube_complex(iq)[0])
+    keep = np.arange(16) != 8
+    rel = np.linalg.norm(got[keep] - ref[keep]) / np.linalg.norm(ref[keep])
+    assert rel <= 1e-5, rel
+    assert np.abs(got[8]).max() <= 1e-6 * np.abs(ref).max()
+    # per-element worst case on the kept bins
+    assert np.abs(got[keep] - ref[keep]).max() <= 2e-5 * np.abs(ref).max()
+    g = np.load(os.path.join(G, "fft_seed%d.npz" % seed))
+    samp = got.reshape(-1)[::int(g["stride"])]
+    idx = np.arange(got.size)[::int(g["stride"])] // (64 * 64 * 8)
+    ok = idx != 8
+    assert np.abs(samp[ok] - g["sample"][ok]).max() <= 2e-5 * np.abs(ref).max()
+    l2 = np.sqrt((np.abs(got.astype(np.complex128)) ** 2).sum(axis=(1, 2, 3)))
+    np.testing.assert_allclose(l2[keep], g["doppler_l2"][keep], rtol=1e-5)
+
+
+def test_point_target_known_answer():
+    g = np.load(os.path.join(G, "fft_point.npz"))
+    tg = json.loads(str(g["targets"]))
+    got = _run(synth.point_target_cube(tg))[0]
+    mag = np.abs(got).sum(axis=3)
+    assert np.unravel_index(mag.argmax(), mag.shape) == (11, 34, 21) == tuple(g["peak"])
+    ref = g["sample"]
+    samp = got.reshape(-1)[::int(g["stride"])]
+    assert np.abs(samp - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_batch_is_independent_and_linear():
+    """size-independent properties at a larger batch: per-frame independence, linearity."""
+    a = synth.adc_cube_int16(5, nframes=8) // 2
+    b = synth.adc_cube_int16(6, nframes=8) // 2
+    ya, yb, yab = _run(a), _run(b), _run((a + b).astype(np.int16))
+    scale = np.abs(yab).max()
+    assert np.abs(yab - (ya + yb)).max() <= 2e-5 * scale
+    single = _run(a[3:4])
+    assert np.array_equal(single[0], ya[3])           # bit-identical regardless of batch position
+    # a constant-over-chirps scene is pure clutter -> all Doppler bins ~ 0
+    const = np.repeat(synth.adc_cube_int16(9)[:, :, :3], 64, axis=2)
+    yc = _run(const)
+    assert np.abs(yc).max() <= 1e-5 * scale
+
+
+def test_empty_and_bad_inputs():
+    from hupr_amd import preprocessing, runtime
+    out = preprocessing.fft_chain(torch.zeros((0, 4, 192, 256, 2), dtype=torch.int16, device="cuda"))
+    assert out.shape == (0, 16, 64, 64, 8)
+    with pytest.raises(ValueError):
+        preprocessing.fft_chain(torch.zeros((1, 4, 192, 256), dtype=torch.int16, device="cuda"))
+    ws = torch.empty(16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(runtime.HuprError):
+        preprocessing.fft_chain(torch.zeros((1, 4, 192, 256, 2), dtype=torch.int16, device="cuda"), ws=ws)
+
+
+def test_extreme_amplitudes():
+    from oracle import fft_chain as offt
+    iq = np.full((1, 4, 192, 256, 2), 32767, dtype=np.int16)
+    iq[:, :, ::2] = -32768                                # alternate chirps: max Doppler energy
+    got = _run(iq)[0]
+    ref = offt.generate_heatmap(synth.adc_cube_complex(iq)[0])
+    assert np.isfinite(got.view(np.float32)).all()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-3
+
+
+def test_fused_loader_vs_oracle():
+    from hupr_amd import preprocessing
+    from oracle import fft_chain as offt, loader as oloader
+    iq = synth.adc_cube_int16(0, nframes=2)
+    dev = torch.from_numpy(iq).cuda()
+    got = preprocessing.fft_chain_loader(dev).cpu().numpy()
+    assert got.shape == (2, 8, 2, 64, 64, 8) and got.dtype == np.float32
+    f_ok = np.arange(8) != 4                       # f=4 is the clutter-nulled bin: normalised noise
+    for n in range(2):
+        ref = oloader.loader_transform(offt.generate_heatmap(synth.adc_cube_complex(iq)[n]))
+        assert np.abs(got[n][f_ok] - ref[f_ok]).max() <= 2e-4
+    flat = got.reshape(2, 8, 2, 4096, 8).astype(np.float64)
+    assert np.abs(flat.mean(axis=3)).max() < 1e-4
+    assert np.abs(flat.std(axis=3, ddof=1) - 1).max() < 1e-4
+    assert np.isfinite(got).all()
+    # unfused route (complex cube -> loader glue) agrees with the fused one
+    two = preprocessing.loader_normalize(preprocessing.fft_chain(dev)).cpu().numpy()
+    assert np.abs(two[:, f_ok] - got[:, f_ok]).max() <= 1e-4
+    g = np.load(os.path.join(G, "loader_seed0.npz"))
+    samp = got[0].reshape(-1)[::int(g["stride"])]
+    fi = np.arange(got[0].size)[::int(g["stride"])] // (2 * 64 * 64 * 8)
+    assert np.abs(samp[fi != 4] - g["full_sample"][fi != 4]).max() <= 2e-4
+
+
+def test_normalize_operator_mirror():
+    from hupr_amd.datasets import Normalize
+    from oracle import loader as oloader
+    g = np.load(os.path.join(G, "loader_seed0.npz"))
+    x = torch.from_numpy(g["slice_in"].astype(np.float32)).permute(2, 0, 1).contiguous().cuda()
+    y = Normalize()(x).permute(1, 2, 0).cpu().numpy()
+    assert np.abs(y - g["slice_out"]).max() <= 1e-4
+
+
+def test_radar_object_dropin():
+    from hupr_amd.preprocessing import RadarObject
+    from oracle import fft_chain as offt
+    fr = synth.adc_cube_complex(synth.adc_cube_int16(4))[0]
+    out = RadarObject().generateHeatmap(fr)
+    assert out.shape == (16, 64, 64, 8) and out.dtype == np.complex128
+    ref = offt.generate_heatmap(fr)
+    keep = np.arange(16) != 8
+    assert np.linalg.norm(out[keep] - ref[keep]) / np.linalg.norm(ref[keep]) <= 1e-5
