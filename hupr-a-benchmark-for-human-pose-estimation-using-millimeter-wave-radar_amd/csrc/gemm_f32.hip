@@ -1,0 +1,557 @@
+// fp32 MFMA GEMM / implicit-GEMM convolution engine for gfx950.
+//
+// One templated kernel serves every GEMM-shaped op of HuPRNet in exact
+// fp32 (v_mfma_f32_32x32x2_f32: bit-equal to an fmaf chain, 157 TF peak):
+//
+//   A operand modes                         B operand modes
+//     A_ROWK   A[m][k], k contiguous          B_NK     B[n][k], k contiguous  (packed weights, "NT")
+//     A_CONV   im2col gather of a              B_KN     B[k][n], n contiguous  ("NN")
+//              channels-last activation        B_CONVK  im2col gather, K-major: k = voxel,
+//     A_KM     A[k][m], m contiguous ("T")              n = (tap, ci)           (weight gradient)
+//
+//   conv fwd / dgrad / 1x1 / temporal merge : A_CONV x B_NK     (+bias, +residual epilogue)
+//   attention S = Q K^T, dP = dO V^T        : A_ROWK x B_NK     (batched)
+//   attention O = P V, dQ = dS K, GCN W x   : A_ROWK x B_KN     (batched)
+//   attention dV = P^T dO, dK = dS^T Q      : A_KM   x B_KN     (batched)
+//   conv weight gradient                    : A_KM   x B_CONVK  (split over the voxel axis)
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN x 32; each wave owns (BM/WM) x (BN/WN) as
+// 32x32 MFMA tiles; operands are staged global -> registers -> LDS with the next tile's global
+// loads in flight during the MFMA phase.  LDS images are chosen per mode so that both the
+// staging stores and the one-float-per-lane MFMA operand reads are bank-conflict free
+// (row stride 33 for k-contiguous tiles, dense rows for k-major tiles).
+#include "hupr_common.h"
+
+namespace hupr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum AMode { A_ROWK = 0, A_CONV = 1, A_KM = 2 };
+enum BMode { B_NK = 0, B_KN = 1, B_CONVK = 2 };
+
+struct ConvGeom {
+    int Di, Hi, Wi, Ci;       // input voxels / channels taken part in the GEMM
+    int in_ld;                // floats between consecutive voxels of the input buffer
+    int Do, Ho, Wo;           // output voxels
+    int kd, kh, kw;           // taps
+    int pd, ph, pw;           // zero padding
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    // batch: z -> (z / zdiv, z % zdiv), pointer += z0 * bs0 + z1 * bs1
+    int zdiv;
+    long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    ConvGeom g;
+    const float* bias;        // [N] or null
+    const float* res;         // residual added in the epilogue, same indexing as C with res_ld
+    long res_ld, res_bs0, res_bs1;
+    int ksplit;               // >1: grid.y slices K, partial tiles go to C + slice*M*ldc... (see host)
+    long split_stride;        // floats between partial outputs
+    int accumulate;           // 1: C += result (read-modify-write; not with ksplit)
+};
+
+constexpr int BK = 32;
+
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+__global__ __launch_bounds__(256) void hupr_k_gemm_f32(GemmArgs p) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;      // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;      // 32x32 MFMA tiles per wave
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "bad tiling");
+    constexpr int A_LD = (AM == A_KM) ? BM : BK + 1;      // LDS row stride (floats)
+    constexpr int B_LD = (BMD == B_NK) ? BK + 1 : BN;
+    constexpr int A_ROWS = (AM == A_KM) ? BK : BM;
+    constexpr int B_ROWS = (BMD == B_NK) ? BN : BK;
+    constexpr int A_F4 = BM * BK / 4 / 256;          // float4 per thread per tile
+    constexpr int B_F4 = BN * BK / 4 / 256;
+    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
+
+    __shared__ float As[A_ROWS * A_LD];
+    __shared__ float Bs[B_ROWS * B_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- block coordinates -------------------------------------------------------------
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    const int z = blockIdx.z, z0 = z / p.zdiv, z1 = z % p.zdiv;
+    const float* __restrict__ Ag = p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
+    const float* __restrict__ Bg = p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
+    float* __restrict__ Cg = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
+
+    // K range of this block (split over blockIdx.y)
+    const int k_tiles_total = (p.K + BK - 1) / BK;
+    const int per = (k_tiles_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = blockIdx.y * per;
+    const int kt_end = min(k_tiles_total, kt_begin + per);
+    if (p.ksplit > 1) Cg += (long)blockIdx.y * p.split_stride;
+
+    const ConvGeom& g = p.g;
+
+    // ---- per-thread staging descriptors ---------------------------------------------------
+    // A_ROWK / A_CONV: float4 index f = tid + 256*i -> row = f / 8, k4 = f % 8
+    // A_KM           : f -> krow = f / (BM/4), c4 = f % (BM/4)
+    float4 ra[A_F4], rb[B_F4];
+    long a_off[A_F4];        // A_ROWK: row offset; A_CONV: base offset of output voxel's (0,0,0) tap
+    int a_vox[A_F4];         // A_CONV: packed (od, oh, ow) ; -1 if row out of range
+    if (AM == A_ROWK) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int row = m0 + (tid + 256 * i) / 8;
+            a_off[i] = (row < p.M) ? (long)row * p.lda : -1;
+        }
+    } else if (AM == A_CONV) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int row = m0 + (tid + 256 * i) / 8;
+            if (row < p.M) {
+                int ow = row % g.Wo, t = row / g.Wo;
+                int oh = t % g.Ho; t /= g.Ho;
+                int od = t % g.Do, b = t / g.Do;
+                a_vox[i] = (od << 20) | (oh << 10) | ow;
+                a_off[i] = (long)b * g.Di * g.Hi * g.Wi;
+            } else {
+                a_vox[i] = -1;
+                a_off[i] = 0;
+            }
+        }
+    }
+
+    auto load_a = [&](int kt) {
+        const int k0 = kt * BK;
+        if (AM == A_ROWK) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int k = k0 + ((tid + 256 * i) & 7) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_off[i] >= 0) {
+                    const float* src = Ag + a_off[i] + k;
+                    if (k + 3 < p.K && ((p.lda & 3) == 0)) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k < p.K) v.x = src[0];
+                        if (k + 1 < p.K) v.y = src[1];
+                        if (k + 2 < p.K) v.z = src[2];
+                        if (k + 3 < p.K) v.w = src[3];
+                    }
+                }
+                ra[i] = v;
+            }
+        } else if (AM == A_CONV) {
+            // whole k-tile lies inside one tap because Ci % 32 == 0
+            const int tap = k0 / g.Ci, ci0 = k0 - tap * g.Ci;
+            const int tw_ = tap % g.kw, tt = tap / g.kw;
+            const int th_ = tt % g.kh, td_ = tt / g.kh;
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_vox[i] >= 0) {
+                    const int id = (a_vox[i] >> 20) + td_ - g.pd;
+                    const int ih = ((a_vox[i] >> 10) & 1023) + th_ - g.ph;
+                    const int iw = (a_vox[i] & 1023) + tw_ - g.pw;
+                    if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi &&
+                        (unsigned)iw < (unsigned)g.Wi) {
+                        const long vox = a_off[i] + ((long)id * g.Hi + ih) * g.Wi + iw;
+                        v = *reinterpret_cast<const float4*>(Ag + vox * g.in_ld + ci0 +
+                                                             ((tid + 256 * i) & 7) * 4);
+                    }
+                }
+                ra[i] = v;
+            }
+        } else {   // A_KM: A[k][m]
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int f = tid + 256 * i;
+                const int k = k0 + f / (BM / 4), m = m0 + (f % (BM / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < p.K) {
+                    const float* src = Ag + (long)k * p.lda + m;
+                    if (m + 3 < p.M && ((p.lda & 3) == 0)) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (m < p.M) v.x = src[0];
+                        if (m + 1 < p.M) v.y = src[1];
+                        if (m + 2 < p.M) v.z = src[2];
+                        if (m + 3 < p.M) v.w = src[3];
+                    }
+                }
+                ra[i] = v;
+            }
+        }
+    };
+
+    auto load_b = [&](int kt) {
+        const int k0 = kt * BK;
+        if (BMD == B_NK) {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int f = tid + 256 * i;
+                const int n = n0 + f / 8, k = k0 + (f & 7) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.N) {
+                    const float* src = Bg + (long)n * p.ldb + k;
+                    if (k + 3 < p.K && ((p.ldb & 3) == 0)) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k < p.K) v.x = src[0];
+                        if (k + 1 < p.K) v.y = src[1];
+                        if (k + 2 < p.K) v.z = src[2];
+                        if (k + 3 < p.K) v.w = src[3];
+                    }
+                }
+                rb[i] = v;
+            }
+        } else if (BMD == B_KN) {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int f = tid + 256 * i;
+                const int k = k0 + f / (BN / 4), n = n0 + (f % (BN / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < p.K) {
+                    const float* src = Bg + (long)k * p.ldb + n;
+                    if (n + 3 < p.N && ((p.ldb & 3) == 0)) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (n < p.N) v.x = src[0];
+                        if (n + 1 < p.N) v.y = src[1];
+                        if (n + 2 < p.N) v.z = src[2];
+                        if (n + 3 < p.N) v.w = src[3];
+                    }
+                }
+                rb[i] = v;
+            }
+        } else {   // B_CONVK: k = output voxel index, n = tap*Ci + ci; BN <= Ci and Ci % BN == 0
+            const int tap = n0 / g.Ci, ci0 = n0 - tap * g.Ci;
+            const int tw_ = tap % g.kw, tt = tap / g.kw;
+            const int th_ = tt % g.kh, td_ = tt / g.kh;
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int f = tid + 256 * i;
+                const int k = k0 + f / (BN / 4), c = (f % (BN / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < p.K && tap < g.kd * g.kh * g.kw) {
+                    int ow = k % g.Wo, t = k / g.Wo;
+                    int oh = t % g.Ho; t /= g.Ho;
+                    int od = t % g.Do, b = t / g.Do;
+                    const int id = od + td_ - g.pd, ih = oh + th_ - g.ph, iw = ow + tw_ - g.pw;
+                    if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi &&
+                        (unsigned)iw < (unsigned)g.Wi) {
+                        const long vox = (((long)b * g.Di + id) * g.Hi + ih) * g.Wi + iw;
+                        v = *reinterpret_cast<const float4*>(Bg + vox * g.in_ld + ci0 + c);
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&]() {
+        if (AM == A_KM) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int f = tid + 256 * i;
+                *reinterpret_cast<float4*>(&As[(f / (BM / 4)) * A_LD + (f % (BM / 4)) * 4]) = ra[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int f = tid + 256 * i;
+                float* d = &As[(f / 8) * A_LD + (f & 7) * 4];
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+            }
+        }
+        if (BMD == B_NK) {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int f = tid + 256 * i;
+                float* d = &Bs[(f / 8) * B_LD + (f & 7) * 4];
+                d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int f = tid + 256 * i;
+                *reinterpret_cast<float4*>(&Bs[(f / (BN / 4)) * B_LD + (f % (BN / 4)) * 4]) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    if (kt_begin < kt_end) {
+        load_a(kt_begin);
+        load_b(kt_begin);
+    }
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        store_tiles();
+        __syncthreads();
+        if (kt + 1 < kt_end) {
+            load_a(kt + 1);
+            load_b(kt + 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 32 + lr;
+                a[i] = (AM == A_KM) ? As[(kk + lh) * A_LD + row] : As[row * A_LD + kk + lh];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * WTN + j * 32 + lr;
+                b[j] = (BMD == B_NK) ? Bs[col * B_LD + kk + lh] : Bs[(kk + lh) * B_LD + col];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[i][j]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5) ------------------
+    const float* __restrict__ resg = p.res ? p.res + z0 * p.res_bs0 + z1 * p.res_bs1 : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + lr;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < p.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (resg) v += resg[(long)row * p.res_ld + col];
+                    float* dst = Cg + (long)row * p.ldc + col;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// split-K reduction (deterministic): out[i] (+)= sum_s part[s][i]; optional layout change for
+// conv weight gradients: partial is [Cout][taps][Ci] (GEMM order), destination is the
+// parameter layout [Cout][Ci][taps] (PyTorch (Cout,Cin,kd,kh,kw)).
+// ------------------------------------------------------------------------------------------
+__global__ void hupr_k_splitk_reduce(const float* __restrict__ part, float* __restrict__ out, long n,
+                                     int splits, long split_stride, int taps, int ci) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[k * split_stride + i];
+    long dst = i;
+    if (taps > 1) {
+        const long per = (long)taps * ci;
+        const long co = i / per, rem = i - co * per;
+        const int tap = rem / ci, c = rem - (long)tap * ci;
+        dst = co * per + (long)c * taps + tap;
+    }
+    out[dst] = s;
+}
+
+// weight packing: w (Cout, Cin, taps) ->
+//   mode 0 (forward) : wp[co][tap][ci]
+//   mode 1 (dgrad)   : wp[ci][taps-1-tap][co]   (flipped taps, in/out swapped)
+__global__ void hupr_k_pack_weights(const float* __restrict__ w, float* __restrict__ wp, int co_n,
+                                    int ci_n, int taps, int mode) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long n = (long)co_n * ci_n * taps;
+    if (i >= n) return;
+    // i indexes the destination (coalesced writes)
+    if (mode == 0) {
+        const int ci = i % ci_n;
+        long t = i / ci_n;
+        const int tap = t % taps;
+        const int co = t / taps;
+        wp[i] = w[((long)co * ci_n + ci) * taps + tap];
+    } else {
+        const int co = i % co_n;
+        long t = i / co_n;
+        const int tapf = t % taps;
+        const int ci = t / taps;
+        wp[i] = w[((long)co * ci_n + ci) * taps + (taps - 1 - tapf)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+static void launch(const GemmArgs& a, int batch, hipStream_t s) {
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    dim3 grid(mt * nt, a.ksplit, batch);
+    hipLaunchKernelGGL((hupr_k_gemm_f32<BM, BN, WM, WN, AM, BMD>), grid, dim3(256), 0, s, a);
+}
+
+template <int AM, int BMD>
+static void dispatch_tiles(const GemmArgs& a, int batch, hipStream_t s) {
+    // choose the N tile from N, the M tile from M
+    if (a.M <= 64) {
+        if (a.N > 64) launch<64, 128, 1, 4, AM, BMD>(a, batch, s);
+        else launch<64, 64, 2, 2, AM, BMD>(a, batch, s);
+    } else if (a.N > 64) {
+        launch<128, 128, 2, 2, AM, BMD>(a, batch, s);
+    } else if (a.N > 32) {
+        launch<128, 64, 2, 2, AM, BMD>(a, batch, s);
+    } else {
+        launch<128, 32, 4, 1, AM, BMD>(a, batch, s);
+    }
+}
+
+static void fill_common(GemmArgs& a) {
+    a.zdiv = 1;
+    a.a_bs0 = a.a_bs1 = a.b_bs0 = a.b_bs1 = a.c_bs0 = a.c_bs1 = 0;
+    a.bias = nullptr;
+    a.res = nullptr;
+    a.res_ld = a.res_bs0 = a.res_bs1 = 0;
+    a.ksplit = 1;
+    a.split_stride = 0;
+    a.accumulate = 0;
+    a.g = ConvGeom{};
+}
+
+}  // namespace hupr
+
+using namespace hupr;
+
+// ---- C ABI ------------------------------------------------------------------------------------
+
+extern "C" int hupr_gemm_f32(int ta, int tb, const float* A, const float* B, float* C, int M, int N,
+                             int K, long lda, long ldb, long ldc, int batch, long a_bs, long b_bs,
+                             long c_bs, const float* res, long res_ld, long res_bs, int accumulate,
+                             hupr_stream_t stream) {
+    HUPR_REQUIRE(A && B && C, "hupr_gemm_f32: null pointer");
+    HUPR_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "hupr_gemm_f32: bad shape %d %d %d x%d", M, N, K, batch);
+    HUPR_REQUIRE(batch <= 65535, "hupr_gemm_f32: batch %d > 65535", batch);
+    GemmArgs a;
+    fill_common(a);
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.a_bs0 = a_bs; a.b_bs0 = b_bs; a.c_bs0 = c_bs;
+    a.res = res; a.res_ld = res_ld; a.res_bs0 = res_bs;
+    a.accumulate = accumulate;
+    hipStream_t s = as_stream(stream);
+    if (ta == 0 && tb == 1) dispatch_tiles<A_ROWK, B_NK>(a, batch, s);        // C = A B^T
+    else if (ta == 0 && tb == 0) dispatch_tiles<A_ROWK, B_KN>(a, batch, s);   // C = A B
+    else if (ta == 1 && tb == 0) dispatch_tiles<A_KM, B_KN>(a, batch, s);     // C = A^T B
+    else return fail(HUPR_ERR_ARG, "hupr_gemm_f32: unsupported transpose combination %d %d", ta, tb);
+    HUPR_LAUNCH_OK("hupr_k_gemm_f32");
+    return HUPR_OK;
+}
+
+static int check_geom(const char* who, int Bn, const ConvGeom& g, int Co) {
+    HUPR_REQUIRE(Bn > 0 && g.Di > 0 && g.Hi > 0 && g.Wi > 0 && g.Do > 0 && g.Ho > 0 && g.Wo > 0,
+                 "%s: bad geometry", who);
+    HUPR_REQUIRE(g.Ci % 32 == 0, "%s: Cin=%d must be a multiple of 32", who, g.Ci);
+    HUPR_REQUIRE(g.Do < 1024 && g.Ho < 1024 && g.Wo < 1024, "%s: extent >= 1024", who);
+    HUPR_REQUIRE(g.in_ld % 4 == 0, "%s: input voxel stride %d not a multiple of 4 floats", who, g.in_ld);
+    HUPR_REQUIRE(Co > 0, "%s: Cout=%d", who, Co);
+    return HUPR_OK;
+}
+
+// y[b,od,oh,ow, 0:Co] (row stride out_ld) = conv(x[b,:,:,:, 0:Ci] (voxel stride in_ld), wp[Co][taps][Ci])
+//                                          (+ bias[Co]) (+ res[..., 0:Co] (row stride res_ld))
+extern "C" int hupr_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* res,
+                                 float* y, int Bn, int Di, int Hi, int Wi, int Ci, int in_ld, int Do,
+                                 int Ho, int Wo, int Co, int out_ld, int res_ld, int kd, int kh, int kw,
+                                 int pd, int ph, int pw, int accumulate, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && wp && y, "hupr_conv_fwd_f32: null pointer");
+    GemmArgs a;
+    fill_common(a);
+    a.g = ConvGeom{Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, kd, kh, kw, pd, ph, pw};
+    int rc = check_geom("hupr_conv_fwd_f32", Bn, a.g, Co);
+    if (rc) return rc;
+    HUPR_REQUIRE(Do == Di + 2 * pd - kd + 1 && Ho == Hi + 2 * ph - kh + 1 && Wo == Wi + 2 * pw - kw + 1,
+                 "hupr_conv_fwd_f32: output extent does not match stride-1 convolution");
+    const long M = (long)Bn * Do * Ho * Wo;
+    HUPR_REQUIRE(M < (1L << 31), "hupr_conv_fwd_f32: too many output voxels");
+    a.A = x; a.B = wp; a.C = y;
+    a.M = (int)M; a.N = Co; a.K = kd * kh * kw * Ci;
+    a.lda = 0; a.ldb = a.K; a.ldc = out_ld;
+    a.bias = bias; a.res = res; a.res_ld = res_ld;
+    a.accumulate = accumulate;
+    dispatch_tiles<A_CONV, B_NK>(a, 1, as_stream(stream));
+    HUPR_LAUNCH_OK("hupr_k_gemm_f32<conv>");
+    return HUPR_OK;
+}
+
+extern "C" size_t hupr_conv_wgrad_ws_bytes(int Bn, int Do, int Ho, int Wo, int Ci, int Co, int kd, int kh,
+                                           int kw) {
+    // worst case number of voxel-axis slices (see hupr_conv_wgrad_f32) x one partial weight tensor
+    return (size_t)64 * Co * kd * kh * kw * Ci * sizeof(float);
+}
+
+// dw (Co, Ci, kd, kh, kw) = sum over output voxels of dy[m][co] * x[m shifted by tap][ci]
+extern "C" int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, int Bn, int Di, int Hi,
+                                   int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld,
+                                   int kd, int kh, int kw, int pd, int ph, int pw, void* ws,
+                                   size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && dy && dw && ws, "hupr_conv_wgrad_f32: null pointer");
+    GemmArgs a;
+    fill_common(a);
+    a.g = ConvGeom{Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, kd, kh, kw, pd, ph, pw};
+    int rc = check_geom("hupr_conv_wgrad_f32", Bn, a.g, Co);
+    if (rc) return rc;
+    const long Mv = (long)Bn * Do * Ho * Wo;
+    HUPR_REQUIRE(Mv < (1L << 31), "hupr_conv_wgrad_f32: too many output voxels");
+    const int taps = kd * kh * kw;
+    a.A = dy; a.B = x; a.C = reinterpret_cast<float*>(ws);
+    a.M = Co; a.N = taps * Ci; a.K = (int)Mv;
+    a.lda = dy_ld; a.ldb = 0; a.ldc = a.N;
+    // slice the voxel axis so the grid fills the chip: target ~1500 workgroups
+    const int bn = (Ci % 64 == 0) ? 64 : 32;
+    const int bm = (Co <= 64 && bn == 64) ? 64 : 128;
+    const long tiles = (long)((Co + bm - 1) / bm) * (a.N / bn);
+    const int ktiles = (int)((Mv + BK - 1) / BK);
+    int splits = (int)((1536 + tiles - 1) / tiles);
+    splits = max(1, min(min(splits, 64), ktiles));
+    a.ksplit = splits;
+    a.split_stride = (long)a.M * a.N;
+    if (ws_bytes < (size_t)splits * a.split_stride * sizeof(float))
+        return fail(HUPR_ERR_WORKSPACE, "hupr_conv_wgrad_f32: workspace %zu < %zu", ws_bytes,
+                    (size_t)splits * a.split_stride * sizeof(float));
+    hipStream_t s = as_stream(stream);
+    if (bn == 64) {
+        if (bm == 64) launch<64, 64, 2, 2, A_KM, B_CONVK>(a, 1, s);
+        else launch<128, 64, 2, 2, A_KM, B_CONVK>(a, 1, s);
+    } else {
+        launch<128, 32, 4, 1, A_KM, B_CONVK>(a, 1, s);    // Co <= 64 rows are masked
+    }
+    HUPR_LAUNCH_OK("hupr_k_gemm_f32<wgrad>");
+    const long n = a.split_stride;
+    hipLaunchKernelGGL(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(ws), dw, n, splits, a.split_stride, taps, Ci);
+    HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
+    return HUPR_OK;
+}
+
+extern "C" int hupr_pack_conv_weights_f32(const float* w, float* wp, int Co, int Ci, int taps, int mode,
+                                          hupr_stream_t stream) {
+    HUPR_REQUIRE(w && wp && Co > 0 && Ci > 0 && taps > 0 && (mode == 0 || mode == 1),
+                 "hupr_pack_conv_weights_f32: bad argument");
+    const long n = (long)Co * Ci * taps;
+    hipLaunchKernelGGL(hupr_k_pack_weights, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, wp,
+                       Co, Ci, taps, mode);
+    HUPR_LAUNCH_OK("hupr_k_pack_weights");
+    return HUPR_OK;
+}

@@ -1,0 +1,334 @@
+// Row softmax (attention), PRGCN adjacency/bias epilogue, sigmoid heads, BCE loss, Gaussian
+// targets, arg-max decode and the fused Adam step.  All HBM-bound or tiny.
+//
+// Reference semantics: models/layers.py:126-133 (softmax over keys), models/gcn_networks.py:23-29,
+// 53-64 (X.A, W.(XA)+b, ReLU, sigmoid), models/networks.py:40, misc/losses.py:23-45,
+// misc/utils.py:6-66, misc/metrics.py:10-38, tools/base.py:44-47 (Adam, coupled L2 decay).
+#include "hupr_common.h"
+
+namespace hupr {
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// in-place softmax of each row of s[rows][n] (n % 4 == 0); one 256-thread block per row
+__global__ __launch_bounds__(256) void hupr_k_softmax_rows(float* __restrict__ s, int n) {
+    __shared__ float red[4];
+    float4* row = reinterpret_cast<float4*>(s + (long)blockIdx.x * n);
+    const int n4 = n >> 2;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = row[i];
+        mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    mx = block_reduce(mx, true, red);
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        float4 v = row[i];
+        v.x = expf(v.x - mx); v.y = expf(v.y - mx); v.z = expf(v.z - mx); v.w = expf(v.w - mx);
+        sum += (v.x + v.y) + (v.z + v.w);
+        row[i] = v;
+    }
+    sum = block_reduce(sum, false, red);
+    const float inv = 1.f / sum;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        float4 v = row[i];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        row[i] = v;
+    }
+}
+
+// in place on dp: ds = p * (dp - sum_j dp_j p_j)
+__global__ __launch_bounds__(256) void hupr_k_softmax_rows_bwd(const float* __restrict__ p, float* __restrict__ dp, int n) {
+    __shared__ float red[4];
+    const float4* pr = reinterpret_cast<const float4*>(p + (long)blockIdx.x * n);
+    float4* gr = reinterpret_cast<float4*>(dp + (long)blockIdx.x * n);
+    const int n4 = n >> 2;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = pr[i], g = gr[i];
+        dot += (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
+    }
+    dot = block_reduce(dot, false, red);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 a = pr[i];
+        float4 g = gr[i];
+        g.x = a.x * (g.x - dot); g.y = a.y * (g.y - dot); g.z = a.z * (g.z - dot); g.w = a.w * (g.w - dot);
+        gr[i] = g;
+    }
+}
+
+// ---- PRGCN epilogue: y[b][f][k'] = act( sum_k t[b][f][k] A[k][k'] + bias[f][k'] ) --------------
+// t, y have row stride ld (>= K), pad columns are written as 0
+__global__ __launch_bounds__(256) void hupr_k_gcn_adj_fwd(const float* __restrict__ t, const float* __restrict__ adj,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          long rows, int F, int K, int ld, int relu) {
+    __shared__ float sa[16 * 16];
+    for (int i = threadIdx.x; i < K * K; i += 256) sa[i] = adj[i];
+    __syncthreads();
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const int f = r % F;
+        float in[16], out[16];
+        for (int k = 0; k < K; ++k) in[k] = t[r * ld + k];
+        for (int kp = 0; kp < K; ++kp) {
+            float s = bias[f * K + kp];
+            for (int k = 0; k < K; ++k) s = fmaf(in[k], sa[k * K + kp], s);
+            out[kp] = relu ? fmaxf(s, 0.f) : s;
+        }
+        for (int k = 0; k < ld; ++k) y[r * ld + k] = (k < K) ? out[k] : 0.f;
+    }
+}
+
+// g = dy * [y>0] (if relu);  dt[b][f][k] = sum_k' g[k'] A[k][k'];  dbias handled by hupr_k_gcn_dbias
+__global__ __launch_bounds__(256) void hupr_k_gcn_adj_bwd(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ adj, float* __restrict__ dt,
+                                                          float* __restrict__ gmasked, long rows, int K, int ld, int relu) {
+    __shared__ float sa[16 * 16];
+    for (int i = threadIdx.x; i < K * K; i += 256) sa[i] = adj[i];
+    __syncthreads();
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        float g[16];
+        for (int k = 0; k < K; ++k) {
+            float v = dy[r * ld + k];
+            if (relu && !(y[r * ld + k] > 0.f)) v = 0.f;
+            g[k] = v;
+        }
+        for (int k = 0; k < ld; ++k) {
+            float s = 0.f;
+            if (k < K)
+                for (int kp = 0; kp < K; ++kp) s = fmaf(g[kp], sa[k * K + kp], s);
+            dt[r * ld + k] = s;
+            gmasked[r * ld + k] = (k < K) ? g[k] : 0.f;
+        }
+    }
+}
+
+// dbias[f][k] = sum_b g[b][f][k]
+__global__ void hupr_k_gcn_dbias(const float* __restrict__ g, float* __restrict__ dbias, int Bn, int F, int K, int ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * K) return;
+    const int f = i / K, k = i % K;
+    float s = 0.f;
+    for (int b = 0; b < Bn; ++b) s += g[((long)b * F + f) * ld + k];
+    dbias[i] = s;
+}
+
+// ---- heads: x (B, HW, ld) channels-last logits -> y (B, K, HW) probabilities (NCHW) --------------
+__global__ void hupr_k_sigmoid_to_nchw(const float* __restrict__ x, float* __restrict__ y, int Bn, int HW, int K, int ld) {
+    const long total = (long)Bn * K * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int hw = i % HW;
+        const long t = i / HW;
+        const int k = t % K, b = t / K;
+        const float v = x[((long)b * HW + hw) * ld + k];
+        y[i] = 1.f / (1.f + expf(-v));
+    }
+}
+// dx (B,HW,ld) = dy (B,K,HW) * y (1-y), pad channels zero
+__global__ void hupr_k_sigmoid_to_nchw_bwd(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                           int Bn, int HW, int K, int ld) {
+    const long total = (long)Bn * HW * ld;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % ld;
+        const long t = i / ld;
+        const int hw = t % HW, b = t / HW;
+        float v = 0.f;
+        if (k < K) {
+            const long j = ((long)b * K + k) * HW + hw;
+            const float p = y[j];
+            v = dy[j] * p * (1.f - p);
+        }
+        dx[i] = v;
+    }
+}
+
+// ---- BCE (nn.BCELoss, mean reduction, log clamped at -100 like PyTorch) -----------------------
+__global__ __launch_bounds__(256) void hupr_k_bce_fwd(const float* __restrict__ p, const float* __restrict__ t, long n,
+                                                      double* __restrict__ partial) {
+    __shared__ double red[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pv = p[i], tv = t[i];
+        const float l1 = fmaxf(logf(pv), -100.f), l0 = fmaxf(logf(1.f - pv), -100.f);
+        acc -= tv * l1 + (1.f - tv) * l0;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void hupr_k_bce_final(const double* __restrict__ partial, int nblk, double inv_n, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[0] = (float)(s * inv_n);
+}
+// dp = gscale * (p - t) / max(p (1-p), 1e-12)     (PyTorch binary_cross_entropy_backward)
+__global__ void hupr_k_bce_bwd(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ gout,
+                               float inv_n, float* __restrict__ dp, long n) {
+    const float gs = gout[0] * inv_n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        dp[i] = gs * (pv - t[i]) / fmaxf(pv * (1.f - pv), 1e-12f);
+    }
+}
+
+// ---- Gaussian targets: joints (B,K,2) int64 image px -> t (B,K,H,W); patch = host table (2*rad+1)^2 --
+__global__ void hupr_k_gaussian_targets(const long long* __restrict__ joints, const float* __restrict__ patch,
+                                        float* __restrict__ t, int BK, int H, int rad, float stride) {
+    const long total = (long)BK * H * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = i % H;
+        const long q = i / H;
+        const int y = q % H, bk = q / H;
+        const int mx = (int)((float)joints[bk * 2 + 0] / stride + 0.5f);
+        const int my = (int)((float)joints[bk * 2 + 1] / stride + 0.5f);
+        float v = 0.f;
+        const bool outside = (mx - rad >= H) || (my - rad >= H) || (mx + rad + 1 < 0) || (my + rad + 1 < 0);
+        const int dx = x - mx + rad, dy = y - my + rad, sz = 2 * rad + 1;
+        if (!outside && dx >= 0 && dx < sz && dy >= 0 && dy < sz) v = patch[dy * sz + dx];
+        t[i] = v;
+    }
+}
+
+// ---- arg-max over HW per (b,k) row, first maximum wins (np.argmax) --------------------------------
+__global__ __launch_bounds__(64) void hupr_k_argmax_rows(const float* __restrict__ p, int n, int* __restrict__ idx,
+                                                         float* __restrict__ maxval) {
+    const float* row = p + (long)blockIdx.x * n;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float v = row[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (threadIdx.x == 0) { idx[blockIdx.x] = bi; maxval[blockIdx.x] = best; }
+}
+
+// ---- Adam with coupled L2 weight decay (torch.optim.Adam semantics), one flat launch --------------
+__global__ __launch_bounds__(256) void hupr_k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pv = p[i];
+        const float gr = fmaf(wd, pv, g[i] * gscale);
+        const float mv = fmaf(b1, m[i], (1.f - b1) * gr);
+        const float vv = fmaf(b2, v[i], (1.f - b2) * gr * gr);
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = pv - (lr / bc1) * (mv / denom);
+    }
+}
+
+static inline int grid1d(long n, int bs = 256, long cap = 4096) { return (int)min(cap, (n + bs - 1) / bs); }
+
+}  // namespace hupr
+
+using namespace hupr;
+
+extern "C" int hupr_softmax_rows_f32(float* s, long rows, int n, hupr_stream_t stream) {
+    HUPR_REQUIRE(s && rows > 0 && n > 0 && n % 4 == 0 && rows < (1L << 31), "hupr_softmax_rows_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_softmax_rows, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), s, n);
+    HUPR_LAUNCH_OK("hupr_k_softmax_rows");
+    return HUPR_OK;
+}
+extern "C" int hupr_softmax_rows_bwd_f32(const float* p, float* dp_inout, long rows, int n, hupr_stream_t stream) {
+    HUPR_REQUIRE(p && dp_inout && rows > 0 && n > 0 && n % 4 == 0 && rows < (1L << 31), "hupr_softmax_rows_bwd_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_softmax_rows_bwd, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), p, dp_inout, n);
+    HUPR_LAUNCH_OK("hupr_k_softmax_rows_bwd");
+    return HUPR_OK;
+}
+
+extern "C" int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,
+                                    int ld, int relu, hupr_stream_t stream) {
+    HUPR_REQUIRE(t && adj && bias && y && Bn > 0 && F > 0 && K > 0 && K <= 16 && ld >= K && ld <= 16, "hupr_gcn_adj_fwd_f32: bad argument");
+    const long rows = (long)Bn * F;
+    hipLaunchKernelGGL(hupr_k_gcn_adj_fwd, dim3(grid1d(rows)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu);
+    HUPR_LAUNCH_OK("hupr_k_gcn_adj_fwd");
+    return HUPR_OK;
+}
+extern "C" int hupr_gcn_adj_bwd_f32(const float* dy, const float* y, const float* adj, float* dt, float* gmasked,
+                                    float* dbias, int Bn, int F, int K, int ld, int relu, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && y && adj && dt && gmasked && dbias && Bn > 0 && F > 0 && K > 0 && K <= 16 && ld >= K && ld <= 16,
+                 "hupr_gcn_adj_bwd_f32: bad argument");
+    const long rows = (long)Bn * F;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(hupr_k_gcn_adj_bwd, dim3(grid1d(rows)), dim3(256), 0, s, dy, y, adj, dt, gmasked, rows, K, ld, relu);
+    HUPR_LAUNCH_OK("hupr_k_gcn_adj_bwd");
+    hipLaunchKernelGGL(hupr_k_gcn_dbias, dim3((F * K + 255) / 256), dim3(256), 0, s, gmasked, dbias, Bn, F, K, ld);
+    HUPR_LAUNCH_OK("hupr_k_gcn_dbias");
+    return HUPR_OK;
+}
+
+extern "C" int hupr_sigmoid_to_nchw_f32(const float* x, float* y, int Bn, int HW, int K, int ld, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && y && Bn > 0 && HW > 0 && K > 0 && ld >= K, "hupr_sigmoid_to_nchw_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_sigmoid_to_nchw, dim3(grid1d((long)Bn * K * HW)), dim3(256), 0, as_stream(stream), x, y, Bn, HW, K, ld);
+    HUPR_LAUNCH_OK("hupr_k_sigmoid_to_nchw");
+    return HUPR_OK;
+}
+extern "C" int hupr_sigmoid_to_nchw_bwd_f32(const float* dy, const float* y, float* dx, int Bn, int HW, int K, int ld,
+                                            hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && y && dx && Bn > 0 && HW > 0 && K > 0 && ld >= K, "hupr_sigmoid_to_nchw_bwd_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_sigmoid_to_nchw_bwd, dim3(grid1d((long)Bn * HW * ld)), dim3(256), 0, as_stream(stream), dy, y, dx, Bn, HW, K, ld);
+    HUPR_LAUNCH_OK("hupr_k_sigmoid_to_nchw_bwd");
+    return HUPR_OK;
+}
+
+extern "C" size_t hupr_bce_ws_bytes(void) { return 1024 * sizeof(double); }
+extern "C" int hupr_bce_fwd_f32(const float* p, const float* t, long n, float* loss, void* ws, size_t ws_bytes,
+                                hupr_stream_t stream) {
+    HUPR_REQUIRE(p && t && loss && ws && n > 0, "hupr_bce_fwd_f32: bad argument");
+    if (ws_bytes < hupr_bce_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_bce_fwd_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int nblk = grid1d(n, 256, 1024);
+    hipLaunchKernelGGL(hupr_k_bce_fwd, dim3(nblk), dim3(256), 0, s, p, t, n, reinterpret_cast<double*>(ws));
+    HUPR_LAUNCH_OK("hupr_k_bce_fwd");
+    hipLaunchKernelGGL(hupr_k_bce_final, dim3(1), dim3(64), 0, s, reinterpret_cast<const double*>(ws), nblk, 1.0 / (double)n, loss);
+    HUPR_LAUNCH_OK("hupr_k_bce_final");
+    return HUPR_OK;
+}
+extern "C" int hupr_bce_bwd_f32(const float* p, const float* t, const float* grad_out, float* dp, long n, hupr_stream_t stream) {
+    HUPR_REQUIRE(p && t && grad_out && dp && n > 0, "hupr_bce_bwd_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_bce_bwd, dim3(grid1d(n)), dim3(256), 0, as_stream(stream), p, t, grad_out, 1.0f / (float)n, dp, n);
+    HUPR_LAUNCH_OK("hupr_k_bce_bwd");
+    return HUPR_OK;
+}
+
+extern "C" int hupr_gaussian_targets_f32(const long long* joints, const float* patch, float* t, int BK, int H, int rad,
+                                         float stride, hupr_stream_t stream) {
+    HUPR_REQUIRE(joints && patch && t && BK > 0 && H > 0 && rad > 0 && stride > 0.f, "hupr_gaussian_targets_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_gaussian_targets, dim3(grid1d((long)BK * H * H)), dim3(256), 0, as_stream(stream), joints, patch, t, BK, H, rad, stride);
+    HUPR_LAUNCH_OK("hupr_k_gaussian_targets");
+    return HUPR_OK;
+}
+
+extern "C" int hupr_argmax_rows_f32(const float* p, long rows, int n, int* idx, float* maxval, hupr_stream_t stream) {
+    HUPR_REQUIRE(p && idx && maxval && rows > 0 && n > 0 && rows < (1L << 31), "hupr_argmax_rows_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_argmax_rows, dim3((unsigned)rows), dim3(64), 0, as_stream(stream), p, n, idx, maxval);
+    HUPR_LAUNCH_OK("hupr_k_argmax_rows");
+    return HUPR_OK;
+}
+
+// step = 1-based step count after increment; gscale multiplies the gradient (e.g. 1/world_size)
+extern "C" int hupr_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int step, float gscale, hupr_stream_t stream) {
+    HUPR_REQUIRE(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, "hupr_adam_step_f32: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(hupr_k_adam, dim3(grid1d(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), gscale);
+    HUPR_LAUNCH_OK("hupr_k_adam");
+    return HUPR_OK;
+}

@@ -1,0 +1,272 @@
+// Memory-bound spatial kernels on channels-last fp32 activations:
+//   * MNet front end (elevation mean + the reference's .view chirp reinterpretation +
+//     Conv3d(2->32,(2,1,1),s(2,1,1)) + MaxPool3d((4,1,1))) fused into one pass over the
+//     (B,G,F,2,R,A,E) input      [models/networks.py:23-33, models/chirp_networks.py:11-21]
+//   * align_corners=True linear resampling (tri-/bilinear, down or up) fwd + bwd
+//     [nn.Upsample / F.interpolate call sites: models/layers.py:84,89,199,204; gcn_networks.py:49,63]
+#include "hupr_common.h"
+
+namespace hupr {
+
+// ------------------------------------------------------------------------------------------
+// MNet.  x[bg][f=8][c=2][R*A pixels][E=8] ; the reference views the 16 (f,c) planes as
+// (ch2 = j/8, t = j%8) with j = 2f+c  (a memory reinterpretation, not a permute).
+// conv: o[co][t2] = bias[co] + sum_{ch2,kt} W[co][ch2][kt] * v[ch2][2*t2+kt],  t2 = 0..3
+// out[bg][pixel][co] = max_t2 o[co][t2]                      (channels-last, depth axis = g)
+// ------------------------------------------------------------------------------------------
+constexpr int kNF = 32;
+
+__device__ __forceinline__ void mnet_load_means(const float* __restrict__ x, long plane_stride, long pix, float* m) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4* p = reinterpret_cast<const float4*>(x + j * plane_stride + pix * 8);
+        const float4 a = p[0], b = p[1];
+        // same association as torch.mean's pairwise-ish sum is not reproducible; plain tree here
+        m[j] = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) * 0.125f;
+    }
+}
+
+__global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       long n_bg, int pixels) {
+    __shared__ float sw[kNF * 4 + kNF];
+    for (int i = threadIdx.x; i < kNF * 4 + kNF; i += 256) sw[i] = (i < kNF * 4) ? w[i] : bias[i - kNF * 4];
+    __syncthreads();
+    const long total = n_bg * pixels;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long bg = idx / pixels, pix = idx - bg * pixels;
+        const float* xb = x + bg * 16 * (long)pixels * 8;
+        float m[16];
+        mnet_load_means(xb, (long)pixels * 8, pix, m);
+        float4* o = reinterpret_cast<float4*>(out + idx * kNF);
+#pragma unroll
+        for (int c4 = 0; c4 < kNF / 4; ++c4) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = c4 * 4 + k;
+                const float w00 = sw[co * 4 + 0], w01 = sw[co * 4 + 1], w10 = sw[co * 4 + 2], w11 = sw[co * 4 + 3];
+                float best = -INFINITY;
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    float v = sw[kNF * 4 + co];
+                    v = fmaf(w00, m[2 * t2], v);
+                    v = fmaf(w01, m[2 * t2 + 1], v);
+                    v = fmaf(w10, m[8 + 2 * t2], v);
+                    v = fmaf(w11, m[8 + 2 * t2 + 1], v);
+                    best = fmaxf(best, v);
+                }
+                r[k] = best;
+            }
+            o[c4] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
+// backward: recompute the arg-max chirp step, accumulate dW[co][ch2][kt] and dbias[co]
+// partial[blk][160]
+__global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ dy,
+                                                       long n_bg, int pixels, float* __restrict__ partial) {
+    __shared__ float sw[kNF * 4 + kNF];
+    __shared__ float red[4][kNF * 5];
+    for (int i = threadIdx.x; i < kNF * 4 + kNF; i += 256) sw[i] = (i < kNF * 4) ? w[i] : bias[i - kNF * 4];
+    __syncthreads();
+    float acc[kNF * 5];
+#pragma unroll
+    for (int i = 0; i < kNF * 5; ++i) acc[i] = 0.f;
+    const long total = n_bg * pixels;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long bg = idx / pixels, pix = idx - bg * pixels;
+        const float* xb = x + bg * 16 * (long)pixels * 8;
+        float m[16];
+        mnet_load_means(xb, (long)pixels * 8, pix, m);
+        const float4* g4 = reinterpret_cast<const float4*>(dy + idx * kNF);
+#pragma unroll
+        for (int c4 = 0; c4 < kNF / 4; ++c4) {
+            const float4 gv = g4[c4];
+            const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = c4 * 4 + k;
+                const float w00 = sw[co * 4 + 0], w01 = sw[co * 4 + 1], w10 = sw[co * 4 + 2], w11 = sw[co * 4 + 3];
+                float best = -INFINITY, a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    float v = sw[kNF * 4 + co];
+                    v = fmaf(w00, m[2 * t2], v);
+                    v = fmaf(w01, m[2 * t2 + 1], v);
+                    v = fmaf(w10, m[8 + 2 * t2], v);
+                    v = fmaf(w11, m[8 + 2 * t2 + 1], v);
+                    if (v > best) {   // first maximum wins, like max_pool3d
+                        best = v;
+                        a0 = m[2 * t2]; a1 = m[2 * t2 + 1]; b0 = m[8 + 2 * t2]; b1 = m[8 + 2 * t2 + 1];
+                    }
+                }
+                acc[co * 4 + 0] = fmaf(gs[k], a0, acc[co * 4 + 0]);
+                acc[co * 4 + 1] = fmaf(gs[k], a1, acc[co * 4 + 1]);
+                acc[co * 4 + 2] = fmaf(gs[k], b0, acc[co * 4 + 2]);
+                acc[co * 4 + 3] = fmaf(gs[k], b1, acc[co * 4 + 3]);
+                acc[kNF * 4 + co] += gs[k];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kNF * 5; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kNF * 5; i += 256)
+        partial[(long)blockIdx.x * kNF * 5 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+__global__ void hupr_k_mnet_bwd_final(const float* __restrict__ partial, int nblk, float* __restrict__ dw,
+                                      float* __restrict__ dbias) {
+    const int i = threadIdx.x;
+    if (i >= kNF * 5) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * kNF * 5 + i];
+    if (i < kNF * 4) dw[i] = (float)s;
+    else dbias[i - kNF * 4] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------
+// linear resampling, align_corners=True (ATen: scale = (in-1)/(out-1) in float, src = scale*dst,
+// i0 = (int)src, lambda = src - i0, i1 = min(i0+1, in-1))
+// x[b][Di][Hi][Wi][C] (voxel stride in_ld) -> y[b][Do][Ho][Wo][C] (voxel stride out_ld)
+// ------------------------------------------------------------------------------------------
+struct Lin {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lin lin_coord(int o, int in, int out) {
+    Lin l;
+    const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float src = scale * (float)o;
+    l.i0 = (int)src;
+    l.i1 = l.i0 + ((l.i0 < in - 1) ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void hupr_k_interp(const float* __restrict__ src, float* __restrict__ dst, int Bn,
+                                                     int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
+                                                     int in_ld, int out_ld) {
+    // forward: src = x (in_ld), dst = y (out_ld).  backward: src = dy (out_ld), dst = dx (in_ld), atomics.
+    const int c4n = C >> 2;
+    const long total = (long)Bn * Do * Ho * Wo * c4n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = idx % c4n;
+        long v = idx / c4n;
+        const int ow = v % Wo; v /= Wo;
+        const int oh = v % Ho; v /= Ho;
+        const int od = v % Do;
+        const int b = v / Do;
+        const Lin ld = lin_coord(od, Di, Do), lh = lin_coord(oh, Hi, Ho), lw = lin_coord(ow, Wi, Wo);
+        const long ovox = (((long)b * Do + od) * Ho + oh) * Wo + ow;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BWD) g = *reinterpret_cast<const float4*>(src + ovox * out_ld + c4 * 4);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int id = a ? ld.i1 : ld.i0;
+            const float wd = a ? ld.w1 : ld.w0;
+            if (a == 1 && Di == 1) continue;
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+                const int ih = bq ? lh.i1 : lh.i0;
+                const float wh = bq ? lh.w1 : lh.w0;
+#pragma unroll
+                for (int cq = 0; cq < 2; ++cq) {
+                    const int iw = cq ? lw.i1 : lw.i0;
+                    const float wgt = wd * wh * (cq ? lw.w1 : lw.w0);
+                    const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
+                    if (!BWD) {
+                        const float4 xv = *reinterpret_cast<const float4*>(src + ivox * in_ld + c4 * 4);
+                        acc.x = fmaf(wgt, xv.x, acc.x); acc.y = fmaf(wgt, xv.y, acc.y);
+                        acc.z = fmaf(wgt, xv.z, acc.z); acc.w = fmaf(wgt, xv.w, acc.w);
+                    } else if (wgt != 0.f) {
+                        float* d = dst + ivox * in_ld + c4 * 4;
+                        atomicAdd(d + 0, wgt * g.x); atomicAdd(d + 1, wgt * g.y);
+                        atomicAdd(d + 2, wgt * g.z); atomicAdd(d + 3, wgt * g.w);
+                    }
+                }
+            }
+        }
+        if (!BWD) *reinterpret_cast<float4*>(dst + ovox * out_ld + c4 * 4) = acc;
+    }
+}
+
+}  // namespace hupr
+
+using namespace hupr;
+
+// (a3) MNet forward.  x: (n_bg = B*G, F=8, 2, pixels = R*A, E=8) fp32;  w: (32,2,2,1,1); bias: (32)
+// out: (n_bg, pixels, 32) channels-last
+extern "C" int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, long n_bg, int pixels,
+                                 hupr_stream_t stream) {
+    HUPR_REQUIRE(x && w && bias && out && n_bg > 0 && pixels > 0, "hupr_mnet_fwd_f32: bad argument");
+    const long total = n_bg * pixels;
+    const int grid = (int)min((long)8192, (total + 255) / 256);
+    hipLaunchKernelGGL(hupr_k_mnet_fwd, dim3(grid), dim3(256), 0, as_stream(stream), x, w, bias, out, n_bg, pixels);
+    HUPR_LAUNCH_OK("hupr_k_mnet_fwd");
+    return HUPR_OK;
+}
+
+extern "C" size_t hupr_mnet_bwd_ws_bytes(void) { return (size_t)1024 * kNF * 5 * sizeof(float); }
+
+extern "C" int hupr_mnet_bwd_f32(const float* x, const float* w, const float* bias, const float* dy, float* dw,
+                                 float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && w && bias && dy && dw && dbias && ws && n_bg > 0 && pixels > 0, "hupr_mnet_bwd_f32: bad argument");
+    if (ws_bytes < hupr_mnet_bwd_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_mnet_bwd_f32: workspace too small");
+    const long total = n_bg * pixels;
+    const int grid = (int)min((long)1024, (total + 255) / 256);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(hupr_k_mnet_bwd, dim3(grid), dim3(256), 0, s, x, w, bias, dy, n_bg, pixels,
+                       reinterpret_cast<float*>(ws));
+    HUPR_LAUNCH_OK("hupr_k_mnet_bwd");
+    hipLaunchKernelGGL(hupr_k_mnet_bwd_final, dim3(1), dim3(256), 0, s, reinterpret_cast<const float*>(ws), grid, dw, dbias);
+    HUPR_LAUNCH_OK("hupr_k_mnet_bwd_final");
+    return HUPR_OK;
+}
+
+static int interp_check(const char* who, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int in_ld,
+                        int out_ld) {
+    HUPR_REQUIRE(Bn > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "%s: bad extents", who);
+    HUPR_REQUIRE(C > 0 && C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && in_ld >= C && out_ld >= C,
+                 "%s: channels/strides must be multiples of 4 (C=%d in_ld=%d out_ld=%d)", who, C, in_ld, out_ld);
+    return HUPR_OK;
+}
+
+extern "C" int hupr_interp_linear_fwd_f32(const float* x, float* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                          int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && y, "hupr_interp_linear_fwd_f32: null pointer");
+    int rc = interp_check("hupr_interp_linear_fwd_f32", Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    if (rc) return rc;
+    const long total = (long)Bn * Do * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(hupr_k_interp<false>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    HUPR_LAUNCH_OK("hupr_k_interp<fwd>");
+    return HUPR_OK;
+}
+
+// dx (dense, in_ld == C required so it can be zero-filled here) = adjoint of the forward map applied to dy
+extern "C" int hupr_interp_linear_bwd_f32(const float* dy, float* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                          int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && dx, "hupr_interp_linear_bwd_f32: null pointer");
+    int rc = interp_check("hupr_interp_linear_bwd_f32", Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    if (rc) return rc;
+    HUPR_REQUIRE(in_ld == C, "hupr_interp_linear_bwd_f32: dx must be dense");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(dx, 0, (size_t)Bn * Di * Hi * Wi * C * sizeof(float), s) != hipSuccess)
+        return fail(HUPR_ERR_LAUNCH, "hupr_interp_linear_bwd_f32: memset failed");
+    const long total = (long)Bn * Do * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(hupr_k_interp<true>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0, s, dy, dx,
+                       Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    HUPR_LAUNCH_OK("hupr_k_interp<bwd>");
+    return HUPR_OK;
+}

@@ -1,0 +1,441 @@
+"""autograd.Function wrappers: one forward/backward pair of C-ABI calls per operator.
+
+Activations are channels-last 5-D tensors ``(B, D, H, W, C)`` (2-D maps use D == 1), fp32,
+contiguous.  Parameters keep the reference's shapes; weight re-packing for the implicit-GEMM
+kernels happens on device each call (35.5 M floats, negligible next to the convolutions).
+
+Nothing here computes with torch ops except allocation, views and gradient bookkeeping.
+"""
+import numpy as np
+import torch
+
+from . import runtime as rt
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Stream-ordered scratch shared by all ops of one device (single compute stream)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _vox(x):
+    """(B, D, H, W) extents and channel count of a channels-last 5-D tensor."""
+    assert x.dim() == 5 and x.dtype == torch.float32, (x.shape, x.dtype)
+    return x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.shape[4]
+
+
+def pack_weights(w, mode):
+    co, ci = w.shape[0], w.shape[1]
+    taps = int(np.prod(w.shape[2:]))
+    wp = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    rt.check(rt.lib().hupr_pack_conv_weights_f32(rt.ptr(_c(w)), rt.ptr(wp), co, ci, taps, mode, rt.stream()))
+    return wp
+
+
+def _conv_raw(x, wp, bias, res, co, k, pad, out_extent):
+    B, Di, Hi, Wi, Ci = _vox(x)
+    Do, Ho, Wo = out_extent
+    y = torch.empty((B, Do, Ho, Wo, co), dtype=torch.float32, device=x.device)
+    rt.check(rt.lib().hupr_conv_fwd_f32(
+        rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
+        rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, Do, Ho, Wo, co, co,
+        co, k[0], k[1], k[2], pad[0], pad[1], pad[2], 0, rt.stream()))
+    return y
+
+
+def _ksize(w):
+    k = tuple(w.shape[2:])
+    return (1,) + k if len(k) == 2 else k
+
+
+class ConvFn(torch.autograd.Function):
+    """Stride-1 convolution (nn.Conv3d / nn.Conv2d of the reference) with optional bias and fused
+    residual add.  ``pad`` is (pd, ph, pw)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, pad):
+        x = _c(x)
+        k = _ksize(weight)
+        B, Di, Hi, Wi, Ci = _vox(x)
+        assert weight.shape[1] == Ci, (weight.shape, x.shape)
+        out_extent = (Di + 2 * pad[0] - k[0] + 1, Hi + 2 * pad[1] - k[1] + 1, Wi + 2 * pad[2] - k[2] + 1)
+        wp = pack_weights(weight, 0)
+        y = _conv_raw(x, wp, bias, _c(res) if res is not None else None, weight.shape[0], k, pad, out_extent)
+        ctx.save_for_backward(x, weight)
+        ctx.pad, ctx.k, ctx.has_bias, ctx.has_res = pad, k, bias is not None, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        k, pad = ctx.k, ctx.pad
+        B, Di, Hi, Wi, Ci = _vox(x)
+        _, Do, Ho, Wo, Co = _vox(dy)
+        L = rt.lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            co_pad = Co
+            dyp, wsrc = dy, weight
+            if Co % 32 != 0:                      # e.g. the 14-channel head: zero-pad the K axis
+                co_pad = (Co + 31) // 32 * 32
+                dyp = torch.zeros((B, Do, Ho, Wo, co_pad), dtype=torch.float32, device=dy.device)
+                dyp[..., :Co] = dy
+                wsrc = torch.zeros((co_pad,) + tuple(weight.shape[1:]), dtype=torch.float32, device=dy.device)
+                wsrc[:Co] = weight
+            wpd = pack_weights(wsrc, 1)           # [Ci][taps reversed][Co]
+            dpad = (k[0] - 1 - pad[0], k[1] - 1 - pad[1], k[2] - 1 - pad[2])
+            dx = _conv_raw(dyp, wpd, None, None, Ci, k, dpad, (Di, Hi, Wi))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            nbytes = L.hupr_conv_wgrad_ws_bytes(B, Do, Ho, Wo, Ci, Co, k[0], k[1], k[2])
+            ws = workspace(nbytes, x.device)
+            rt.check(L.hupr_conv_wgrad_f32(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Do, Ho, Wo,
+                                           Co, Co, k[0], k[1], k[2], pad[0], pad[1], pad[2], rt.ptr(ws),
+                                           ws.numel(), rt.stream()))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Co, dtype=torch.float32, device=dy.device)
+            ws = workspace(L.hupr_bn_ws_bytes(Co), dy.device)
+            rt.check(L.hupr_colsum_f32(rt.ptr(dy), B * Do * Ho * Wo, Co, rt.ptr(db), rt.ptr(ws), ws.numel(),
+                                       rt.stream()))
+        dres = dy if ctx.has_res else None
+        return dx, dw, db, dres, None
+
+
+def conv(x, weight, bias=None, res=None, pad=(0, 0, 0)):
+    return ConvFn.apply(x, weight, bias, res, tuple(pad))
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm (+ReLU), and the BasicBlock3D tail  relu(bn_a(x1) + bn_b(x2))
+# ----------------------------------------------------------------------------------------------
+def _bn_params(x, bn, training):
+    """-> (scale, shift, save_mean, save_invstd) for one nn.BatchNorm3d-like parameter holder."""
+    L = rt.lib()
+    C = x.shape[-1]
+    M = x.numel() // C
+    dev = x.device
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale)
+    mean = torch.empty_like(scale)
+    invstd = torch.empty_like(scale)
+    if training:
+        ws = workspace(L.hupr_bn_ws_bytes(C), dev)
+        track = bn.running_mean is not None
+        rt.check(L.hupr_bn_train_stats_f32(
+            rt.ptr(x), M, C, rt.ptr(bn.weight), rt.ptr(bn.bias),
+            rt.ptr(bn.running_mean) if track else None, rt.ptr(bn.running_var) if track else None,
+            float(bn.momentum), float(bn.eps), rt.ptr(mean), rt.ptr(invstd), rt.ptr(scale), rt.ptr(shift),
+            rt.ptr(ws), ws.numel(), rt.stream()))
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+    else:
+        rt.check(L.hupr_bn_eval_params_f32(rt.ptr(bn.weight), rt.ptr(bn.bias), rt.ptr(bn.running_mean),
+                                           rt.ptr(bn.running_var), float(bn.eps), C, rt.ptr(scale),
+                                           rt.ptr(shift), rt.stream()))
+        mean.copy_(bn.running_mean)
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+    return scale, shift, mean, invstd
+
+
+def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training):
+    L = rt.lib()
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    ws = workspace(L.hupr_bn_ws_bytes(C), x.device)
+    rt.check(L.hupr_bn_bwd_f32(rt.ptr(dy), rt.ptr(y_mask) if y_mask is not None else None, rt.ptr(x), rt.ptr(mean),
+                               rt.ptr(invstd), rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C,
+                               1 if training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
+    return dx, dg, db
+
+
+class BNActFn(torch.autograd.Function):
+    """y = [relu](batch_norm(x)).  ``bn`` is the parameter holder (running stats updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, training, relu):
+        x = _c(x)
+        scale, shift, mean, invstd = _bn_params(x, bn, training)
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        rt.check(rt.lib().hupr_scale_shift_act_f32(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
+                                                  rt.ptr(y), x.numel() // C, C, 1 if relu else 0, rt.stream()))
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        dx, dg, db = _bn_bwd(_c(dy), y, x, mean, invstd, gamma, ctx.training)
+        return dx, dg, db, None, None, None
+
+
+class BNAddBNReLUFn(torch.autograd.Function):
+    """y = relu(bn_a(x1) + bn_b(x2)) — the tail of BasicBlock3D.forward (models/layers.py:66-70)."""
+
+    @staticmethod
+    def forward(ctx, x1, g1, b1, bn1, x2, g2, b2, bn2, training):
+        x1, x2 = _c(x1), _c(x2)
+        s1, t1, m1, i1 = _bn_params(x1, bn1, training)
+        s2, t2, m2, i2 = _bn_params(x2, bn2, training)
+        C = x1.shape[-1]
+        y = torch.empty_like(x1)
+        rt.check(rt.lib().hupr_scale_shift_act_f32(rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(x2), rt.ptr(s2),
+                                                  rt.ptr(t2), rt.ptr(y), x1.numel() // C, C, 1, rt.stream()))
+        ctx.save_for_backward(x1, x2, y, m1, i1, g1, m2, i2, g2)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, y, m1, i1, g1, m2, i2, g2 = ctx.saved_tensors
+        dy = _c(dy)
+        dx1, dg1, db1 = _bn_bwd(dy, y, x1, m1, i1, g1, ctx.training)
+        dx2, dg2, db2 = _bn_bwd(dy, y, x2, m2, i2, g2, ctx.training)
+        return dx1, dg1, db1, None, dx2, dg2, db2, None, None
+
+
+class PReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = _c(x)
+        y = torch.empty_like(x)
+        rt.check(rt.lib().hupr_prelu_fwd_f32(rt.ptr(x), rt.ptr(alpha), rt.ptr(y), x.numel(), rt.stream()))
+        ctx.save_for_backward(x, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha = ctx.saved_tensors
+        L = rt.lib()
+        dx = torch.empty_like(x)
+        da = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = workspace(L.hupr_prelu_ws_bytes(), x.device)
+        rt.check(L.hupr_prelu_bwd_f32(rt.ptr(_c(dy)), rt.ptr(x), rt.ptr(alpha), rt.ptr(dx), rt.ptr(da), x.numel(),
+                                      rt.ptr(ws), ws.numel(), rt.stream()))
+        return dx, da
+
+
+# ----------------------------------------------------------------------------------------------
+class MNetFn(torch.autograd.Function):
+    """x (B,G,F,2,R,A,E) -> (B, G, R, A, 32) channels-last with depth axis = group frame."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        B, G, F, two, R, A, E = x.shape
+        if (F, two, E) != (8, 2, 8) or weight.shape != (32, 2, 2, 1, 1):
+            raise ValueError("MNet kernel is specialised for F=8, 2 (re/im), E=8, 32 filters")
+        out = torch.empty((B, G, R, A, 32), dtype=torch.float32, device=x.device)
+        rt.check(rt.lib().hupr_mnet_fwd_f32(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(out), B * G, R * A,
+                                           rt.stream()))
+        ctx.save_for_backward(x, weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        L = rt.lib()
+        B, G, F, two, R, A, E = x.shape
+        dw = torch.empty_like(weight)
+        db = torch.empty_like(bias)
+        ws = workspace(L.hupr_mnet_bwd_ws_bytes(), x.device)
+        rt.check(L.hupr_mnet_bwd_f32(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(_c(dy)), rt.ptr(dw), rt.ptr(db),
+                                     B * G, R * A, rt.ptr(ws), ws.numel(), rt.stream()))
+        return None, dw, db
+
+
+class InterpFn(torch.autograd.Function):
+    """align_corners=True linear resampling of a channels-last (B,D,H,W,C) tensor to ``size``."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = _c(x)
+        B, Di, Hi, Wi, C = _vox(x)
+        Do, Ho, Wo = size
+        y = torch.empty((B, Do, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        rt.check(rt.lib().hupr_interp_linear_fwd_f32(rt.ptr(x), rt.ptr(y), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C,
+                                                    rt.stream()))
+        ctx.in_shape = (B, Di, Hi, Wi, C)
+        ctx.size = size
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Di, Hi, Wi, C = ctx.in_shape
+        Do, Ho, Wo = ctx.size
+        dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=dy.device)
+        rt.check(rt.lib().hupr_interp_linear_bwd_f32(rt.ptr(_c(dy)), rt.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C,
+                                                    rt.stream()))
+        return dx, None
+
+
+def interp(x, size):
+    return InterpFn.apply(x, tuple(size))
+
+
+# ----------------------------------------------------------------------------------------------
+def gemm(ta, tb, A, B, M, N, K, lda, ldb, batch, a_bs, b_bs, out=None, res=None, accumulate=False):
+    """Batched row-major fp32 GEMM on raw strides; returns C (batch, M, N) dense."""
+    if out is None:
+        out = torch.empty((batch, M, N), dtype=torch.float32, device=A.device)
+    rt.check(rt.lib().hupr_gemm_f32(ta, tb, rt.ptr(A), rt.ptr(B), rt.ptr(out), M, N, K, lda, ldb, N, batch, a_bs, b_bs,
+                                   M * N, rt.ptr(res) if res is not None else None, N, M * N if res is not None else 0,
+                                   1 if accumulate else 0, rt.stream()))
+    return out
+
+
+class AttentionFn(torch.autograd.Function):
+    """MSCSA attention (models/layers.py:126-133) on token-major tensors (B, N, C):
+    S[j,k] = sum_c K[j,c] Q[k,c];  P = softmax over keys j;  out[k,c] = sum_j P[j,k] V[j,c] (+ V[k,c])."""
+
+    @staticmethod
+    def forward(ctx, k, q, v, residual):
+        k, q, v = _c(k), _c(q), _c(v)
+        B, N, C = v.shape
+        L = rt.lib()
+        # St[kq][j] = q . k  -> softmax over j is a row softmax
+        P = gemm(0, 1, q, k, N, N, C, C, C, B, N * C, N * C)
+        rt.check(L.hupr_softmax_rows_f32(rt.ptr(P), B * N, N, rt.stream()))
+        out = gemm(0, 0, P, v, N, C, N, N, C, B, N * N, N * C, res=v if residual else None)
+        ctx.save_for_backward(k, q, v, P)
+        ctx.residual = residual
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, q, v, P = ctx.saved_tensors
+        dout = _c(dout)
+        B, N, C = v.shape
+        L = rt.lib()
+        # dV[j][c] = sum_kq P[kq][j] dout[kq][c]  (+ dout for the residual path)
+        dv = gemm(1, 0, P, dout, N, C, N, N, C, B, N * N, N * C, res=dout if ctx.residual else None)
+        # dP[kq][j] = sum_c dout[kq][c] v[j][c]
+        dS = gemm(0, 1, dout, v, N, N, C, C, C, B, N * C, N * C)
+        rt.check(L.hupr_softmax_rows_bwd_f32(rt.ptr(P), rt.ptr(dS), B * N, N, rt.stream()))
+        dq = gemm(0, 0, dS, k, N, C, N, N, C, B, N * N, N * C)      # dQ[kq][c] = sum_j dS[kq][j] k[j][c]
+        dk = gemm(1, 0, dS, q, N, C, N, N, C, B, N * N, N * C)      # dK[j][c] = sum_kq dS[kq][j] q[kq][c]
+        return dk, dq, dv, None
+
+
+class GCNLayerFn(torch.autograd.Function):
+    """y = act( (W x) A + bias ) == W (x A) + bias  (models/gcn_networks.py:23-29); x, y: (B, F, ld=16)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, adj, relu):
+        x = _c(x)
+        B, F, ld = x.shape
+        K = bias.shape[1]
+        L = rt.lib()
+        t = gemm(0, 0, weight, x, F, ld, F, F, ld, B, 0, F * ld)
+        y = torch.empty_like(x)
+        rt.check(L.hupr_gcn_adj_fwd_f32(rt.ptr(t), rt.ptr(adj), rt.ptr(_c(bias)), rt.ptr(y), B, F, K, ld, 1 if relu else 0,
+                                        rt.stream()))
+        ctx.save_for_backward(x, weight, y, adj)
+        ctx.relu, ctx.K = relu, K
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y, adj = ctx.saved_tensors
+        B, F, ld = x.shape
+        K = ctx.K
+        L = rt.lib()
+        dt = torch.empty_like(x)
+        gm = torch.empty_like(x)
+        dbias = torch.empty((F, K), dtype=torch.float32, device=x.device)
+        rt.check(L.hupr_gcn_adj_bwd_f32(rt.ptr(_c(dy)), rt.ptr(y), rt.ptr(adj), rt.ptr(dt), rt.ptr(gm), rt.ptr(dbias), B, F, K,
+                                        ld, 1 if ctx.relu else 0, rt.stream()))
+        dx = gemm(1, 0, weight, dt, F, ld, F, F, ld, B, 0, F * ld)              # W^T dt
+        # dW[f][g] = sum_{b,k} dt[b][f][k] x[b][g][k]: fold the batch into the reduction axis
+        dt2 = dt.permute(1, 0, 2).reshape(F, B * ld)
+        x2 = x.permute(1, 0, 2).reshape(F, B * ld)
+        dw = gemm(0, 1, _c(dt2), _c(x2), F, F, B * ld, B * ld, B * ld, 1, 0, 0)[0]
+        return dx, dw, dbias, None, None
+
+
+class SigmoidHeadFn(torch.autograd.Function):
+    """channels-last logits (B, HW, ld) -> probabilities (B, K, HW) in NCHW order."""
+
+    @staticmethod
+    def forward(ctx, x, K):
+        x = _c(x)
+        B, HW, ld = x.shape
+        y = torch.empty((B, K, HW), dtype=torch.float32, device=x.device)
+        rt.check(rt.lib().hupr_sigmoid_to_nchw_f32(rt.ptr(x), rt.ptr(y), B, HW, K, ld, rt.stream()))
+        ctx.save_for_backward(y)
+        ctx.ld = ld
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        B, K, HW = y.shape
+        dx = torch.empty((B, HW, ctx.ld), dtype=torch.float32, device=y.device)
+        rt.check(rt.lib().hupr_sigmoid_to_nchw_bwd_f32(rt.ptr(_c(dy)), rt.ptr(y), rt.ptr(dx), B, HW, K, ctx.ld, rt.stream()))
+        return dx, None
+
+
+class BCEFn(torch.autograd.Function):
+    """nn.BCELoss(reduction='mean') on probabilities."""
+
+    @staticmethod
+    def forward(ctx, p, t):
+        p, t = _c(p), _c(t)
+        L = rt.lib()
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        ws = workspace(L.hupr_bce_ws_bytes(), p.device)
+        rt.check(L.hupr_bce_fwd_f32(rt.ptr(p), rt.ptr(t), p.numel(), rt.ptr(loss), rt.ptr(ws), ws.numel(), rt.stream()))
+        ctx.save_for_backward(p, t)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        g = _c(g.reshape(1).to(torch.float32))
+        rt.check(rt.lib().hupr_bce_bwd_f32(rt.ptr(p), rt.ptr(t), rt.ptr(g), rt.ptr(dp), p.numel(), rt.stream()))
+        return dp, None
+
+
+_PATCH_CACHE = {}
+
+
+def gaussian_targets(joints, hsize=64, isize=256, sigma=2):
+    """joints (B,K,2) int64 GPU tensor -> (B,K,H,W) fp32 targets (misc/utils.py:6-66)."""
+    joints = _c(joints.to(torch.int64))
+    B, K, _ = joints.shape
+    rad = 3 * sigma
+    key = (sigma, joints.device)
+    if key not in _PATCH_CACHE:
+        ax = np.arange(2 * rad + 1, dtype=np.float32)
+        g = np.exp(-((ax[None, :] - rad) ** 2 + (ax[:, None] - rad) ** 2) / (2 * sigma ** 2))
+        _PATCH_CACHE[key] = torch.from_numpy(g.astype(np.float32)).to(joints.device)
+    t = torch.empty((B, K, hsize, hsize), dtype=torch.float32, device=joints.device)
+    rt.check(rt.lib().hupr_gaussian_targets_f32(rt.ptr(joints), rt.ptr(_PATCH_CACHE[key]), rt.ptr(t), B * K, hsize, rad,
+                                               float(isize) / float(hsize), rt.stream()))
+    return t
+
+
+def argmax_rows(p):
+    """p (rows, n) GPU -> (idx int32 (rows,), maxval (rows,)) with first-max tie-break."""
+    p = _c(p)
+    rows, n = p.shape
+    idx = torch.empty(rows, dtype=torch.int32, device=p.device)
+    mx = torch.empty(rows, dtype=torch.float32, device=p.device)
+    rt.check(rt.lib().hupr_argmax_rows_f32(rt.ptr(p), rows, n, rt.ptr(idx), rt.ptr(mx), rt.stream()))
+    return idx, mx

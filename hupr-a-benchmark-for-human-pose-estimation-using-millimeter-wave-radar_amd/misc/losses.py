@@ -1,0 +1,44 @@
+"""LossComputer (reference misc/losses.py:8-48) with device-side targets, BCE and decode."""
+import torch
+
+from .. import functional as F_
+from .metrics import get_max_preds
+
+
+class LossComputer():
+    def __init__(self, cfg, device):
+        self.device = device
+        self.cfg = cfg
+        self.numFrames = cfg.DATASET.numFrames
+        self.numGroupFrames = cfg.DATASET.numGroupFrames
+        self.numKeypoints = cfg.DATASET.numKeypoints
+        self.heatmapSize = self.width = self.height = cfg.DATASET.heatmapSize
+        self.imgSize = self.imgWidth = self.imgHeight = cfg.DATASET.imgSize
+        self.lossDecay = cfg.TRAINING.lossDecay
+        self.alpha = 0.0
+        self.beta = 1.0
+
+    def targets(self, gt):
+        sigma = {64: 2, 128: 3}[self.heatmapSize]
+        return F_.gaussian_targets(gt.to(self.device), self.heatmapSize, self.imgSize, sigma)
+
+    def computeLoss(self, preds, gt, decode=True):
+        """preds = (heatmap (B,K,1,H,W), gcn_heatmap (B,1,K,H,W)); gt (B,K,2) integer joints.
+        -> (loss, loss2, pred2d ndarray, gt2d ndarray) — same tuple as the reference."""
+        heatmaps = self.targets(gt)
+        preds1, preds2 = preds
+        K, H, W = self.numKeypoints, self.height, self.width
+        loss1 = F_.BCEFn.apply(preds1.reshape(-1, K, H, W), heatmaps)
+        loss2 = F_.BCEFn.apply(preds2.reshape(-1, K, H, W), heatmaps)
+        if self.alpha < 1.0:
+            self.alpha += self.lossDecay
+            self.beta -= self.lossDecay
+        if self.lossDecay != -1:
+            loss = self.alpha * loss1 + self.beta * loss2
+        else:
+            loss = loss1 + loss2
+        if not decode:
+            return loss, loss2, None, None
+        pred2d, _ = get_max_preds(preds2.detach().reshape(-1, K, H, W))
+        gt2d, _ = get_max_preds(heatmaps)
+        return loss, loss2, pred2d, gt2d

@@ -1,0 +1,21 @@
+"""MNet (reference models/chirp_networks.py:11-21) on the fused gfx950 front-end kernel.
+
+The module keeps the reference's parameter holder ``temporalConvWx1x1`` (an nn.Conv3d whose
+forward is never called) so ``state_dict`` keys, shapes and default initialisation are the
+reference's; the arithmetic (elevation mean + .view reinterpretation + conv + max-pool) runs in
+``hupr_mnet_fwd_f32`` straight from the (B,G,F,2,R,A,E) loader tensor.
+"""
+import torch.nn as nn
+
+from .. import functional as F_
+
+
+class MNet(nn.Module):
+    def __init__(self, in_channels, out_channels, numFrames):
+        super().__init__()
+        self.temporalConvWx1x1 = nn.Conv3d(in_channels, out_channels, (2, 1, 1), (2, 1, 1), (0, 0, 0))
+        self.numFrames = numFrames
+
+    def forward(self, VRDAEmaps):
+        """VRDAEmaps: (B,G,F,2,R,A,E) fp32 -> channels-last (B, G, R, A, out_channels)."""
+        return F_.MNetFn.apply(VRDAEmaps, self.temporalConvWx1x1.weight, self.temporalConvWx1x1.bias)

@@ -1,0 +1,191 @@
+"""Encoder / decoder blocks of HuPRNet (reference models/layers.py) on gfx950 kernels.
+
+Module and parameter names replicate the reference so checkpoints interchange; the nn.Conv*/
+nn.BatchNorm*/nn.PReLU children are parameter holders only — every forward below goes through
+``functional`` (C-ABI kernels) on channels-last (B,D,H,W,C) tensors.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as F_
+from .gcn_networks import PRGCN
+
+
+def _conv(x, m, res=None):
+    """Run a parameter-holder nn.Conv2d/nn.Conv3d (stride 1) through the implicit-GEMM kernel."""
+    p = m.padding
+    pad = (0, p[0], p[1]) if len(p) == 2 else tuple(p)
+    return F_.conv(x, m.weight, m.bias, res, pad)
+
+
+class BasicBlock2D(nn.Module):
+    """conv-act-conv + conv residual, then act (reference :8-38).  Decoder uses batchnorm=False."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, batchnorm=True,
+                 activation=nn.ReLU):
+        super().__init__()
+        if batchnorm:
+            raise NotImplementedError("the reference only instantiates BasicBlock2D with batchnorm=False")
+        self.main = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=False),
+            activation(),
+            nn.Conv2d(out_channels, out_channels, kernel_size, stride, padding, bias=False),
+        )
+        self.downsample = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, 1, 1, bias=False))
+        self.relu = activation()
+        if not isinstance(self.relu, nn.PReLU):
+            raise NotImplementedError("decoder activation must be nn.PReLU (networks.py:21)")
+
+    def forward(self, x):
+        residual = _conv(x, self.downsample[0])
+        out = _conv(x, self.main[0])
+        out = F_.PReLUFn.apply(out, self.main[1].weight)
+        out = _conv(out, self.main[2], res=residual)          # main(x) + residual fused in the epilogue
+        return F_.PReLUFn.apply(out, self.relu.weight)
+
+
+class BasicBlock3D(nn.Module):
+    """conv-BN-ReLU-conv-BN + (conv-BN) residual, then ReLU (reference :40-70)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, batchnorm=True,
+                 activation=nn.ReLU):
+        super().__init__()
+        if not batchnorm or activation is not nn.ReLU:
+            raise NotImplementedError("the reference only instantiates BasicBlock3D with BN + ReLU")
+        self.main = nn.Sequential(
+            nn.Conv3d(in_channels, out_channels, kernel_size, stride, padding, bias=False),
+            nn.BatchNorm3d(out_channels),
+            activation(),
+            nn.Conv3d(out_channels, out_channels, kernel_size, stride, padding, bias=False),
+            nn.BatchNorm3d(out_channels),
+        )
+        self.downsample = nn.Sequential(
+            nn.Conv3d(in_channels, out_channels, 3, 1, 1, bias=False),
+            nn.BatchNorm3d(out_channels),
+        )
+        self.relu = activation()
+
+    def forward(self, x):
+        res = _conv(x, self.downsample[0])
+        out = _conv(x, self.main[0])
+        bn1 = self.main[1]
+        out = F_.BNActFn.apply(out, bn1.weight, bn1.bias, bn1, self.training, True)
+        out = _conv(out, self.main[3])
+        bn2, bnd = self.main[4], self.downsample[1]
+        return F_.BNAddBNReLUFn.apply(out, bn2.weight, bn2.bias, bn2, res, bnd.weight, bnd.bias, bnd, self.training)
+
+
+class _Resample(nn.Module):
+    """Parameter-less stand-in for nn.Upsample(scale_factor, align_corners=True) at the same index
+    of the reference's nn.Sequential (keeps the children numbering, e.g. layer2.1 / layer2.2)."""
+
+    def __init__(self, scale_factor, dims):
+        super().__init__()
+        self.scale_factor, self.dims = scale_factor, dims
+
+    def forward(self, x):
+        B, D, H, W, C = x.shape
+        s = self.scale_factor
+        size = (int(D * s) if self.dims == 3 else D, int(H * s), int(W * s))
+        return F_.interp(x, size)
+
+
+class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
+    def __init__(self, cfg, batchnorm=True, activation=nn.ReLU):
+        super().__init__()
+        self.numGroupFrames = cfg.DATASET.numGroupFrames
+        self.numFilters = nf = cfg.MODEL.numFilters
+        self.width = cfg.DATASET.heatmapSize
+        self.height = cfg.DATASET.heatmapSize
+        self.numKeypoints = cfg.DATASET.numKeypoints
+        self.decoderLayer3 = nn.Sequential(
+            BasicBlock2D(nf * 8 * 4, nf * 8, 3, 1, 1, batchnorm, activation),
+            BasicBlock2D(nf * 8, nf * 4, 3, 1, 1, batchnorm, activation),
+            _Resample(2.0, 2),
+        )
+        self.decoderLayer2 = nn.Sequential(
+            BasicBlock2D(nf * 4 * 5, nf * 4, 3, 1, 1, batchnorm, activation),
+            BasicBlock2D(nf * 4, nf * 2, 3, 1, 1, batchnorm, activation),
+            _Resample(2.0, 2),
+        )
+        self.decoderLayer1 = nn.Sequential(
+            BasicBlock2D(nf * 2 * 5, nf * 2, 3, 1, 1, batchnorm, activation),
+            BasicBlock2D(nf * 2, nf, 3, 1, 1, batchnorm, activation),
+            nn.Conv2d(nf, self.numKeypoints, 1, 1, 0, bias=False),
+        )
+        # unnormalised skeleton adjacency with self loops, as the literal matrix of the reference (:97-112)
+        edges = {0: (0, 1, 3), 1: (0, 1, 2), 2: (1, 2), 3: (0, 3, 4), 4: (3, 4, 5), 5: (4, 5), 6: (6, 7),
+                 7: (6, 7), 8: (6, 8, 9), 9: (8, 9, 10), 10: (9, 10), 11: (6, 11, 12), 12: (11, 12, 13),
+                 13: (12, 13)}
+        A = torch.zeros(14, 14)
+        for r, cols in edges.items():
+            A[r, list(cols)] = 1.0
+        self.gcn = PRGCN(cfg, A)
+        filterList = [nf * 8, nf * 4, nf * 2]
+        mk = lambda: nn.ModuleList([nn.Conv2d(i, i, 1, 1, 0, bias=False) for i in filterList])
+        self.phi_cross_hori, self.theta_cross_hori = mk(), mk()
+        self.phi_cross_vert, self.theta_cross_vert = mk(), mk()
+        self.phi_self_hori, self.theta_self_hori = mk(), mk()
+        self.phi_self_vert, self.theta_self_vert = mk(), mk()
+        self.sigmoid = nn.Sigmoid()
+
+    @staticmethod
+    def attention(k, q, maps, residual=False):
+        """k, q, maps: channels-last (B,1,H,W,C).  Softmax over keys, value = maps (reference :126-133)."""
+        B, _, H, W, C = maps.shape
+        out = F_.AttentionFn.apply(k.reshape(B, H * W, C), q.reshape(B, H * W, C), maps.reshape(B, H * W, C),
+                                   residual)
+        return out.reshape(B, 1, H, W, C)
+
+    def _level(self, i, ra, re):
+        k_c_h, q_c_v = _conv(ra, self.phi_cross_hori[i]), _conv(re, self.theta_cross_vert[i])
+        k_c_v, q_c_h = _conv(re, self.phi_cross_vert[i]), _conv(ra, self.theta_cross_hori[i])
+        k_h, q_h = _conv(ra, self.phi_self_hori[i]), _conv(ra, self.theta_self_hori[i])
+        k_v, q_v = _conv(re, self.phi_self_vert[i]), _conv(re, self.theta_self_vert[i])
+        return [self.attention(k_c_h, q_c_v, ra, residual=True), self.attention(k_h, q_h, ra),
+                self.attention(k_c_v, q_c_h, re, residual=True), self.attention(k_v, q_v, re)]
+
+    def forward(self, ral1maps, ral2maps, ramaps, rel1maps, rel2maps, remaps):
+        maps = self.decoderLayer3(torch.cat(self._level(0, ramaps, remaps), 4))
+        maps = self.decoderLayer2(torch.cat([maps] + self._level(1, ral2maps, rel2maps), 4))
+        x = torch.cat([maps] + self._level(2, ral1maps, rel1maps), 4)
+        x = self.decoderLayer1[1](self.decoderLayer1[0](x))
+        # 1x1 head with the 14 output channels zero-padded to 16 so later kernels stay float4-aligned
+        head = self.decoderLayer1[2]
+        w16 = torch.nn.functional.pad(head.weight, (0, 0, 0, 0, 0, 0, 0, 16 - self.numKeypoints))
+        maps16 = F_.conv(x, w16, None, None, (0, 0, 0))
+        return maps16, self.gcn(maps16)
+
+
+class Encoder3D(nn.Module):
+    def __init__(self, cfg, batchnorm=True, activation=nn.ReLU):
+        super().__init__()
+        self.numGroupFrames = G = cfg.DATASET.numGroupFrames
+        self.numFilters = nf = cfg.MODEL.numFilters
+        self.width = cfg.DATASET.heatmapSize
+        self.height = cfg.DATASET.heatmapSize
+        self.layer1 = nn.Sequential(
+            nn.Conv3d(nf, nf * 2, 3, 1, 1),
+            BasicBlock3D(nf * 2, nf * 2, 3, 1, 1),
+        )
+        self.layer2 = nn.Sequential(
+            _Resample(0.5, 3),
+            BasicBlock3D(nf * 2, nf * 4, 3, 1, 1),
+            BasicBlock3D(nf * 4, nf * 4, 3, 1, 1),
+        )
+        self.layer3 = nn.Sequential(
+            _Resample(0.5, 3),
+            BasicBlock3D(nf * 4, nf * 8, 3, 1, 1),
+            BasicBlock3D(nf * 8, nf * 8, 3, 1, 1),
+        )
+        self.l1temporalMerge = nn.Conv3d(nf * 2, nf * 2, (G, 1, 1), 1, 0, bias=False)
+        self.l2temporalMerge = nn.Conv3d(nf * 4, nf * 4, (G // 2, 1, 1), 1, 0, bias=False)
+        self.temporalMerge = nn.Conv3d(nf * 8, nf * 8, (G // 4, 1, 1), 1, 0, bias=False)
+
+    def forward(self, maps):
+        """maps: channels-last (B, G, R, A, nf) -> three channels-last (B,1,h,w,c) feature maps."""
+        l1maps = self.layer1[1](_conv(maps, self.layer1[0]))
+        l2maps = self.layer2(l1maps)
+        l3maps = self.layer3(l2maps)
+        return (_conv(l1maps, self.l1temporalMerge), _conv(l2maps, self.l2temporalMerge),
+                _conv(l3maps, self.temporalMerge))

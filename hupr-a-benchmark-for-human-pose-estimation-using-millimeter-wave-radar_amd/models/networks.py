@@ -1,0 +1,42 @@
+"""HuPRNet — the nn.Module drop-in surface (reference models/networks.py:7-41).
+
+Same constructor (cfg attribute tree), same ``forward(VRDAEmaps_hori, VRDAEmaps_vert)`` signature
+with (B,G,F,2,R,A,E) fp32 inputs, same outputs ``(heatmap (B,K,1,H,W), gcn_heatmap (B,1,K,H,W))``
+and the same 255 ``state_dict`` entries; all arithmetic runs in hand-written gfx950 kernels
+through the C ABI (include/hupr.h).  CUDA/ROCm tensors only — there is no CPU fallback.
+"""
+import torch.nn as nn
+
+from .. import functional as F_
+from .chirp_networks import MNet
+from .layers import Encoder3D, MultiScaleCrossSelfAttentionPRGCN
+
+
+class HuPRNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.numFrames = cfg.DATASET.numFrames
+        self.numFilters = cfg.MODEL.numFilters
+        self.rangeSize = cfg.DATASET.rangeSize
+        self.heatmapSize = cfg.DATASET.heatmapSize
+        self.azimuthSize = cfg.DATASET.azimuthSize
+        self.elevationSize = cfg.DATASET.elevationSize
+        self.numGroupFrames = cfg.DATASET.numGroupFrames
+        self.numKeypoints = cfg.DATASET.numKeypoints
+        self.RAchirpNet = MNet(2, self.numFilters, self.numFrames)
+        self.REchirpNet = MNet(2, self.numFilters, self.numFrames)
+        self.RAradarEncoder = Encoder3D(cfg)
+        self.REradarEncoder = Encoder3D(cfg)
+        self.radarDecoder = MultiScaleCrossSelfAttentionPRGCN(cfg, batchnorm=False, activation=nn.PReLU)
+
+    def forward_chirp(self, VRDAEmaps_hori, VRDAEmaps_vert):
+        return self.RAchirpNet(VRDAEmaps_hori), self.REchirpNet(VRDAEmaps_vert)
+
+    def forward(self, VRDAEmaps_hori, VRDAEmaps_vert):
+        RAmaps, REmaps = self.forward_chirp(VRDAEmaps_hori, VRDAEmaps_vert)
+        RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(RAmaps)
+        REl1feat, REl2feat, REfeat = self.REradarEncoder(REmaps)
+        maps16, gcn_heatmap = self.radarDecoder(RAl1feat, RAl2feat, RAfeat, REl1feat, REl2feat, REfeat)
+        B, _, H, W, ld = maps16.shape
+        heatmap = F_.SigmoidHeadFn.apply(maps16.reshape(B, H * W, ld), self.numKeypoints)
+        return heatmap.reshape(B, self.numKeypoints, 1, H, W), gcn_heatmap

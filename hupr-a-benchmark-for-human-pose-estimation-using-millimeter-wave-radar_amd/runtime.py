@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhupr_hip.so")
 
 c_void_p, c_int, c_size_t, c_float, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
                                                 ctypes.c_float, ctypes.c_char_p)
-c_i64 = ctypes.c_int64
+c_long = ctypes.c_long
 
 # name -> (restype, argtypes); must list every symbol declared in include/hupr.h
 SIGNATURES = {
@@ -24,6 +24,39 @@ SIGNATURES = {
     "hupr_fft_chain_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_fft_chain_loader_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_loader_normalize_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "hupr_gemm_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long,
+                              c_long, c_int, c_long, c_long, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
+    "hupr_conv_fwd_f32": (c_int, [c_void_p] * 5 + [c_int] * 19 + [c_void_p]),
+    "hupr_conv_wgrad_ws_bytes": (c_size_t, [c_int] * 9),
+    "hupr_conv_wgrad_f32": (c_int, [c_void_p] * 3 + [c_int] * 17 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_pack_conv_weights_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "hupr_bn_ws_bytes": (c_size_t, [c_int]),
+    "hupr_bn_train_stats_f32": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                        c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_bn_eval_params_f32": (c_int, [c_void_p] * 4 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "hupr_scale_shift_act_f32": (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_void_p]),
+    "hupr_bn_bwd_f32": (c_int, [c_void_p] * 9 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_prelu_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "hupr_prelu_ws_bytes": (c_size_t, []),
+    "hupr_prelu_bwd_f32": (c_int, [c_void_p] * 5 + [c_long, c_void_p, c_size_t, c_void_p]),
+    "hupr_mnet_fwd_f32": (c_int, [c_void_p] * 4 + [c_long, c_int, c_void_p]),
+    "hupr_mnet_bwd_ws_bytes": (c_size_t, []),
+    "hupr_mnet_bwd_f32": (c_int, [c_void_p] * 6 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_interp_linear_fwd_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "hupr_interp_linear_bwd_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "hupr_softmax_rows_f32": (c_int, [c_void_p, c_long, c_int, c_void_p]),
+    "hupr_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "hupr_gcn_adj_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "hupr_gcn_adj_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    "hupr_sigmoid_to_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "hupr_sigmoid_to_nchw_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "hupr_bce_ws_bytes": (c_size_t, []),
+    "hupr_bce_fwd_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_bce_bwd_f32": (c_int, [c_void_p] * 4 + [c_long, c_void_p]),
+    "hupr_gaussian_targets_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_float, c_void_p]),
+    "hupr_argmax_rows_f32": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
+    "hupr_adam_step_f32": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 5 + [c_int, c_float, c_void_p]),
 }
 
 _lib = None

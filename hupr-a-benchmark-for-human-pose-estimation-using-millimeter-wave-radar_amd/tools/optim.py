@@ -1,0 +1,58 @@
+"""Adam with coupled L2 weight decay on the gfx950 fused kernel.
+
+Same update rule and ``state_dict`` layout as ``torch.optim.Adam`` (what the reference builds in
+tools/base.py:47: lr 1e-4, betas (0.9, 0.999), weight_decay 1e-4 on every parameter), so the
+reference's ``optimizer_state_dict`` checkpoints interchange.  One kernel launch per parameter
+tensor, or one per flat bucket when the parameters were flattened by ``tools.distributed``.
+"""
+import torch
+
+from .. import runtime as rt
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self.grad_scale = 1.0            # e.g. 1/world_size when gradients were sum-all-reduced
+        self._flat = None                # optional [(param_flat, grad_flat)] installed by tools.distributed
+
+    def attach_flat_buckets(self, buckets):
+        """buckets: list of (flat_param, flat_grad) fp32 GPU tensors covering all parameters in order."""
+        self._flat = buckets
+        self._flat_state = [dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p, _ in buckets]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = rt.lib()
+        s = rt.stream()
+        if self._flat is not None:
+            g0 = self.param_groups[0]
+            b1, b2 = g0["betas"]
+            for (p, g), st in zip(self._flat, self._flat_state):
+                st["step"] += 1
+                rt.check(L.hupr_adam_step_f32(rt.ptr(p), rt.ptr(g), rt.ptr(st["exp_avg"]), rt.ptr(st["exp_avg_sq"]),
+                                              p.numel(), g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], st["step"],
+                                              self.grad_scale, s))
+            return loss
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                rt.check(L.hupr_adam_step_f32(rt.ptr(p), rt.ptr(g), rt.ptr(st["exp_avg"]), rt.ptr(st["exp_avg_sq"]),
+                                              p.numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                              int(st["step"].item()), self.grad_scale, s))
+        return loss

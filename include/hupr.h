@@ -59,6 +59,111 @@ int hupr_fft_chain_loader_f32(const int16_t* adc_iq, int n_sf, float* out, void*
  * cube_c64 : float2 [n_sf][16][64][64][8]  ->  out float [n_sf][8][2][64][64][8]            */
 int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* out, hupr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * HuPRNet operators.  Activations are CHANNELS-LAST fp32: x[b][d][h][w][c] ("voxel stride" =
+ * floats between consecutive voxels, >= c, lets an op read/write a channel slice of a wider
+ * concat buffer).  Parameters keep the reference's state_dict shapes.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Generic batched fp32 MFMA GEMM, row-major.  ta/tb: 0 = as stored, 1 = transposed.
+ *   (ta,tb) = (0,1): C[m][n] = sum_k A[m][k] B[n][k]      attention S = Q K^T, dP = dO V^T   (models/layers.py:129)
+ *   (0,0):          C[m][n] = sum_k A[m][k] B[k][n]      O = P V (:131), dQ = dS K, PRGCN W.x  (gcn_networks.py:25)
+ *   (1,0):          C[m][n] = sum_k A[k][m] B[k][n]      dV = P^T dO, dK = dS^T Q
+ * res (optional) is added in the epilogue (cross-attention residual, models/layers.py:146,148).
+ * accumulate != 0: C += result. */
+int hupr_gemm_f32(int ta, int tb, const float* A, const float* B, float* C, int M, int N, int K, long lda,
+                  long ldb, long ldc, int batch, long a_batch_stride, long b_batch_stride, long c_batch_stride,
+                  const float* res, long res_ld, long res_batch_stride, int accumulate, hupr_stream_t stream);
+
+/* (a4,a6) stride-1 convolution as implicit GEMM — replaces nn.Conv3d / nn.Conv2d forward and, with
+ * weights packed in mode 1, their input-gradient (models/layers.py:10-23,42-62,81-95,115-123,194-210).
+ * x : [Bn][Di][Hi][Wi] voxels, in_ld floats apart, first Ci channels used (Ci % 32 == 0)
+ * wp: packed weights [Co][kd*kh*kw][Ci]   (hupr_pack_conv_weights_f32)
+ * y : [Bn][Do][Ho][Wo] voxels, out_ld floats apart, first Co channels written
+ * bias [Co] and res (same voxel indexing, res_ld) optional. */
+int hupr_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* res, float* y, int Bn,
+                      int Di, int Hi, int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int out_ld,
+                      int res_ld, int kd, int kh, int kw, int pd, int ph, int pw, int accumulate,
+                      hupr_stream_t stream);
+
+/* weight gradient of the same convolution: dw in the PARAMETER layout (Co, Ci, kd, kh, kw). */
+size_t hupr_conv_wgrad_ws_bytes(int Bn, int Do, int Ho, int Wo, int Ci, int Co, int kd, int kh, int kw);
+int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, int Bn, int Di, int Hi, int Wi, int Ci,
+                        int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
+                        int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream);
+
+/* w (Co, Ci, taps) parameter layout -> mode 0: [Co][taps][Ci] (forward), mode 1: [Ci][taps reversed][Co] (dgrad) */
+int hupr_pack_conv_weights_f32(const float* w, float* wp, int Co, int Ci, int taps, int mode, hupr_stream_t stream);
+
+/* (a4) BatchNorm3d pieces (models/layers.py:46,49,53); x is [M voxels][C]. */
+size_t hupr_bn_ws_bytes(int C);
+int hupr_bn_train_stats_f32(const float* x, long M, int C, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                            float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
+                            hupr_stream_t stream);
+int hupr_bn_eval_params_f32(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, int C, float* scale, float* shift,
+                            hupr_stream_t stream);
+/* y = act(x1*scale1+shift1 [+ x2*scale2+shift2]); act: 0 identity, 1 ReLU  (BasicBlock3D.forward :66-70) */
+int hupr_scale_shift_act_f32(const float* x1, const float* scale1, const float* shift1, const float* x2,
+                             const float* scale2, const float* shift2, float* y, long M, int C, int act,
+                             hupr_stream_t stream);
+int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float* x, const float* save_mean,
+                    const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta, long M,
+                    int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
+
+/* out[c] = sum_rows x[row][c] — bias gradient of Encoder3D.layer1.0 (models/layers.py:195); ws as hupr_bn_ws_bytes */
+int hupr_colsum_f32(const float* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
+
+/* (a6) nn.PReLU() with one shared slope (models/layers.py:26,32) */
+int hupr_prelu_fwd_f32(const float* x, const float* alpha, float* y, long n, hupr_stream_t stream);
+size_t hupr_prelu_ws_bytes(void);
+int hupr_prelu_bwd_f32(const float* dy, const float* x, const float* alpha, float* dx, float* dalpha, long n,
+                       void* ws, size_t ws_bytes, hupr_stream_t stream);
+
+/* (a3) MNet front end — replaces HuPRNet.forward_chirp + MNet.forward (models/networks.py:23-33,
+ * models/chirp_networks.py:17-21): elevation mean, the (F,2)->(2,F) .view, Conv3d(2->32,(2,1,1),s(2,1,1)),
+ * MaxPool3d((4,1,1)).  x: (n_bg=B*G, 8, 2, pixels=R*A, 8) fp32; out: (n_bg, pixels, 32) channels-last. */
+int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, long n_bg, int pixels,
+                      hupr_stream_t stream);
+size_t hupr_mnet_bwd_ws_bytes(void);
+int hupr_mnet_bwd_f32(const float* x, const float* w, const float* bias, const float* dy, float* dw, float* dbias,
+                      long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream);
+
+/* tri-/bilinear align_corners=True resampling (models/layers.py:84,89,199,204; gcn_networks.py:49,63) */
+int hupr_interp_linear_fwd_f32(const float* x, float* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                               int C, int in_ld, int out_ld, hupr_stream_t stream);
+int hupr_interp_linear_bwd_f32(const float* dy, float* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                               int C, int in_ld, int out_ld, hupr_stream_t stream);
+
+/* (a5) softmax over the key axis, in place on rows of length n (models/layers.py:131), and its backward */
+int hupr_softmax_rows_f32(float* s, long rows, int n, hupr_stream_t stream);
+int hupr_softmax_rows_bwd_f32(const float* p, float* dp_inout, long rows, int n, hupr_stream_t stream);
+
+/* (a7) PRGCN: y = act(t . A + bias) with t = W . x computed by hupr_gemm_f32 (gcn_networks.py:23-29,53-58) */
+int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,
+                         int ld, int relu, hupr_stream_t stream);
+int hupr_gcn_adj_bwd_f32(const float* dy, const float* y, const float* adj, float* dt, float* gmasked,
+                         float* dbias, int Bn, int F, int K, int ld, int relu, hupr_stream_t stream);
+
+/* (a8) sigmoid heads: channels-last logits (B,HW,ld) -> NCHW probabilities (B,K,HW)  (networks.py:40, gcn_networks.py:64) */
+int hupr_sigmoid_to_nchw_f32(const float* x, float* y, int Bn, int HW, int K, int ld, hupr_stream_t stream);
+int hupr_sigmoid_to_nchw_bwd_f32(const float* dy, const float* y, float* dx, int Bn, int HW, int K, int ld,
+                                 hupr_stream_t stream);
+
+/* (a9) loss / targets / decode (misc/losses.py:23-45, misc/utils.py:6-66, misc/metrics.py:10-38) */
+size_t hupr_bce_ws_bytes(void);
+int hupr_bce_fwd_f32(const float* p, const float* t, long n, float* loss, void* ws, size_t ws_bytes,
+                     hupr_stream_t stream);
+int hupr_bce_bwd_f32(const float* p, const float* t, const float* grad_out, float* dp, long n, hupr_stream_t stream);
+int hupr_gaussian_targets_f32(const long long* joints, const float* patch, float* t, int BK, int H, int rad,
+                              float stride, hupr_stream_t stream);
+int hupr_argmax_rows_f32(const float* p, long rows, int n, int* idx, float* maxval, hupr_stream_t stream);
+
+/* (a10) Adam with coupled L2 weight decay (tools/base.py:47), one flat launch */
+int hupr_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int step, float gscale, hupr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

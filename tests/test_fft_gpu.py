@@ -61,7 +61,7 @@ def test_batch_is_independent_and_linear():
     single = _run(a[3:4])
     assert np.array_equal(single[0], ya[3])           # bit-identical regardless of batch position
     # a constant-over-chirps scene is pure clutter -> all Doppler bins ~ 0
-    const = np.repeat(synth.adc_cube_int16(9)[:, :, :3], 64, axis=2)
+    const = np.tile(synth.adc_cube_int16(9)[:, :, :3], (1, 1, 64, 1, 1))
     yc = _run(const)
     assert np.abs(yc).max() <= 1e-5 * scale
 

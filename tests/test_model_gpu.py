@@ -1,0 +1,119 @@
+"""GPU (-m gpu): whole-model parity of the HIP HuPRNet against golden vectors produced by the
+imported reference (tests/golden/model_{eval,train}.npz).  north_star gates: heat-maps within
+1e-3 max-abs (fp32), arg-max joint indices bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hupr_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _build(g):
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.models import HuPRNet
+    cfg = load_config()
+    net = HuPRNet(cfg).cuda()
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.hupr_state(int(g["model_seed"]), gain=float(g["gain"])).items()}
+    net.load_state_dict(sd)              # strict: the 255 reference keys
+    return cfg, net
+
+
+def _inputs(g):
+    h, v = synth.model_inputs(2, int(g["input_seed"]))
+    return torch.from_numpy(h).cuda(), torch.from_numpy(v).cuda()
+
+
+def test_state_dict_contract_on_device():
+    c = json.load(open(os.path.join(G, "contract.json")))
+    g = np.load(os.path.join(G, "model_eval.npz"))
+    _, net = _build(g)
+    assert [[k, list(v.shape)] for k, v in net.state_dict().items()] == [[k, s] for k, s, _ in c["state_dict"]]
+    assert "radarDecoder.gcn.A" not in net.state_dict()
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_forward_matches_reference(mode):
+    from hupr_amd.misc import LossComputer
+    g = np.load(os.path.join(G, "model_%s.npz" % mode))
+    cfg, net = _build(g)
+    net.train(mode == "train")
+    h, v = _inputs(g)
+    with torch.no_grad():
+        p1, p2 = net(h, v)
+    assert p1.shape == (2, 14, 1, 64, 64) and p2.shape == (2, 1, 14, 64, 64)
+    e1 = np.abs(p1.cpu().numpy() - g["heatmap"]).max()
+    e2 = np.abs(p2.cpu().numpy() - g["gcn_heatmap"]).max()
+    print("max-abs heatmap %.3e gcn %.3e" % (e1, e2))
+    assert e1 <= 1e-3 and e2 <= 1e-3
+    assert np.array_equal(p2.reshape(2, 14, -1).argmax(-1).cpu().numpy(), g["argmax2"])
+    assert np.array_equal(p1.reshape(2, 14, -1).argmax(-1).cpu().numpy(), g["argmax1"])
+    gt = torch.from_numpy(synth.keypoints(2, int(g["kp_seed"])))
+    loss, loss2, pred2d, gt2d = LossComputer(cfg, "cuda").computeLoss((p1, p2), gt)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 and abs(loss2.item() - float(g["loss2"])) < 1e-4
+    assert np.array_equal(pred2d, g["pred2d"]) and np.array_equal(gt2d, g["gt2d"])
+    if mode == "train":
+        sd = net.state_dict()
+        for k in g.files:
+            if k.startswith("stat:"):
+                np.testing.assert_allclose(sd[k[5:]].cpu().numpy(), g[k], rtol=2e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_backward_matches_reference(mode):
+    from hupr_amd.misc import LossComputer
+    g = np.load(os.path.join(G, "model_%s.npz" % mode))
+    cfg, net = _build(g)
+    net.train(mode == "train")
+    h, v = _inputs(g)
+    gt = torch.from_numpy(synth.keypoints(2, int(g["kp_seed"])))
+    p = net(h, v)
+    loss, *_ = LossComputer(cfg, "cuda").computeLoss(p, gt, decode=False)
+    loss.backward()
+    names = [str(n) for n in g["grad_names"]]
+    params = dict(net.named_parameters())
+    assert list(params) == names
+    worst = 0.0
+    for i, n in enumerate(names):
+        gr = params[n].grad
+        assert gr is not None, n
+        ref_l2 = float(g["grad_l2"][i])
+        got_l2 = gr.double().norm().item()
+        rel = abs(got_l2 - ref_l2) / (ref_l2 + 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 2e-3, "%s: grad L2 %.6e vs %.6e" % (n, got_l2, ref_l2)
+        f = gr.reshape(-1)
+        step = max(1, f.numel() // 64)
+        samp = f[::step][:64].cpu().numpy()
+        ref = g["grad_sample"][i][:samp.size]
+        scale = ref_l2 / np.sqrt(f.numel()) + 1e-12          # rms magnitude of this gradient
+        assert np.abs(samp - ref).max() <= 5e-2 * scale + 1e-9, n
+    print("worst relative grad-L2 error %.3e" % worst)
+
+
+def test_training_step_decreases_loss_and_adam_matches():
+    """A few fused-Adam steps on a fixed batch: loss goes down and parameters stay finite."""
+    from hupr_amd.misc import LossComputer
+    from hupr_amd.tools.optim import FusedAdam
+    g = np.load(os.path.join(G, "model_train.npz"))
+    cfg, net = _build(g)
+    net.train()
+    h, v = _inputs(g)
+    gt = torch.from_numpy(synth.keypoints(2, int(g["kp_seed"])))
+    opt = FusedAdam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    lc = LossComputer(cfg, "cuda")
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss, *_ = lc.computeLoss(net(h, v), gt, decode=False)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print(losses)
+    assert losses[-1] < losses[0]
+    assert all(torch.isfinite(p).all() for p in net.parameters())

@@ -1,0 +1,329 @@
+"""GPU (-m gpu): every HuPRNet operator kernel, through the C ABI, against the same op in
+torch-CPU fp32/fp64 (the oracle's building blocks).  Tolerances are fp32-roundoff class."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def cl(x):      # NCDHW -> channels-last (B,D,H,W,C) contiguous
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(x):   # channels-last -> NCDHW
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def close(got, ref, tol, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-30
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e)" % (what, err, scale, err / scale)
+
+
+CONV_CASES = [
+    # B, Ci, Co, D, H, W, k, pad, bias
+    (2, 32, 64, 4, 16, 16, (3, 3, 3), (1, 1, 1), True),
+    (1, 64, 64, 8, 12, 20, (3, 3, 3), (1, 1, 1), False),
+    (2, 64, 128, 2, 8, 8, (3, 3, 3), (1, 1, 1), False),
+    (1, 128, 256, 2, 16, 16, (3, 3, 3), (1, 1, 1), False),
+    (2, 64, 64, 8, 16, 16, (8, 1, 1), (0, 0, 0), False),      # temporal merge
+    (2, 128, 128, 4, 8, 8, (4, 1, 1), (0, 0, 0), False),
+    (3, 320, 64, 1, 16, 16, (1, 3, 3), (0, 1, 1), False),     # decoder 2-D conv, odd batch
+    (2, 64, 32, 1, 16, 16, (1, 3, 3), (0, 1, 1), False),
+    (2, 256, 256, 1, 16, 16, (1, 1, 1), (0, 0, 0), False),    # q/k projection
+    (2, 32, 16, 1, 16, 16, (1, 1, 1), (0, 0, 0), False),      # padded head
+    (1, 32, 32, 1, 7, 9, (1, 3, 3), (0, 1, 1), False),        # ragged M (63 voxels)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case):
+    from hupr_amd import functional as F_
+    B, Ci, Co, D, H, W, k, pad, has_bias = case
+    x = rnd(B, Ci, D, H, W, seed=1)
+    w = rnd(Co, Ci, *k, seed=2, scale=(Ci * np.prod(k)) ** -0.5)
+    b = rnd(Co, seed=3) if has_bias else None
+    xr, wr = x.clone().double().requires_grad_(True), w.clone().double().requires_grad_(True)
+    br = b.clone().double().requires_grad_(True) if has_bias else None
+    yr = F.conv3d(xr, wr, br, 1, pad)
+    gy = rnd(*yr.shape, seed=4)
+    yr.backward(gy.double())
+    xg = cl(x).cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if has_bias else None
+    if len(k) == 3 and k[0] == 1 and D == 1:
+        wg_in = wg.reshape(Co, Ci, k[1], k[2])     # exercise the Conv2d weight shape
+    else:
+        wg_in = wg
+    y = F_.conv(xg, wg_in, bg, None, pad)
+    close(ncdhw(y), yr, 2e-5, "conv fwd")
+    y.backward(cl(gy).cuda())
+    close(ncdhw(xg.grad), xr.grad, 2e-5, "conv dgrad")
+    close(wg.grad, wr.grad, 5e-5, "conv wgrad")
+    if has_bias:
+        close(bg.grad, br.grad, 2e-5, "conv dbias")
+
+
+def test_conv_residual_epilogue():
+    from hupr_amd import functional as F_
+    x, w, r = rnd(2, 64, 1, 16, 16, seed=5), rnd(64, 64, 3, 3, seed=6, scale=0.05), rnd(2, 64, 1, 16, 16, seed=7)
+    ref = F.conv2d(x[:, :, 0], w, None, 1, 1) + r[:, :, 0]
+    xg, rg = cl(x).cuda().requires_grad_(True), cl(r).cuda().requires_grad_(True)
+    y = F_.conv(xg, w.cuda(), None, rg, (0, 1, 1))
+    close(ncdhw(y)[:, :, 0], ref, 2e-5, "conv+res")
+    y.sum().backward()
+    assert torch.equal(rg.grad, torch.ones_like(rg))
+
+
+GEMM_CASES = [(0, 1, 3, 200, 136, 64), (0, 0, 2, 256, 64, 256), (1, 0, 2, 130, 64, 200), (0, 1, 1, 1024, 1024, 448),
+              (0, 0, 2, 1024, 16, 1024), (1, 0, 1, 64, 100, 33), (0, 1, 2, 14, 30, 10)]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_modes(case):
+    from hupr_amd import functional as F_
+    ta, tb, batch, M, N, K = case
+    A = rnd(batch, *((K, M) if ta else (M, K)), seed=8)
+    Bm = rnd(batch, *((N, K) if tb else (K, N)), seed=9)
+    ref = torch.matmul(A.double().transpose(1, 2) if ta else A.double(), Bm.double().transpose(1, 2) if tb else Bm.double())
+    lda, ldb = (M if ta else K), (K if tb else N)
+    out = F_.gemm(ta, tb, A.cuda(), Bm.cuda(), M, N, K, lda, ldb, batch, A[0].numel(), Bm[0].numel())
+    close(out, ref, 2e-5, "gemm %r" % (case,))
+    res = rnd(batch, M, N, seed=10)
+    out2 = F_.gemm(ta, tb, A.cuda(), Bm.cuda(), M, N, K, lda, ldb, batch, A[0].numel(), Bm[0].numel(), res=res.cuda())
+    close(out2, ref + res.double(), 2e-5, "gemm+res")
+    out3 = F_.gemm(ta, tb, A.cuda(), Bm.cuda(), M, N, K, lda, ldb, batch, A[0].numel(), Bm[0].numel(),
+                   out=out2.clone(), accumulate=True)
+    close(out3, 2 * ref + res.double(), 2e-5, "gemm accumulate")
+
+
+class _BN:
+    def __init__(self, C, seed):
+        self.weight = (1 + 0.3 * rnd(C, seed=seed)).cuda().requires_grad_(True)
+        self.bias = (0.2 * rnd(C, seed=seed + 1)).cuda().requires_grad_(True)
+        self.running_mean = (0.1 * rnd(C, seed=seed + 2)).cuda()
+        self.running_var = (1 + 0.2 * rnd(C, seed=seed + 3).abs()).cuda()
+        self.num_batches_tracked = torch.zeros((), dtype=torch.long).cuda()
+        self.momentum, self.eps = 0.1, 1e-5
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("C,vox", [(64, (2, 4, 8, 8)), (128, (3, 2, 5, 7)), (256, (1, 2, 4, 4))])
+def test_bn_relu_and_block_tail(training, C, vox):
+    from hupr_amd import functional as F_
+    B, D, H, W = vox
+    x1, x2 = rnd(B, C, D, H, W, seed=11) * 2 + 0.5, rnd(B, C, D, H, W, seed=12)
+    bn1, bn2 = _BN(C, 20), _BN(C, 30)
+
+    def ref_bn(x, bn, rm, rv):
+        return F.batch_norm(x, rm, rv, bn.weight.detach().cpu().double().requires_grad_(True) if False else None, None,
+                            training, 0.1, 1e-5)
+    # reference in fp64 with autograd
+    params = []
+    for bn in (bn1, bn2):
+        params.append((bn.weight.detach().cpu().double().requires_grad_(True), bn.bias.detach().cpu().double().requires_grad_(True),
+                       bn.running_mean.cpu().double().clone(), bn.running_var.cpu().double().clone()))
+    x1r, x2r = x1.double().requires_grad_(True), x2.double().requires_grad_(True)
+    (w1, b1, rm1, rv1), (w2, b2, rm2, rv2) = params
+    y1r = F.relu(F.batch_norm(x1r, rm1, rv1, w1, b1, training, 0.1, 1e-5))
+    gy = rnd(B, C, D, H, W, seed=13)
+    x1g = cl(x1).cuda().requires_grad_(True)
+    y1 = F_.BNActFn.apply(x1g, bn1.weight, bn1.bias, bn1, training, True)
+    close(ncdhw(y1), y1r, 1e-5, "bn+relu fwd")
+    y1r.backward(gy.double())
+    y1.backward(cl(gy).cuda())
+    close(ncdhw(x1g.grad), x1r.grad, 5e-5, "bn+relu dx")
+    close(bn1.weight.grad, w1.grad, 5e-5, "bn dgamma")
+    close(bn1.bias.grad, b1.grad, 5e-5, "bn dbeta")
+    if training:
+        close(bn1.running_mean, rm1, 1e-5, "running_mean")
+        close(bn1.running_var, rv1, 1e-5, "running_var")
+        assert int(bn1.num_batches_tracked) == 1
+    # block tail relu(bn_a(x1) + bn_b(x2))
+    for t in (x1r, x2r, w1, b1, w2, b2):
+        t.grad = None
+    bn1.weight.grad = bn1.bias.grad = None
+    (_, _, rm1b, rv1b) = (None, None, bn1.running_mean.cpu().double().clone(), bn1.running_var.cpu().double().clone())
+    yr = F.relu(F.batch_norm(x1r, rm1b, rv1b, w1, b1, training, 0.1, 1e-5) + F.batch_norm(x2r, rm2, rv2, w2, b2, training, 0.1, 1e-5))
+    x1g2, x2g = cl(x1).cuda().requires_grad_(True), cl(x2).cuda().requires_grad_(True)
+    y = F_.BNAddBNReLUFn.apply(x1g2, bn1.weight, bn1.bias, bn1, x2g, bn2.weight, bn2.bias, bn2, training)
+    close(ncdhw(y), yr, 1e-5, "tail fwd")
+    yr.backward(gy.double())
+    y.backward(cl(gy).cuda())
+    close(ncdhw(x1g2.grad), x1r.grad, 5e-5, "tail dx1")
+    close(ncdhw(x2g.grad), x2r.grad, 5e-5, "tail dx2")
+    close(bn2.weight.grad, w2.grad, 5e-5, "tail dgamma2")
+    close(bn2.bias.grad, b2.grad, 5e-5, "tail dbeta2")
+
+
+def test_prelu():
+    from hupr_amd import functional as F_
+    x, a = rnd(2, 1, 16, 16, 64, seed=14), torch.tensor([0.25])
+    xr, ar = x.double().requires_grad_(True), a.double().requires_grad_(True)
+    yr = F.prelu(xr, ar)
+    g = rnd(*x.shape, seed=15)
+    yr.backward(g.double())
+    xg, ag = x.cuda().requires_grad_(True), a.cuda().requires_grad_(True)
+    y = F_.PReLUFn.apply(xg, ag)
+    close(y, yr, 1e-6, "prelu fwd")
+    y.backward(g.cuda())
+    close(xg.grad, xr.grad, 1e-6, "prelu dx")
+    close(ag.grad, ar.grad, 1e-5, "prelu dalpha")
+
+
+@pytest.mark.parametrize("shape,size", [((2, 8, 16, 16, 64), (4, 8, 8)), ((1, 4, 32, 32, 128), (2, 16, 16)),
+                                        ((2, 1, 16, 16, 128), (1, 32, 32)), ((2, 1, 64, 64, 16), (1, 32, 32)),
+                                        ((2, 1, 32, 32, 16), (1, 64, 64))])
+def test_interp_align_corners(shape, size):
+    from hupr_amd import functional as F_
+    B, D, H, W, C = shape
+    x = rnd(B, C, D, H, W, seed=16)
+    xr = x.clone().requires_grad_(True)
+    if D == 1:
+        yr = F.interpolate(xr[:, :, 0], size=size[1:], mode="bilinear", align_corners=True).unsqueeze(2)
+    else:
+        yr = F.interpolate(xr, size=size, mode="trilinear", align_corners=True)
+    g = rnd(*yr.shape, seed=17)
+    yr.backward(g)
+    xg = cl(x).cuda().requires_grad_(True)
+    y = F_.interp(xg, size)
+    close(ncdhw(y), yr, 2e-6, "interp fwd")
+    y.backward(cl(g).cuda())
+    close(ncdhw(xg.grad), xr.grad, 1e-5, "interp bwd")
+
+
+def test_mnet_front_end():
+    from hupr_amd import functional as F_
+    B, G = 2, 3
+    x = rnd(B, G, 8, 2, 16, 16, 8, seed=18)
+    w, b = rnd(32, 2, 2, 1, 1, seed=19, scale=0.5), rnd(32, seed=20, scale=0.5)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    m = x.double().mean(dim=6).reshape(B * G, 2, 8, 16, 16)            # the reference's .view
+    yr = F.max_pool3d(F.conv3d(m, wr, br, (2, 1, 1)), (4, 1, 1), (4, 1, 1)).squeeze(2)   # (BG,32,R,A)
+    g = rnd(*yr.shape, seed=21)
+    yr.backward(g.double())
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = F_.MNetFn.apply(x.cuda(), wg, bg)                               # (B,G,R,A,32)
+    close(y.reshape(B * G, 16, 16, 32).permute(0, 3, 1, 2), yr, 1e-5, "mnet fwd")
+    y.backward(g.permute(0, 2, 3, 1).reshape(B, G, 16, 16, 32).contiguous().cuda())
+    close(wg.grad, wr.grad, 5e-5, "mnet dW")
+    close(bg.grad, br.grad, 5e-5, "mnet dbias")
+
+
+@pytest.mark.parametrize("N,C,residual", [(256, 256, True), (1024, 128, False), (320, 64, True)])
+def test_attention(N, C, residual):
+    from hupr_amd import functional as F_
+    B = 2
+    k, q, v = rnd(B, N, C, seed=22, scale=C ** -0.25), rnd(B, N, C, seed=23, scale=C ** -0.25), rnd(B, N, C, seed=24)
+    kr, qr, vr = (t.double().requires_grad_(True) for t in (k, q, v))
+    s = torch.einsum("bjc,bkc->bjk", kr, qr)                           # S[j,k]
+    outr = torch.einsum("bjc,bjk->bkc", vr, F.softmax(s, 1))           # softmax over keys j
+    if residual:
+        outr = outr + vr
+    g = rnd(B, N, C, seed=25)
+    outr.backward(g.double())
+    kg, qg, vg = (t.cuda().requires_grad_(True) for t in (k, q, v))
+    out = F_.AttentionFn.apply(kg, qg, vg, residual)
+    close(out, outr, 2e-5, "attention fwd")
+    out.backward(g.cuda())
+    close(vg.grad, vr.grad, 5e-5, "attention dV")
+    close(qg.grad, qr.grad, 1e-4, "attention dQ")
+    close(kg.grad, kr.grad, 1e-4, "attention dK")
+
+
+def test_attention_large_logits_stable():
+    from hupr_amd import functional as F_
+    k, q, v = rnd(1, 256, 64, seed=26) * 6, rnd(1, 256, 64, seed=27) * 6, rnd(1, 256, 64, seed=28)
+    s = torch.einsum("bjc,bkc->bjk", k.double(), q.double())
+    ref = torch.einsum("bjc,bjk->bkc", v.double(), F.softmax(s, 1))
+    out = F_.AttentionFn.apply(k.cuda(), q.cuda(), v.cuda(), False)
+    assert torch.isfinite(out).all()
+    close(out, ref, 1e-4, "attention big logits")
+
+
+def test_gcn_layer():
+    from hupr_amd import functional as F_
+    from oracle.model import adjacency
+    B, Fdim, K = 2, 1024, 14
+    x = torch.zeros(B, Fdim, 16)
+    x[..., :K] = rnd(B, Fdim, K, seed=29)
+    w, b = rnd(Fdim, Fdim, seed=30, scale=1 / 32), rnd(Fdim, K, seed=31, scale=1 / 32)
+    A = adjacency()
+    xr, wr, br = x[..., :K].double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.relu(torch.matmul(wr, torch.matmul(xr, A.double())) + br)
+    g = rnd(B, Fdim, K, seed=32)
+    yr.backward(g.double())
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = F_.GCNLayerFn.apply(xg, wg, bg, A.cuda(), True)
+    close(y[..., :K], yr, 2e-5, "gcn fwd")
+    assert (y[..., K:] == 0).all()
+    g16 = torch.zeros(B, Fdim, 16)
+    g16[..., :K] = g
+    y.backward(g16.cuda())
+    close(xg.grad[..., :K], xr.grad, 5e-5, "gcn dx")
+    close(wg.grad, wr.grad, 5e-5, "gcn dW")
+    close(bg.grad, br.grad, 5e-5, "gcn dbias")
+
+
+def test_heads_loss_targets_argmax():
+    from hupr_amd import functional as F_, synth
+    from oracle import loss as oloss
+    B, K, H = 2, 14, 64
+    x = torch.zeros(B, H * H, 16)
+    x[..., :K] = rnd(B, H * H, K, seed=33) * 2
+    xr = x[..., :K].double().requires_grad_(True)
+    pr = torch.sigmoid(xr).permute(0, 2, 1)                      # (B,K,HW)
+    gt = synth.keypoints(B, 7)
+    tg, _ = oloss.batch_targets(gt)
+    tgt = torch.from_numpy(tg).reshape(B, K, H * H)
+    lr = F.binary_cross_entropy(pr, tgt.double())
+    lr.backward()
+    xg = x.cuda().requires_grad_(True)
+    p = F_.SigmoidHeadFn.apply(xg, K)
+    close(p, pr, 1e-6, "sigmoid head")
+    t_dev = F_.gaussian_targets(torch.from_numpy(gt).cuda())
+    assert torch.equal(t_dev.cpu(), torch.from_numpy(tg)), "targets must be bit-exact"
+    loss = F_.BCEFn.apply(p.reshape(B, K, H, H), t_dev)
+    assert abs(loss.item() - lr.item()) < 1e-5
+    loss.backward()
+    close(xg.grad[..., :K], xr.grad, 1e-5, "bce+sigmoid grad")
+    assert (xg.grad[..., K:] == 0).all()
+    # argmax with ties: first maximum wins; compare with the oracle decode
+    hm = rnd(B * K, H * H, seed=34)
+    hm[0, 100] = hm[0, 3000] = 50.0
+    hm[1] = -1.0
+    idx, mx = F_.argmax_rows(hm.cuda())
+    ref = hm.numpy().argmax(axis=1)
+    assert np.array_equal(idx.cpu().numpy(), ref) and idx[0] == 100 and idx[1] == 0
+    from hupr_amd.misc import get_max_preds
+    pred, _ = get_max_preds(hm.reshape(B, K, H, H).cuda())
+    pred_ref, _ = oloss.argmax_decode(hm.reshape(B, K, H, H).numpy())
+    assert np.array_equal(pred, pred_ref)
+    # edge joints: clipped / fully outside patches
+    edge = np.array([[[0, 0], [255, 255], [-40, 100], [400, 400]] + [[128, 128]] * 10])
+    te, _ = oloss.batch_targets(edge)
+    assert torch.equal(F_.gaussian_targets(torch.from_numpy(edge).cuda()).cpu(), torch.from_numpy(te))
+
+
+def test_adam_step_matches_torch():
+    from hupr_amd import runtime as rt
+    n = 10007
+    p, g = rnd(n, seed=35), rnd(n, seed=36)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-4)
+    pd, m, v = p.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 4):
+        pr.grad = g.clone() * step
+        opt.step()
+        gd = (g * step).cuda()
+        rt.check(rt.lib().hupr_adam_step_f32(rt.ptr(pd), rt.ptr(gd), rt.ptr(m), rt.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-4,
+                                            step, 1.0, rt.stream()))
+    close(pd, pr, 1e-6, "adam")
