@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py — radar frames/sec of the hot path (FFT -> heat-map, forward + backward + Adam).
+
+Workload (BASELINE.json configs[2], "C3"): per step and per GPU, 32 samples; every sample's
+2 x 8 sensor-frames are synthetic int16 IWR1843 ADC cubes already resident in HBM; the timed
+step = on-GPU FFT chain fused with the loader normalisation -> HuPRNet forward -> BCE x2 ->
+backward -> (N>1: RCCL gradient all-reduce overlapped with backward) -> fused Adam.
+One radar frame = one sample.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_GFLOP, STEP_GFLOP = 137.09, 411.3          # per sample
+PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md: dense fp32 MFMA peak
+
+
+def cpu_baseline(seconds_hint=20.0):
+    """The oracle (CPU restatement, validated against the imported reference) timed on this host:
+    un-cached FFT (16 sensor-frames per sample, vectorised NumPy) + loader glue + HuPRNet
+    fwd+bwd+Adam in torch-CPU fp32, on a bounded sample of 2 radar frames."""
+    from hupr_amd import synth
+    from oracle import fft_chain as offt, loader as oloader, loss as oloss, model as omodel
+    B = 2
+    t0 = time.time()
+    hv = []
+    for sensor in range(2):
+        per_sample = []
+        for b in range(B):
+            frames = []
+            for gfr in range(8):
+                iq = synth.adc_cube_int16(100 + b, frame=gfr, sensor=sensor)
+                cube = offt.generate_heatmap(synth.adc_cube_complex(iq)[0])
+                frames.append(oloader.loader_transform(cube))
+            per_sample.append(np.stack(frames))
+        hv.append(torch.from_numpy(np.stack(per_sample)))
+    t_pre = time.time() - t0
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.hupr_state(1).items()}
+    params = [k for k, _, kind in synth.hupr_param_specs() if not kind.startswith("bn_r") and kind != "bn_nbt"]
+    for k in params:
+        sd[k].requires_grad_(True)
+    opt = torch.optim.Adam([sd[k] for k in params], lr=1e-4, weight_decay=1e-4)
+    gt = synth.keypoints(B, 3)
+    t0 = time.time()
+    p = omodel.forward(sd, hv[0], hv[1], train=True)
+    loss, *_ = oloss.compute_loss(p, gt)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    t_model = time.time() - t0
+    fps = B / (t_pre + t_model)
+    return {"value": round(fps, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d radar frames: un-cached vectorised-NumPy FFT chain + loader glue %.2fs, HuPRNet fwd+bwd+Adam "
+                      "torch-CPU fp32 B=%d %.2fs (host has %d logical cores)" % (B, t_pre, B, t_model, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from hupr_amd import functional as F_, synth
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+
+    cfg = load_config()
+    eng = TrainEngine(cfg, device=dev, seed=0)
+    B, G = args.batch, cfg.DATASET.numGroupFrames
+    # synthetic ADC cubes: 16 distinct sensor-frames per sensor per rank, tiled to B*G (values differ per rank)
+    base_h = torch.from_numpy(synth.adc_cube_int16(10 + rank, sensor=0, nframes=16)).to(dev)
+    base_v = torch.from_numpy(synth.adc_cube_int16(10 + rank, sensor=1, nframes=16)).to(dev)
+    reps = (B * G + 15) // 16
+    adc_h = base_h.repeat(reps, 1, 1, 1, 1)[:B * G].contiguous()
+    adc_v = base_v.repeat(reps, 1, 1, 1, 1)[:B * G].contiguous()
+    joints = torch.from_numpy(synth.keypoints(B, 20 + rank)).to(dev)
+
+    # roofline probe: the Encoder3D.layer1 64->64 3x3x3 convolutions (forward and input-gradient launches share
+    # one kernel instantiation and one shape) — the kernel that dominates the profile
+    probe_events = []
+
+    def probe(x, co, k):
+        if x.shape[-1] == 64 and co == 64 and k == (3, 3, 3) and x.shape[1] == 8:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            probe_events.append((s, e))
+            return s, e
+        return None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step_from_adc(adc_h, adc_v, joints)
+    barrier()
+    F_.CONV_PROBE = probe
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = eng.train_step_from_adc(adc_h, adc_v, joints)
+    barrier()
+    dt = time.perf_counter() - t0
+    F_.CONV_PROBE = None
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        frames = world * B * args.steps
+        value = frames / dt
+        ms = [s.elapsed_time(e) for s, e in probe_events]
+        kflop = 2.0 * (B * 8 * 64 * 64) * 64 * (27 * 64)
+        roof = None
+        if ms:
+            avg = float(np.mean(ms)) * 1e-3
+            ach = kflop / avg / 1e12
+            roof = {"bound": "mfma", "kernel": "hupr_k_gemm_f32<128,64,2,2,A_CONV,B_NK> (Encoder3D.layer1 64->64 3x3x3, fwd+dgrad)",
+                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None, "launches": len(ms), "avg_ms": round(avg * 1e3, 4), "flop_per_launch": kflop}
+        out = {
+            "metric": "radar frames/sec (FFT->heatmap fwd+bwd)", "value": round(value, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: mscsa_prgcn training fwd+bwd+Adam with on-GPU FFT preprocess fused into the loader "
+                                   "(16 un-cached sensor-frames per sample)", "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world, "model_gflop_per_frame": STEP_GFLOP},
+            "model_tflops": round(value * STEP_GFLOP / 1e3, 2),
+            "model_frac_of_f32_mfma_peak": round(value * STEP_GFLOP / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
+            "loss": round(float(loss.item()), 5),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@ import torch
 from . import runtime as rt
 
 _ws_cache = {}
+CONV_PROBE = None      # bench.py installs a callable(x, co, k) -> (start_event, end_event) | None
 
 
 def workspace(nbytes, device):
@@ -46,10 +47,15 @@ def _conv_raw(x, wp, bias, res, co, k, pad, out_extent):
     B, Di, Hi, Wi, Ci = _vox(x)
     Do, Ho, Wo = out_extent
     y = torch.empty((B, Do, Ho, Wo, co), dtype=torch.float32, device=x.device)
+    ev = CONV_PROBE(x, co, k) if CONV_PROBE is not None else None
+    if ev is not None:
+        ev[0].record()
     rt.check(rt.lib().hupr_conv_fwd_f32(
         rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
         rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, Do, Ho, Wo, co, co,
         co, k[0], k[1], k[2], pad[0], pad[1], pad[2], 0, rt.stream()))
+    if ev is not None:
+        ev[1].record()
     return y
 
 

@@ -1,0 +1,58 @@
+"""Training/inference engine shared by the Runner and bench.py: HuPRNet + LossComputer +
+flat gradient buckets (+ RCCL all-reduce when world_size > 1) + fused Adam, optionally fed by the
+on-GPU FFT loader (int16 ADC cubes -> normalised network input, config "C3" of BASELINE.json)."""
+import torch
+import torch.distributed as dist
+
+from ..misc.losses import LossComputer
+from ..models import HuPRNet
+from ..preprocessing.process_iwr1843 import fft_chain_loader
+from .distributed import GradientBuckets
+from .optim import FusedAdam
+
+
+class TrainEngine:
+    def __init__(self, cfg, device="cuda", lr=None, seed=0, bucket_bytes=48 << 20):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.manual_seed(seed)
+        self.model = HuPRNet(cfg).to(self.device)
+        self.lossComputer = LossComputer(cfg, self.device)
+        self.buckets = GradientBuckets(self.model, bucket_bytes=bucket_bytes)
+        self.buckets.broadcast_parameters(0)
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.optimizer = FusedAdam(self.model.parameters(), lr=lr if lr is not None else cfg.TRAINING.lr,
+                                   betas=(0.9, 0.999), weight_decay=1e-4)
+        self.optimizer.attach_flat_buckets(self.buckets.flat_pairs())
+        self.optimizer.grad_scale = 1.0 / self.world_size
+        self.G = cfg.DATASET.numGroupFrames
+        self._fft_ws = None
+
+    # -- data -------------------------------------------------------------------------------------
+    def preprocess(self, adc_hori, adc_vert):
+        """int16 ADC cubes (B*G, 4, 192, 256, 2) per sensor -> two (B,G,F,2,R,A,E) fp32 network inputs."""
+        n = adc_hori.shape[0]
+        B = n // self.G
+        h = fft_chain_loader(adc_hori).view(B, self.G, 8, 2, 64, 64, 8)
+        v = fft_chain_loader(adc_vert).view(B, self.G, 8, 2, 64, 64, 8)
+        return h, v
+
+    # -- steps ------------------------------------------------------------------------------------
+    def train_step(self, hori, vert, joints):
+        self.model.train()
+        self.buckets.prepare()
+        preds = self.model(hori, vert)
+        loss, loss2, _, _ = self.lossComputer.computeLoss(preds, joints, decode=False)
+        loss.backward()
+        self.buckets.finish()
+        self.optimizer.step()
+        return loss, loss2
+
+    def train_step_from_adc(self, adc_hori, adc_vert, joints):
+        h, v = self.preprocess(adc_hori, adc_vert)
+        return self.train_step(h, v, joints)
+
+    @torch.no_grad()
+    def infer(self, hori, vert):
+        self.model.eval()
+        return self.model(hori, vert)
