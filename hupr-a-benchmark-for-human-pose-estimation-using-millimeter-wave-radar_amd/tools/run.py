@@ -1,0 +1,106 @@
+"""Runner — train / eval loops with the reference's surface (tools/run.py:13-86):
+``Runner(args, cfg)``, ``.loadModelWeight(mode)``, ``.train()``, ``.eval(visualization, epoch) -> AP``.
+
+Differences that are the point of this build: the step runs through ``TrainEngine`` (HIP kernels,
+flat gradient buckets, RCCL all-reduce when launched under torchrun), the FFT preprocessing can run
+on the GPU inside the step (synthetic/raw-ADC datasets), and losses are not synchronised every step.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.utils.data as data
+
+from ..datasets import getDataset
+from ..misc.oks_eval import evaluate_keypoints
+from .base import BaseRunner
+from .engine import TrainEngine
+
+
+def _collate(batch):
+    out = {}
+    for k in batch[0]:
+        v = [b[k] for b in batch]
+        out[k] = torch.stack(v) if isinstance(v[0], torch.Tensor) else torch.as_tensor(v)
+    return out
+
+
+class Runner(BaseRunner):
+    def __init__(self, args, cfg):
+        super().__init__(args, cfg)
+        if self.device != "cuda":
+            raise RuntimeError("the HIP runner needs a GPU (no CPU fallback)")
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if not args.eval:
+            self.trainSet = getDataset("train", cfg, args)
+            sampler = data.distributed.DistributedSampler(self.trainSet, shuffle=True, drop_last=True) if self.world > 1 else None
+            self.trainLoader = data.DataLoader(self.trainSet, cfg.TRAINING.batchSize, shuffle=sampler is None,
+                                               sampler=sampler, num_workers=0, collate_fn=_collate,
+                                               drop_last=self.world > 1)      # ragged last step only single-GPU
+        else:
+            self.trainLoader = [0]
+        self.testSet = getDataset("test" if args.eval else "val", cfg, args)
+        self.testLoader = data.DataLoader(self.testSet, cfg.TEST.batchSize, shuffle=False, num_workers=0, collate_fn=_collate)
+        warm = cfg.TRAINING.warmupEpoch
+        self.stepSize = len(self.trainLoader) * warm
+        LR = cfg.TRAINING.lr if warm == -1 else cfg.TRAINING.lr / (cfg.TRAINING.warmupGrowth ** self.stepSize)
+        self.engine = TrainEngine(cfg, device=torch.device("cuda", torch.cuda.current_device()), lr=LR, seed=args.seed)
+        self.model, self.optimizer, self.lossComputer = self.engine.model, self.engine.optimizer, self.engine.lossComputer
+        for d in (self.dir, self.visDir):
+            os.makedirs(d, exist_ok=True)
+        if not args.eval:
+            print("==========>Train set size:", len(self.trainLoader))
+        print("==========>Test set size:", len(self.testLoader))
+
+    def _inputs(self, batch):
+        dev = self.engine.device
+        if "adc_hori" in batch:          # raw ADC cubes: FFT chain + loader glue on the GPU
+            B, G = batch["adc_hori"].shape[:2]
+            h = batch["adc_hori"].to(dev).reshape(B * G, 4, 192, 256, 2)
+            v = batch["adc_vert"].to(dev).reshape(B * G, 4, 192, 256, 2)
+            return self.engine.preprocess(h, v)
+        return batch["VRDAEmap_hori"].float().to(dev), batch["VRDAEmap_vert"].float().to(dev)
+
+    def eval(self, visualization=True, epoch=-1):
+        self.logger.clear(len(self.testLoader.dataset))
+        savePreds, gts = [], []
+        for batch in self.testLoader:
+            keypoints = batch["jointsGroup"]
+            hori, vert = self._inputs(batch)
+            preds = self.engine.infer(hori, vert)
+            with torch.no_grad():
+                loss, loss2, pred2d, _ = self.lossComputer.computeLoss(preds, keypoints)
+            self.logger.display(loss, loss2, keypoints.size(0), epoch)
+            self.saveKeypoints(savePreds, pred2d * self.imgHeatmapRatio, batch["bbox"], batch["imageId"])
+            for j in range(keypoints.size(0)):
+                gts.append({"image_id": int(batch["imageId"][j]), "keypoints": keypoints[j].numpy().astype(np.float64),
+                            "bbox": batch["bbox"][j].numpy().astype(np.float64)})
+        self.writeKeypoints(savePreds)
+        stats = evaluate_keypoints(gts, savePreds)
+        names = ["AP", "Ap .5", "AP .75", "AP (M)", "AP (L)", "AR", "AR .5", "AR .75", "AR (M)", "AR (L)"]
+        print("  ".join("%s: %.3f" % (n, s) for n, s in zip(names, stats)))
+        return float(stats[0])
+
+    def train(self):
+        for epoch in range(self.start_epoch, self.cfg.TRAINING.epochs):
+            loss_list = []
+            self.logger.clear(len(self.trainLoader.dataset))
+            if self.world > 1:
+                self.trainLoader.sampler.set_epoch(epoch)
+            for idxBatch, batch in enumerate(self.trainLoader):
+                hori, vert = self._inputs(batch)
+                loss, loss2 = self.engine.train_step(hori, vert, batch["jointsGroup"])
+                self.logger.display(loss, loss2, batch["jointsGroup"].size(0), epoch)
+                if idxBatch % self.cfg.TRAINING.lrDecayIter == 0:
+                    self.adjustLR(epoch)
+                loss_list.append(loss.detach())
+                if getattr(self.args, "max_steps", 0) and idxBatch + 1 >= self.args.max_steps:
+                    break
+            accAP = self.eval(visualization=False, epoch=epoch)
+            if self.rank == 0:
+                self.saveModelWeight(epoch, accAP)
+                self.saveLosslist(epoch, [float(l) for l in loss_list], "train")
+            if getattr(self.args, "max_epochs", 0) and epoch + 1 - self.start_epoch >= self.args.max_epochs:
+                break

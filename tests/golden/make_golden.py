@@ -9,6 +9,7 @@ Fixtures are data (inputs are regenerable from seeds; expected outputs are store
   loader_seed0.npz                     Normalize + Doppler select         (datasets/base.py:13-24, dataset.py:144-150)
   model_eval.npz, model_train.npz      HuPRNet fwd (+ autograd bwd)        (models/*.py)
   loss_seed0.npz                       LossComputer/generateTarget/argmax (misc/losses.py, utils.py, metrics.py)
+  oks_eval.json                        COCOeval('keypoints') stats on a synthetic set (misc/coco.py, misc/cocoeval.py)
   contract.json                        state_dict keys/shapes, YAML dump, Runner helper outputs (tools/base.py)
 """
 import hashlib
@@ -182,9 +183,71 @@ def make_contract(net, cfg):
     print("contract ok", len(contract["state_dict"]), "keys")
 
 
+def make_oks():
+    """200-image synthetic GT + detections through the reference's pycocotools fork
+    (misc/coco.py + misc/cocoeval.py loaded as a package with an empty ``mask`` submodule)."""
+    import importlib.util
+    import tempfile
+    import types
+    np.float = float                     # misc/cocoeval.py:381-382 uses the removed alias
+    pkg = types.ModuleType("_refcoco")
+    pkg.__path__ = [os.path.join(ref_import.REF, "misc")]
+    sys.modules["_refcoco"] = pkg
+    sys.modules["_refcoco.mask"] = types.ModuleType("_refcoco.mask")
+    mods = {}
+    for name in ("coco", "cocoeval"):
+        spec = importlib.util.spec_from_file_location("_refcoco." + name, os.path.join(ref_import.REF, "misc", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules["_refcoco." + name] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    n_img = 200
+    joints = synth.uniform((n_img, 14, 2), 30, 226, "oks_gt").astype(np.float64).round()
+    noise = synth.normal((n_img, 14, 2), "oks_noise", dtype=np.float64) * synth.uniform((n_img, 1, 1), 1.0, 14.0, "oks_lvl").astype(np.float64)
+    det = np.round((joints + noise) / 4.0) * 4.0                       # detections live on the 4-px heat-map grid
+    images, anns, dts, gts = [], [], [], []
+    for i in range(n_img):
+        iid = 100000 * (1 + i // 50) + i
+        x0, y0 = joints[i].min(0)
+        x1, y1 = joints[i].max(0)
+        bbox = [float(x0), float(y0), float(x1 - x0), float(y1 - y0)]
+        kp = np.concatenate([joints[i], np.full((14, 1), 2.0)], 1).reshape(-1).tolist()
+        anns.append({"num_keypoints": 14, "area": bbox[2] * bbox[3] / 2, "iscrowd": 0, "keypoints": kp, "image_id": iid,
+                     "bbox": bbox, "category_id": 1, "id": iid})
+        images.append({"file_name": "%09d.jpg" % i, "height": 256, "width": 256, "id": iid})
+        dk = np.concatenate([det[i], np.ones((14, 1))], 1).reshape(-1).tolist()
+        dts.append({"category_id": 1, "image_id": iid, "score": 1.0, "keypoints": dk})
+        gts.append({"image_id": iid, "keypoints": joints[i].tolist(), "bbox": bbox})
+    gtj = {"info": {}, "licenses": [], "images": images, "annotations": anns,
+           "categories": [{"supercategory": "person", "id": 1, "name": "person", "keypoints": ["k%d" % k for k in range(14)], "skeleton": []}]}
+    with tempfile.TemporaryDirectory() as td:
+        gp, dp = os.path.join(td, "gt.json"), os.path.join(td, "dt.json")
+        json.dump(gtj, open(gp, "w"))
+        json.dump(dts, open(dp, "w"))
+        coco = mods["coco"].COCO(gp)
+        cdt = coco.loadRes(dp)
+        ev = mods["cocoeval"].COCOeval(coco, cdt, "keypoints")
+        ev.params.useSegm = None
+        ev.evaluate()
+        ev.accumulate()
+        ev.summarize()
+        stats = [float(x) for x in ev.stats]
+        ev.evaluate(3)                   # per-keypoint variant used by evaluateEach (dataset.py:48-66)
+        ev.accumulate()
+        ev.summarize()
+        stats_k3 = [float(x) for x in ev.stats]
+    with open(os.path.join(HERE, "oks_eval.json"), "w") as f:
+        json.dump({"gts": gts, "dts": dts, "stats": stats, "stats_keypoint3": stats_k3}, f)
+    print("oks stats", stats[:5])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "oks":
+        make_oks()
+        sys.exit(0)
     assert ref_import.available(), "reference tree not found"
     ro = make_fft()
     make_loader(ro)
     net, cfg = make_model()
     make_contract(net, cfg)
+    make_oks()

@@ -1,0 +1,80 @@
+"""CPU (-m "not gpu"): the N>1 path — flat gradient buckets + all-reduce + per-rank data shards —
+exercised with world_size 2 over gloo on a small torch module (the HIP model itself needs a GPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hupr_amd.tools.distributed import GradientBuckets
+    torch.manual_seed(1234 + rank)          # different init per rank on purpose: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 1))
+    gb = GradientBuckets(net, bucket_bytes=1024)      # small buckets -> several collectives
+    gb.broadcast_parameters(0)
+    assert len(gb.buckets) >= 2
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 1, generator=g)
+    shard = slice(rank * 4, rank * 4 + 4)             # data-parallel shard of the global batch
+    for _ in range(2):                                 # two iterations: views/zeroing are re-armed
+        gb.prepare()
+        loss = ((net(X[shard]) - Y[shard]) ** 2).sum()
+        loss.backward()
+        gb.finish()
+    flat = torch.cat([b.flat_grad for b in gb.buckets])
+    # every p.grad is still a view into its bucket
+    for b in gb.buckets:
+        for p, v in zip(b.params, b.views):
+            assert p.grad.data_ptr() == v.data_ptr()
+    out[rank] = (flat.clone(), torch.cat([b.flat_param for b in gb.buckets]).clone())
+    if rank == 0:
+        # single-process reference on the full batch with the broadcast weights
+        ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 1))
+        ref.load_state_dict(net.state_dict())
+        ((ref(X) - Y) ** 2).sum().backward()
+        want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+        out["ref"] = want
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_matches_single_process():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g0, p0 = out[0]
+    g1, p1 = out[1]
+    assert torch.equal(p0, p1), "parameters must be identical after broadcast"
+    assert torch.allclose(g0, g1) and torch.allclose(g0, out["ref"], atol=1e-5), "sum of shard grads == full-batch grad"
+
+
+def test_single_process_buckets_are_flat_views():
+    from hupr_amd.tools.distributed import GradientBuckets
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    before = [p.detach().clone() for p in net.parameters()]
+    gb = GradientBuckets(net, bucket_bytes=1 << 20)
+    assert len(gb.buckets) == 1 and gb.world_size == 1
+    for p, q in zip(net.parameters(), before):
+        assert torch.equal(p, q)
+    net(torch.ones(3, 4)).sum().backward()
+    gb.finish()
+    b = gb.buckets[0]
+    assert b.flat_grad.abs().sum() > 0 and b.pending == 0
+    # parameters alias the flat buffer: an in-place flat update is visible through the module
+    b.flat_param.zero_()
+    assert all(p.abs().sum() == 0 for p in net.parameters())

@@ -1,0 +1,137 @@
+"""CPU (-m "not gpu"): host-side logic pinned against outputs captured from the reference
+(tests/golden/contract.json, oks_eval.json) — config tree, Runner helpers, LR schedule, window
+gather, OKS evaluator."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import ref_import
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CONTRACT = json.load(open(os.path.join(G, "contract.json")))
+
+
+class Args:
+    gpuIDs, seed, dir, visDir, eval = [], 0, "x", "none", True
+
+
+def _cfg():
+    from hupr_amd.config_tree import load_config
+    return load_config()
+
+
+def test_yaml_is_the_reference_config_key_by_key():
+    from hupr_amd.config_tree import CONFIG_DIR
+    mine = yaml.safe_load(open(os.path.join(CONFIG_DIR, "mscsa_prgcn.yaml")))
+    assert mine == CONTRACT["yaml"]
+    cfg = _cfg()
+    assert cfg.DATASET.numKeypoints == 14 and cfg.TRAINING.lossDecay == -1 and cfg.TEST.batchSize == 32
+    assert cfg.DATASET.trainName[:3] == [2, 3, 4] and len(cfg.DATASET.idxToJoints) == 14
+
+
+def test_cli_flags_match_reference_defaults():
+    from hupr_amd.main import parse
+    a = parse(["--config", "mscsa_prgcn.yaml", "--dir", "d", "--gpuIDs", "[0,1]", "-sr", "10", "--eval", "--keypoints"])
+    assert (a.seed, a.dir, a.visDir, a.gpuIDs, a.eval, a.sampling_ratio, a.keypoints) == (0, "d", "none", [0, 1], True, 10, True)
+    assert parse([]).sampling_ratio == 1 and parse([]).eval is False
+
+
+def test_runner_helpers_match_reference_outputs():
+    from hupr_amd.tools.base import BaseRunner
+    r = BaseRunner(Args(), _cfg())
+    sk = CONTRACT["saveKeypoints"]
+    recs = r.saveKeypoints([], np.array(sk["preds"], dtype=np.float32), torch.tensor(sk["bbox"]), torch.tensor([100123, 1500042]))
+    assert len(recs) == 2
+    for got, ref in zip(recs, sk["records"]):
+        assert set(got) == set(ref)
+        assert got["image_id"] == ref["image_id"] and got["score"] == 1.0 and got["category_id"] == 1
+        np.testing.assert_allclose(got["center"], ref["center"])
+        np.testing.assert_allclose(got["scale"], ref["scale"])
+        np.testing.assert_allclose(got["keypoints"], ref["keypoints"])
+    c, s = r._xywh2cs(50.0, 60.0, 100.0, 150.0)
+    np.testing.assert_allclose(c, [100, 135])
+    np.testing.assert_allclose(s, [0.9375, 0.9375])
+
+
+def test_lr_schedule_matches_reference_sequence():
+    from hupr_amd.tools.base import BaseRunner
+    cfg = _cfg()
+    r = BaseRunner(Args(), cfg)
+    r.optimizer = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=cfg.TRAINING.lr)
+    lrs = []
+    for epoch in range(3):
+        for it in range(5790):
+            if it % cfg.TRAINING.lrDecayIter == 0:
+                r.adjustLR(epoch)
+            if it % 1000 == 0:
+                lrs.append(r.optimizer.param_groups[0]["lr"])
+    np.testing.assert_allclose(lrs, CONTRACT["lr_schedule"], rtol=1e-12)
+
+
+def _ref_window(index, duration, G):
+    """the reference's loop (datasets/dataset.py:125-139) transcribed only as a test oracle"""
+    padSize = index % duration
+    idx = index - G // 2 - 1
+    out = []
+    for j in range(G):
+        if (j + padSize) <= G // 2:
+            idx = index - padSize
+        elif j > (duration - 1 - padSize) + G // 2:
+            idx = index + (duration - 1 - padSize)
+        else:
+            idx += 1
+        out.append(idx)
+    return out
+
+
+@pytest.mark.parametrize("index", [0, 1, 3, 4, 5, 300, 595, 596, 598, 599, 600, 601, 1199, 1203])
+def test_window_indices_edge_clamping(index):
+    from hupr_amd.datasets import window_indices
+    w = window_indices(index, 600, 8)
+    assert w == _ref_window(index, 600, 8)
+    seq = index // 600
+    assert all(seq * 600 <= i <= seq * 600 + 599 for i in w)        # never crosses a sequence boundary
+    if 4 < index % 600 < 595:
+        assert w == list(range(index - 4, index + 4))
+
+
+def test_oks_evaluator_matches_reference_cocoeval():
+    from hupr_amd.misc.oks_eval import evaluate_keypoints
+    g = json.load(open(os.path.join(G, "oks_eval.json")))
+    np.testing.assert_allclose(evaluate_keypoints(g["gts"], g["dts"]), g["stats"], atol=1e-12)
+    np.testing.assert_allclose(evaluate_keypoints(g["gts"], g["dts"], idx_keypoint=3), g["stats_keypoint3"], atol=1e-12)
+    # identical keypoints => AP 1; a missing detection lowers recall; empty input is well-defined
+    perfect = [{"image_id": x["image_id"], "score": 1.0,
+                "keypoints": np.concatenate([np.array(x["keypoints"]), np.ones((14, 1))], 1).reshape(-1).tolist()} for x in g["gts"]]
+    assert evaluate_keypoints(g["gts"], perfect)[0] == pytest.approx(1.0)
+    assert evaluate_keypoints(g["gts"], perfect[:-10])[5] < 1.0
+    assert evaluate_keypoints([], [])[0] == -1.0
+
+
+def test_checkpoint_roundtrip_keys(tmp_path):
+    from hupr_amd.tools.base import BaseRunner
+    r = BaseRunner(Args(), _cfg())
+    r.dir = str(tmp_path)
+    r.model = torch.nn.Linear(2, 2)
+    r.optimizer = torch.optim.Adam(r.model.parameters(), lr=1e-3)
+    r.args.eval = False
+    r.saveModelWeight(0, 0.5)
+    ck = torch.load(os.path.join(r.dir, "checkpoint.pth"))
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "accuracy"}
+    assert os.path.exists(os.path.join(r.dir, "model_best.pth")) and os.path.exists(os.path.join(r.dir, "checkpoint_0.pth"))
+    r.model.weight.data.zero_()
+    r.loadModelWeight("checkpoint")            # resume path works (broken in the reference as shipped)
+    assert r.start_epoch == 0 and r.logger.showBestAP() == 0.5 and r.model.weight.abs().sum() > 0
+    r.args.eval = True
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not mounted")
+def test_adjacency_equals_live_reference():
+    from hupr_amd.models import HuPRNet
+    from oracle.model import adjacency
+    net = HuPRNet(_cfg())
+    assert torch.equal(net.radarDecoder.gcn.A, adjacency())
