@@ -1,0 +1,65 @@
+// Shared argument structures of the GEMM / implicit-GEMM convolution engines (fp32 and bf16 MFMA).
+#pragma once
+#include "hupr_common.h"
+
+namespace hupr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum AMode { A_ROWK = 0, A_CONV = 1, A_KM = 2 };
+enum BMode { B_NK = 0, B_KN = 1, B_CONVK = 2 };
+
+struct ConvGeom {
+    int Di, Hi, Wi, Ci;       // input voxels / channels taken part in the GEMM
+    int in_ld;                // floats between consecutive voxels of the input buffer
+    int Do, Ho, Wo;           // output voxels
+    int kd, kh, kw;           // taps
+    int pd, ph, pw;           // zero padding
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    // batch: z -> (z / zdiv, z % zdiv), pointer += z0 * bs0 + z1 * bs1
+    int zdiv;
+    long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    ConvGeom g;
+    const float* bias;        // [N] or null
+    const float* res;         // residual added in the epilogue, same indexing as C with res_ld
+    long res_ld, res_bs0, res_bs1;
+    int ksplit;               // >1: grid.y slices K, partial tiles go to C + slice*M*ldc... (see host)
+    long split_stride;        // floats between partial outputs
+    int accumulate;           // 1: C += result (read-modify-write; not with ksplit)
+};
+
+
+inline void fill_common(GemmArgs& a) {
+    a.zdiv = 1;
+    a.a_bs0 = a.a_bs1 = a.b_bs0 = a.b_bs1 = a.c_bs0 = a.c_bs1 = 0;
+    a.bias = nullptr;
+    a.res = nullptr;
+    a.res_ld = a.res_bs0 = a.res_bs1 = 0;
+    a.ksplit = 1;
+    a.split_stride = 0;
+    a.accumulate = 0;
+    a.g = ConvGeom{};
+}
+
+inline int check_geom(const char* who, int Bn, const ConvGeom& g, int Co, int ci_mult) {
+    HUPR_REQUIRE(Bn > 0 && g.Di > 0 && g.Hi > 0 && g.Wi > 0 && g.Do > 0 && g.Ho > 0 && g.Wo > 0,
+                 "%s: bad geometry", who);
+    HUPR_REQUIRE(g.Ci % ci_mult == 0, "%s: Cin=%d must be a multiple of %d", who, g.Ci, ci_mult);
+    HUPR_REQUIRE(g.Do < 1024 && g.Ho < 1024 && g.Wo < 1024, "%s: extent >= 1024", who);
+    HUPR_REQUIRE(g.in_ld % 4 == 0, "%s: input voxel stride %d not a multiple of 4 floats", who, g.in_ld);
+    HUPR_REQUIRE(Co > 0, "%s: Cout=%d", who, Co);
+    return HUPR_OK;
+}
+
+// split-K partial reduction + optional [Co][taps][Ci] -> (Co,Ci,taps) relayout (gemm_f32.hip)
+void launch_splitk_reduce(const float* part, float* out, long n, int splits, long split_stride, int taps, int ci,
+                          hipStream_t s);
+
+}  // namespace hupr

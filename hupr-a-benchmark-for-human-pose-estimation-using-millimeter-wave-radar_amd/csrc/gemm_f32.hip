@@ -20,40 +20,9 @@
 // loads in flight during the MFMA phase.  LDS images are chosen per mode so that both the
 // staging stores and the one-float-per-lane MFMA operand reads are bank-conflict free
 // (row stride 33 for k-contiguous tiles, dense rows for k-major tiles).
-#include "hupr_common.h"
+#include "gemm_common.h"
 
 namespace hupr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum AMode { A_ROWK = 0, A_CONV = 1, A_KM = 2 };
-enum BMode { B_NK = 0, B_KN = 1, B_CONVK = 2 };
-
-struct ConvGeom {
-    int Di, Hi, Wi, Ci;       // input voxels / channels taken part in the GEMM
-    int in_ld;                // floats between consecutive voxels of the input buffer
-    int Do, Ho, Wo;           // output voxels
-    int kd, kh, kw;           // taps
-    int pd, ph, pw;           // zero padding
-};
-
-struct GemmArgs {
-    const float* A;
-    const float* B;
-    float* C;
-    int M, N, K;
-    long lda, ldb, ldc;
-    // batch: z -> (z / zdiv, z % zdiv), pointer += z0 * bs0 + z1 * bs1
-    int zdiv;
-    long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
-    ConvGeom g;
-    const float* bias;        // [N] or null
-    const float* res;         // residual added in the epilogue, same indexing as C with res_ld
-    long res_ld, res_bs0, res_bs1;
-    int ksplit;               // >1: grid.y slices K, partial tiles go to C + slice*M*ldc... (see host)
-    long split_stride;        // floats between partial outputs
-    int accumulate;           // 1: C += result (read-modify-write; not with ksplit)
-};
 
 constexpr int BK = 32;
 
@@ -226,16 +195,17 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_f32(GemmArgs p) {
                 }
                 rb[i] = v;
             }
-        } else {   // B_CONVK: k = output voxel index, n = tap*Ci + ci; BN <= Ci and Ci % BN == 0
-            const int tap = n0 / g.Ci, ci0 = n0 - tap * g.Ci;
-            const int tw_ = tap % g.kw, tt = tap / g.kw;
-            const int th_ = tt % g.kh, td_ = tt / g.kh;
+        } else {   // B_CONVK: k = output voxel index, n = tap*Ci + ci (a tile may span several taps)
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int f = tid + 256 * i;
-                const int k = k0 + f / (BN / 4), c = (f % (BN / 4)) * 4;
+                const int k = k0 + f / (BN / 4);
+                const int n = n0 + (f % (BN / 4)) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < p.K && tap < g.kd * g.kh * g.kw) {
+                if (k < p.K && n < p.N) {
+                    const int tap = n / g.Ci, ci = n - tap * g.Ci;
+                    const int tw_ = tap % g.kw, tt = tap / g.kw;
+                    const int th_ = tt % g.kh, td_ = tt / g.kh;
                     int ow = k % g.Wo, t = k / g.Wo;
                     int oh = t % g.Ho; t /= g.Ho;
                     int od = t % g.Do, b = t / g.Do;
@@ -243,7 +213,7 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_f32(GemmArgs p) {
                     if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi &&
                         (unsigned)iw < (unsigned)g.Wi) {
                         const long vox = (((long)b * g.Di + id) * g.Hi + ih) * g.Wi + iw;
-                        v = *reinterpret_cast<const float4*>(Bg + vox * g.in_ld + ci0 + c);
+                        v = *reinterpret_cast<const float4*>(Bg + vox * g.in_ld + ci);
                     }
                 }
                 rb[i] = v;
@@ -405,29 +375,23 @@ static void launch(const GemmArgs& a, int batch, hipStream_t s) {
 
 template <int AM, int BMD>
 static void dispatch_tiles(const GemmArgs& a, int batch, hipStream_t s) {
-    // choose the N tile from N, the M tile from M
-    if (a.M <= 64) {
-        if (a.N > 64) launch<64, 128, 1, 4, AM, BMD>(a, batch, s);
-        else launch<64, 64, 2, 2, AM, BMD>(a, batch, s);
-    } else if (a.N > 64) {
-        launch<128, 128, 2, 2, AM, BMD>(a, batch, s);
+    // largest tile that still gives >= ~2 workgroups per CU (256 CUs); N tile from N
+    auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
+    if (a.N > 64) {
+        if (a.M > 64 && blocks(128, 128) >= 512) launch<128, 128, 2, 2, AM, BMD>(a, batch, s);
+        else launch<64, 128, 1, 4, AM, BMD>(a, batch, s);
     } else if (a.N > 32) {
-        launch<128, 64, 2, 2, AM, BMD>(a, batch, s);
+        if (a.M > 64 && blocks(128, 64) >= 512) launch<128, 64, 2, 2, AM, BMD>(a, batch, s);
+        else launch<64, 64, 2, 2, AM, BMD>(a, batch, s);
     } else {
         launch<128, 32, 4, 1, AM, BMD>(a, batch, s);
     }
 }
 
-static void fill_common(GemmArgs& a) {
-    a.zdiv = 1;
-    a.a_bs0 = a.a_bs1 = a.b_bs0 = a.b_bs1 = a.c_bs0 = a.c_bs1 = 0;
-    a.bias = nullptr;
-    a.res = nullptr;
-    a.res_ld = a.res_bs0 = a.res_bs1 = 0;
-    a.ksplit = 1;
-    a.split_stride = 0;
-    a.accumulate = 0;
-    a.g = ConvGeom{};
+void launch_splitk_reduce(const float* part, float* out, long n, int splits, long split_stride, int taps, int ci,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, out, n, splits, split_stride,
+                       taps, ci);
 }
 
 }  // namespace hupr
@@ -459,16 +423,6 @@ extern "C" int hupr_gemm_f32(int ta, int tb, const float* A, const float* B, flo
     return HUPR_OK;
 }
 
-static int check_geom(const char* who, int Bn, const ConvGeom& g, int Co) {
-    HUPR_REQUIRE(Bn > 0 && g.Di > 0 && g.Hi > 0 && g.Wi > 0 && g.Do > 0 && g.Ho > 0 && g.Wo > 0,
-                 "%s: bad geometry", who);
-    HUPR_REQUIRE(g.Ci % 32 == 0, "%s: Cin=%d must be a multiple of 32", who, g.Ci);
-    HUPR_REQUIRE(g.Do < 1024 && g.Ho < 1024 && g.Wo < 1024, "%s: extent >= 1024", who);
-    HUPR_REQUIRE(g.in_ld % 4 == 0, "%s: input voxel stride %d not a multiple of 4 floats", who, g.in_ld);
-    HUPR_REQUIRE(Co > 0, "%s: Cout=%d", who, Co);
-    return HUPR_OK;
-}
-
 // y[b,od,oh,ow, 0:Co] (row stride out_ld) = conv(x[b,:,:,:, 0:Ci] (voxel stride in_ld), wp[Co][taps][Ci])
 //                                          (+ bias[Co]) (+ res[..., 0:Co] (row stride res_ld))
 extern "C" int hupr_conv_fwd_f32(const float* x, const float* wp, const float* bias, const float* res,
@@ -479,7 +433,7 @@ extern "C" int hupr_conv_fwd_f32(const float* x, const float* wp, const float* b
     GemmArgs a;
     fill_common(a);
     a.g = ConvGeom{Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, kd, kh, kw, pd, ph, pw};
-    int rc = check_geom("hupr_conv_fwd_f32", Bn, a.g, Co);
+    int rc = check_geom("hupr_conv_fwd_f32", Bn, a.g, Co, 32);
     if (rc) return rc;
     HUPR_REQUIRE(Do == Di + 2 * pd - kd + 1 && Ho == Hi + 2 * ph - kh + 1 && Wo == Wi + 2 * pw - kw + 1,
                  "hupr_conv_fwd_f32: output extent does not match stride-1 convolution");
@@ -510,7 +464,7 @@ extern "C" int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, i
     GemmArgs a;
     fill_common(a);
     a.g = ConvGeom{Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, kd, kh, kw, pd, ph, pw};
-    int rc = check_geom("hupr_conv_wgrad_f32", Bn, a.g, Co);
+    int rc = check_geom("hupr_conv_wgrad_f32", Bn, a.g, Co, 32);
     if (rc) return rc;
     const long Mv = (long)Bn * Do * Ho * Wo;
     HUPR_REQUIRE(Mv < (1L << 31), "hupr_conv_wgrad_f32: too many output voxels");
@@ -518,12 +472,12 @@ extern "C" int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, i
     a.A = dy; a.B = x; a.C = reinterpret_cast<float*>(ws);
     a.M = Co; a.N = taps * Ci; a.K = (int)Mv;
     a.lda = dy_ld; a.ldb = 0; a.ldc = a.N;
-    // slice the voxel axis so the grid fills the chip: target ~1500 workgroups
-    const int bn = (Ci % 64 == 0) ? 64 : 32;
-    const int bm = (Co <= 64 && bn == 64) ? 64 : 128;
-    const long tiles = (long)((Co + bm - 1) / bm) * (a.N / bn);
+    // 128-wide n tiles (spanning taps when Ci < 128); slice the voxel axis so the grid fills the chip
+    const int bn = 128;
+    const int bm = (Co <= 64) ? 64 : 128;
+    const long tiles = (long)((Co + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     const int ktiles = (int)((Mv + BK - 1) / BK);
-    int splits = (int)((1536 + tiles - 1) / tiles);
+    int splits = (int)((1024 + tiles - 1) / tiles);
     splits = max(1, min(min(splits, 64), ktiles));
     a.ksplit = splits;
     a.split_stride = (long)a.M * a.N;
@@ -531,12 +485,8 @@ extern "C" int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, i
         return fail(HUPR_ERR_WORKSPACE, "hupr_conv_wgrad_f32: workspace %zu < %zu", ws_bytes,
                     (size_t)splits * a.split_stride * sizeof(float));
     hipStream_t s = as_stream(stream);
-    if (bn == 64) {
-        if (bm == 64) launch<64, 64, 2, 2, A_KM, B_CONVK>(a, 1, s);
-        else launch<128, 64, 2, 2, A_KM, B_CONVK>(a, 1, s);
-    } else {
-        launch<128, 32, 4, 1, A_KM, B_CONVK>(a, 1, s);    // Co <= 64 rows are masked
-    }
+    if (bm == 64) launch<64, 128, 1, 4, A_KM, B_CONVK>(a, 1, s);
+    else launch<128, 128, 2, 2, A_KM, B_CONVK>(a, 1, s);
     HUPR_LAUNCH_OK("hupr_k_gemm_f32<wgrad>");
     const long n = a.split_stride;
     hipLaunchKernelGGL(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s,

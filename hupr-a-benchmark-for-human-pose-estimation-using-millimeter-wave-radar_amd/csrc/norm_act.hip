@@ -9,7 +9,7 @@
 
 namespace hupr {
 
-constexpr int kStatBlocks = 512;
+constexpr int kStatBlocks = 256;
 
 // ------------------------------------------------------------------------------------------
 // column statistics: for every channel c: S1 = sum_r f(r,c), S2 = sum_r g(r,c)
@@ -72,6 +72,28 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const float* __restrict__
     for (int i = tid; i < 2 * C; i += 256) partial[(long)blockIdx.x * 2 * C + i] = sh[i];
 }
 
+
+// sum partial[b][2][C] over b for channel c; 256 threads = 4 row-groups x 64 channels per block
+__device__ __forceinline__ bool reduce_partials(const double* __restrict__ partial, int nblk, int C, int& c,
+                                                double& s1, double& s2) {
+    __shared__ double sh1[4][64], sh2[4][64];
+    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    c = blockIdx.x * 64 + cl;
+    double a = 0.0, b2 = 0.0;
+    if (c < C) {
+        for (int b = g; b < nblk; b += 4) {
+            a += partial[(long)b * 2 * C + c];
+            b2 += partial[(long)b * 2 * C + C + c];
+        }
+    }
+    sh1[g][cl] = a;
+    sh2[g][cl] = b2;
+    __syncthreads();
+    s1 = (sh1[0][cl] + sh1[1][cl]) + (sh1[2][cl] + sh1[3][cl]);
+    s2 = (sh2[0][cl] + sh2[1][cl]) + (sh2[2][cl] + sh2[3][cl]);
+    return g == 0 && c < C;
+}
+
 // forward finalize: batch mean / biased var -> save_mean, save_invstd, scale, shift; running stats
 __global__ void hupr_k_bn_finalize_fwd(const double* __restrict__ partial, int nblk, long M, int C,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -79,13 +101,9 @@ __global__ void hupr_k_bn_finalize_fwd(const double* __restrict__ partial, int n
                                        float momentum, float eps, float* __restrict__ save_mean,
                                        float* __restrict__ save_invstd, float* __restrict__ scale,
                                        float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partial[(long)b * 2 * C + c];
-        s2 += partial[(long)b * 2 * C + C + c];
-    }
+    int c;
+    double s1, s2;
+    if (!reduce_partials(partial, nblk, C, c, s1, s2)) return;
     const double mean = s1 / (double)M;
     double var = s2 / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -146,13 +164,9 @@ __global__ __launch_bounds__(256) void hupr_k_scale_shift_act(const float* __res
 __global__ void hupr_k_bn_finalize_bwd(const double* __restrict__ partial, int nblk, int C,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ sums /* [2][C] floats */) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partial[(long)b * 2 * C + c];
-        s2 += partial[(long)b * 2 * C + C + c];
-    }
+    int c;
+    double s1, s2;
+    if (!reduce_partials(partial, nblk, C, c, s1, s2)) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     sums[c] = (float)s1;
@@ -240,10 +254,9 @@ __global__ void hupr_k_sum_partials(const double* __restrict__ partial, int n, f
 }
 
 __global__ void hupr_k_colsum_final(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 2 * C + c];
+    int c;
+    double s, unused;
+    if (!reduce_partials(partial, nblk, C, c, s, unused)) return;
     out[c] = (float)s;
 }
 
@@ -276,7 +289,7 @@ extern "C" int hupr_bn_train_stats_f32(const float* x, long M, int C, const floa
     hipLaunchKernelGGL(hupr_k_colstats<0>, dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, nullptr, nullptr,
                        nullptr, nullptr, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + 127) / 128), dim3(128), 0, s, partial, nblk, M, C, gamma,
+    hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, M, C, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd");
     return HUPR_OK;
@@ -322,7 +335,7 @@ extern "C" int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float
     hipLaunchKernelGGL(hupr_k_colstats<1>, dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, dy, y_mask, save_mean,
                        save_invstd, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<1>");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + 127) / 128), dim3(128), 0, s, partial, nblk, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, C, dgamma, dbeta, sums);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd");
     const long n4 = M * C / 4;
     hipLaunchKernelGGL(hupr_k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, s, dy, y_mask, x, save_mean, save_invstd,
@@ -366,7 +379,7 @@ extern "C" int hupr_colsum_f32(const float* x, long M, int C, float* out, void* 
     hipLaunchKernelGGL(hupr_k_colstats<0>, dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, nullptr, nullptr,
                        nullptr, nullptr, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
-    hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + 127) / 128), dim3(128), 0, s, partial, nblk, C, out);
+    hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, C, out);
     HUPR_LAUNCH_OK("hupr_k_colsum_final");
     return HUPR_OK;
 }

@@ -124,12 +124,19 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__
 
 __global__ void hupr_k_mnet_bwd_final(const float* __restrict__ partial, int nblk, float* __restrict__ dw,
                                       float* __restrict__ dbias) {
-    const int i = threadIdx.x;
-    if (i >= kNF * 5) return;
+    __shared__ double red[4];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * kNF * 5 + i];
-    if (i < kNF * 4) dw[i] = (float)s;
-    else dbias[i - kNF * 4] = (float)s;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * kNF * 5 + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        if (i < kNF * 4) dw[i] = (float)s;
+        else dbias[i - kNF * 4] = (float)s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -229,7 +236,7 @@ extern "C" int hupr_mnet_bwd_f32(const float* x, const float* w, const float* bi
     hipLaunchKernelGGL(hupr_k_mnet_bwd, dim3(grid), dim3(256), 0, s, x, w, bias, dy, n_bg, pixels,
                        reinterpret_cast<float*>(ws));
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd");
-    hipLaunchKernelGGL(hupr_k_mnet_bwd_final, dim3(1), dim3(256), 0, s, reinterpret_cast<const float*>(ws), grid, dw, dbias);
+    hipLaunchKernelGGL(hupr_k_mnet_bwd_final, dim3(kNF * 5), dim3(256), 0, s, reinterpret_cast<const float*>(ws), grid, dw, dbias);
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd_final");
     return HUPR_OK;
 }

@@ -13,6 +13,19 @@ from . import runtime as rt
 
 _ws_cache = {}
 CONV_PROBE = None      # bench.py installs a callable(x, co, k) -> (start_event, end_event) | None
+MATH = "f32"           # matrix-pipe arithmetic of the GEMM-shaped ops: "f32" (parity path) or "bf16"
+
+
+def set_math(mode):
+    """Select v_mfma_f32_32x32x2_f32 ("f32", exact) or v_mfma_f32_32x32x16_bf16 ("bf16", fp32 accumulate)."""
+    global MATH
+    if mode not in ("f32", "bf16"):
+        raise ValueError("math mode must be 'f32' or 'bf16'")
+    MATH = mode
+
+
+def _fn(stem):
+    return getattr(rt.lib(), "hupr_%s_%s" % (stem, MATH))
 
 
 def workspace(nbytes, device):
@@ -50,7 +63,7 @@ def _conv_raw(x, wp, bias, res, co, k, pad, out_extent):
     ev = CONV_PROBE(x, co, k) if CONV_PROBE is not None else None
     if ev is not None:
         ev[0].record()
-    rt.check(rt.lib().hupr_conv_fwd_f32(
+    rt.check(_fn("conv_fwd")(
         rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
         rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, Do, Ho, Wo, co, co,
         co, k[0], k[1], k[2], pad[0], pad[1], pad[2], 0, rt.stream()))
@@ -106,7 +119,7 @@ class ConvFn(torch.autograd.Function):
             dw = torch.empty_like(weight)
             nbytes = L.hupr_conv_wgrad_ws_bytes(B, Do, Ho, Wo, Ci, Co, k[0], k[1], k[2])
             ws = workspace(nbytes, x.device)
-            rt.check(L.hupr_conv_wgrad_f32(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Do, Ho, Wo,
+            rt.check(_fn("conv_wgrad")(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Do, Ho, Wo,
                                            Co, Co, k[0], k[1], k[2], pad[0], pad[1], pad[2], rt.ptr(ws),
                                            ws.numel(), rt.stream()))
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -299,7 +312,7 @@ def gemm(ta, tb, A, B, M, N, K, lda, ldb, batch, a_bs, b_bs, out=None, res=None,
     """Batched row-major fp32 GEMM on raw strides; returns C (batch, M, N) dense."""
     if out is None:
         out = torch.empty((batch, M, N), dtype=torch.float32, device=A.device)
-    rt.check(rt.lib().hupr_gemm_f32(ta, tb, rt.ptr(A), rt.ptr(B), rt.ptr(out), M, N, K, lda, ldb, N, batch, a_bs, b_bs,
+    rt.check(_fn("gemm")(ta, tb, rt.ptr(A), rt.ptr(B), rt.ptr(out), M, N, K, lda, ldb, N, batch, a_bs, b_bs,
                                    M * N, rt.ptr(res) if res is not None else None, N, M * N if res is not None else 0,
                                    1 if accumulate else 0, rt.stream()))
     return out

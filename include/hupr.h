@@ -95,6 +95,20 @@ int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, int Bn, int 
 /* w (Co, Ci, taps) parameter layout -> mode 0: [Co][taps][Ci] (forward), mode 1: [Ci][taps reversed][Co] (dgrad) */
 int hupr_pack_conv_weights_f32(const float* w, float* wp, int Co, int Ci, int taps, int mode, hupr_stream_t stream);
 
+/* bf16-MFMA variants of the three entry points above: identical signatures and fp32 tensors in HBM;
+ * operands are rounded to bf16 while staged into LDS, products accumulate in fp32 (16x the matrix rate).
+ * The fp32 entry points remain the parity path (north_star: fp32 within 1e-3; bf16 for configs C2/C4). */
+int hupr_gemm_bf16(int ta, int tb, const float* A, const float* B, float* C, int M, int N, int K, long lda,
+                   long ldb, long ldc, int batch, long a_batch_stride, long b_batch_stride, long c_batch_stride,
+                   const float* res, long res_ld, long res_batch_stride, int accumulate, hupr_stream_t stream);
+int hupr_conv_fwd_bf16(const float* x, const float* wp, const float* bias, const float* res, float* y, int Bn,
+                       int Di, int Hi, int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int out_ld,
+                       int res_ld, int kd, int kh, int kw, int pd, int ph, int pw, int accumulate,
+                       hupr_stream_t stream);
+int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int Di, int Hi, int Wi, int Ci,
+                         int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
+                         int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream);
+
 /* (a4) BatchNorm3d pieces (models/layers.py:46,49,53); x is [M voxels][C]. */
 size_t hupr_bn_ws_bytes(int C);
 int hupr_bn_train_stats_f32(const float* x, long M, int C, const float* gamma, const float* beta,

@@ -327,3 +327,67 @@ def test_adam_step_matches_torch():
         rt.check(rt.lib().hupr_adam_step_f32(rt.ptr(pd), rt.ptr(gd), rt.ptr(m), rt.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-4,
                                             step, 1.0, rt.stream()))
     close(pd, pr, 1e-6, "adam")
+
+
+# ---- bf16 matrix pipe (fp32 tensors, bf16 operands, fp32 accumulate): looser, rounding-level gates --------
+@pytest.fixture
+def bf16_math():
+    from hupr_amd import functional as F_
+    F_.set_math("bf16")
+    yield
+    F_.set_math("f32")
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bf16(case, bf16_math):
+    """Against an fp64 convolution of the bf16-ROUNDED operands the kernel must agree to fp32-accumulation
+    accuracy (this checks indexing/transposes exactly); against unrounded operands to bf16 accuracy."""
+    from hupr_amd import functional as F_
+    B, Ci, Co, D, H, W, k, pad, has_bias = case
+    x = rnd(B, Ci, D, H, W, seed=1)
+    w = rnd(Co, Ci, *k, seed=2, scale=(Ci * np.prod(k)) ** -0.5)
+    b = rnd(Co, seed=3) if has_bias else None
+    gy = rnd(B, Co, D + 2 * pad[0] - k[0] + 1, H + 2 * pad[1] - k[1] + 1, W + 2 * pad[2] - k[2] + 1, seed=4)
+    xq, wq, gq = _bf16_round(x), _bf16_round(w), _bf16_round(gy)
+    yr = F.conv3d(xq, wq, b.double() if has_bias else None, 1, pad)
+    # gradients w.r.t. x and w with rounded co-operands
+    xr, wr = xq.clone().requires_grad_(True), wq.clone().requires_grad_(True)
+    F.conv3d(xr, wq, None, 1, pad).backward(gq)
+    F.conv3d(xq, wr, None, 1, pad).backward(gq)
+    xg, wg = cl(x).cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if has_bias else None
+    y = F_.conv(xg, wg, bg, None, pad)
+    close(ncdhw(y), yr, 2e-5, "bf16 conv fwd")
+    y.backward(cl(gy).cuda())
+    close(ncdhw(xg.grad), xr.grad, 2e-5, "bf16 conv dgrad")
+    close(wg.grad, wr.grad, 5e-5, "bf16 conv wgrad")
+    full = F.conv3d(x.double(), w.double(), b.double() if has_bias else None, 1, pad)
+    close(ncdhw(y), full, 2e-2, "bf16 conv vs unrounded")
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_bf16(case, bf16_math):
+    from hupr_amd import functional as F_
+    ta, tb, batch, M, N, K = case
+    A = rnd(batch, *((K, M) if ta else (M, K)), seed=8)
+    Bm = rnd(batch, *((N, K) if tb else (K, N)), seed=9)
+    Aq, Bq = _bf16_round(A), _bf16_round(Bm)
+    ref = torch.matmul(Aq.transpose(1, 2) if ta else Aq, Bq.transpose(1, 2) if tb else Bq)
+    lda, ldb = (M if ta else K), (K if tb else N)
+    res = rnd(batch, M, N, seed=10)
+    out = F_.gemm(ta, tb, A.cuda(), Bm.cuda(), M, N, K, lda, ldb, batch, A[0].numel(), Bm[0].numel(), res=res.cuda())
+    close(out, ref + res.double(), 2e-5, "bf16 gemm %r" % (case,))
+
+
+def test_attention_bf16(bf16_math):
+    from hupr_amd import functional as F_
+    B, N, C = 2, 256, 128
+    k, q, v = rnd(B, N, C, seed=22, scale=C ** -0.25), rnd(B, N, C, seed=23, scale=C ** -0.25), rnd(B, N, C, seed=24)
+    s = torch.einsum("bjc,bkc->bjk", k.double(), q.double())
+    ref = torch.einsum("bjc,bjk->bkc", v.double(), F.softmax(s, 1)) + v.double()
+    out = F_.AttentionFn.apply(k.cuda(), q.cuda(), v.cuda(), True)
+    close(out, ref, 2e-2, "bf16 attention")
