@@ -1,0 +1,290 @@
+// LDS halo-tiled 3x3x3 / 1x3x3 "same" convolution on the bf16 matrix pipe (fp32 tensors, fp32 accumulate).
+//
+// The implicit-GEMM kernel (gemm_bf16.hip) re-gathers every im2col row for each of the 27 taps, so at
+// bf16 MFMA rates it is bound by global->LDS bytes (~23 B/clk/CU sustained, ~12 % matrix utilisation).
+// Here a workgroup owns a spatial tile of 128 output voxels (2x8x8, or 1x8x16 for 2-D maps) and a
+// 64- (or 32-) wide slice of output channels:
+//   * the input halo ((TD+kd-1) x 10 x (TW+2) voxels x KC channels) is loaded ONCE per channel
+//     chunk, rounded to bf16 and kept in LDS; all taps read their shifted A fragments from it
+//     (lane = output voxel, address = halo base + tap offset, ds_read_b128 of 8 channels);
+//   * the per-tap weight tile [BN][KC] (pre-packed bf16, L2 resident) is double-buffered through LDS,
+//     next tap's tile in flight during the MFMAs, one barrier per tap;
+//   * A bytes from global drop from 27x to ~3x the tile, so the kernel is matrix/LDS bound.
+// Used for forward and (with tap-reversed, transposed weights) the input gradient.
+#include "gemm_common.h"
+
+namespace hupr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct HaloArgs {
+    const float* x;          // [Bn][D][H][W] voxels, in_ld floats apart, Ci channels used
+    const __bf16* wp;        // packed bf16 weights [Co][T][Ci]
+    const float* bias;       // [Co] or null
+    const float* res;        // residual (voxel stride res_ld) or null
+    float* y;                // [Bn][D][H][W] voxels, out_ld floats apart
+    int Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld;
+    int kd;                  // 1 or 3 (kh = kw = 3)
+    int TD, log2TW;          // tile: TD x 8 x (1 << log2TW), TD * 8 * TW == 128
+    int nd, nh, nw;          // tiles per axis
+    int n_co_tiles;
+};
+
+constexpr int kHaloMaxVox = 4 * 10 * 10;     // (2+2) x (8+2) x (8+2); the 2-D tile needs 1 x 10 x 18 = 180
+
+template <int BN, int KC>
+__global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
+    // KC = 64: unpadded 128-byte rows whose 16-byte chunks are XOR-swizzled — halo rows by
+    //   key = ((hx >> 1) & 3) | ((hy & 1) << 2), weight rows by key = (n >> 1) & 7 — which makes every
+    //   ds_read_b128 lane group (rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of the 32-row fragment) hit 16
+    //   distinct slots for all 27 tap shifts (a padded pitch cannot: the shifted halo rows are 3-way conflicted).
+    // KC = 32 (only the Cin = 32 stem): padded 80-byte rows.
+    constexpr bool SWZ = (KC == 64);
+    constexpr int LDK = SWZ ? KC : KC + 8;            // bf16 elements per LDS row
+    constexpr int WN = (BN == 64) ? 2 : 1, WM = 4 / WN;
+    constexpr int WTM = 128 / WM;                     // rows per wave: 64 (BN=64) or 32 (BN=32)
+    constexpr int TM = WTM / 32;
+    constexpr int C8 = KC / 8;                        // 8-channel groups per row
+    constexpr int B_LD = (BN * C8) / 256;             // 16-byte weight loads per thread per tap
+    static_assert((BN * C8) % 256 == 0 || BN * C8 == 128, "weight tile must split evenly over the threads");
+
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[kHaloMaxVox * LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int TW = 1 << p.log2TW, TD = p.TD;
+    const int pd = p.kd >> 1;
+    const int HD = TD + p.kd - 1, HH = 10, HW = TW + 2;
+    const int T = p.kd * 9;
+
+    // block -> (spatial tile, co tile); co fastest so consecutive workgroups reuse the same halo via L2
+    // XCD-aware order: workgroup b runs on XCD b % 8, so each XCD gets a contiguous run of tiles and spatial
+    // neighbours (which share halo voxels) meet in the same L2 instead of re-fetching through the fabric.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int cot = bid % p.n_co_tiles;
+    int st = bid / p.n_co_tiles;
+    const int twi = st % p.nw; st /= p.nw;
+    const int thi = st % p.nh; st /= p.nh;
+    const int tdi = st % p.nd;
+    const int b = st / p.nd;
+    const int d0 = tdi * TD, h0 = thi * 8, w0 = twi * TW;
+    const int n0 = cot * BN;
+
+    // A fragment rows of this lane: tile voxel -> halo index of its (0,0,0) tap
+    int abase[TM], awx[TM], ahy[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + lr;
+        const int wx = row & (TW - 1), hy = (row >> p.log2TW) & 7, dz = row >> (p.log2TW + 3);
+        abase[i] = ((dz * HH + hy) * HW + wx) * LDK;
+        awx[i] = wx;
+        ahy[i] = hy;
+    }
+    const int bkey = ((wn * 32 + lr) >> 1) & 7;       // weight row swizzle key of this lane's B fragment row
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    constexpr int B_LD_ = (B_LD > 0) ? B_LD : 1;     // 32x32 tile: 128 loads, threads 128..255 duplicate
+    static_assert(B_LD_ <= 2, "at most two 16-byte weight loads per thread per tap");
+    uint4 rb0a, rb0b, rb1a, rb1b;      // two register sets: weight tiles are fetched two taps ahead
+    // Branch-free on purpose (rows past Co are clamped, their columns are never stored): with straight-line
+    // loads hipcc emits counted s_waitcnt vmcnt(N) and the two-tap prefetch really stays in flight.
+    const __bf16* bsrc[B_LD_];
+    int bdst[B_LD_];
+#pragma unroll
+    for (int i = 0; i < B_LD_; ++i) {
+        const int f = (tid + 256 * i) % (BN * C8);
+        const int n = min(n0 + f / C8, p.Co - 1);
+        bsrc[i] = p.wp + (long)n * T * p.Ci + (f % C8) * 8;
+        bdst[i] = (f / C8) * LDK + (SWZ ? (((f % C8) ^ ((f / C8) >> 1)) & 7) : (f % C8)) * 8;
+    }
+    // (macros with named scalars, not lambdas over a pointer or loops over an array: anything the compiler
+    //  cannot index statically is demoted to scratch memory and the prefetch degenerates)
+#define HUPR_LOAD_B(RA, RBB, tap, c0)                                                            \
+    RA = *reinterpret_cast<const uint4*>(bsrc[0] + (long)(tap) * p.Ci + (c0));                   \
+    if constexpr (B_LD_ > 1) RBB = *reinterpret_cast<const uint4*>(bsrc[B_LD_ - 1] + (long)(tap) * p.Ci + (c0));
+#define HUPR_STORE_B(RA, RBB, buf)                                                               \
+    *reinterpret_cast<uint4*>(&Bs[buf][bdst[0]]) = RA;                                           \
+    if constexpr (B_LD_ > 1) *reinterpret_cast<uint4*>(&Bs[buf][bdst[B_LD_ - 1]]) = RBB;
+
+    auto compute_tap = [&](int tap) {
+        const int tw_ = tap % 3, tt = tap / 3;
+        const int th_ = tt % 3, td_ = tt / 3;
+        const int toff = ((td_ * HH + th_) * HW + tw_) * LDK;
+        const __bf16* Bt = Bs[tap & 1];
+        int akey[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) akey[i] = (((awx[i] + tw_) >> 1) & 3) | (((ahy[i] + th_) & 1) << 2);
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            const int cw = ks * 2 + lh;                 // 16-byte chunk wanted by this lane half
+            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(&Bt[(wn * 32 + lr) * LDK + (SWZ ? (cw ^ bkey) : cw) * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&Hs[abase[i] + toff + (SWZ ? (cw ^ akey[i]) : cw) * 8]);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nvox = HD * HH * HW;
+    for (int c0 = 0; c0 < p.Ci; c0 += KC) {
+        HUPR_LOAD_B(rb0a, rb0b, 0, c0)
+        if (T > 1) { HUPR_LOAD_B(rb1a, rb1b, 1, c0) }
+        if (c0 > 0) __syncthreads();            // previous chunk's readers are done with Hs / Bs
+        // ---- halo chunk: global fp32 -> bf16 LDS, zero outside the tensor.  Loads are issued in batches of
+        // four items per thread before any is converted/stored, so their latencies overlap. -------------------
+        for (int it0 = tid; it0 < nvox * C8; it0 += 4 * 256) {
+            float4 va[4], vc[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * 256;
+                va[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                vc[u] = va[u];
+                dst[u] = -1;
+                if (it < nvox * C8) {
+                    const int vox = it / C8, c8 = it - vox * C8;
+                    const int hx = vox % HW;
+                    const int t = vox / HW;
+                    const int hy = t % HH, hz = t / HH;
+                    const int d = d0 + hz - pd, h = h0 + hy - 1, w = w0 + hx - 1;
+                    dst[u] = vox * LDK + (SWZ ? (c8 ^ (((hx >> 1) & 3) | ((hy & 1) << 2))) : c8) * 8;
+                    if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+                        const float* src = p.x + ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8;
+                        va[u] = *reinterpret_cast<const float4*>(src);
+                        vc[u] = *reinterpret_cast<const float4*>(src + 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dst[u] >= 0) {
+                    bf16x8 v;
+                    v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;
+                    v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;
+                    *reinterpret_cast<bf16x8*>(&Hs[dst[u]]) = v;
+                }
+            }
+        }
+        HUPR_STORE_B(rb0a, rb0b, 0)
+        __syncthreads();
+        // ---- taps: iteration `tap` computes from Bs[tap&1]; the tile of tap+1 sits in one register set
+        // (stored to LDS at the end of this iteration), the tile of tap+2 is being fetched into the other ----
+        for (int tap = 0; tap < T; tap += 2) {
+            // even tap: rb1 holds tap+1, fetch tap+2 into rb0
+            if (tap + 2 < T) { HUPR_LOAD_B(rb0a, rb0b, tap + 2, c0) }
+            compute_tap(tap);
+            if (tap + 1 < T) { HUPR_STORE_B(rb1a, rb1b, 1) }
+            __syncthreads();
+            if (tap + 1 >= T) break;
+            // odd tap: rb0 holds tap+2, fetch tap+3 into rb1
+            if (tap + 3 < T) { HUPR_LOAD_B(rb1a, rb1b, tap + 3, c0) }
+            compute_tap(tap + 1);
+            if (tap + 2 < T) { HUPR_STORE_B(rb0a, rb0b, 0) }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (tile voxel) ----
+    const int col = n0 + wn * 32 + lr;
+    if (col < p.Co) {
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int wx = row & (TW - 1), hy = (row >> p.log2TW) & 7, dz = row >> (p.log2TW + 3);
+                const long m = (((long)b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx;
+                float v = acc[i][r] + bv;
+                if (p.res) v += p.res[m * p.res_ld + col];
+                p.y[m * p.out_ld + col] = v;
+            }
+        }
+    }
+}
+
+// w (Co, Ci, taps) fp32 parameter layout -> bf16  mode 0: [Co][tap][Ci]   mode 1: [Ci][taps-1-tap][Co]
+__global__ void hupr_k_pack_weights_bf16(const float* __restrict__ w, __bf16* __restrict__ wp, int co_n, int ci_n,
+                                         int taps, int mode) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)co_n * ci_n * taps;
+    if (i >= n) return;
+    if (mode == 0) {
+        const int ci = i % ci_n;
+        const long t = i / ci_n;
+        const int tap = t % taps, co = t / taps;
+        wp[i] = (__bf16)w[((long)co * ci_n + ci) * taps + tap];
+    } else {
+        const int co = i % co_n;
+        const long t = i / co_n;
+        const int tapf = t % taps, ci = t / taps;
+        wp[i] = (__bf16)w[((long)co * ci_n + ci) * taps + (taps - 1 - tapf)];
+    }
+}
+
+}  // namespace hupr
+
+using namespace hupr;
+
+extern "C" int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
+                                           hupr_stream_t stream) {
+    HUPR_REQUIRE(w && wp_bf16 && Co > 0 && Ci > 0 && taps > 0 && (mode == 0 || mode == 1),
+                 "hupr_pack_conv_weights_bf16: bad argument");
+    const long n = (long)Co * Ci * taps;
+    hipLaunchKernelGGL(hupr_k_pack_weights_bf16, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w,
+                       reinterpret_cast<__bf16*>(wp_bf16), Co, Ci, taps, mode);
+    HUPR_LAUNCH_OK("hupr_k_pack_weights_bf16");
+    return HUPR_OK;
+}
+
+// 1 if hupr_conv3x3_halo_bf16 supports this geometry (else use hupr_conv_fwd_bf16)
+extern "C" int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw) {
+    if (kh != 3 || kw != 3 || ph != 1 || pw != 1) return 0;
+    if (!((kd == 3 && pd == 1) || (kd == 1 && pd == 0))) return 0;
+    if (Ci % 32 != 0 || H % 8 != 0) return 0;
+    if (kd == 3) return (D % 2 == 0 && W % 8 == 0) ? 1 : 0;
+    return (D == 1 && W % 16 == 0) ? 1 : 0;
+}
+
+// y = conv3x3(x) (+bias) (+res): stride 1, "same" padding; kd = 3 (pad 1) or kd = 1.
+// wp_bf16: weights packed by hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci]).
+extern "C" int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const float* bias, const float* res, float* y,
+                                      int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld,
+                                      int kd, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && wp_bf16 && y, "hupr_conv3x3_halo_bf16: null pointer");
+    HUPR_REQUIRE(hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1), "hupr_conv3x3_halo_bf16: unsupported geometry");
+    HUPR_REQUIRE(Bn > 0 && Co > 0 && in_ld % 4 == 0, "hupr_conv3x3_halo_bf16: bad argument");
+    HaloArgs a;
+    a.x = x; a.wp = reinterpret_cast<const __bf16*>(wp_bf16); a.bias = bias; a.res = res; a.y = y;
+    a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.out_ld = out_ld; a.res_ld = res_ld;
+    a.kd = kd;
+    if (kd == 3) { a.TD = 2; a.log2TW = 3; } else { a.TD = 1; a.log2TW = 4; }
+    a.nd = D / a.TD; a.nh = H / 8; a.nw = W >> a.log2TW;
+    const bool n32 = (Co <= 32);
+    const int bn = n32 ? 32 : 64;
+    a.n_co_tiles = (Co + bn - 1) / bn;
+    const long blocks = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
+    HUPR_REQUIRE(blocks < (1L << 31), "hupr_conv3x3_halo_bf16: grid too large");
+    hipStream_t s = as_stream(stream);
+    if (Ci % 64 == 0) {
+        if (n32) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<32, 64>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<64, 64>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else {
+        if (n32) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<64, 32>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
+    HUPR_LAUNCH_OK("hupr_k_conv_halo_bf16");
+    return HUPR_OK;
+}

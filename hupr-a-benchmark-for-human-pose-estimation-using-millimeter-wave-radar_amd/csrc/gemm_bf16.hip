@@ -73,7 +73,13 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_bf16(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed), so give each XCD a contiguous run of
+    // tiles — neighbouring output tiles share im2col halos / operand panels through that XCD's L2.
+    int tile = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
     const int z = blockIdx.z, z0 = z / p.zdiv, z1 = z % p.zdiv;
     const float* __restrict__ Ag = p.A + z0 * p.a_bs0 + z1 * p.a_bs1;

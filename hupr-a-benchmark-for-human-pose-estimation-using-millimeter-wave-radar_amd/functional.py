@@ -56,11 +56,41 @@ def pack_weights(w, mode):
     return wp
 
 
-def _conv_raw(x, wp, bias, res, co, k, pad, out_extent):
+def pack_weights_bf16(w, mode):
+    co, ci = w.shape[0], w.shape[1]
+    taps = int(np.prod(w.shape[2:]))
+    wp = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+    rt.check(rt.lib().hupr_pack_conv_weights_bf16(rt.ptr(_c(w)), rt.ptr(wp), co, ci, taps, mode, rt.stream()))
+    return wp
+
+
+USE_HALO = True        # bf16 mode: LDS halo-tiled kernel for 3x3(x3) "same" convolutions
+
+
+def _halo_ok(x, k, pad):
+    if MATH != "bf16" or not USE_HALO:
+        return False
+    B, Di, Hi, Wi, Ci = _vox(x)
+    return bool(rt.lib().hupr_conv3x3_halo_supported(Di, Hi, Wi, Ci, k[0], k[1], k[2], pad[0], pad[1], pad[2]))
+
+
+def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent):
+    """weight: parameter-layout tensor (Co', Ci', taps...) packed here (mode 0 forward / 1 input gradient)."""
     B, Di, Hi, Wi, Ci = _vox(x)
     Do, Ho, Wo = out_extent
     y = torch.empty((B, Do, Ho, Wo, co), dtype=torch.float32, device=x.device)
     ev = CONV_PROBE(x, co, k) if CONV_PROBE is not None else None
+    if _halo_ok(x, k, pad):
+        wp = pack_weights_bf16(weight, mode)
+        if ev is not None:
+            ev[0].record()
+        rt.check(rt.lib().hupr_conv3x3_halo_bf16(
+            rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
+            rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
+        if ev is not None:
+            ev[1].record()
+        return y
+    wp = pack_weights(weight, mode)
     if ev is not None:
         ev[0].record()
     rt.check(_fn("conv_fwd")(
@@ -88,8 +118,7 @@ class ConvFn(torch.autograd.Function):
         B, Di, Hi, Wi, Ci = _vox(x)
         assert weight.shape[1] == Ci, (weight.shape, x.shape)
         out_extent = (Di + 2 * pad[0] - k[0] + 1, Hi + 2 * pad[1] - k[1] + 1, Wi + 2 * pad[2] - k[2] + 1)
-        wp = pack_weights(weight, 0)
-        y = _conv_raw(x, wp, bias, _c(res) if res is not None else None, weight.shape[0], k, pad, out_extent)
+        y = _conv_raw(x, weight, 0, bias, _c(res) if res is not None else None, weight.shape[0], k, pad, out_extent)
         ctx.save_for_backward(x, weight)
         ctx.pad, ctx.k, ctx.has_bias, ctx.has_res = pad, k, bias is not None, res is not None
         return y
@@ -112,10 +141,14 @@ class ConvFn(torch.autograd.Function):
                 dyp[..., :Co] = dy
                 wsrc = torch.zeros((co_pad,) + tuple(weight.shape[1:]), dtype=torch.float32, device=dy.device)
                 wsrc[:Co] = weight
-            wpd = pack_weights(wsrc, 1)           # [Ci][taps reversed][Co]
             dpad = (k[0] - 1 - pad[0], k[1] - 1 - pad[1], k[2] - 1 - pad[2])
-            dx = _conv_raw(dyp, wpd, None, None, Ci, k, dpad, (Di, Hi, Wi))
-        if ctx.needs_input_grad[1]:
+            dx = _conv_raw(dyp, wsrc, 1, None, None, Ci, k, dpad, (Di, Hi, Wi))      # packs [Ci][taps reversed][Co]
+        if ctx.needs_input_grad[1] and _halo_ok(x, k, pad) and Ci % 64 == 0 and Co % 8 == 0:
+            dw = torch.empty_like(weight)
+            ws = workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, k[0]), x.device)
+            rt.check(L.hupr_conv3x3_wgrad_halo_bf16(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Co, Co, k[0],
+                                                    rt.ptr(ws), ws.numel(), rt.stream()))
+        elif ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             nbytes = L.hupr_conv_wgrad_ws_bytes(B, Do, Ho, Wo, Ci, Co, k[0], k[1], k[2])
             ws = workspace(nbytes, x.device)

@@ -109,6 +109,22 @@ int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int
                          int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
                          int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream);
 
+/* LDS halo-tiled 3x3x3 / 1x3x3 "same" convolution on the bf16 matrix pipe (forward, and input gradient
+ * with mode-1 packed weights): the input halo of a 128-voxel tile is staged once as bf16 and all taps
+ * run from LDS.  wp_bf16 from hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci] bf16). */
+int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
+                                hupr_stream_t stream);
+int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw);
+int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const float* bias, const float* res, float* y,
+                           int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd,
+                           hupr_stream_t stream);
+
+/* Weight gradient of the same 3x3(x3) convolutions, halo-tiled (x halo + dy tile staged once per 128-voxel tile,
+ * operands transposed by ds_read_b64_tr_b16).  Requires Ci % 64 == 0; dw in parameter layout (Co,Ci,kd,3,3). */
+size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd);
+int hupr_conv3x3_wgrad_halo_bf16(const float* x, const float* dy, float* dw, int Bn, int D, int H, int W, int Ci,
+                                 int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes, hupr_stream_t stream);
+
 /* (a4) BatchNorm3d pieces (models/layers.py:46,49,53); x is [M voxels][C]. */
 size_t hupr_bn_ws_bytes(int C);
 int hupr_bn_train_stats_f32(const float* x, long M, int C, const float* gamma, const float* beta,
