@@ -1,0 +1,349 @@
+// Fused (flash-style) MSCSA attention on the bf16 matrix pipe — no N x N matrix ever reaches HBM.
+//
+// Reference semantics (models/layers.py:126-133), token-major fp32 tensors (B, N, C):
+//     S[j,q] = sum_c K[j,c] Q[q,c]     P = softmax over keys j     out[q,c] = sum_j P[j,q] V[j,c] (+ V[q,c])
+// i.e. standard single-head attention with scale 1; C = 64 or 128, N % 128 == 0.
+//
+// All tiles are computed in the "keys x queries" orientation S^T = K Q^T so that one lane owns one query
+// column: the online-softmax statistics (running max / sum, LSE, D = rowsum(dO o O)) are lane-local
+// scalars and the only cross-lane step is one exchange between the two half-waves.  A probability tile
+// in its MFMA accumulator layout is ALREADY a valid B operand for the next MFMA (K slot 8h+i <-> key
+// 16u + 8(i>>2) + 4h + (i&3)); the matching A operand (V^T, K^T, dO^T, Q^T: rows = channels, K = tokens)
+// is produced from the row-major LDS image by ds_read_b64_tr_b16 with exactly those rows.
+//
+//   forward : per 128-query workgroup (32 per wave) stream 64-key tiles: S^T, online softmax, O^T += V^T P^T
+//   backward: dQ kernel (same walk): P^T = exp(S^T - LSE), dP^T = V dO^T, dS^T = P^T o (dP^T - D),
+//             dQ^T += K^T dS^T;   dK/dV kernel (per 128-key workgroup, stream 64-query tiles):
+//             S = Q K^T, P, dP = dO V^T, dS;  dV^T += dO^T P,  dK^T += Q^T dS   (+ dO for the residual)
+#include "gemm_common.h"
+
+namespace hupr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+struct Img {   // row-major bf16 LDS image [rows][D] with XOR-swizzled 16-byte chunks
+    static constexpr int CH = D / 8;
+    static __device__ __forceinline__ int key(int row) { return (D == 64) ? ((row >> 1) & 7) : (row & 15); }
+    static __device__ __forceinline__ int off(int row, int chunk) { return row * D + ((chunk ^ key(row)) << 3); }   // bf16 elements
+};
+
+// stage ROWS x D fp32 rows (row stride ld) into a swizzled bf16 image; rows >= n_valid are zero
+template <int D, int ROWS>
+__device__ __forceinline__ void stage_rows(__bf16* img, const float* __restrict__ src, long ld, int tid) {
+    constexpr int CH = D / 8, ITEMS = ROWS * CH, PER = ITEMS / 256;
+    static_assert(ITEMS % 256 == 0, "tile must split over 256 threads");
+    float4 a[PER], c[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+        const float* s = src + (long)row * ld + ch * 8;
+        a[i] = *reinterpret_cast<const float4*>(s);
+        c[i] = *reinterpret_cast<const float4*>(s + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+        bf16x8 v;
+        v[0] = (__bf16)a[i].x; v[1] = (__bf16)a[i].y; v[2] = (__bf16)a[i].z; v[3] = (__bf16)a[i].w;
+        v[4] = (__bf16)c[i].x; v[5] = (__bf16)c[i].y; v[6] = (__bf16)c[i].z; v[7] = (__bf16)c[i].w;
+        *reinterpret_cast<bf16x8*>(&img[Img<D>::off(row, ch)]) = v;
+    }
+}
+
+// B-operand fragments (cols = token of this lane, K = channels) straight from global fp32: frag[ks] covers
+// channels 16 ks + 8 h .. +7 of row `tok`
+template <int D>
+__device__ __forceinline__ void load_frags(bf16x8* frag, const float* __restrict__ rowp, int lh) {
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        const float4 a = *reinterpret_cast<const float4*>(rowp + ks * 16 + lh * 8);
+        const float4 c = *reinterpret_cast<const float4*>(rowp + ks * 16 + lh * 8 + 4);
+        bf16x8 v;
+        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+        v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+        frag[ks] = v;
+    }
+}
+
+// acc[t] (t = 0,1: image rows 32t..32t+31) = img(64 rows x D) . frags  ->  tile [image row][lane token]
+template <int D>
+__device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img, const bf16x8* frag, int lr, int lh) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, ks * 2 + lh)]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[ks], acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// out[ct] (channels 32ct..) += img^T (channels x 64 image rows) . W, where W is a [64 image rows][lane token] tile
+// held in accumulator layout w[2][16] (as produced by mma_rows_x_frags).  K slot 8h+i of K-step (t,u) <-> image row
+// 32t + 16u + 8(i>>2) + 4h + (i&3); the A operand rows are fetched with transpose-reads.
+template <int D>
+__device__ __forceinline__ void mma_tr_x_tile(f32x16* out, const __bf16* img, const f32x16* w, int lane) {
+    const int g = lane >> 4, s = lane & 15, h = g >> 1;
+    const int col = 16 * (g & 1) + 4 * (s & 3);            // first of the 4 channels this supplier lane addresses
+    const int rsub = s >> 2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 b;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b[i] = (__bf16)w[t][8 * u + i];
+            const int row0 = 32 * t + 16 * u + 4 * h + rsub, row1 = row0 + 8;
+#pragma unroll
+            for (int ct = 0; ct < D / 32; ++ct) {
+                const int c = 32 * ct + col;                   // channel; chunk = c >> 3, 8-byte half = (c >> 2) & 1
+                const __bf16* p0 = &img[Img<D>::off(row0, c >> 3) + (c & 4)];
+                const __bf16* p1 = &img[Img<D>::off(row1, c >> 3) + (c & 4)];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+                union { struct { s16x4 a, b; } s2; bf16x8 v; } uu;
+                uu.s2.a = lo;
+                uu.s2.b = hi;
+                out[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uu.v, b, out[ct], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// write an accumulator tile set acc[ct] ([channel][lane token]) to dst[token][channel] (+ scale, + optional add)
+template <int D>
+__device__ __forceinline__ void store_ct(float* __restrict__ dst_row, const f32x16* acc, float scale,
+                                         const float* __restrict__ add_row, int lh) {
+#pragma unroll
+    for (int ct = 0; ct < D / 32; ++ct) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int c = 32 * ct + 8 * q4 + 4 * lh;
+            float4 v = make_float4(acc[ct][4 * q4] * scale, acc[ct][4 * q4 + 1] * scale, acc[ct][4 * q4 + 2] * scale,
+                                   acc[ct][4 * q4 + 3] * scale);
+            if (add_row) {
+                const float4 a = *reinterpret_cast<const float4*>(add_row + c);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+            *reinterpret_cast<float4*>(dst_row + c) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void hupr_k_attn_fwd(const float* __restrict__ K, const float* __restrict__ Q,
+                                                       const float* __restrict__ V, float* __restrict__ out,
+                                                       float* __restrict__ lse, int N, int residual) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const long base = (long)blockIdx.y * N * D;
+    const int q = blockIdx.x * 128 + wave * 32 + lr;         // this lane's query
+    bf16x8 qf[D / 16];
+    load_frags<D>(qf, Q + base + (long)q * D, lh);
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int ct = 0; ct < D / 32; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        __syncthreads();
+        stage_rows<D, 64>(Ks, K + base + (long)j0 * D, D, tid);
+        stage_rows<D, 64>(Vs, V + base + (long)j0 * D, D, tid);
+        __syncthreads();
+        f32x16 st[2];
+        mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T tile: rows = keys, this lane's column = its query
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other half-wave holds the other 32 keys
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __expf(st[t][r] - m_new);
+                st[t][r] = pv;
+                sum += pv;
+            }
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int ct = 0; ct < D / 32; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        mma_tr_x_tile<D>(o, Vs, st, lane);                    // O^T += V^T P^T
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, residual ? V + base + (long)q * D : nullptr, lh);
+    if (lh == 0) lse[(long)blockIdx.y * N + q] = m_run + __logf(l_tot);
+}
+
+// D[q] = sum_c dO[q,c] * (out[q,c] - (residual ? V[q,c] : 0))
+template <int D>
+__global__ __launch_bounds__(256) void hupr_k_attn_prep(const float* __restrict__ dO, const float* __restrict__ out,
+                                                        const float* __restrict__ V, float* __restrict__ Dq, long rows,
+                                                        int residual) {
+    // 16 lanes per row (D/16 floats each)
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    float acc = 0.f;
+    if (row < rows) {
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) {
+            const long o = row * D + (sub + 16 * i) * 4;
+            const float4 g = *reinterpret_cast<const float4*>(dO + o);
+            float4 y = *reinterpret_cast<const float4*>(out + o);
+            if (residual) {
+                const float4 v = *reinterpret_cast<const float4*>(V + o);
+                y.x -= v.x; y.y -= v.y; y.z -= v.z; y.w -= v.w;
+            }
+            acc += (g.x * y.x + g.y * y.y) + (g.z * y.z + g.w * y.w);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+    if (row < rows && sub == 0) Dq[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dQ: same walk as the forward
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const float* __restrict__ K, const float* __restrict__ Q,
+                                                          const float* __restrict__ V, const float* __restrict__ dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ Dq,
+                                                          float* __restrict__ dQ, int N) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const long base = (long)blockIdx.y * N * D;
+    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    bf16x8 qf[D / 16], gf[D / 16];
+    load_frags<D>(qf, Q + base + (long)q * D, lh);
+    load_frags<D>(gf, dO + base + (long)q * D, lh);
+    const float lse_q = lse[(long)blockIdx.y * N + q], d_q = Dq[(long)blockIdx.y * N + q];
+    f32x16 dq[D / 32];
+#pragma unroll
+    for (int ct = 0; ct < D / 32; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[ct][r] = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        __syncthreads();
+        stage_rows<D, 64>(Ks, K + base + (long)j0 * D, D, tid);
+        stage_rows<D, 64>(Vs, V + base + (long)j0 * D, D, tid);
+        __syncthreads();
+        f32x16 st[2], dp[2];
+        mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T
+        mma_rows_x_frags<D>(dp, Vs, gf, lr, lh);              // dP^T = V dO^T
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = __expf(st[t][r] - lse_q) * (dp[t][r] - d_q);   // dS^T
+        mma_tr_x_tile<D>(dq, Ks, st, lane);                   // dQ^T += K^T dS^T
+    }
+    store_ct<D>(dQ + base + (long)q * D, dq, 1.f, nullptr, lh);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dK / dV: a workgroup owns 128 keys (32 per wave) and streams 64-query tiles
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dkv(const float* __restrict__ K, const float* __restrict__ Q,
+                                                           const float* __restrict__ V, const float* __restrict__ dO,
+                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
+                                                           float* __restrict__ dK, float* __restrict__ dV, int N,
+                                                           int residual) {
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * D];
+    __shared__ __attribute__((aligned(16))) __bf16 Gs[64 * D];
+    __shared__ float s_lse[64], s_d[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const long base = (long)blockIdx.y * N * D;
+    const int key = blockIdx.x * 128 + wave * 32 + lr;        // this lane's key
+    bf16x8 kf[D / 16], vf[D / 16];
+    load_frags<D>(kf, K + base + (long)key * D, lh);
+    load_frags<D>(vf, V + base + (long)key * D, lh);
+    f32x16 dk[D / 32], dv[D / 32];
+#pragma unroll
+    for (int ct = 0; ct < D / 32; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.f; dv[ct][r] = 0.f; }
+    for (int q0 = 0; q0 < N; q0 += 64) {
+        __syncthreads();
+        stage_rows<D, 64>(Qs, Q + base + (long)q0 * D, D, tid);
+        stage_rows<D, 64>(Gs, dO + base + (long)q0 * D, D, tid);
+        if (tid < 64) {
+            s_lse[tid] = lse[(long)blockIdx.y * N + q0 + tid];
+            s_d[tid] = Dq[(long)blockIdx.y * N + q0 + tid];
+        }
+        __syncthreads();
+        f32x16 s[2], dp[2];
+        mma_rows_x_frags<D>(s, Qs, kf, lr, lh);               // S tile: rows = queries, this lane's column = its key
+        mma_rows_x_frags<D>(dp, Gs, vf, lr, lh);              // dP = dO V^T
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float pv = __expf(s[t][r] - s_lse[qi]);
+                dp[t][r] = pv * (dp[t][r] - s_d[qi]);          // dS
+                s[t][r] = pv;                                   // P
+            }
+        mma_tr_x_tile<D>(dv, Gs, s, lane);                    // dV^T += dO^T P
+        mma_tr_x_tile<D>(dk, Qs, dp, lane);                   // dK^T += Q^T dS
+    }
+    store_ct<D>(dK + base + (long)key * D, dk, 1.f, nullptr, lh);
+    store_ct<D>(dV + base + (long)key * D, dv, 1.f, residual ? dO + base + (long)key * D : nullptr, lh);
+}
+
+}  // namespace hupr
+
+using namespace hupr;
+
+extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C == 128) && N % 128 == 0 && N >= 128) ? 1 : 0; }
+
+// out (B,N,C) = softmax_keys(K Q^T)-weighted V (+V); lse (B,N) saved for the backward
+extern "C" int hupr_attn_fwd_bf16(const float* K, const float* Q, const float* V, float* out, float* lse, int Bn, int N, int C,
+                                  int residual, hupr_stream_t stream) {
+    HUPR_REQUIRE(K && Q && V && out && lse && Bn > 0, "hupr_attn_fwd_bf16: bad argument");
+    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "hupr_attn_fwd_bf16: unsupported shape N=%d C=%d", N, C);
+    dim3 grid(N / 128, Bn);
+    if (C == 64) hipLaunchKernelGGL(hupr_k_attn_fwd<64>, grid, dim3(256), 0, as_stream(stream), K, Q, V, out, lse, N, residual);
+    else hipLaunchKernelGGL(hupr_k_attn_fwd<128>, grid, dim3(256), 0, as_stream(stream), K, Q, V, out, lse, N, residual);
+    HUPR_LAUNCH_OK("hupr_k_attn_fwd");
+    return HUPR_OK;
+}
+
+// dK, dQ, dV (B,N,C) from dout; Dq: scratch (B,N) floats
+extern "C" int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const float* out, const float* dout,
+                                  const float* lse, float* dK, float* dQ, float* dV, float* Dq, int Bn, int N, int C,
+                                  int residual, hupr_stream_t stream) {
+    HUPR_REQUIRE(K && Q && V && out && dout && lse && dK && dQ && dV && Dq && Bn > 0, "hupr_attn_bwd_bf16: bad argument");
+    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "hupr_attn_bwd_bf16: unsupported shape N=%d C=%d", N, C);
+    hipStream_t s = as_stream(stream);
+    const long rows = (long)Bn * N;
+    dim3 grid(N / 128, Bn);
+    if (C == 64) {
+        hipLaunchKernelGGL(hupr_k_attn_prep<64>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout, out, V, Dq, rows, residual);
+        hipLaunchKernelGGL(hupr_k_attn_bwd_dq<64>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dQ, N);
+        hipLaunchKernelGGL(hupr_k_attn_bwd_dkv<64>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dK, dV, N, residual);
+    } else {
+        hipLaunchKernelGGL(hupr_k_attn_prep<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout, out, V, Dq, rows, residual);
+        hipLaunchKernelGGL(hupr_k_attn_bwd_dq<128>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dQ, N);
+        hipLaunchKernelGGL(hupr_k_attn_bwd_dkv<128>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dK, dV, N, residual);
+    }
+    HUPR_LAUNCH_OK("hupr_k_attn_bwd");
+    return HUPR_OK;
+}

@@ -64,6 +64,7 @@ def pack_weights_bf16(w, mode):
     return wp
 
 
+USE_FLASH = True       # bf16 mode: fused attention kernels where supported (C in {64,128}, N % 128 == 0)
 USE_HALO = True        # bf16 mode: LDS halo-tiled kernel for 3x3(x3) "same" convolutions
 
 
@@ -360,6 +361,15 @@ class AttentionFn(torch.autograd.Function):
         k, q, v = _c(k), _c(q), _c(v)
         B, N, C = v.shape
         L = rt.lib()
+        ctx.flash = MATH == "bf16" and USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
+        if ctx.flash:
+            out = torch.empty_like(v)
+            lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
+            rt.check(L.hupr_attn_fwd_bf16(rt.ptr(k), rt.ptr(q), rt.ptr(v), rt.ptr(out), rt.ptr(lse), B, N, C,
+                                          1 if residual else 0, rt.stream()))
+            ctx.save_for_backward(k, q, v, out, lse)
+            ctx.residual = residual
+            return out
         # St[kq][j] = q . k  -> softmax over j is a row softmax
         P = gemm(0, 1, q, k, N, N, C, C, C, B, N * C, N * C)
         rt.check(L.hupr_softmax_rows_f32(rt.ptr(P), B * N, N, rt.stream()))
@@ -370,6 +380,16 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.flash:
+            k, q, v, out, lse = ctx.saved_tensors
+            dout = _c(dout)
+            B, N, C = v.shape
+            dk, dq, dv = torch.empty_like(k), torch.empty_like(q), torch.empty_like(v)
+            dq_scr = torch.empty((B, N), dtype=torch.float32, device=v.device)
+            rt.check(rt.lib().hupr_attn_bwd_bf16(rt.ptr(k), rt.ptr(q), rt.ptr(v), rt.ptr(out), rt.ptr(dout), rt.ptr(lse),
+                                                rt.ptr(dk), rt.ptr(dq), rt.ptr(dv), rt.ptr(dq_scr), B, N, C,
+                                                1 if ctx.residual else 0, rt.stream()))
+            return dk, dq, dv, None
         k, q, v, P = ctx.saved_tensors
         dout = _c(dout)
         B, N, C = v.shape

@@ -170,6 +170,15 @@ int hupr_interp_linear_bwd_f32(const float* dy, float* dx, int Bn, int Di, int H
 int hupr_softmax_rows_f32(float* s, long rows, int n, hupr_stream_t stream);
 int hupr_softmax_rows_bwd_f32(const float* p, float* dp_inout, long rows, int n, hupr_stream_t stream);
 
+/* (a5) fused flash-style attention on the bf16 matrix pipe (C in {64,128}, N % 128 == 0): no N x N matrix in HBM.
+ * K, Q, V, out, dout, dK, dQ, dV: (B,N,C) fp32 token-major; lse, Dq_scratch: (B,N) fp32. */
+int hupr_attn_flash_supported(int N, int C);
+int hupr_attn_fwd_bf16(const float* K, const float* Q, const float* V, float* out, float* lse, int Bn, int N, int C,
+                       int residual, hupr_stream_t stream);
+int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const float* out, const float* dout,
+                       const float* lse, float* dK, float* dQ, float* dV, float* Dq_scratch, int Bn, int N, int C,
+                       int residual, hupr_stream_t stream);
+
 /* (a7) PRGCN: y = act(t . A + bias) with t = W . x computed by hupr_gemm_f32 (gcn_networks.py:23-29,53-58) */
 int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,
                          int ld, int relu, hupr_stream_t stream);

@@ -391,3 +391,47 @@ def test_attention_bf16(bf16_math):
     ref = torch.einsum("bjc,bjk->bkc", v.double(), F.softmax(s, 1)) + v.double()
     out = F_.AttentionFn.apply(k.cuda(), q.cuda(), v.cuda(), True)
     close(out, ref, 2e-2, "bf16 attention")
+
+
+@pytest.mark.parametrize("N,C,residual", [(256, 64, True), (512, 64, False), (256, 128, True), (4096, 64, False)])
+def test_flash_attention_bf16(N, C, residual, bf16_math):
+    """Fused attention kernels (bf16 operands): forward and all three gradients vs an fp64 reference."""
+    from hupr_amd import functional as F_
+    assert F_.rt.lib().hupr_attn_flash_supported(N, C)
+    B = 2
+    k, q, v = rnd(B, N, C, seed=42, scale=C ** -0.25), rnd(B, N, C, seed=43, scale=C ** -0.25), rnd(B, N, C, seed=44)
+    kr, qr, vr = (t.double().requires_grad_(True) for t in (k, q, v))
+    s = torch.einsum("bjc,bkc->bjk", kr, qr)
+    outr = torch.einsum("bjc,bjk->bkc", vr, F.softmax(s, 1))
+    if residual:
+        outr = outr + vr
+    g = rnd(B, N, C, seed=45)
+    outr.backward(g.double())
+    kg, qg, vg = (t.cuda().requires_grad_(True) for t in (k, q, v))
+    out = F_.AttentionFn.apply(kg, qg, vg, residual)
+    close(out, outr, 2e-2, "flash fwd")
+    out.backward(g.cuda())
+    close(vg.grad, vr.grad, 2e-2, "flash dV")
+    close(qg.grad, qr.grad, 3e-2, "flash dQ")
+    close(kg.grad, kr.grad, 3e-2, "flash dK")
+    # and against the materialised bf16 path (same operand rounding): tighter
+    F_.USE_FLASH = False
+    try:
+        k2, q2, v2 = (t.cuda().requires_grad_(True) for t in (k, q, v))
+        out2 = F_.AttentionFn.apply(k2, q2, v2, residual)
+        out2.backward(g.cuda())
+    finally:
+        F_.USE_FLASH = True
+    close(out, out2, 1e-2, "flash vs materialised fwd")
+    close(vg.grad, v2.grad, 1e-2, "flash vs materialised dV")
+
+
+def test_flash_attention_large_logits(bf16_math):
+    from hupr_amd import functional as F_
+    k, q, v = rnd(1, 256, 64, seed=46) * 5, rnd(1, 256, 64, seed=47) * 5, rnd(1, 256, 64, seed=48)
+    kq, qq = k.to(torch.bfloat16).double(), q.to(torch.bfloat16).double()
+    s = torch.einsum("bjc,bkc->bjk", kq, qq)
+    ref = torch.einsum("bjc,bjk->bkc", v.to(torch.bfloat16).double(), F.softmax(s, 1))
+    out = F_.AttentionFn.apply(k.cuda(), q.cuda(), v.cuda(), False)
+    assert torch.isfinite(out).all()
+    close(out, ref, 2e-2, "flash big logits")
