@@ -78,14 +78,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with a single rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist.is_initialized() else 0)
 
     from hupr_amd import functional as F_, synth
     from hupr_amd.config_tree import load_config
@@ -116,7 +116,7 @@ def main():
         return None
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,11 +127,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = eng.train_step_from_adc(adc_h, adc_v, joints)
+    t_enq = time.perf_counter() - t0          # host time to enqueue all steps (GPU still running)
     barrier()
     dt = time.perf_counter() - t0
     F_.CONV_PROBE = None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -157,12 +158,13 @@ def main():
             "model_tflops": round(value * STEP_GFLOP / 1e3, 2),
             "model_frac_of_mfma_peak": round(value * STEP_GFLOP / 1e3 / world / peak, 4),
             "loss": round(float(loss.item()), 5),
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

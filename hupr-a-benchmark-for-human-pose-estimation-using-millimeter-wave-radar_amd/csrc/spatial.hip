@@ -159,11 +159,27 @@ __device__ __forceinline__ Lin lin_coord(int o, int in, int out) {
     return l;
 }
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void hupr_k_interp(const float* __restrict__ src, float* __restrict__ dst, int Bn,
-                                                     int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
-                                                     int in_ld, int out_ld) {
-    // forward: src = x (in_ld), dst = y (out_ld).  backward: src = dy (out_ld), dst = dx (in_ld), atomics.
+// contributions of output index o (0..out-1) to input index i: linear weights with align_corners=True.
+// For input index i the contributing outputs are those whose i0 == i (weight w0) or i1 == i (weight w1, i1 != i0).
+// Because src = scale*o is monotone, they form a contiguous range; we scan a conservative window around i/scale.
+__device__ __forceinline__ void lin_range(int i, int in, int out, int& lo, int& hi) {
+    if (out == 1 || in == 1) { lo = 0; hi = out - 1; return; }
+    const float inv = (float)(out - 1) / (float)(in - 1);
+    lo = max(0, (int)floorf((float)(i - 1) * inv) - 1);
+    hi = min(out - 1, (int)ceilf((float)(i + 1) * inv) + 1);
+}
+__device__ __forceinline__ float lin_weight(int o, int i, int in, int out) {
+    const Lin l = lin_coord(o, in, out);
+    float w = 0.f;
+    if (l.i0 == i) w += l.w0;
+    if (l.i1 == i) w += l.w1;                            // at the clamped upper edge both taps hit the same voxel
+    return w;
+}
+
+// forward: y[o] = sum over the 8 corner voxels
+__global__ __launch_bounds__(256) void hupr_k_interp_fwd(const float* __restrict__ src, float* __restrict__ dst, int Bn,
+                                                         int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
+                                                         int in_ld, int out_ld) {
     const int c4n = C >> 2;
     const long total = (long)Bn * Do * Ho * Wo * c4n;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -176,13 +192,11 @@ __global__ __launch_bounds__(256) void hupr_k_interp(const float* __restrict__ s
         const Lin ld = lin_coord(od, Di, Do), lh = lin_coord(oh, Hi, Ho), lw = lin_coord(ow, Wi, Wo);
         const long ovox = (((long)b * Do + od) * Ho + oh) * Wo + ow;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (BWD) g = *reinterpret_cast<const float4*>(src + ovox * out_ld + c4 * 4);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
+            if (a == 1 && Di == 1) continue;
             const int id = a ? ld.i1 : ld.i0;
             const float wd = a ? ld.w1 : ld.w0;
-            if (a == 1 && Di == 1) continue;
 #pragma unroll
             for (int bq = 0; bq < 2; ++bq) {
                 const int ih = bq ? lh.i1 : lh.i0;
@@ -192,19 +206,54 @@ __global__ __launch_bounds__(256) void hupr_k_interp(const float* __restrict__ s
                     const int iw = cq ? lw.i1 : lw.i0;
                     const float wgt = wd * wh * (cq ? lw.w1 : lw.w0);
                     const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
-                    if (!BWD) {
-                        const float4 xv = *reinterpret_cast<const float4*>(src + ivox * in_ld + c4 * 4);
-                        acc.x = fmaf(wgt, xv.x, acc.x); acc.y = fmaf(wgt, xv.y, acc.y);
-                        acc.z = fmaf(wgt, xv.z, acc.z); acc.w = fmaf(wgt, xv.w, acc.w);
-                    } else if (wgt != 0.f) {
-                        float* d = dst + ivox * in_ld + c4 * 4;
-                        atomicAdd(d + 0, wgt * g.x); atomicAdd(d + 1, wgt * g.y);
-                        atomicAdd(d + 2, wgt * g.z); atomicAdd(d + 3, wgt * g.w);
-                    }
+                    const float4 xv = *reinterpret_cast<const float4*>(src + ivox * in_ld + c4 * 4);
+                    acc.x = fmaf(wgt, xv.x, acc.x); acc.y = fmaf(wgt, xv.y, acc.y);
+                    acc.z = fmaf(wgt, xv.z, acc.z); acc.w = fmaf(wgt, xv.w, acc.w);
                 }
             }
         }
-        if (!BWD) *reinterpret_cast<float4*>(dst + ovox * out_ld + c4 * 4) = acc;
+        *reinterpret_cast<float4*>(dst + ovox * out_ld + c4 * 4) = acc;
+    }
+}
+
+// backward, gather form: each thread owns one INPUT voxel (x 4 channels) and sums the output gradients that
+// touched it — deterministic, no atomics, no zero-fill pass.
+__global__ __launch_bounds__(256) void hupr_k_interp_bwd(const float* __restrict__ dy, float* __restrict__ dx, int Bn,
+                                                         int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
+                                                         int in_ld, int out_ld) {
+    const int c4n = C >> 2;
+    const long total = (long)Bn * Di * Hi * Wi * c4n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = idx % c4n;
+        long v = idx / c4n;
+        const int iw = v % Wi; v /= Wi;
+        const int ih = v % Hi; v /= Hi;
+        const int id = v % Di;
+        const int b = v / Di;
+        int dlo, dhi, hlo, hhi, wlo, whi;
+        lin_range(id, Di, Do, dlo, dhi);
+        lin_range(ih, Hi, Ho, hlo, hhi);
+        lin_range(iw, Wi, Wo, wlo, whi);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int od = dlo; od <= dhi; ++od) {
+            const float wd = (Di == 1 && Do == 1) ? 1.f : lin_weight(od, id, Di, Do);
+            if (wd == 0.f) continue;
+            for (int oh = hlo; oh <= hhi; ++oh) {
+                const float wh = lin_weight(oh, ih, Hi, Ho);
+                if (wh == 0.f) continue;
+                for (int ow = wlo; ow <= whi; ++ow) {
+                    const float ww = lin_weight(ow, iw, Wi, Wo);
+                    if (ww == 0.f) continue;
+                    const float wgt = wd * wh * ww;
+                    const long ovox = (((long)b * Do + od) * Ho + oh) * Wo + ow;
+                    const float4 g = *reinterpret_cast<const float4*>(dy + ovox * out_ld + c4 * 4);
+                    acc.x = fmaf(wgt, g.x, acc.x); acc.y = fmaf(wgt, g.y, acc.y);
+                    acc.z = fmaf(wgt, g.z, acc.z); acc.w = fmaf(wgt, g.w, acc.w);
+                }
+            }
+        }
+        const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
+        *reinterpret_cast<float4*>(dx + ivox * in_ld + c4 * 4) = acc;
     }
 }
 
@@ -255,25 +304,21 @@ extern "C" int hupr_interp_linear_fwd_f32(const float* x, float* y, int Bn, int 
     int rc = interp_check("hupr_interp_linear_fwd_f32", Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     if (rc) return rc;
     const long total = (long)Bn * Do * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(hupr_k_interp<false>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(hupr_k_interp_fwd, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
                        as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
-    HUPR_LAUNCH_OK("hupr_k_interp<fwd>");
+    HUPR_LAUNCH_OK("hupr_k_interp_fwd");
     return HUPR_OK;
 }
 
-// dx (dense, in_ld == C required so it can be zero-filled here) = adjoint of the forward map applied to dy
+// dx = adjoint of the forward map applied to dy (gather form: deterministic, every dx voxel written once)
 extern "C" int hupr_interp_linear_bwd_f32(const float* dy, float* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
                                           int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
     HUPR_REQUIRE(dy && dx, "hupr_interp_linear_bwd_f32: null pointer");
     int rc = interp_check("hupr_interp_linear_bwd_f32", Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     if (rc) return rc;
-    HUPR_REQUIRE(in_ld == C, "hupr_interp_linear_bwd_f32: dx must be dense");
-    hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(dx, 0, (size_t)Bn * Di * Hi * Wi * C * sizeof(float), s) != hipSuccess)
-        return fail(HUPR_ERR_LAUNCH, "hupr_interp_linear_bwd_f32: memset failed");
-    const long total = (long)Bn * Do * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(hupr_k_interp<true>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0, s, dy, dx,
-                       Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
-    HUPR_LAUNCH_OK("hupr_k_interp<bwd>");
+    const long total = (long)Bn * Di * Hi * Wi * (C / 4);
+    hipLaunchKernelGGL(hupr_k_interp_bwd, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    HUPR_LAUNCH_OK("hupr_k_interp_bwd");
     return HUPR_OK;
 }

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
                     const int hy = t2 % HH, hz = t2 / HH;
                     const int d = d0 + hz + td - pd, h = h0 + hy - 1, w = w0 + hx - 1;
                     dst[u] = vox * 64 + c8 * 8;
-                    if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+                    if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W &&
+                        ci0 + c8 * 8 < p.Ci) {     // Cin = 32 layers: the upper half of the 64-wide tile is zero
                         const float* src = p.x + ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + ci0 + c8 * 8;
                         va[u] = *reinterpret_cast<const float4*>(src);
                         vc[u] = *reinterpret_cast<const float4*>(src + 4);
@@ -177,7 +178,7 @@ using namespace hupr;
 extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
     // at most 256 groups, but never more than 128 MiB of partials
     const size_t one = (size_t)Co * kd * 9 * Ci * sizeof(float);
-    size_t groups = 256;
+    size_t groups = 128;
     while (groups > 1 && groups * one > ((size_t)128 << 20)) groups >>= 1;
     return groups * one;
 }
@@ -186,7 +187,7 @@ extern "C" int hupr_conv3x3_wgrad_halo_bf16(const float* x, const float* dy, flo
                                             int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
                                             hupr_stream_t stream) {
     HUPR_REQUIRE(x && dy && dw && ws, "hupr_conv3x3_wgrad_halo_bf16: null pointer");
-    HUPR_REQUIRE(Bn > 0 && Co > 0 && Ci % 64 == 0 && Co % 8 == 0 && in_ld % 4 == 0 && dy_ld % 4 == 0,
+    HUPR_REQUIRE(Bn > 0 && Co > 0 && Ci % 8 == 0 && Co % 8 == 0 && in_ld % 4 == 0 && dy_ld % 4 == 0,
                  "hupr_conv3x3_wgrad_halo_bf16: unsupported channels Ci=%d Co=%d", Ci, Co);
     HUPR_REQUIRE(H % 8 == 0 && ((kd == 3 && D % 2 == 0 && W % 8 == 0) || (kd == 1 && D == 1 && W % 16 == 0)),
                  "hupr_conv3x3_wgrad_halo_bf16: unsupported geometry");
@@ -196,12 +197,12 @@ extern "C" int hupr_conv3x3_wgrad_halo_bf16(const float* x, const float* dy, flo
     a.kd = kd;
     if (kd == 3) { a.TD = 2; a.log2TW = 3; } else { a.TD = 1; a.log2TW = 4; }
     a.nd = D / a.TD; a.nh = H / 8; a.nw = W >> a.log2TW;
-    a.n_ci_tiles = Ci / 64;
+    a.n_ci_tiles = (Ci + 63) / 64;
     a.n_co_tiles = (Co + 63) / 64;
     a.n_spatial = Bn * a.nd * a.nh * a.nw;
     const int pairs = a.n_ci_tiles * a.n_co_tiles * kd;
     const size_t one = (size_t)Co * kd * 9 * Ci * sizeof(float);
-    int groups = max(1, 768 / pairs);
+    int groups = max(1, min(128, 768 / pairs));      // ~3 workgroups per CU, at most 128 partial tensors
     groups = min(groups, a.n_spatial);
     while (groups > 1 && (size_t)groups * one > ws_bytes) groups >>= 1;
     if ((size_t)groups * one > ws_bytes) return fail(HUPR_ERR_WORKSPACE, "hupr_conv3x3_wgrad_halo_bf16: workspace too small");

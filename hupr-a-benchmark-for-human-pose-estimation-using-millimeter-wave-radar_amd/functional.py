@@ -144,7 +144,7 @@ class ConvFn(torch.autograd.Function):
                 wsrc[:Co] = weight
             dpad = (k[0] - 1 - pad[0], k[1] - 1 - pad[1], k[2] - 1 - pad[2])
             dx = _conv_raw(dyp, wsrc, 1, None, None, Ci, k, dpad, (Di, Hi, Wi))      # packs [Ci][taps reversed][Co]
-        if ctx.needs_input_grad[1] and _halo_ok(x, k, pad) and Ci % 64 == 0 and Co % 8 == 0:
+        if ctx.needs_input_grad[1] and _halo_ok(x, k, pad) and Ci % 32 == 0 and Co % 8 == 0:
             dw = torch.empty_like(weight)
             ws = workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, k[0]), x.device)
             rt.check(L.hupr_conv3x3_wgrad_halo_bf16(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Co, Co, k[0],

@@ -45,6 +45,9 @@ class GradientBuckets:
 
     def __init__(self, module, bucket_bytes=48 << 20, process_group=None):
         self.group = process_group
+        # HUPR_FORCE_ALLREDUCE=1: run the collectives even with one rank (exercises RCCL + the side stream on a 1-GPU box)
+        import os
+        self.force_collective = os.environ.get("HUPR_FORCE_ALLREDUCE", "0") == "1" and dist.is_initialized()
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
@@ -92,7 +95,7 @@ class GradientBuckets:
             self._launch(b)
 
     def _launch(self, b):
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_collective:
             return
         if self.use_streams:
             ev = torch.cuda.Event()
@@ -106,14 +109,14 @@ class GradientBuckets:
     def finish(self):
         """Block the compute stream on outstanding collectives (call after backward)."""
         for b in self.buckets:
-            if b.pending != 0 and self.world_size > 1:
+            if b.pending != 0 and (self.world_size > 1 or self.force_collective):
                 # a parameter received no gradient this iteration: reduce what we have
                 b.pending = 0
                 self._launch(b)
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-        if self.use_streams and self.world_size > 1:
+        if self.use_streams and (self.world_size > 1 or self.force_collective):
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def flat_pairs(self):
