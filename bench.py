@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="matrix-pipe arithmetic of the GEMM-shaped ops (tensors stay fp32 in HBM; accumulate fp32)")
     args = ap.parse_args()
 
@@ -142,12 +142,20 @@ def main():
         ms = [s.elapsed_time(e) for s, e in probe_events]
         kflop = 2.0 * (B * 8 * 64 * 64) * 64 * (27 * 64)
         roof = None
+        pmc = {}
+        try:      # HBM bytes per launch of the same kernel/shape, measured offline with rocprofv3 --pmc (see profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json"))).get(args.dtype, {})
+        except Exception:
+            pass
         if ms:
             avg = float(np.mean(ms)) * 1e-3
             ach = kflop / avg / 1e12
-            roof = {"bound": "mfma", "kernel": "hupr_k_gemm_%s<128,64,2,2,A_CONV,B_NK> (Encoder3D.layer1 64->64 3x3x3, fwd+dgrad)" % args.dtype,
+            kname = "hupr_k_conv_halo_bf16<64,64>" if args.dtype == "bf16" else "hupr_k_gemm_f32<128,64,2,2,A_CONV,B_NK>"
+            roof = {"bound": "mfma", "kernel": kname + " (Encoder3D.layer1 64->64 3x3x3, fwd+dgrad launches)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "launches": len(ms), "avg_ms": round(avg * 1e3, 4), "flop_per_launch": kflop}
+                    "traffic": pmc.get("traffic_bytes_per_launch") if B == 32 else None,
+                    "traffic_note": "HBM bytes/launch from rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_pmc_dominant_kernels.md",
+                    "launches": len(ms), "avg_ms": round(avg * 1e3, 4), "flop_per_launch": kflop}
         out = {
             "metric": "radar frames/sec (FFT->heatmap fwd+bwd)", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
