@@ -27,7 +27,13 @@
 
 namespace hupr {
 
-constexpr int kRx = 4, kChirps = 192, kLoops = 64, kSamples = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: one global_store_dwordx4, never scalarised
+
+// A wave exchanging data with ITSELF through LDS needs no workgroup barrier: DS instructions of one wave execute in
+// order.  This only stops the compiler from reordering the LDS accesses across the exchange point.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+constexpr int kRx = 4, kChirps = 192, kSamples = 256;
 constexpr int kVant = 12;            // 8 azimuth + 4 elevation virtual antennas
 constexpr int kRange = 64, kDop = 16, kAz = 64, kEl = 8;
 constexpr int kRangeHi = 94;         // kept range bins 94,93,...,31
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
         x[3] = cmul(x[3], tw[(3 * lane) & 255]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) buf[pad32(lane + 64 * q)] = x[q];
-        __syncthreads();
+        wave_lds_fence();
         // stage 1 (span 16)
         {
             const int n = lane & 15, base = (lane >> 4) * 64 + n;
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q) buf[pad32(base + 16 * q)] = x[q];
         }
-        __syncthreads();
+        wave_lds_fence();
         // stage 2 (span 4)
         {
             const int n = lane & 3, base = (lane >> 2) * 16 + n;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q) buf[pad32(base + 4 * q)] = x[q];
         }
-        __syncthreads();
+        wave_lds_fence();
         // stage 3 (span 1), results stay in registers; position p = 4*lane+q holds bin
         // k = digit-reverse_4(p) = (lane>>4) + 4*((lane>>2)&3) + 16*(lane&3) + 64*q
         {
@@ -137,8 +143,9 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
                 if (r >= 0 && r < kRange) dop[r * kDopStride + cc] = x[q];
             }
         }
-        __syncthreads();   // rbuf reuse + dop visibility
+        wave_lds_fence();   // rbuf is reused by the same wave for its next chirp
     }
+    __syncthreads();       // every wave's columns of the Doppler tile are in place
 
     // Doppler: 64 FFTs of 64 points, 16 lanes each -> 16 FFTs per pass
     const int n = tid & 15;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
         x[3] = cmul(x[3], tw[(12 * n) & 255]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) row[n + 16 * q] = x[q];
-        __syncthreads();
+        wave_lds_fence();
         {   // stage 1 (span 4)
             const int m = n & 3, base = (n >> 2) * 16 + m;
 #pragma unroll
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q) row[base + 4 * q] = x[q];
         }
-        __syncthreads();
+        wave_lds_fence();
         {   // stage 2 (span 1); position 4n+q holds Doppler bin d = (n>>2) + 4*(n&3) + 16*q
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[q] = row[4 * n + q];
@@ -302,22 +309,22 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
                 re[e] = (v.o[e].x - mean[e]) * rstd[e];
                 im[e] = (v.o[e].y - mean[8 + e]) * rstd[8 + e];
             }
-            float4* pr = reinterpret_cast<float4*>(base_re + ((size_t)r * kAz + a_out) * kEl);
-            float4* pi = reinterpret_cast<float4*>(base_im + ((size_t)r * kAz + a_out) * kEl);
-            pr[0] = make_float4(re[0], re[1], re[2], re[3]);
-            pr[1] = make_float4(re[4], re[5], re[6], re[7]);
-            pi[0] = make_float4(im[0], im[1], im[2], im[3]);
-            pi[1] = make_float4(im[4], im[5], im[6], im[7]);
+            f32x4* pr = reinterpret_cast<f32x4*>(base_re + ((size_t)r * kAz + a_out) * kEl);
+            f32x4* pi = reinterpret_cast<f32x4*>(base_im + ((size_t)r * kAz + a_out) * kEl);
+            pr[0] = (f32x4){re[0], re[1], re[2], re[3]};
+            pr[1] = (f32x4){re[4], re[5], re[6], re[7]};
+            pi[0] = (f32x4){im[0], im[1], im[2], im[3]};
+            pi[1] = (f32x4){im[4], im[5], im[6], im[7]};
         }
     } else {
         float2* out = reinterpret_cast<float2*>(out_) + ((size_t)(sf * kDop + i) * kRange) * kAz * kEl;
         for (int j = 0; j < 16; ++j) {
             const int r = wave * 16 + j;
             AngleOut v = angle_cell(cells + r * kVant, twl);
-            float4* p = reinterpret_cast<float4*>(out + ((size_t)r * kAz + a_out) * kEl);
+            f32x4* p = reinterpret_cast<f32x4*>(out + ((size_t)r * kAz + a_out) * kEl);
 #pragma unroll
             for (int e = 0; e < kEl; e += 2)
-                p[e >> 1] = make_float4(v.o[e].x, v.o[e].y, v.o[e + 1].x, v.o[e + 1].y);
+                p[e >> 1] = (f32x4){v.o[e].x, v.o[e].y, v.o[e + 1].x, v.o[e + 1].y};
         }
     }
 }

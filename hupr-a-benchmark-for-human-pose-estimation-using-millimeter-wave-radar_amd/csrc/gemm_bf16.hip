@@ -16,6 +16,7 @@ namespace hupr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
 
 constexpr int BKH = 64;                 // k elements per tile
 constexpr int LDH = BKH + 8;            // LDS row stride in bf16 elements (144 bytes)
@@ -31,7 +32,8 @@ __device__ __forceinline__ bf16x8 cvt8(const float4& a, const float4& b) {
 __device__ __forceinline__ float4 ld4(const float* __restrict__ src, int i, int n, bool vec_ok) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i + 3 < n && vec_ok) {
-        v = *reinterpret_cast<const float4*>(src);
+        const f32x4n t = *reinterpret_cast<const f32x4n*>(src);      // native vector: stays one dwordx4 load
+        v = make_float4(t.x, t.y, t.z, t.w);
     } else {
         if (i < n) v.x = src[0];
         if (i + 1 < n) v.y = src[1];

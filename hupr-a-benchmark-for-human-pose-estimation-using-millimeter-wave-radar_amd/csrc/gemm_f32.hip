@@ -24,6 +24,12 @@
 
 namespace hupr {
 
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldv4(const float* p) {   // native vector load: stays one global_load_dwordx4
+    const f32x4n t = *reinterpret_cast<const f32x4n*>(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 constexpr int BK = 32;
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_f32(GemmArgs p) {
                 if (a_off[i] >= 0) {
                     const float* src = Ag + a_off[i] + k;
                     if (k + 3 < p.K && ((p.lda & 3) == 0)) {
-                        v = *reinterpret_cast<const float4*>(src);
+                        v = ldv4(src);
                     } else {
                         if (k < p.K) v.x = src[0];
                         if (k + 1 < p.K) v.y = src[1];
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_f32(GemmArgs p) {
                 if (k < p.K) {
                     const float* src = Ag + (long)k * p.lda + m;
                     if (m + 3 < p.M && ((p.lda & 3) == 0)) {
-                        v = *reinterpret_cast<const float4*>(src);
+                        v = ldv4(src);
                     } else {
                         if (m < p.M) v.x = src[0];
                         if (m + 1 < p.M) v.y = src[1];
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_f32(GemmArgs p) {
                 if (n < p.N) {
                     const float* src = Bg + (long)n * p.ldb + k;
                     if (k + 3 < p.K && ((p.ldb & 3) == 0)) {
-                        v = *reinterpret_cast<const float4*>(src);
+                        v = ldv4(src);
                     } else {
                         if (k < p.K) v.x = src[0];
                         if (k + 1 < p.K) v.y = src[1];
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_f32(GemmArgs p) {
                 if (k < p.K) {
                     const float* src = Bg + (long)k * p.ldb + n;
                     if (n + 3 < p.N && ((p.ldb & 3) == 0)) {
-                        v = *reinterpret_cast<const float4*>(src);
+                        v = ldv4(src);
                     } else {
                         if (n < p.N) v.x = src[0];
                         if (n + 1 < p.N) v.y = src[1];

@@ -33,3 +33,11 @@ t_l = timeit(lambda: preprocessing.fft_chain_loader(iq, ws=ws, out=out_l))
 b_c, b_l = n_sf * 4980736, n_sf * 2883584
 print("n_sf=%d  c64: %.1f us  %.0f GB/s (%.3f of 8 TB/s) | loader: %.1f us  %.0f GB/s (%.3f)  | %.0f sensor-frames/s"
       % (n_sf, t_c * 1e6, b_c / t_c / 1e9, b_c / t_c / 8e12, t_l * 1e6, b_l / t_l / 1e9, b_l / t_l / 8e12, n_sf / t_l))
+
+# ---- per-kernel split (events around each C-ABI call are not possible: two kernels per call) and a pure-bandwidth baseline
+if len(sys.argv) > 2 and sys.argv[2] == "detail":
+    big = torch.empty(n_sf * 524288, dtype=torch.float32, device="cuda")      # same bytes as the loader output
+    t_fill = timeit(lambda: big.fill_(1.0))
+    src = torch.empty_like(big)
+    t_copy = timeit(lambda: big.copy_(src))
+    print("baseline: fill %.0f GB/s, copy (r+w) %.0f GB/s" % (big.numel() * 4 / t_fill / 1e9, 2 * big.numel() * 4 / t_copy / 1e9))
