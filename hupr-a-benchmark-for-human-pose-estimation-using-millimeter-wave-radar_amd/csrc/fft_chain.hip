@@ -24,6 +24,7 @@
 // Algorithmic HBM bytes per sensor-frame: 786 432 read + 4 194 304 (c64) or 2 097 152 (loader)
 // written; the RD intermediate adds 2 x 98 304.
 #include "hupr_common.h"
+#include "twiddles.h"
 
 namespace hupr {
 
@@ -67,11 +68,7 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
     const int rx = vant & 3;
     const int tx = (vant < 4) ? 0 : (vant < 8 ? 2 : 1);
 
-    {
-        double s, c;
-        sincospi(-2.0 * tid / 256.0, &s, &c);
-        tw[tid] = make_float2((float)c, (float)s);
-    }
+    tw[tid] = kTw256[tid];
     __syncthreads();
 
     // each int32 holds one (I,Q) sample
@@ -79,23 +76,22 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
                          ((size_t)(sf * kRx + rx) * kChirps) * kSamples;
     float2* buf = rbuf[wave];
 
-    int32_t raw[4];
-    {
-        const int32_t* row = src + (size_t)(3 * (wave * 16) + tx) * kSamples;
+    // All 16 chirps of this wave are requested up front (64 VGPRs): one HBM round trip (~2 us) is several times longer
+    // than a 256-point FFT, so a one-chirp-ahead prefetch leaves every FFT waiting on its loads.
+    int32_t raw[16][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) raw[q] = row[lane + 64 * q];
+    for (int j = 0; j < 16; ++j) {
+        const int32_t* row = src + (size_t)(3 * (wave * 16 + j) + tx) * kSamples;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw[j][q] = row[lane + 64 * q];
     }
+#pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int cc = wave * 16 + j;
         float2 x[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            x[q] = make_float2((float)(int16_t)(raw[q] & 0xffff), (float)(raw[q] >> 16));
-        if (j + 1 < 16) {   // prefetch next chirp while this one is transformed
-            const int32_t* row = src + (size_t)(3 * (cc + 1) + tx) * kSamples;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) raw[q] = row[lane + 64 * q];
-        }
+            x[q] = make_float2((float)(int16_t)(raw[j][q] & 0xffff), (float)(raw[j][q] >> 16));
         // stage 0 (span 64) straight from registers
         r4(x[0], x[1], x[2], x[3]);
         x[1] = cmul(x[1], tw[lane]);
@@ -249,11 +245,7 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
 
     const float2* src = rd + (size_t)(sf * kDop + i) * kRange * kVant;
     for (int t = tid; t < kRange * kVant; t += 256) cells[t] = src[t];
-    if (tid < 64) {
-        double s, c;
-        sincospi(-2.0 * tid / 64.0, &s, &c);
-        tw64[tid] = make_float2((float)c, (float)s);
-    }
+    if (tid < 64) tw64[tid] = kTw256[4 * tid];
     __syncthreads();
 
     // lane == azimuth-FFT output bin a'; twl[a] = W_64^{a a'}
