@@ -443,3 +443,39 @@ extern "C" int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* 
     HUPR_LAUNCH_OK("hupr_k_loader_normalize");
     return HUPR_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// DCA1000 raw capture -> device ADC layout (reference getadcDataFromDCA1000, process_iwr1843.py:54-83)
+// raw: int16 groups [I(2k), I(2k+1), Q(2k), Q(2k+1)]; per chirp the complex stream is [rx0 x256][rx1 x256][rx2 x256][rx3 x256].
+// out: int16 [frame][rx][chirp 192][sample 256][I,Q].  One thread moves one 8-byte group (two samples): coalesced
+// 8-byte reads, 8-byte writes.
+// ------------------------------------------------------------------------------------------
+namespace hupr {
+__global__ __launch_bounds__(256) void hupr_k_dca1000_deinterleave(const short4* __restrict__ raw, short4* __restrict__ out,
+                                                                   long n_groups) {
+    for (long gidx = (long)blockIdx.x * 256 + threadIdx.x; gidx < n_groups; gidx += (long)gridDim.x * 256) {
+        const short4 v = raw[gidx];                       // I0 I1 Q0 Q1 of stream samples n = 2g, 2g+1
+        const long n = gidx * 2;
+        const int s = (int)(n & 255);                     // sample index inside the rx run (even)
+        const long run = n >> 8;                          // = chirp * 4 + rx
+        const int rx = (int)(run & 3);
+        const long chirp = run >> 2;
+        const long frame = chirp / kChirps;
+        const int c = (int)(chirp - frame * kChirps);
+        const long dst = (((frame * kRx + rx) * kChirps + c) * kSamples + s) * 2;      // int16 index, multiple of 4
+        out[dst >> 2] = make_short4(v.x, v.z, v.y, v.w);  // (I0,Q0,I1,Q1)
+    }
+}
+}  // namespace hupr
+
+extern "C" int hupr_dca1000_deinterleave(const int16_t* raw, int16_t* adc_iq, int n_frames, hupr_stream_t stream) {
+    HUPR_REQUIRE(n_frames >= 0, "hupr_dca1000_deinterleave: n_frames=%d", n_frames);
+    if (n_frames == 0) return HUPR_OK;
+    HUPR_REQUIRE(raw && adc_iq && ((uintptr_t)raw & 7) == 0 && ((uintptr_t)adc_iq & 7) == 0,
+                 "hupr_dca1000_deinterleave: null or misaligned pointer");
+    const long n_groups = (long)n_frames * kRx * kChirps * kSamples / 2;
+    hipLaunchKernelGGL(hupr::hupr_k_dca1000_deinterleave, dim3((unsigned)min((long)8192, (n_groups + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), reinterpret_cast<const short4*>(raw), reinterpret_cast<short4*>(adc_iq), n_groups);
+    HUPR_LAUNCH_OK("hupr_k_dca1000_deinterleave");
+    return HUPR_OK;
+}

@@ -66,6 +66,18 @@ def loader_normalize(cube):
     return out
 
 
+def dca1000_frames(raw):
+    """raw: int16 GPU tensor (whole adc_data.bin stream) -> int16 GPU tensor (n_frames,4,192,256,2), the FFT-chain
+    input layout (reference getadcDataFromDCA1000 :54-83 + the per-frame slicing of :190-191)."""
+    if raw.dtype != torch.int16 or raw.dim() != 1:
+        raise ValueError("raw must be a flat int16 tensor")
+    per_frame = NUM_RX * NUM_CHIRP * NUM_SAMPLE * 2
+    n_frames = raw.numel() // per_frame
+    out = torch.empty((n_frames, NUM_RX, NUM_CHIRP, NUM_SAMPLE, 2), dtype=torch.int16, device=raw.device)
+    rt.check(rt.lib().hupr_dca1000_deinterleave(rt.ptr(raw), rt.ptr(out), n_frames, rt.stream()))
+    return out
+
+
 class RadarObject:
     """Same constants and operator surface as the reference class (process_iwr1843.py:8-34)."""
 
@@ -84,6 +96,15 @@ class RadarObject:
         self.numGroupChirp = 4
         self.numKeypoints = 14
         self.device = device
+
+    def getadcDataFromDCA1000(self, fileName):
+        """<fileName>/adc_data.bin -> complex128 ndarray (4, n_chirps, 256), like the reference; the de-interleave
+        runs on the GPU.  Use ``dca1000_frames`` directly to keep the cube on the device for ``fft_chain``."""
+        import os
+        raw = np.fromfile(os.path.join(fileName, "adc_data.bin"), dtype=np.int16)
+        fr = dca1000_frames(torch.from_numpy(raw).to(self.device)).cpu().numpy()      # (F,4,192,256,2)
+        z = fr[..., 0].astype(np.float64) + 1j * fr[..., 1].astype(np.float64)
+        return np.ascontiguousarray(z.transpose(1, 0, 2, 3).reshape(self.numRX, -1, self.numADCSamples))
 
     def generateHeatmap(self, frame):
         """frame: complex ndarray (4,192,256) -> complex128 ndarray (16,64,64,8)."""

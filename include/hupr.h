@@ -59,6 +59,11 @@ int hupr_fft_chain_loader_f32(const int16_t* adc_iq, int n_sf, float* out, void*
  * cube_c64 : float2 [n_sf][16][64][64][8]  ->  out float [n_sf][8][2][64][64][8]            */
 int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* out, hupr_stream_t stream);
 
+/* (f1) DCA1000 raw capture -> ADC layout above — replaces RadarObject.getadcDataFromDCA1000,
+ *      preprocessing/process_iwr1843.py:54-83 (2-lane LVDS groups [I0,I1,Q0,Q1]; per chirp [rx0][rx1][rx2][rx3] x 256).
+ * raw : int16 stream of n_frames * 786 432 / 2 values;  adc_iq: int16 [n_frames][4][192][256][2]. */
+int hupr_dca1000_deinterleave(const int16_t* raw, int16_t* adc_iq, int n_frames, hupr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * HuPRNet operators.  Activations are CHANNELS-LAST fp32: x[b][d][h][w][c] ("voxel stride" =
  * floats between consecutive voxels, >= c, lets an op read/write a channel slice of a wider

@@ -129,3 +129,19 @@ def test_radar_object_dropin():
     ref = offt.generate_heatmap(fr)
     keep = np.arange(16) != 8
     assert np.linalg.norm(out[keep] - ref[keep]) / np.linalg.norm(ref[keep]) <= 1e-5
+
+
+def test_dca1000_ingest_bit_exact(tmp_path):
+    """raw .bin -> GPU de-interleave is pure integer shuffling: bit-exact vs the oracle; then the FFT chain runs on it."""
+    from hupr_amd import preprocessing
+    from oracle import dca1000
+    raw = synth.randint((3 * 4 * 192 * 256 * 2,), -2048, 2048, "dca_gpu").astype(np.int16)
+    dev = preprocessing.dca1000_frames(torch.from_numpy(raw).cuda())
+    assert dev.shape == (3, 4, 192, 256, 2)
+    assert np.array_equal(dev.cpu().numpy(), dca1000.frames_int16(raw))
+    raw.tofile(tmp_path / "adc_data.bin")
+    z = preprocessing.RadarObject().getadcDataFromDCA1000(str(tmp_path))
+    assert z.shape == (4, 576, 256) and np.array_equal(z, dca1000.parse_dca1000(raw))
+    assert preprocessing.dca1000_frames(torch.zeros(0, dtype=torch.int16, device="cuda")).shape[0] == 0
+    cube = preprocessing.fft_chain(dev)
+    assert cube.shape == (3, 16, 64, 64, 8) and torch.isfinite(torch.view_as_real(cube)).all()

@@ -141,3 +141,22 @@ def test_oracle_vs_live_reference_fft():
     ro = ref_import.radar_object()
     fr = synth.adc_cube_complex(synth.adc_cube_int16(11))[0]
     assert np.array_equal(ro.generateHeatmap(fr), fft_chain.generate_heatmap(fr))
+
+
+def test_dca1000_oracle_matches_golden_and_reference(tmp_path):
+    from oracle import dca1000
+    g = np.load(os.path.join(G, "dca1000_small.npz"))
+    raw = synth.randint((int(g["n_int16"]),), -2048, 2048, str(g["seed_key"])).astype(np.int16)
+    assert sha(raw) == str(g["sha_in"])
+    z = dca1000.parse_dca1000(raw)
+    assert z.shape == (4, 384, 256) and sha(z) == str(g["sha_out"])
+    np.testing.assert_array_equal(z.reshape(-1)[::997], g["sample"])
+    fr = dca1000.frames_int16(raw)
+    assert fr.shape == (2, 4, 192, 256, 2)
+    assert np.array_equal(synth.adc_cube_complex(fr)[0], z[:, :192])
+    if ref_import.available():
+        import contextlib, io
+        raw.tofile(tmp_path / "adc_data.bin")
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = ref_import.radar_object().getadcDataFromDCA1000(str(tmp_path))
+        assert np.array_equal(ref, z)
