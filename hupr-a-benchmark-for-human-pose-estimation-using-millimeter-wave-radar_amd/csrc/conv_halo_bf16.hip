@@ -16,6 +16,7 @@
 namespace hupr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector: stays in registers (a struct uint4 array did not)
 
 struct HaloArgs {
     const float* x;          // [Bn][D][H][W] voxels, in_ld floats apart, Ci channels used
@@ -48,8 +49,9 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
     constexpr int B_LD = (BN * C8) / 256;             // 16-byte weight loads per thread per tap
     static_assert((BN * C8) % 256 == 0 || BN * C8 == 128, "weight tile must split evenly over the threads");
 
+    constexpr int TS = 3;                             // taps per stage: one kernel row (kw = 0,1,2)
     __shared__ __attribute__((aligned(16))) __bf16 Hs[kHaloMaxVox * LDK];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[TS][BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -95,10 +97,8 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     constexpr int B_LD_ = (B_LD > 0) ? B_LD : 1;     // 32x32 tile: 128 loads, threads 128..255 duplicate
-    static_assert(B_LD_ <= 2, "at most two 16-byte weight loads per thread per tap");
-    uint4 rb0a, rb0b, rb1a, rb1b;      // two register sets: weight tiles are fetched two taps ahead
     // Branch-free on purpose (rows past Co are clamped, their columns are never stored): with straight-line
-    // loads hipcc emits counted s_waitcnt vmcnt(N) and the two-tap prefetch really stays in flight.
+    // loads hipcc emits counted s_waitcnt vmcnt(N) and the prefetch really stays in flight.
     const __bf16* bsrc[B_LD_];
     int bdst[B_LD_];
 #pragma unroll
@@ -108,20 +108,12 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
         bsrc[i] = p.wp + (long)n * T * p.Ci + (f % C8) * 8;
         bdst[i] = (f / C8) * LDK + (SWZ ? (((f % C8) ^ ((f / C8) >> 1)) & 7) : (f % C8)) * 8;
     }
-    // (macros with named scalars, not lambdas over a pointer or loops over an array: anything the compiler
-    //  cannot index statically is demoted to scratch memory and the prefetch degenerates)
-#define HUPR_LOAD_B(RA, RBB, tap, c0)                                                            \
-    RA = *reinterpret_cast<const uint4*>(bsrc[0] + (long)(tap) * p.Ci + (c0));                   \
-    if constexpr (B_LD_ > 1) RBB = *reinterpret_cast<const uint4*>(bsrc[B_LD_ - 1] + (long)(tap) * p.Ci + (c0));
-#define HUPR_STORE_B(RA, RBB, buf)                                                               \
-    *reinterpret_cast<uint4*>(&Bs[buf][bdst[0]]) = RA;                                           \
-    if constexpr (B_LD_ > 1) *reinterpret_cast<uint4*>(&Bs[buf][bdst[B_LD_ - 1]]) = RBB;
+    u32x4 rb[TS * B_LD_];                             // next stage's weight tiles, in flight during the MFMAs
 
-    auto compute_tap = [&](int tap) {
+    auto compute_tap = [&](int tap, const __bf16* Bt) {
         const int tw_ = tap % 3, tt = tap / 3;
         const int th_ = tt % 3, td_ = tt / 3;
         const int toff = ((td_ * HH + th_) * HW + tw_) * LDK;
-        const __bf16* Bt = Bs[tap & 1];
         int akey[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) akey[i] = (((awx[i] + tw_) >> 1) & 3) | (((ahy[i] + th_) & 1) << 2);
@@ -138,18 +130,23 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
     };
 
     const int nvox = HD * HH * HW;
+    const int n_stage = T / TS;                       // 9 (3-D) or 3 (2-D)
+    constexpr int NI = (kHaloMaxVox * C8 + 255) / 256;   // halo items (8 channels of one voxel) per thread
     for (int c0 = 0; c0 < p.Ci; c0 += KC) {
-        HUPR_LOAD_B(rb0a, rb0b, 0, c0)
-        if (T > 1) { HUPR_LOAD_B(rb1a, rb1b, 1, c0) }
-        if (c0 > 0) __syncthreads();            // previous chunk's readers are done with Hs / Bs
-        // ---- halo chunk: global fp32 -> bf16 LDS, zero outside the tensor.  Loads are issued in batches of
-        // four items per thread before any is converted/stored, so their latencies overlap. -------------------
-        for (int it0 = tid; it0 < nvox * C8; it0 += 4 * 256) {
-            float4 va[4], vc[4];
-            int dst[4];
+        // weights of stage 0
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = it0 + u * 256;
+        for (int t = 0; t < TS; ++t)
+#pragma unroll
+            for (int i = 0; i < B_LD_; ++i) rb[t * B_LD_ + i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (long)t * p.Ci + c0);
+        if (c0 > 0) __syncthreads();            // previous chunk's readers are done with Hs / Bs
+        // ---- halo chunk: global fp32 -> bf16 LDS, zero outside the tensor.  ALL of this thread's loads are issued
+        // before any is converted/stored, so the fill costs about one memory round trip. -----------------------------
+        {
+            float4 va[NI], vc[NI];
+            int dst[NI];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int it = tid + u * 256;
                 va[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 vc[u] = va[u];
                 dst[u] = -1;
@@ -168,7 +165,7 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NI; ++u) {
                 if (dst[u] >= 0) {
                     bf16x8 v;
                     v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;
@@ -177,22 +174,23 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
                 }
             }
         }
-        HUPR_STORE_B(rb0a, rb0b, 0)
-        __syncthreads();
-        // ---- taps: iteration `tap` computes from Bs[tap&1]; the tile of tap+1 sits in one register set
-        // (stored to LDS at the end of this iteration), the tile of tap+2 is being fetched into the other ----
-        for (int tap = 0; tap < T; tap += 2) {
-            // even tap: rb1 holds tap+1, fetch tap+2 into rb0
-            if (tap + 2 < T) { HUPR_LOAD_B(rb0a, rb0b, tap + 2, c0) }
-            compute_tap(tap);
-            if (tap + 1 < T) { HUPR_STORE_B(rb1a, rb1b, 1) }
+        // ---- stages of three taps: compute from Bs while the next stage's weights travel to registers ---------------
+        for (int st_ = 0; st_ < n_stage; ++st_) {
+#pragma unroll
+            for (int t = 0; t < TS; ++t)
+#pragma unroll
+                for (int i = 0; i < B_LD_; ++i) *reinterpret_cast<u32x4*>(&Bs[t][bdst[i]]) = rb[t * B_LD_ + i];
             __syncthreads();
-            if (tap + 1 >= T) break;
-            // odd tap: rb0 holds tap+2, fetch tap+3 into rb1
-            if (tap + 3 < T) { HUPR_LOAD_B(rb1a, rb1b, tap + 3, c0) }
-            compute_tap(tap + 1);
-            if (tap + 2 < T) { HUPR_STORE_B(rb0a, rb0b, 0) }
-            __syncthreads();
+            if (st_ + 1 < n_stage) {
+#pragma unroll
+                for (int t = 0; t < TS; ++t)
+#pragma unroll
+                    for (int i = 0; i < B_LD_; ++i)
+                        rb[t * B_LD_ + i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (long)((st_ + 1) * TS + t) * p.Ci + c0);
+            }
+#pragma unroll
+            for (int t = 0; t < TS; ++t) compute_tap(st_ * TS + t, Bs[t]);
+            __syncthreads();                      // all waves are done with Bs (and, on the last stage, with Hs)
         }
     }
 
