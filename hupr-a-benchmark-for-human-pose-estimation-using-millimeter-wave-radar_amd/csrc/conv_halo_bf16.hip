@@ -11,25 +11,11 @@
 //     next tap's tile in flight during the MFMAs, one barrier per tap;
 //   * A bytes from global drop from 27x to ~3x the tile, so the kernel is matrix/LDS bound.
 // Used for forward and (with tap-reversed, transposed weights) the input gradient.
-#include "gemm_common.h"
+#include "conv_halo.h"
 
 namespace hupr {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector: stays in registers (a struct uint4 array did not)
 
-struct HaloArgs {
-    const float* x;          // [Bn][D][H][W] voxels, in_ld floats apart, Ci channels used
-    const __bf16* wp;        // packed bf16 weights [Co][T][Ci]
-    const float* bias;       // [Co] or null
-    const float* res;        // residual (voxel stride res_ld) or null
-    float* y;                // [Bn][D][H][W] voxels, out_ld floats apart
-    int Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld;
-    int kd;                  // 1 or 3 (kh = kw = 3)
-    int TD, log2TW;          // tile: TD x 8 x (1 << log2TW), TD * 8 * TW == 128
-    int nd, nh, nw;          // tiles per axis
-    int n_co_tiles;
-};
 
 constexpr int kHaloMaxVox = 4 * 10 * 10;     // (2+2) x (8+2) x (8+2); the 2-D tile needs 1 x 10 x 18 = 180
 
@@ -141,7 +127,7 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
         if (c0 > 0) __syncthreads();            // previous chunk's readers are done with Hs / Bs
         // ---- halo chunk: global fp32 -> bf16 LDS, zero outside the tensor.  ALL of this thread's loads are issued
         // before any is converted/stored, so the fill costs about one memory round trip. -----------------------------
-        {
+        if (!(p.ablate & 1)) {
             float4 va[NI], vc[NI];
             int dst[NI];
 #pragma unroll
@@ -188,15 +174,17 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
                     for (int i = 0; i < B_LD_; ++i)
                         rb[t * B_LD_ + i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (long)((st_ + 1) * TS + t) * p.Ci + c0);
             }
+            if (!(p.ablate & 2)) {
 #pragma unroll
-            for (int t = 0; t < TS; ++t) compute_tap(st_ * TS + t, Bs[t]);
+                for (int t = 0; t < TS; ++t) compute_tap(st_ * TS + t, Bs[t]);
+            }
             __syncthreads();                      // all waves are done with Bs (and, on the last stage, with Hs)
         }
     }
 
     // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (tile voxel) ----
     const int col = n0 + wn * 32 + lr;
-    if (col < p.Co) {
+    if (col < p.Co && !(p.ablate & 4)) {
         const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -247,6 +235,11 @@ extern "C" int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co
     return HUPR_OK;
 }
 
+static int g_halo_ablate = 0;
+static int g_halo_variant = 0;      // 0 auto, 1 force the 128-voxel kernel (A/B comparisons)
+extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
+extern "C" void hupr_debug_halo_variant(int v) { g_halo_variant = v; }
+
 // 1 if hupr_conv3x3_halo_bf16 supports this geometry (else use hupr_conv_fwd_bf16)
 extern "C" int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw) {
     if (kh != 3 || kw != 3 || ph != 1 || pw != 1) return 0;
@@ -268,6 +261,11 @@ extern "C" int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const
     a.x = x; a.wp = reinterpret_cast<const __bf16*>(wp_bf16); a.bias = bias; a.res = res; a.y = y;
     a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.out_ld = out_ld; a.res_ld = res_ld;
     a.kd = kd;
+    a.ablate = g_halo_ablate;
+    if (g_halo_variant != 1 && launch_conv_halo256(a, Bn, as_stream(stream))) {
+        HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16");
+        return HUPR_OK;
+    }
     if (kd == 3) { a.TD = 2; a.log2TW = 3; } else { a.TD = 1; a.log2TW = 4; }
     a.nd = D / a.TD; a.nh = H / 8; a.nw = W >> a.log2TW;
     const bool n32 = (Co <= 32);

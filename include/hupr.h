@@ -119,6 +119,8 @@ int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int
  * run from LDS.  wp_bf16 from hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci] bf16). */
 int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
                                 hupr_stream_t stream);
+void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel */
+void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */
 int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw);
 int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const float* bias, const float* res, float* y,
                            int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd,

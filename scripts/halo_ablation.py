@@ -1,0 +1,25 @@
+"""A/B of the two halo conv kernels and phase ablation on the dominant shapes (one process, interleaved rounds)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hupr_amd import functional as F_
+F_.set_math("bf16")
+L = F_.rt.lib()
+shapes = {"l1 64>64 @8x64x64": (64, 64, 8, 64, 64, (3, 3, 3), (1, 1, 1)), "l2 128>128 @4x32x32": (128, 128, 4, 32, 32, (3, 3, 3), (1, 1, 1)),
+          "dec1.0 320>64 @64x64": (320, 64, 1, 64, 64, (1, 3, 3), (0, 1, 1)), "dec2.0 640>128 @32x32": (640, 128, 1, 32, 32, (1, 3, 3), (0, 1, 1))}
+for name, (Ci, Co, D, H, W, k, pad) in shapes.items():
+    x = torch.randn(32, D, H, W, Ci, device="cuda"); w = torch.randn(Co, Ci, *k, device="cuda") * 0.05
+    flop = 2.0 * 32 * D * H * W * Co * Ci * k[0] * 9
+    res = {}
+    for rnd in range(3):
+        for variant, bits, label in ((1, 0, "v128 full"), (0, 0, "v256 full"), (0, 1, "v256 no-fill"), (0, 2, "v256 no-mfma"), (0, 4, "v256 no-store"), (0, 7, "v256 skeleton")):
+            L.hupr_debug_halo_variant(variant); L.hupr_debug_halo_ablate(bits)
+            for _ in range(2): F_._conv_raw(x, w, 0, None, None, Co, k, pad, (D, H, W))
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10): F_._conv_raw(x, w, 0, None, None, Co, k, pad, (D, H, W))
+            e.record(); torch.cuda.synchronize()
+            res.setdefault(label, []).append(s.elapsed_time(e) / 10 * 1e3)
+    L.hupr_debug_halo_ablate(0); L.hupr_debug_halo_variant(0)
+    print(name, " | ".join("%s %.0f us%s" % (k_, min(v), " (%.0f TF/s)" % (flop / min(v) / 1e6) if "full" in k_ else "") for k_, v in res.items()))

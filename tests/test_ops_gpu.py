@@ -435,3 +435,26 @@ def test_flash_attention_large_logits(bf16_math):
     out = F_.AttentionFn.apply(k.cuda(), q.cuda(), v.cuda(), False)
     assert torch.isfinite(out).all()
     close(out, ref, 2e-2, "flash big logits")
+
+
+def test_conv_halo256_persistent_kernel_matches_128_voxel_kernel(bf16_math):
+    """The 256-voxel persistent kernel only engages for >= 256 tiles; check it against the 128-voxel kernel (same
+    operand rounding, same accumulation order) and against fp64 on rounded operands at such a size."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    B, C, D, H, W = 4, 64, 8, 64, 64
+    x = rnd(B, D, H, W, C, seed=50).cuda()
+    w = rnd(128, C, 3, 3, 3, seed=51, scale=0.03).cuda()
+    bias = rnd(128, seed=52).cuda()
+    res = rnd(B, D, H, W, 128, seed=53).cuda()
+    try:
+        L.hupr_debug_halo_variant(1)
+        y128 = F_._conv_raw(x, w, 0, bias, res, 128, (3, 3, 3), (1, 1, 1), (D, H, W))
+        L.hupr_debug_halo_variant(0)
+        y256 = F_._conv_raw(x, w, 0, bias, res, 128, (3, 3, 3), (1, 1, 1), (D, H, W))
+    finally:
+        L.hupr_debug_halo_variant(0)
+    close(y256, y128, 1e-6, "halo256 vs halo128")
+    xs = x[:1, :, :16, :16].contiguous()          # fp64 reference on a crop that still covers every tap/halo case
+    ref = F.conv3d(_bf16_round(ncdhw(x.cpu()))[:1], _bf16_round(w.cpu()), bias.cpu().double(), 1, 1)
+    close(ncdhw(y256.cpu())[:1] - ncdhw(res.cpu())[:1].double(), ref, 2e-5, "halo256 vs fp64")
