@@ -8,12 +8,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector: stays in registers (a struct uint4 array did not)
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// Activation storage of x / res / y: fp32 (ABF = false) or bf16 (ABF = true); leading dimensions are in elements.
 struct HaloArgs {
-    const float* x;          // [Bn][D][H][W] voxels, in_ld floats apart, Ci channels used
+    const void* x;           // [Bn][D][H][W] voxels, in_ld elements apart, Ci channels used
     const __bf16* wp;        // packed bf16 weights [Co][T][Ci]
     const float* bias;       // [Co] or null
-    const float* res;        // residual (voxel stride res_ld) or null
-    float* y;                // [Bn][D][H][W] voxels, out_ld floats apart
+    const void* res;         // residual (voxel stride res_ld) or null
+    void* y;                 // [Bn][D][H][W] voxels, out_ld elements apart
     int Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld;
     int kd;                  // 1 or 3 (kh = kw = 3)
     int TD, log2TW;          // tile: TD x 8 x (1 << log2TW), TD * 8 * TW == 128
@@ -23,6 +26,32 @@ struct HaloArgs {
 };
 
 // 256-voxel persistent variant; returns false when the geometry is not supported
-bool launch_conv_halo256(HaloArgs a, int Bn, hipStream_t s);
+bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
+
+// Epilogue of both kernels.  The MFMAs are issued as D' = W * X^T, so a lane holds ONE voxel (column lane & 31 of the
+// 32-voxel group) and 16 channels n = 8 g + 4 (lane >> 5) + j  (g = r >> 2, j = r & 3): four 4-channel runs that go
+// out as 16-byte (fp32) or 8-byte (bf16) vector stores with a single voxel address per accumulator tile.
+template <bool ABF>
+__device__ __forceinline__ void halo_store_voxel(const HaloArgs& p, const f32x16& acc, long m, int chb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch = chb + 8 * g;
+        if (ch < p.Co) {
+            f32x4n v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            if (p.bias) v += (f32x4n){p.bias[ch], p.bias[ch + 1], p.bias[ch + 2], p.bias[ch + 3]};   // parameters may be 4-byte aligned views
+            if constexpr (ABF) {
+                if (p.res) {
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.res) + m * p.res_ld + ch);
+                    v += (f32x4n){(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+                }
+                const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.y) + m * p.out_ld + ch) = o;
+            } else {
+                if (p.res) v += *reinterpret_cast<const f32x4n*>(static_cast<const float*>(p.res) + m * p.res_ld + ch);
+                *reinterpret_cast<f32x4n*>(static_cast<float*>(p.y) + m * p.out_ld + ch) = v;
+            }
+        }
+    }
+}
 
 }  // namespace hupr

@@ -16,10 +16,11 @@ namespace hupr {
 
 constexpr int kHalo256MaxVox = 6 * 10 * 10;      // 3-D: (4+2) x 10 x 10 = 600;  2-D: 1 x 18 x 18 = 324
 
+template <bool ABF>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
     constexpr int NI = (kHalo256MaxVox * C8 + 511) / 512;      // 10 halo items (8 channels of a voxel) per thread ...
-    constexpr int NH = NI / 2;                                 // ... issued as two half batches (register budget: 256)
+    constexpr int NH = ABF ? NI : NI / 2;                      // ... fp32 sources: two half batches (register budget: 256)
     constexpr int NB = TS * BN * C8 / 512;                     // 3 weight loads per thread per stage
     __shared__ __attribute__((aligned(16))) __bf16 Hs[kHalo256MaxVox * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[TS][BN * LDK];
@@ -62,14 +63,15 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 
     f32x16 acc[2];
     u32x4 rb[NB];
-    f32x4n va[NH], vc[NH];
+    f32x4n va[ABF ? 1 : NH], vc[ABF ? 1 : NH];
+    u32x4 vb[ABF ? NH : 1];
     int dst[NH];
 
 #define HUPR_HALO_ISSUE(U0)                                                                                        \
     _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
         const int it = tid + (u + (U0)) * 512;                                                                      \
-        va[u] = (f32x4n){0.f, 0.f, 0.f, 0.f};                                                                       \
-        vc[u] = va[u];                                                                                              \
+        if constexpr (ABF) vb[u] = (u32x4){0u, 0u, 0u, 0u};                                                         \
+        else { va[u] = (f32x4n){0.f, 0.f, 0.f, 0.f}; vc[u] = va[u]; }                                               \
         dst[u] = -1;                                                                                                \
         if (it < nvox * C8 && !(p.ablate & 1)) {                                                                    \
             const int vox = it >> 3, c8 = it & 7;                                                                   \
@@ -79,36 +81,37 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             const int d = d0 + hz - pd, h = h0 + hy - 1, w = w0 + hx - 1;                                           \
             dst[u] = vox * LDK + ((c8 ^ (((hx >> 1) & 3) | ((hy & 1) << 2))) << 3);                                 \
             if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {        \
-                const float* src = p.x + ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8;       \
-                va[u] = *reinterpret_cast<const f32x4n*>(src);                                                      \
-                vc[u] = *reinterpret_cast<const f32x4n*>(src + 4);                                                  \
+                const long off = ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8;               \
+                if constexpr (ABF) {                                                                                \
+                    vb[u] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.x) + off);                 \
+                } else {                                                                                            \
+                    const float* src = static_cast<const float*>(p.x) + off;                                        \
+                    va[u] = *reinterpret_cast<const f32x4n*>(src);                                                  \
+                    vc[u] = *reinterpret_cast<const f32x4n*>(src + 4);                                              \
+                }                                                                                                   \
             }                                                                                                       \
         }                                                                                                           \
     }
 #define HUPR_HALO_COMMIT()                                                                                         \
     _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
         if (dst[u] >= 0) {                                                                                          \
-            bf16x8 v;                                                                                               \
-            v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;         \
-            v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;         \
-            *reinterpret_cast<bf16x8*>(&Hs[dst[u]]) = v;                                                            \
+            if constexpr (ABF) {                                                                                    \
+                *reinterpret_cast<u32x4*>(&Hs[dst[u]]) = vb[u];                                                     \
+            } else {                                                                                                \
+                bf16x8 v;                                                                                           \
+                v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;     \
+                v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;     \
+                *reinterpret_cast<bf16x8*>(&Hs[dst[u]]) = v;                                                        \
+            }                                                                                                       \
         }                                                                                                           \
     }
 #define HUPR_STORE_TILE(B_, D0_, H0_, W0_, N0_)                                                                    \
-    {                                                                                                               \
-        const int col = (N0_) + wn * 32 + lr;                                                                       \
-        if (col < p.Co && !(p.ablate & 4)) {                                                                        \
-            const float bv = p.bias ? p.bias[col] : 0.f;                                                            \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
-                _Pragma("unroll 4") for (int r = 0; r < 16; ++r) {                                                  \
-                    const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;                             \
-                    const int wx = row & (TW - 1), hy = (row >> log2TW) & (TH - 1), dz = row >> (log2TW + log2TH);  \
-                    const long m = (((long)(B_) * p.D + (D0_) + dz) * p.H + (H0_) + hy) * p.W + (W0_) + wx;         \
-                    float v = acc[i][r] + bv;                                                                       \
-                    if (p.res) v += p.res[m * p.res_ld + col];                                                      \
-                    p.y[m * p.out_ld + col] = v;                                                                    \
-                }                                                                                                   \
-            }                                                                                                       \
+    if (!(p.ablate & 4)) {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+            const int row = wm * 64 + i * 32 + lr;                                                                  \
+            const int wx = row & (TW - 1), hy = (row >> log2TW) & (TH - 1), dz = row >> (log2TW + log2TH);          \
+            const long m = (((long)(B_) * p.D + (D0_) + dz) * p.H + (H0_) + hy) * p.W + (W0_) + wx;                 \
+            halo_store_voxel<ABF>(p, acc[i], m, (N0_) + wn * 32 + 4 * lh);                                          \
         }                                                                                                           \
     }
 
@@ -140,8 +143,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const u32x4*>(wbase + wsrc[j] + (long)wt[j] * p.Ci + c0);
             __syncthreads();                                     // every wave is done with Hs / Bs of the previous chunk
             HUPR_HALO_COMMIT()
-            HUPR_HALO_ISSUE(NH)
-            HUPR_HALO_COMMIT()
+            if constexpr (!ABF) {
+                HUPR_HALO_ISSUE(NH)
+                HUPR_HALO_COMMIT()
+            }
             for (int st_ = 0; st_ < n_stage; ++st_) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(&Bs[wt[j]][wdst[j]]) = rb[j];
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
                                 const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&Hs[abase[i] + toff + ((cw ^ akey[i]) << 3)]);
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[i], 0, 0, 0);
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, afrag, acc[i], 0, 0, 0);   // D'[channel][voxel]
                             }
                         }
                     }
@@ -185,11 +190,12 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #undef HUPR_STORE_TILE
 }
 
-bool launch_conv_halo256(HaloArgs a, int Bn, hipStream_t s) {
+bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     const bool big3 = (a.kd == 3 && a.D % 4 == 0 && a.H % 8 == 0 && a.W % 8 == 0);
     const bool big2 = (a.kd == 1 && a.D == 1 && a.H % 16 == 0 && a.W % 16 == 0);
     // measured (scripts/halo_ablation.py): +8 % on the 3-D encoder layers, neutral to -6 % on the 2-D decoder maps
-    if (a.Ci % 64 != 0 || a.Co % 64 != 0 || !(big3 || (big2 && a.ablate == 0x100))) return false;
+    (void)big2;
+    if (a.Ci % 64 != 0 || a.Co % 64 != 0 || !big3) return false;
     a.TD = big3 ? 4 : 1;
     a.log2TW = big3 ? 3 : 4;
     a.nd = a.D / a.TD;
@@ -198,7 +204,9 @@ bool launch_conv_halo256(HaloArgs a, int Bn, hipStream_t s) {
     a.n_co_tiles = a.Co / 64;
     const long tiles = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
     if (tiles >= (1L << 31) || tiles < 256) return false;          // small problems: the 128-voxel kernel fills the chip better
-    hipLaunchKernelGGL(hupr_k_conv_halo256_bf16, dim3(256), dim3(512), 0, s, a);   // one persistent workgroup per CU
+    // one persistent workgroup per CU
+    if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(256), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<false>, dim3(256), dim3(512), 0, s, a);
     return true;
 }
 

@@ -19,7 +19,7 @@ namespace hupr {
 
 constexpr int kHaloMaxVox = 4 * 10 * 10;     // (2+2) x (8+2) x (8+2); the 2-D tile needs 1 x 10 x 18 = 180
 
-template <int BN, int KC>
+template <int BN, int KC, bool ABF>
 __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
     // KC = 64: unpadded 128-byte rows whose 16-byte chunks are XOR-swizzled — halo rows by
     //   key = ((hx >> 1) & 3) | ((hy & 1) << 2), weight rows by key = (n >> 1) & 7 — which makes every
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&Hs[abase[i] + toff + (SWZ ? (cw ^ akey[i]) : cw) * 8]);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, afrag, acc[i], 0, 0, 0);   // D'[channel][voxel]
             }
         }
     };
@@ -128,6 +128,30 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
         // ---- halo chunk: global fp32 -> bf16 LDS, zero outside the tensor.  ALL of this thread's loads are issued
         // before any is converted/stored, so the fill costs about one memory round trip. -----------------------------
         if (!(p.ablate & 1)) {
+            if constexpr (ABF) {
+                u32x4 va[NI];
+                int dst[NI];
+#pragma unroll
+                for (int u = 0; u < NI; ++u) {
+                    const int it = tid + u * 256;
+                    va[u] = (u32x4){0u, 0u, 0u, 0u};
+                    dst[u] = -1;
+                    if (it < nvox * C8) {
+                        const int vox = it / C8, c8 = it - vox * C8;
+                        const int hx = vox % HW;
+                        const int t = vox / HW;
+                        const int hy = t % HH, hz = t / HH;
+                        const int d = d0 + hz - pd, h = h0 + hy - 1, w = w0 + hx - 1;
+                        dst[u] = vox * LDK + (SWZ ? (c8 ^ (((hx >> 1) & 3) | ((hy & 1) << 2))) : c8) * 8;
+                        if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+                            va[u] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.x) +
+                                        ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NI; ++u)
+                    if (dst[u] >= 0) *reinterpret_cast<u32x4*>(&Hs[dst[u]]) = va[u];
+            } else {
             float4 va[NI], vc[NI];
             int dst[NI];
 #pragma unroll
@@ -144,7 +168,7 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
                     const int d = d0 + hz - pd, h = h0 + hy - 1, w = w0 + hx - 1;
                     dst[u] = vox * LDK + (SWZ ? (c8 ^ (((hx >> 1) & 3) | ((hy & 1) << 2))) : c8) * 8;
                     if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
-                        const float* src = p.x + ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8;
+                        const float* src = static_cast<const float*>(p.x) + ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8;
                         va[u] = *reinterpret_cast<const float4*>(src);
                         vc[u] = *reinterpret_cast<const float4*>(src + 4);
                     }
@@ -158,6 +182,7 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
                     v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;
                     *reinterpret_cast<bf16x8*>(&Hs[dst[u]]) = v;
                 }
+            }
             }
         }
         // ---- stages of three taps: compute from Bs while the next stage's weights travel to registers ---------------
@@ -182,21 +207,14 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
         }
     }
 
-    // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (tile voxel) ----
-    const int col = n0 + wn * 32 + lr;
-    if (col < p.Co && !(p.ablate & 4)) {
-        const float bv = p.bias ? p.bias[col] : 0.f;
+    // ---- epilogue (conv_halo.h): this lane's voxel of each 32-voxel group, 4 x 4 channels ----
+    if (!(p.ablate & 4)) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int wx = row & (TW - 1), hy = (row >> p.log2TW) & 7, dz = row >> (p.log2TW + 3);
-                const long m = (((long)b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx;
-                float v = acc[i][r] + bv;
-                if (p.res) v += p.res[m * p.res_ld + col];
-                p.y[m * p.out_ld + col] = v;
-            }
+            const int row = wm * WTM + i * 32 + lr;
+            const int wx = row & (TW - 1), hy = (row >> p.log2TW) & 7, dz = row >> (p.log2TW + 3);
+            const long m = (((long)b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx;
+            halo_store_voxel<ABF>(p, acc[i], m, n0 + wn * 32 + 4 * lh);
         }
     }
 }
@@ -249,20 +267,20 @@ extern "C" int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, 
     return (D == 1 && W % 16 == 0) ? 1 : 0;
 }
 
-// y = conv3x3(x) (+bias) (+res): stride 1, "same" padding; kd = 3 (pad 1) or kd = 1.
-// wp_bf16: weights packed by hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci]).
-extern "C" int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const float* bias, const float* res, float* y,
-                                      int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld,
-                                      int kd, hupr_stream_t stream) {
-    HUPR_REQUIRE(x && wp_bf16 && y, "hupr_conv3x3_halo_bf16: null pointer");
-    HUPR_REQUIRE(hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1), "hupr_conv3x3_halo_bf16: unsupported geometry");
-    HUPR_REQUIRE(Bn > 0 && Co > 0 && in_ld % 4 == 0, "hupr_conv3x3_halo_bf16: bad argument");
+static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y, int Bn, int D,
+                        int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd, bool abf,
+                        hupr_stream_t stream, const char* who) {
+    HUPR_REQUIRE(x && wp_bf16 && y, "%s: null pointer", who);
+    HUPR_REQUIRE(hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1), "%s: unsupported geometry", who);
+    const int al = abf ? 8 : 4;                      // 16-byte halo loads, 4-channel output vectors
+    HUPR_REQUIRE(Bn > 0 && Co > 0 && Co % 4 == 0 && in_ld % al == 0 && out_ld % 4 == 0 && (!res || res_ld % 4 == 0),
+                 "%s: bad argument (Co, leading dimensions must be multiples of 4; bf16 in_ld of 8)", who);
     HaloArgs a;
     a.x = x; a.wp = reinterpret_cast<const __bf16*>(wp_bf16); a.bias = bias; a.res = res; a.y = y;
     a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.out_ld = out_ld; a.res_ld = res_ld;
     a.kd = kd;
     a.ablate = g_halo_ablate;
-    if (g_halo_variant != 1 && launch_conv_halo256(a, Bn, as_stream(stream))) {
+    if (g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {
         HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16");
         return HUPR_OK;
     }
@@ -272,15 +290,36 @@ extern "C" int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const
     const int bn = n32 ? 32 : 64;
     a.n_co_tiles = (Co + bn - 1) / bn;
     const long blocks = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
-    HUPR_REQUIRE(blocks < (1L << 31), "hupr_conv3x3_halo_bf16: grid too large");
+    HUPR_REQUIRE(blocks < (1L << 31), "%s: grid too large", who);
     hipStream_t s = as_stream(stream);
+#define HUPR_HALO_LAUNCH(BN_, KC_)                                                                                       \
+    do {                                                                                                                 \
+        if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);     \
+    } while (0)
     if (Ci % 64 == 0) {
-        if (n32) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<32, 64>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<64, 64>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (n32) HUPR_HALO_LAUNCH(32, 64); else HUPR_HALO_LAUNCH(64, 64);
     } else {
-        if (n32) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<32, 32>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<64, 32>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (n32) HUPR_HALO_LAUNCH(32, 32); else HUPR_HALO_LAUNCH(64, 32);
     }
+#undef HUPR_HALO_LAUNCH
     HUPR_LAUNCH_OK("hupr_k_conv_halo_bf16");
     return HUPR_OK;
+}
+
+// y = conv3x3(x) (+bias) (+res): stride 1, "same" padding; kd = 3 (pad 1) or kd = 1.
+// wp_bf16: weights packed by hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci]).  fp32 activations in HBM.
+extern "C" int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const float* bias, const float* res, float* y,
+                                      int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld,
+                                      int kd, hupr_stream_t stream) {
+    return conv3x3_halo(x, wp_bf16, bias, res, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld, kd, false, stream,
+                        "hupr_conv3x3_halo_bf16");
+}
+
+// Same operator on bf16 activations (x, res, y stored as bf16; leading dimensions in elements).
+extern "C" int hupr_conv3x3_halo_bf16act(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y,
+                                         int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld,
+                                         int kd, hupr_stream_t stream) {
+    return conv3x3_halo(x, wp_bf16, bias, res, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld, kd, true, stream,
+                        "hupr_conv3x3_halo_bf16act");
 }

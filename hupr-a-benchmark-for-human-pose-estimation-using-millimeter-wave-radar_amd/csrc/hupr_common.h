@@ -54,6 +54,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Activation storage helpers: 4 consecutive channels as fp32 (16 B) or bf16 (8 B), always computed on as fp32.
+typedef __bf16 hupr_bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ float4 ld_act4(const T* p);
+template <> __device__ __forceinline__ float4 ld_act4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld_act4<__bf16>(const __bf16* p) {
+    const hupr_bf16x4 v = *reinterpret_cast<const hupr_bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st_act4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st_act4(__bf16* p, float4 v) {
+    const hupr_bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<hupr_bf16x4*>(p) = o;
+}
+
 static inline hipStream_t as_stream(hupr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -17,9 +17,9 @@ constexpr int kStatBlocks = 256;
 //   MODE 1 (backward): f = dy',           g = dy' * xhat      dy' = dy * [y > 0] if y given
 // partial[blk][2][C] doubles
 // ------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void hupr_k_colstats(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       const float* __restrict__ y,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const T* __restrict__ y,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, long M, int C,
                                                        double* __restrict__ partial) {
@@ -41,16 +41,16 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const float* __restrict__
     }
     if (rsub < rows_per_pass) {
         for (long r = r0 + rsub; r < r1; r += rows_per_pass) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c4 * 4);
+            const float4 xv = ld_act4(x + r * C + c4 * 4);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
             if (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { s1[k] += xs[k]; s2[k] = fmaf(xs[k], xs[k], s2[k]); }
             } else {
-                const float4 gv = *reinterpret_cast<const float4*>(dy + r * C + c4 * 4);
+                const float4 gv = ld_act4(dy + r * C + c4 * 4);
                 float gs[4] = {gv.x, gv.y, gv.z, gv.w};
                 if (y) {
-                    const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c4 * 4);
+                    const float4 yv = ld_act4(y + r * C + c4 * 4);
                     const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) gs[k] = ys[k] > 0.f ? gs[k] : 0.f;
@@ -132,21 +132,22 @@ __global__ void hupr_k_bn_eval_params(const float* __restrict__ gamma, const flo
 }
 
 // y = act(x1*s1 + t1 (+ x2*s2 + t2)) ; act: 0 none, 1 relu
-__global__ __launch_bounds__(256) void hupr_k_scale_shift_act(const float* __restrict__ x1,
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_scale_shift_act(const T* __restrict__ x1,
                                                               const float* __restrict__ s1,
                                                               const float* __restrict__ t1,
-                                                              const float* __restrict__ x2,
+                                                              const T* __restrict__ x2,
                                                               const float* __restrict__ s2,
                                                               const float* __restrict__ t2,
-                                                              float* __restrict__ y, long n4, int C, int act) {
+                                                              T* __restrict__ y, long n4, int C, int act) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
-        float4 v = reinterpret_cast<const float4*>(x1)[i];
+        float4 v = ld_act4(x1 + i * 4);
         const float4 a = *reinterpret_cast<const float4*>(s1 + c), b = *reinterpret_cast<const float4*>(t1 + c);
         v.x = fmaf(v.x, a.x, b.x); v.y = fmaf(v.y, a.y, b.y);
         v.z = fmaf(v.z, a.z, b.z); v.w = fmaf(v.w, a.w, b.w);
         if (x2) {
-            const float4 u = reinterpret_cast<const float4*>(x2)[i];
+            const float4 u = ld_act4(x2 + i * 4);
             const float4 a2 = *reinterpret_cast<const float4*>(s2 + c), b2 = *reinterpret_cast<const float4*>(t2 + c);
             v.x += fmaf(u.x, a2.x, b2.x); v.y += fmaf(u.y, a2.y, b2.y);
             v.z += fmaf(u.z, a2.z, b2.z); v.w += fmaf(u.w, a2.w, b2.w);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void hupr_k_scale_shift_act(const float* __res
         if (act == 1) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        reinterpret_cast<float4*>(y)[i] = v;
+        st_act4(y + i * 4, v);
     }
 }
 
@@ -173,21 +174,22 @@ __global__ void hupr_k_bn_finalize_bwd(const double* __restrict__ partial, int n
     sums[C + c] = (float)s2;
 }
 
-__global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
-                                                           const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const T* __restrict__ x,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, float inv_m,
-                                                           float* __restrict__ dx, long n4, int C, int train) {
+                                                           T* __restrict__ dx, long n4, int C, int train) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
-        const float4 gv = reinterpret_cast<const float4*>(dy)[i];
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 gv = ld_act4(dy + i * 4);
+        const float4 xv = ld_act4(x + i * 4);
         float g[4] = {gv.x, gv.y, gv.z, gv.w};
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         if (y) {
-            const float4 yv = reinterpret_cast<const float4*>(y)[i];
+            const float4 yv = ld_act4(y + i * 4);
             const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) g[k] = ys[k] > 0.f ? g[k] : 0.f;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const float* __restri
                 o[k] = w * g[k];
             }
         }
-        reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        st_act4(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -274,25 +276,40 @@ static int bn_check(const char* who, long M, int C) {
 }
 
 // (a4) BatchNorm3d, training mode: batch statistics + running-stat update (momentum), and the
-// folded per-channel scale/shift used by hupr_scale_shift_act_f32.  models/layers.py:46,49,53
-extern "C" int hupr_bn_train_stats_f32(const float* x, long M, int C, const float* gamma, const float* beta,
-                                       float* running_mean, float* running_var, float momentum, float eps,
-                                       float* save_mean, float* save_invstd, float* scale, float* shift,
-                                       void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale && shift && ws, "hupr_bn_train_stats_f32: null pointer");
-    int rc = bn_check("hupr_bn_train_stats_f32", M, C);
+// folded per-channel scale/shift used by hupr_scale_shift_act_*.  models/layers.py:46,49,53
+template <typename T>
+static int bn_train_stats(const char* who, const T* x, long M, int C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                          float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale && shift && ws, "%s: null pointer", who);
+    int rc = bn_check(who, M, C);
     if (rc) return rc;
-    if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "hupr_bn_train_stats_f32: workspace too small");
+    if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(hupr_k_colstats<0>, dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, nullptr, nullptr,
-                       nullptr, nullptr, M, C, partial);
+    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
+                       (const T*)nullptr, nullptr, nullptr, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
     hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, M, C, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd");
     return HUPR_OK;
+}
+
+extern "C" int hupr_bn_train_stats_f32(const float* x, long M, int C, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps,
+                                       float* save_mean, float* save_invstd, float* scale, float* shift,
+                                       void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return bn_train_stats("hupr_bn_train_stats_f32", x, M, C, gamma, beta, running_mean, running_var, momentum, eps,
+                          save_mean, save_invstd, scale, shift, ws, ws_bytes, stream);
+}
+extern "C" int hupr_bn_train_stats_bf16act(const void* x, long M, int C, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, float momentum, float eps,
+                                           float* save_mean, float* save_invstd, float* scale, float* shift,
+                                           void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return bn_train_stats("hupr_bn_train_stats_bf16act", static_cast<const __bf16*>(x), M, C, gamma, beta, running_mean,
+                          running_var, momentum, eps, save_mean, save_invstd, scale, shift, ws, ws_bytes, stream);
 }
 
 extern "C" int hupr_bn_eval_params_f32(const float* gamma, const float* beta, const float* running_mean,
@@ -306,42 +323,67 @@ extern "C" int hupr_bn_eval_params_f32(const float* gamma, const float* beta, co
 }
 
 // y = act(x1*scale1 + shift1 [+ x2*scale2 + shift2]); act 0 = identity, 1 = ReLU
-extern "C" int hupr_scale_shift_act_f32(const float* x1, const float* scale1, const float* shift1, const float* x2,
-                                        const float* scale2, const float* shift2, float* y, long M, int C, int act,
-                                        hupr_stream_t stream) {
-    HUPR_REQUIRE(x1 && scale1 && shift1 && y, "hupr_scale_shift_act_f32: null pointer");
-    HUPR_REQUIRE(!x2 || (scale2 && shift2), "hupr_scale_shift_act_f32: second branch needs scale/shift");
-    int rc = bn_check("hupr_scale_shift_act_f32", M, C);
+template <typename T>
+static int scale_shift_act(const char* who, const T* x1, const float* scale1, const float* shift1, const T* x2,
+                           const float* scale2, const float* shift2, T* y, long M, int C, int act, hupr_stream_t stream) {
+    HUPR_REQUIRE(x1 && scale1 && shift1 && y, "%s: null pointer", who);
+    HUPR_REQUIRE(!x2 || (scale2 && shift2), "%s: second branch needs scale/shift", who);
+    int rc = bn_check(who, M, C);
     if (rc) return rc;
     const long n4 = M * C / 4;
-    hipLaunchKernelGGL(hupr_k_scale_shift_act, dim3(ew_grid(n4)), dim3(256), 0, as_stream(stream), x1, scale1, shift1,
+    hipLaunchKernelGGL(hupr_k_scale_shift_act<T>, dim3(ew_grid(n4)), dim3(256), 0, as_stream(stream), x1, scale1, shift1,
                        x2, scale2, shift2, y, n4, C, act);
     HUPR_LAUNCH_OK("hupr_k_scale_shift_act");
     return HUPR_OK;
 }
+extern "C" int hupr_scale_shift_act_f32(const float* x1, const float* scale1, const float* shift1, const float* x2,
+                                        const float* scale2, const float* shift2, float* y, long M, int C, int act,
+                                        hupr_stream_t stream) {
+    return scale_shift_act("hupr_scale_shift_act_f32", x1, scale1, shift1, x2, scale2, shift2, y, M, C, act, stream);
+}
+extern "C" int hupr_scale_shift_act_bf16act(const void* x1, const float* scale1, const float* shift1, const void* x2,
+                                            const float* scale2, const float* shift2, void* y, long M, int C, int act,
+                                            hupr_stream_t stream) {
+    return scale_shift_act("hupr_scale_shift_act_bf16act", static_cast<const __bf16*>(x1), scale1, shift1,
+                           static_cast<const __bf16*>(x2), scale2, shift2, static_cast<__bf16*>(y), M, C, act, stream);
+}
 
 // BatchNorm backward through an optional ReLU mask (y > 0).  train=1: batch-stat formula.
-extern "C" int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float* x, const float* save_mean,
-                               const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                               long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(dy && x && save_mean && save_invstd && gamma && dx && dgamma && dbeta && ws, "hupr_bn_bwd_f32: null pointer");
-    int rc = bn_check("hupr_bn_bwd_f32", M, C);
+template <typename T>
+static int bn_bwd(const char* who, const T* dy, const T* y_mask, const T* x, const float* save_mean,
+                  const float* save_invstd, const float* gamma, T* dx, float* dgamma, float* dbeta, long M, int C,
+                  int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && x && save_mean && save_invstd && gamma && dx && dgamma && dbeta && ws, "%s: null pointer", who);
+    int rc = bn_check(who, M, C);
     if (rc) return rc;
-    if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "hupr_bn_bwd_f32: workspace too small");
+    if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
     float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 2 * C * sizeof(double));
-    hipLaunchKernelGGL(hupr_k_colstats<1>, dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, dy, y_mask, save_mean,
+    hipLaunchKernelGGL((hupr_k_colstats<1, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, dy, y_mask, save_mean,
                        save_invstd, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<1>");
     hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, C, dgamma, dbeta, sums);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd");
     const long n4 = M * C / 4;
-    hipLaunchKernelGGL(hupr_k_bn_bwd_apply, dim3(ew_grid(n4)), dim3(256), 0, s, dy, y_mask, x, save_mean, save_invstd,
+    hipLaunchKernelGGL(hupr_k_bn_bwd_apply<T>, dim3(ew_grid(n4)), dim3(256), 0, s, dy, y_mask, x, save_mean, save_invstd,
                        gamma, sums, 1.0f / (float)M, dx, n4, C, train);
     HUPR_LAUNCH_OK("hupr_k_bn_bwd_apply");
     return HUPR_OK;
+}
+extern "C" int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float* x, const float* save_mean,
+                               const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                               long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return bn_bwd("hupr_bn_bwd_f32", dy, y_mask, x, save_mean, save_invstd, gamma, dx, dgamma, dbeta, M, C, train, ws,
+                  ws_bytes, stream);
+}
+extern "C" int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const void* x, const float* save_mean,
+                                   const float* save_invstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                                   long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return bn_bwd("hupr_bn_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y_mask),
+                  static_cast<const __bf16*>(x), save_mean, save_invstd, gamma, static_cast<__bf16*>(dx), dgamma, dbeta,
+                  M, C, train, ws, ws_bytes, stream);
 }
 
 extern "C" int hupr_prelu_fwd_f32(const float* x, const float* alpha, float* y, long n, hupr_stream_t stream) {
@@ -368,18 +410,47 @@ extern "C" int hupr_prelu_bwd_f32(const float* dy, const float* x, const float* 
 }
 
 // out[c] = sum over rows of x[row][c]   (bias gradient of a convolution)
-extern "C" int hupr_colsum_f32(const float* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(x && out && ws, "hupr_colsum_f32: null pointer");
-    int rc = bn_check("hupr_colsum_f32", M, C);
+template <typename T>
+static int colsum(const char* who, const T* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && out && ws, "%s: null pointer", who);
+    int rc = bn_check(who, M, C);
     if (rc) return rc;
-    if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "hupr_colsum_f32: workspace too small");
+    if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(hupr_k_colstats<0>, dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, nullptr, nullptr,
-                       nullptr, nullptr, M, C, partial);
+    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
+                       (const T*)nullptr, nullptr, nullptr, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
     hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, C, out);
     HUPR_LAUNCH_OK("hupr_k_colsum_final");
+    return HUPR_OK;
+}
+extern "C" int hupr_colsum_f32(const float* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return colsum("hupr_colsum_f32", x, M, C, out, ws, ws_bytes, stream);
+}
+extern "C" int hupr_colsum_bf16act(const void* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return colsum("hupr_colsum_bf16act", static_cast<const __bf16*>(x), M, C, out, ws, ws_bytes, stream);
+}
+
+// fp32 <-> bf16 activation casts at the boundary of the bf16-activation region (n % 4 == 0)
+namespace hupr {
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void hupr_k_cast(const TI* __restrict__ x, TO* __restrict__ y, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) st_act4(y + i * 4, ld_act4(x + i * 4));
+}
+}  // namespace hupr
+extern "C" int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && y && n > 0 && n % 4 == 0, "hupr_cast_f32_to_bf16: bad argument");
+    hipLaunchKernelGGL((hupr_k_cast<float, __bf16>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), x,
+                       static_cast<__bf16*>(y), n / 4);
+    HUPR_LAUNCH_OK("hupr_k_cast");
+    return HUPR_OK;
+}
+extern "C" int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && y && n > 0 && n % 4 == 0, "hupr_cast_bf16_to_f32: bad argument");
+    hipLaunchKernelGGL((hupr_k_cast<__bf16, float>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream),
+                       static_cast<const __bf16*>(x), y, n / 4);
+    HUPR_LAUNCH_OK("hupr_k_cast");
     return HUPR_OK;
 }

@@ -26,8 +26,9 @@ __device__ __forceinline__ void mnet_load_means(const float* __restrict__ x, lon
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       const float* __restrict__ bias, T* __restrict__ out,
                                                        long n_bg, int pixels) {
     __shared__ float sw[kNF * 4 + kNF];
     for (int i = threadIdx.x; i < kNF * 4 + kNF; i += 256) sw[i] = (i < kNF * 4) ? w[i] : bias[i - kNF * 4];
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__
         const float* xb = x + bg * 16 * (long)pixels * 8;
         float m[16];
         mnet_load_means(xb, (long)pixels * 8, pix, m);
-        float4* o = reinterpret_cast<float4*>(out + idx * kNF);
+        T* o = out + idx * kNF;
 #pragma unroll
         for (int c4 = 0; c4 < kNF / 4; ++c4) {
             float r[4];
@@ -58,15 +59,16 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__
                 }
                 r[k] = best;
             }
-            o[c4] = make_float4(r[0], r[1], r[2], r[3]);
+            st_act4(o + c4 * 4, make_float4(r[0], r[1], r[2], r[3]));
         }
     }
 }
 
 // backward: recompute the arg-max chirp step, accumulate dW[co][ch2][kt] and dbias[co]
 // partial[blk][160]
+template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, const float* __restrict__ dy,
+                                                       const float* __restrict__ bias, const T* __restrict__ dy,
                                                        long n_bg, int pixels, float* __restrict__ partial) {
     __shared__ float sw[kNF * 4 + kNF];
     __shared__ float red[4][kNF * 5];
@@ -81,10 +83,10 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__
         const float* xb = x + bg * 16 * (long)pixels * 8;
         float m[16];
         mnet_load_means(xb, (long)pixels * 8, pix, m);
-        const float4* g4 = reinterpret_cast<const float4*>(dy + idx * kNF);
+        const T* g4 = dy + idx * kNF;
 #pragma unroll
         for (int c4 = 0; c4 < kNF / 4; ++c4) {
-            const float4 gv = g4[c4];
+            const float4 gv = ld_act4(g4 + c4 * 4);
             const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -177,7 +179,8 @@ __device__ __forceinline__ float lin_weight(int o, int i, int in, int out) {
 }
 
 // forward: y[o] = sum over the 8 corner voxels
-__global__ __launch_bounds__(256) void hupr_k_interp_fwd(const float* __restrict__ src, float* __restrict__ dst, int Bn,
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_interp_fwd(const T* __restrict__ src, T* __restrict__ dst, int Bn,
                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                                                          int in_ld, int out_ld) {
     const int c4n = C >> 2;
@@ -206,19 +209,20 @@ __global__ __launch_bounds__(256) void hupr_k_interp_fwd(const float* __restrict
                     const int iw = cq ? lw.i1 : lw.i0;
                     const float wgt = wd * wh * (cq ? lw.w1 : lw.w0);
                     const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
-                    const float4 xv = *reinterpret_cast<const float4*>(src + ivox * in_ld + c4 * 4);
+                    const float4 xv = ld_act4(src + ivox * in_ld + c4 * 4);
                     acc.x = fmaf(wgt, xv.x, acc.x); acc.y = fmaf(wgt, xv.y, acc.y);
                     acc.z = fmaf(wgt, xv.z, acc.z); acc.w = fmaf(wgt, xv.w, acc.w);
                 }
             }
         }
-        *reinterpret_cast<float4*>(dst + ovox * out_ld + c4 * 4) = acc;
+        st_act4(dst + ovox * out_ld + c4 * 4, acc);
     }
 }
 
 // backward, gather form: each thread owns one INPUT voxel (x 4 channels) and sums the output gradients that
 // touched it — deterministic, no atomics, no zero-fill pass.
-__global__ __launch_bounds__(256) void hupr_k_interp_bwd(const float* __restrict__ dy, float* __restrict__ dx, int Bn,
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_interp_bwd(const T* __restrict__ dy, T* __restrict__ dx, int Bn,
                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                                                          int in_ld, int out_ld) {
     const int c4n = C >> 2;
@@ -246,14 +250,14 @@ __global__ __launch_bounds__(256) void hupr_k_interp_bwd(const float* __restrict
                     if (ww == 0.f) continue;
                     const float wgt = wd * wh * ww;
                     const long ovox = (((long)b * Do + od) * Ho + oh) * Wo + ow;
-                    const float4 g = *reinterpret_cast<const float4*>(dy + ovox * out_ld + c4 * 4);
+                    const float4 g = ld_act4(dy + ovox * out_ld + c4 * 4);
                     acc.x = fmaf(wgt, g.x, acc.x); acc.y = fmaf(wgt, g.y, acc.y);
                     acc.z = fmaf(wgt, g.z, acc.z); acc.w = fmaf(wgt, g.w, acc.w);
                 }
             }
         }
         const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
-        *reinterpret_cast<float4*>(dx + ivox * in_ld + c4 * 4) = acc;
+        st_act4(dx + ivox * in_ld + c4 * 4, acc);
     }
 }
 
@@ -262,32 +266,51 @@ __global__ __launch_bounds__(256) void hupr_k_interp_bwd(const float* __restrict
 using namespace hupr;
 
 // (a3) MNet forward.  x: (n_bg = B*G, F=8, 2, pixels = R*A, E=8) fp32;  w: (32,2,2,1,1); bias: (32)
-// out: (n_bg, pixels, 32) channels-last
-extern "C" int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, long n_bg, int pixels,
-                                 hupr_stream_t stream) {
-    HUPR_REQUIRE(x && w && bias && out && n_bg > 0 && pixels > 0, "hupr_mnet_fwd_f32: bad argument");
+// out: (n_bg, pixels, 32) channels-last, fp32 or (bf16act) bf16
+template <typename T>
+static int mnet_fwd(const char* who, const float* x, const float* w, const float* bias, T* out, long n_bg, int pixels,
+                    hupr_stream_t stream) {
+    HUPR_REQUIRE(x && w && bias && out && n_bg > 0 && pixels > 0, "%s: bad argument", who);
     const long total = n_bg * pixels;
     const int grid = (int)min((long)8192, (total + 255) / 256);
-    hipLaunchKernelGGL(hupr_k_mnet_fwd, dim3(grid), dim3(256), 0, as_stream(stream), x, w, bias, out, n_bg, pixels);
+    hipLaunchKernelGGL(hupr_k_mnet_fwd<T>, dim3(grid), dim3(256), 0, as_stream(stream), x, w, bias, out, n_bg, pixels);
     HUPR_LAUNCH_OK("hupr_k_mnet_fwd");
     return HUPR_OK;
+}
+extern "C" int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, long n_bg, int pixels,
+                                 hupr_stream_t stream) {
+    return mnet_fwd("hupr_mnet_fwd_f32", x, w, bias, out, n_bg, pixels, stream);
+}
+extern "C" int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, long n_bg, int pixels,
+                                     hupr_stream_t stream) {
+    return mnet_fwd("hupr_mnet_fwd_bf16act", x, w, bias, static_cast<__bf16*>(out), n_bg, pixels, stream);
 }
 
 extern "C" size_t hupr_mnet_bwd_ws_bytes(void) { return (size_t)1024 * kNF * 5 * sizeof(float); }
 
-extern "C" int hupr_mnet_bwd_f32(const float* x, const float* w, const float* bias, const float* dy, float* dw,
-                                 float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(x && w && bias && dy && dw && dbias && ws && n_bg > 0 && pixels > 0, "hupr_mnet_bwd_f32: bad argument");
-    if (ws_bytes < hupr_mnet_bwd_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_mnet_bwd_f32: workspace too small");
+template <typename T>
+static int mnet_bwd(const char* who, const float* x, const float* w, const float* bias, const T* dy, float* dw,
+                    float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && w && bias && dy && dw && dbias && ws && n_bg > 0 && pixels > 0, "%s: bad argument", who);
+    if (ws_bytes < hupr_mnet_bwd_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     const long total = n_bg * pixels;
     const int grid = (int)min((long)1024, (total + 255) / 256);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(hupr_k_mnet_bwd, dim3(grid), dim3(256), 0, s, x, w, bias, dy, n_bg, pixels,
+    hipLaunchKernelGGL(hupr_k_mnet_bwd<T>, dim3(grid), dim3(256), 0, s, x, w, bias, dy, n_bg, pixels,
                        reinterpret_cast<float*>(ws));
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd");
     hipLaunchKernelGGL(hupr_k_mnet_bwd_final, dim3(kNF * 5), dim3(256), 0, s, reinterpret_cast<const float*>(ws), grid, dw, dbias);
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd_final");
     return HUPR_OK;
+}
+extern "C" int hupr_mnet_bwd_f32(const float* x, const float* w, const float* bias, const float* dy, float* dw,
+                                 float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return mnet_bwd("hupr_mnet_bwd_f32", x, w, bias, dy, dw, dbias, n_bg, pixels, ws, ws_bytes, stream);
+}
+extern "C" int hupr_mnet_bwd_bf16act(const float* x, const float* w, const float* bias, const void* dy, float* dw,
+                                     float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return mnet_bwd("hupr_mnet_bwd_bf16act", x, w, bias, static_cast<const __bf16*>(dy), dw, dbias, n_bg, pixels, ws,
+                    ws_bytes, stream);
 }
 
 static int interp_check(const char* who, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int in_ld,
@@ -298,27 +321,47 @@ static int interp_check(const char* who, int Bn, int Di, int Hi, int Wi, int Do,
     return HUPR_OK;
 }
 
-extern "C" int hupr_interp_linear_fwd_f32(const float* x, float* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
-                                          int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
-    HUPR_REQUIRE(x && y, "hupr_interp_linear_fwd_f32: null pointer");
-    int rc = interp_check("hupr_interp_linear_fwd_f32", Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+template <typename T>
+static int interp_fwd(const char* who, const T* x, T* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
+                      int in_ld, int out_ld, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && y, "%s: null pointer", who);
+    int rc = interp_check(who, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     if (rc) return rc;
     const long total = (long)Bn * Do * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(hupr_k_interp_fwd, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(hupr_k_interp_fwd<T>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
                        as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     HUPR_LAUNCH_OK("hupr_k_interp_fwd");
     return HUPR_OK;
 }
+extern "C" int hupr_interp_linear_fwd_f32(const float* x, float* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                          int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    return interp_fwd("hupr_interp_linear_fwd_f32", x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld, stream);
+}
+extern "C" int hupr_interp_linear_fwd_bf16act(const void* x, void* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                              int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    return interp_fwd("hupr_interp_linear_fwd_bf16act", static_cast<const __bf16*>(x), static_cast<__bf16*>(y), Bn, Di,
+                      Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld, stream);
+}
 
 // dx = adjoint of the forward map applied to dy (gather form: deterministic, every dx voxel written once)
-extern "C" int hupr_interp_linear_bwd_f32(const float* dy, float* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
-                                          int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
-    HUPR_REQUIRE(dy && dx, "hupr_interp_linear_bwd_f32: null pointer");
-    int rc = interp_check("hupr_interp_linear_bwd_f32", Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+template <typename T>
+static int interp_bwd(const char* who, const T* dy, T* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
+                      int in_ld, int out_ld, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && dx, "%s: null pointer", who);
+    int rc = interp_check(who, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     if (rc) return rc;
     const long total = (long)Bn * Di * Hi * Wi * (C / 4);
-    hipLaunchKernelGGL(hupr_k_interp_bwd, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    hipLaunchKernelGGL(hupr_k_interp_bwd<T>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     HUPR_LAUNCH_OK("hupr_k_interp_bwd");
     return HUPR_OK;
+}
+extern "C" int hupr_interp_linear_bwd_f32(const float* dy, float* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                          int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    return interp_bwd("hupr_interp_linear_bwd_f32", dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld, stream);
+}
+extern "C" int hupr_interp_linear_bwd_bf16act(const void* dy, void* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                              int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    return interp_bwd("hupr_interp_linear_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), Bn, Di,
+                      Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld, stream);
 }

@@ -21,10 +21,11 @@ namespace hupr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradHaloArgs {
-    const float* x;        // [Bn][D][H][W] voxels, in_ld floats apart
-    const float* dy;       // [Bn][D][H][W] voxels, dy_ld floats apart
+    const void* x;         // [Bn][D][H][W] voxels, in_ld elements apart   (fp32, or bf16 when ABF)
+    const void* dy;        // [Bn][D][H][W] voxels, dy_ld elements apart
     float* part;           // [groups][Co][T][Ci]
     int Bn, D, H, W, Ci, in_ld, Co, dy_ld;
     int kd, TD, log2TW, nd, nh, nw;
@@ -46,6 +47,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const __bf16* base, int off0, int off1
     return u.v;
 }
 
+template <bool ABF>
 __global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
     __shared__ __attribute__((aligned(16))) __bf16 Xh[kWgHaloVox * 64];
     __shared__ __attribute__((aligned(16))) __bf16 DYs[128 * 64];
@@ -86,15 +88,19 @@ __global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
         __syncthreads();                               // previous tile's fragments are consumed
         // ---- stage x halo (td plane) and dy tile, fp32 -> bf16, batched loads -----------------------------
         const int items_x = nvox_h * 8, items = items_x + 128 * 8;
-        for (int it0 = tid; it0 < items; it0 += 4 * 256) {
-            float4 va[4], vc[4];
-            int dst[4];
+        constexpr int NB = ABF ? 6 : 4;                // 16-byte (bf16) / 32-byte (fp32) items in flight per thread
+        for (int it0 = tid; it0 < items; it0 += NB * 256) {
+            float4 va[ABF ? 1 : NB], vc[ABF ? 1 : NB];
+            u32x4 vb[ABF ? NB : 1];
+            int dst[NB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const int it = it0 + u * 256;
-                va[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                vc[u] = va[u];
+                if constexpr (ABF) vb[u] = (u32x4){0u, 0u, 0u, 0u};
+                else { va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vc[u] = va[u]; }
                 dst[u] = -1;
+                long off = -1;
+                bool is_x = true;
                 if (it < items_x) {
                     const int vox = it >> 3, c8 = it & 7;
                     const int hx = vox % HW;
@@ -103,31 +109,39 @@ __global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
                     const int d = d0 + hz + td - pd, h = h0 + hy - 1, w = w0 + hx - 1;
                     dst[u] = vox * 64 + c8 * 8;
                     if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W &&
-                        ci0 + c8 * 8 < p.Ci) {     // Cin = 32 layers: the upper half of the 64-wide tile is zero
-                        const float* src = p.x + ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + ci0 + c8 * 8;
-                        va[u] = *reinterpret_cast<const float4*>(src);
-                        vc[u] = *reinterpret_cast<const float4*>(src + 4);
-                    }
+                        ci0 + c8 * 8 < p.Ci)       // Cin = 32 layers: the upper half of the 64-wide tile is zero
+                        off = ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + ci0 + c8 * 8;
                 } else if (it < items) {
                     const int j = it - items_x;
                     const int v = j >> 3, c8 = j & 7;
                     const int wx = v & (TW - 1), hy = (v >> p.log2TW) & 7, dz = v >> (p.log2TW + 3);
                     dst[u] = 0x40000000 | (v * 64 + c8 * 8);
-                    if (co0 + c8 * 8 < p.Co) {
-                        const float* src = p.dy + ((((long)b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx) * p.dy_ld + co0 + c8 * 8;
+                    is_x = false;
+                    if (co0 + c8 * 8 < p.Co)
+                        off = ((((long)b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx) * p.dy_ld + co0 + c8 * 8;
+                }
+                if (off >= 0) {
+                    if constexpr (ABF) {
+                        vb[u] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(is_x ? p.x : p.dy) + off);
+                    } else {
+                        const float* src = static_cast<const float*>(is_x ? p.x : p.dy) + off;
                         va[u] = *reinterpret_cast<const float4*>(src);
                         vc[u] = *reinterpret_cast<const float4*>(src + 4);
                     }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 if (dst[u] >= 0) {
-                    bf16x8 v;
-                    v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;
-                    v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;
                     __bf16* base = (dst[u] & 0x40000000) ? DYs : Xh;
-                    *reinterpret_cast<bf16x8*>(&base[dst[u] & 0x3fffffff]) = v;
+                    if constexpr (ABF) {
+                        *reinterpret_cast<u32x4*>(&base[dst[u] & 0x3fffffff]) = vb[u];
+                    } else {
+                        bf16x8 v;
+                        v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;
+                        v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;
+                        *reinterpret_cast<bf16x8*>(&base[dst[u] & 0x3fffffff]) = v;
+                    }
                 }
             }
         }
@@ -183,14 +197,14 @@ extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
     return groups * one;
 }
 
-extern "C" int hupr_conv3x3_wgrad_halo_bf16(const float* x, const float* dy, float* dw, int Bn, int D, int H, int W, int Ci,
-                                            int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
-                                            hupr_stream_t stream) {
-    HUPR_REQUIRE(x && dy && dw && ws, "hupr_conv3x3_wgrad_halo_bf16: null pointer");
-    HUPR_REQUIRE(Bn > 0 && Co > 0 && Ci % 8 == 0 && Co % 8 == 0 && in_ld % 4 == 0 && dy_ld % 4 == 0,
-                 "hupr_conv3x3_wgrad_halo_bf16: unsupported channels Ci=%d Co=%d", Ci, Co);
+static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci, int in_ld, int Co,
+                      int dy_ld, int kd, void* ws, size_t ws_bytes, bool abf, hupr_stream_t stream, const char* who) {
+    HUPR_REQUIRE(x && dy && dw && ws, "%s: null pointer", who);
+    const int al = abf ? 8 : 4;
+    HUPR_REQUIRE(Bn > 0 && Co > 0 && Ci % 8 == 0 && Co % 8 == 0 && in_ld % al == 0 && dy_ld % al == 0,
+                 "%s: unsupported channels Ci=%d Co=%d", who, Ci, Co);
     HUPR_REQUIRE(H % 8 == 0 && ((kd == 3 && D % 2 == 0 && W % 8 == 0) || (kd == 1 && D == 1 && W % 16 == 0)),
-                 "hupr_conv3x3_wgrad_halo_bf16: unsupported geometry");
+                 "%s: unsupported geometry", who);
     WgradHaloArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws);
     a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.dy_ld = dy_ld;
@@ -208,10 +222,27 @@ extern "C" int hupr_conv3x3_wgrad_halo_bf16(const float* x, const float* dy, flo
     if ((size_t)groups * one > ws_bytes) return fail(HUPR_ERR_WORKSPACE, "hupr_conv3x3_wgrad_halo_bf16: workspace too small");
     a.groups = groups;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(hupr_k_wgrad_halo_bf16, dim3(groups, kd, a.n_ci_tiles * a.n_co_tiles), dim3(256), 0, s, a);
+    const dim3 grid(groups, kd, a.n_ci_tiles * a.n_co_tiles);
+    if (abf) hipLaunchKernelGGL(hupr_k_wgrad_halo_bf16<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(hupr_k_wgrad_halo_bf16<false>, grid, dim3(256), 0, s, a);
     HUPR_LAUNCH_OK("hupr_k_wgrad_halo_bf16");
     const long n = (long)Co * kd * 9 * Ci;
     launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, groups, n, kd * 9, Ci, s);
     HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
     return HUPR_OK;
+}
+
+extern "C" int hupr_conv3x3_wgrad_halo_bf16(const float* x, const float* dy, float* dw, int Bn, int D, int H, int W, int Ci,
+                                            int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
+                                            hupr_stream_t stream) {
+    return wgrad_halo(x, dy, dw, Bn, D, H, W, Ci, in_ld, Co, dy_ld, kd, ws, ws_bytes, false, stream,
+                      "hupr_conv3x3_wgrad_halo_bf16");
+}
+
+// x and dy stored as bf16 (leading dimensions in elements); dw stays fp32 in parameter layout.
+extern "C" int hupr_conv3x3_wgrad_halo_bf16act(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W,
+                                               int Ci, int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
+                                               hupr_stream_t stream) {
+    return wgrad_halo(x, dy, dw, Bn, D, H, W, Ci, in_ld, Co, dy_ld, kd, ws, ws_bytes, true, stream,
+                      "hupr_conv3x3_wgrad_halo_bf16act");
 }

@@ -14,6 +14,7 @@ from . import runtime as rt
 _ws_cache = {}
 CONV_PROBE = None      # bench.py installs a callable(x, co, k) -> (start_event, end_event) | None
 MATH = "f32"           # matrix-pipe arithmetic of the GEMM-shaped ops: "f32" (parity path) or "bf16"
+ACT_BF16 = True        # bf16 mode only: the 3-D encoders keep their activations in HBM as bf16 ("bf16act" kernels)
 
 
 def set_math(mode):
@@ -26,6 +27,16 @@ def set_math(mode):
 
 def _fn(stem):
     return getattr(rt.lib(), "hupr_%s_%s" % (stem, MATH))
+
+
+def act_bf16():
+    """True when the encoder island stores activations as bf16 (bf16 math + ACT_BF16)."""
+    return MATH == "bf16" and ACT_BF16
+
+
+def _act(stem, t):
+    """C entry point of an activation-dtype-generic operator for tensor ``t`` (fp32 or bf16 storage)."""
+    return getattr(rt.lib(), "hupr_%s_%s" % (stem, "bf16act" if t.dtype == torch.bfloat16 else "f32"))
 
 
 def workspace(nbytes, device):
@@ -44,7 +55,7 @@ def _c(t):
 
 def _vox(x):
     """(B, D, H, W) extents and channel count of a channels-last 5-D tensor."""
-    assert x.dim() == 5 and x.dtype == torch.float32, (x.shape, x.dtype)
+    assert x.dim() == 5 and x.dtype in (torch.float32, torch.bfloat16), (x.shape, x.dtype)
     return x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.shape[4]
 
 
@@ -68,10 +79,12 @@ USE_FLASH = True       # bf16 mode: fused attention kernels where supported (C i
 USE_HALO = True        # bf16 mode: LDS halo-tiled kernel for 3x3(x3) "same" convolutions
 
 
-def _halo_ok(x, k, pad):
-    if MATH != "bf16" or not USE_HALO:
+def _halo_ok(x, k, pad, co=4):
+    if MATH != "bf16" or not USE_HALO or co % 4 != 0:
         return False
     B, Di, Hi, Wi, Ci = _vox(x)
+    if x.dtype == torch.bfloat16 and Ci % 8 != 0:
+        return False
     return bool(rt.lib().hupr_conv3x3_halo_supported(Di, Hi, Wi, Ci, k[0], k[1], k[2], pad[0], pad[1], pad[2]))
 
 
@@ -79,18 +92,23 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent):
     """weight: parameter-layout tensor (Co', Ci', taps...) packed here (mode 0 forward / 1 input gradient)."""
     B, Di, Hi, Wi, Ci = _vox(x)
     Do, Ho, Wo = out_extent
-    y = torch.empty((B, Do, Ho, Wo, co), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, Do, Ho, Wo, co), dtype=x.dtype, device=x.device)
     ev = CONV_PROBE(x, co, k) if CONV_PROBE is not None else None
-    if _halo_ok(x, k, pad):
+    abf = x.dtype == torch.bfloat16
+    if _halo_ok(x, k, pad, co):
+        assert res is None or res.dtype == x.dtype
         wp = pack_weights_bf16(weight, mode)
         if ev is not None:
             ev[0].record()
-        rt.check(rt.lib().hupr_conv3x3_halo_bf16(
-            rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
-            rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
+        fn = rt.lib().hupr_conv3x3_halo_bf16act if abf else rt.lib().hupr_conv3x3_halo_bf16
+        rt.check(fn(rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
+                    rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
         if ev is not None:
             ev[1].record()
         return y
+    if abf:
+        raise rt.HuprError("bf16-stored activations are only supported by the halo-tiled 3x3 convolutions "
+                           "(shape %r, kernel %r); cast to fp32 first" % (tuple(x.shape), k))
     wp = pack_weights(weight, mode)
     if ev is not None:
         ev[0].record()
@@ -128,6 +146,7 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = _c(dy)
+        assert dy.dtype == x.dtype, (dy.dtype, x.dtype)
         k, pad = ctx.k, ctx.pad
         B, Di, Hi, Wi, Ci = _vox(x)
         _, Do, Ho, Wo, Co = _vox(dy)
@@ -138,7 +157,7 @@ class ConvFn(torch.autograd.Function):
             dyp, wsrc = dy, weight
             if Co % 32 != 0:                      # e.g. the 14-channel head: zero-pad the K axis
                 co_pad = (Co + 31) // 32 * 32
-                dyp = torch.zeros((B, Do, Ho, Wo, co_pad), dtype=torch.float32, device=dy.device)
+                dyp = torch.zeros((B, Do, Ho, Wo, co_pad), dtype=dy.dtype, device=dy.device)
                 dyp[..., :Co] = dy
                 wsrc = torch.zeros((co_pad,) + tuple(weight.shape[1:]), dtype=torch.float32, device=dy.device)
                 wsrc[:Co] = weight
@@ -147,8 +166,11 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and _halo_ok(x, k, pad) and Ci % 32 == 0 and Co % 8 == 0:
             dw = torch.empty_like(weight)
             ws = workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, k[0]), x.device)
-            rt.check(L.hupr_conv3x3_wgrad_halo_bf16(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Co, Co, k[0],
-                                                    rt.ptr(ws), ws.numel(), rt.stream()))
+            fn = L.hupr_conv3x3_wgrad_halo_bf16act if x.dtype == torch.bfloat16 else L.hupr_conv3x3_wgrad_halo_bf16
+            rt.check(fn(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Co, Co, k[0],
+                        rt.ptr(ws), ws.numel(), rt.stream()))
+        elif ctx.needs_input_grad[1] and x.dtype == torch.bfloat16:
+            raise rt.HuprError("no bf16-activation weight-gradient kernel for shape %r" % (tuple(x.shape),))
         elif ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             nbytes = L.hupr_conv_wgrad_ws_bytes(B, Do, Ho, Wo, Ci, Co, k[0], k[1], k[2])
@@ -159,8 +181,8 @@ class ConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(Co, dtype=torch.float32, device=dy.device)
             ws = workspace(L.hupr_bn_ws_bytes(Co), dy.device)
-            rt.check(L.hupr_colsum_f32(rt.ptr(dy), B * Do * Ho * Wo, Co, rt.ptr(db), rt.ptr(ws), ws.numel(),
-                                       rt.stream()))
+            rt.check(_act("colsum", dy)(rt.ptr(dy), B * Do * Ho * Wo, Co, rt.ptr(db), rt.ptr(ws), ws.numel(),
+                                        rt.stream()))
         dres = dy if ctx.has_res else None
         return dx, dw, db, dres, None
 
@@ -185,7 +207,7 @@ def _bn_params(x, bn, training):
     if training:
         ws = workspace(L.hupr_bn_ws_bytes(C), dev)
         track = bn.running_mean is not None
-        rt.check(L.hupr_bn_train_stats_f32(
+        rt.check(_act("bn_train_stats", x)(
             rt.ptr(x), M, C, rt.ptr(bn.weight), rt.ptr(bn.bias),
             rt.ptr(bn.running_mean) if track else None, rt.ptr(bn.running_var) if track else None,
             float(bn.momentum), float(bn.eps), rt.ptr(mean), rt.ptr(invstd), rt.ptr(scale), rt.ptr(shift),
@@ -209,7 +231,8 @@ def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training):
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty_like(dg)
     ws = workspace(L.hupr_bn_ws_bytes(C), x.device)
-    rt.check(L.hupr_bn_bwd_f32(rt.ptr(dy), rt.ptr(y_mask) if y_mask is not None else None, rt.ptr(x), rt.ptr(mean),
+    assert dy.dtype == x.dtype and (y_mask is None or y_mask.dtype == x.dtype)
+    rt.check(_act("bn_bwd", x)(rt.ptr(dy), rt.ptr(y_mask) if y_mask is not None else None, rt.ptr(x), rt.ptr(mean),
                                rt.ptr(invstd), rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C,
                                1 if training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
     return dx, dg, db
@@ -224,8 +247,8 @@ class BNActFn(torch.autograd.Function):
         scale, shift, mean, invstd = _bn_params(x, bn, training)
         C = x.shape[-1]
         y = torch.empty_like(x)
-        rt.check(rt.lib().hupr_scale_shift_act_f32(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
-                                                  rt.ptr(y), x.numel() // C, C, 1 if relu else 0, rt.stream()))
+        rt.check(_act("scale_shift_act", x)(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
+                                            rt.ptr(y), x.numel() // C, C, 1 if relu else 0, rt.stream()))
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
         ctx.training = training
         return y
@@ -247,8 +270,9 @@ class BNAddBNReLUFn(torch.autograd.Function):
         s2, t2, m2, i2 = _bn_params(x2, bn2, training)
         C = x1.shape[-1]
         y = torch.empty_like(x1)
-        rt.check(rt.lib().hupr_scale_shift_act_f32(rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(x2), rt.ptr(s2),
-                                                  rt.ptr(t2), rt.ptr(y), x1.numel() // C, C, 1, rt.stream()))
+        assert x1.dtype == x2.dtype
+        rt.check(_act("scale_shift_act", x1)(rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(x2), rt.ptr(s2),
+                                             rt.ptr(t2), rt.ptr(y), x1.numel() // C, C, 1, rt.stream()))
         ctx.save_for_backward(x1, x2, y, m1, i1, g1, m2, i2, g2)
         ctx.training = training
         return y
@@ -288,14 +312,14 @@ class MNetFn(torch.autograd.Function):
     """x (B,G,F,2,R,A,E) -> (B, G, R, A, 32) channels-last with depth axis = group frame."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, out_dtype=torch.float32):
         x = _c(x)
         B, G, F, two, R, A, E = x.shape
         if (F, two, E) != (8, 2, 8) or weight.shape != (32, 2, 2, 1, 1):
             raise ValueError("MNet kernel is specialised for F=8, 2 (re/im), E=8, 32 filters")
-        out = torch.empty((B, G, R, A, 32), dtype=torch.float32, device=x.device)
-        rt.check(rt.lib().hupr_mnet_fwd_f32(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(out), B * G, R * A,
-                                           rt.stream()))
+        out = torch.empty((B, G, R, A, 32), dtype=out_dtype, device=x.device)
+        rt.check(_act("mnet_fwd", out)(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(out), B * G, R * A,
+                                       rt.stream()))
         ctx.save_for_backward(x, weight, bias)
         return out
 
@@ -307,9 +331,10 @@ class MNetFn(torch.autograd.Function):
         dw = torch.empty_like(weight)
         db = torch.empty_like(bias)
         ws = workspace(L.hupr_mnet_bwd_ws_bytes(), x.device)
-        rt.check(L.hupr_mnet_bwd_f32(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(_c(dy)), rt.ptr(dw), rt.ptr(db),
-                                     B * G, R * A, rt.ptr(ws), ws.numel(), rt.stream()))
-        return None, dw, db
+        dy = _c(dy)
+        rt.check(_act("mnet_bwd", dy)(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(dy), rt.ptr(dw), rt.ptr(db),
+                                      B * G, R * A, rt.ptr(ws), ws.numel(), rt.stream()))
+        return None, dw, db, None
 
 
 class InterpFn(torch.autograd.Function):
@@ -320,9 +345,8 @@ class InterpFn(torch.autograd.Function):
         x = _c(x)
         B, Di, Hi, Wi, C = _vox(x)
         Do, Ho, Wo = size
-        y = torch.empty((B, Do, Ho, Wo, C), dtype=torch.float32, device=x.device)
-        rt.check(rt.lib().hupr_interp_linear_fwd_f32(rt.ptr(x), rt.ptr(y), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C,
-                                                    rt.stream()))
+        y = torch.empty((B, Do, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        rt.check(_act("interp_linear_fwd", x)(rt.ptr(x), rt.ptr(y), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C, rt.stream()))
         ctx.in_shape = (B, Di, Hi, Wi, C)
         ctx.size = size
         return y
@@ -331,14 +355,43 @@ class InterpFn(torch.autograd.Function):
     def backward(ctx, dy):
         B, Di, Hi, Wi, C = ctx.in_shape
         Do, Ho, Wo = ctx.size
-        dx = torch.empty(ctx.in_shape, dtype=torch.float32, device=dy.device)
-        rt.check(rt.lib().hupr_interp_linear_bwd_f32(rt.ptr(_c(dy)), rt.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C,
-                                                    rt.stream()))
+        dy = _c(dy)
+        dx = torch.empty(ctx.in_shape, dtype=dy.dtype, device=dy.device)
+        rt.check(_act("interp_linear_bwd", dy)(rt.ptr(dy), rt.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C, rt.stream()))
         return dx, None
 
 
 def interp(x, size):
     return InterpFn.apply(x, tuple(size))
+
+
+def _cast(x, dtype):
+    x = _c(x)
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    if dtype == torch.bfloat16:
+        rt.check(rt.lib().hupr_cast_f32_to_bf16(rt.ptr(x), rt.ptr(y), x.numel(), rt.stream()))
+    else:
+        rt.check(rt.lib().hupr_cast_bf16_to_f32(rt.ptr(x), rt.ptr(y), x.numel(), rt.stream()))
+    return y
+
+
+class CastFn(torch.autograd.Function):
+    """Boundary of the bf16-activation region: y = x in ``dtype``; the gradient comes back in x's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.in_dtype = x.dtype
+        return _cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _cast(dy, ctx.in_dtype), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
 
 
 # ----------------------------------------------------------------------------------------------

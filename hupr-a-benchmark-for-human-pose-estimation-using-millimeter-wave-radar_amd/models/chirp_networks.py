@@ -5,6 +5,7 @@ forward is never called) so ``state_dict`` keys, shapes and default initialisati
 reference's; the arithmetic (elevation mean + .view reinterpretation + conv + max-pool) runs in
 ``hupr_mnet_fwd_f32`` straight from the (B,G,F,2,R,A,E) loader tensor.
 """
+import torch
 import torch.nn as nn
 
 from .. import functional as F_
@@ -17,5 +18,7 @@ class MNet(nn.Module):
         self.numFrames = numFrames
 
     def forward(self, VRDAEmaps):
-        """VRDAEmaps: (B,G,F,2,R,A,E) fp32 -> channels-last (B, G, R, A, out_channels)."""
-        return F_.MNetFn.apply(VRDAEmaps, self.temporalConvWx1x1.weight, self.temporalConvWx1x1.bias)
+        """VRDAEmaps: (B,G,F,2,R,A,E) fp32 -> channels-last (B, G, R, A, out_channels); stored as bf16 when the
+        encoders run on bf16 activations (functional.act_bf16())."""
+        return F_.MNetFn.apply(VRDAEmaps, self.temporalConvWx1x1.weight, self.temporalConvWx1x1.bias,
+                               torch.bfloat16 if F_.act_bf16() else torch.float32)

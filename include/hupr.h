@@ -210,6 +210,41 @@ int hupr_argmax_rows_f32(const float* p, long rows, int n, int* idx, float* maxv
 int hupr_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, float gscale, hupr_stream_t stream);
 
+/* ---- bf16-activation variants ("bf16act") -------------------------------------------------------------
+ * Same operators with the ACTIVATION tensors (x, y, dy, dx, residual) stored as bf16 in HBM; parameters,
+ * statistics, weight gradients and all arithmetic stay fp32 (fp32 accumulate on the matrix pipe).  The
+ * 3-D encoders (models/layers.py:160-191) run on them in bf16 mode: the layer-1 convolution sits at the
+ * HBM/MFMA ridge with fp32 tensors (453 flop/B vs 312), bf16 storage doubles its intensity and halves every
+ * BatchNorm / resampling pass.  Leading dimensions are in elements; bf16 conv inputs need in_ld % 8 == 0. */
+int hupr_conv3x3_halo_bf16act(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y,
+                              int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd,
+                              hupr_stream_t stream);
+int hupr_conv3x3_wgrad_halo_bf16act(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci,
+                                    int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
+                                    hupr_stream_t stream);
+int hupr_bn_train_stats_bf16act(const void* x, long M, int C, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                                float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
+                                hupr_stream_t stream);
+int hupr_scale_shift_act_bf16act(const void* x1, const float* scale1, const float* shift1, const void* x2,
+                                 const float* scale2, const float* shift2, void* y, long M, int C, int act,
+                                 hupr_stream_t stream);
+int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const void* x, const float* save_mean,
+                        const float* save_invstd, const float* gamma, void* dx, float* dgamma, float* dbeta, long M,
+                        int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_colsum_bf16act(const void* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, long n_bg, int pixels,
+                          hupr_stream_t stream);
+int hupr_mnet_bwd_bf16act(const float* x, const float* w, const float* bias, const void* dy, float* dw, float* dbias,
+                          long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_interp_linear_fwd_bf16act(const void* x, void* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                   int C, int in_ld, int out_ld, hupr_stream_t stream);
+int hupr_interp_linear_bwd_bf16act(const void* dy, void* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                   int C, int in_ld, int out_ld, hupr_stream_t stream);
+/* boundary casts of the bf16-activation region (n % 4 == 0) */
+int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream);
+int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,8 +7,9 @@ F_.set_math("bf16")
 L = F_.rt.lib()
 shapes = {"l1 64>64 @8x64x64": (64, 64, 8, 64, 64, (3, 3, 3), (1, 1, 1)), "l2 128>128 @4x32x32": (128, 128, 4, 32, 32, (3, 3, 3), (1, 1, 1)),
           "dec1.0 320>64 @64x64": (320, 64, 1, 64, 64, (1, 3, 3), (0, 1, 1)), "dec2.0 640>128 @32x32": (640, 128, 1, 32, 32, (1, 3, 3), (0, 1, 1))}
+ACT = torch.bfloat16 if "--bf16act" in sys.argv else torch.float32
 for name, (Ci, Co, D, H, W, k, pad) in shapes.items():
-    x = torch.randn(32, D, H, W, Ci, device="cuda"); w = torch.randn(Co, Ci, *k, device="cuda") * 0.05
+    x = torch.randn(32, D, H, W, Ci, device="cuda").to(ACT); w = torch.randn(Co, Ci, *k, device="cuda") * 0.05
     flop = 2.0 * 32 * D * H * W * Co * Ci * k[0] * 9
     res = {}
     for rnd in range(3):

@@ -455,6 +455,136 @@ def test_conv_halo256_persistent_kernel_matches_128_voxel_kernel(bf16_math):
     finally:
         L.hupr_debug_halo_variant(0)
     close(y256, y128, 1e-6, "halo256 vs halo128")
-    xs = x[:1, :, :16, :16].contiguous()          # fp64 reference on a crop that still covers every tap/halo case
     ref = F.conv3d(_bf16_round(ncdhw(x.cpu()))[:1], _bf16_round(w.cpu()), bias.cpu().double(), 1, 1)
     close(ncdhw(y256.cpu())[:1] - ncdhw(res.cpu())[:1].double(), ref, 2e-5, "halo256 vs fp64")
+
+
+# ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
+# The fp32-activation kernels round x to bf16 while staging, so on bf16-representable inputs both variants perform the
+# SAME arithmetic; the bf16act result must equal the fp32 result rounded once to bf16 (store rounding only).
+def _q(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+HALO_ACT_CASES = [
+    # B, Ci, Co, D, H, W, kd, bias, res
+    (2, 32, 64, 4, 16, 16, 3, True, False),      # stem (KC = 32 kernel, bias)
+    (4, 64, 128, 8, 64, 64, 3, False, True),     # engages the 256-voxel persistent kernel
+    (2, 128, 256, 2, 16, 16, 3, False, False),
+    (3, 320, 64, 1, 16, 16, 1, False, True),     # 2-D tile
+]
+
+
+@pytest.mark.parametrize("case", HALO_ACT_CASES)
+def test_conv_halo_bf16_activations(case, bf16_math):
+    from hupr_amd import functional as F_
+    B, Ci, Co, D, H, W, kd, has_bias, has_res = case
+    k, pad = (kd, 3, 3), (kd // 2, 1, 1)
+    x = _q(rnd(B, D, H, W, Ci, seed=60)).cuda()
+    w = rnd(Co, Ci, *k, seed=61, scale=(Ci * 9 * kd) ** -0.5).cuda()
+    bias = rnd(Co, seed=62).cuda() if has_bias else None
+    res = _q(rnd(B, D, H, W, Co, seed=63)).cuda() if has_res else None
+    y32 = F_._conv_raw(x, w, 0, bias, res, Co, k, pad, (D, H, W))
+    y16 = F_._conv_raw(x.bfloat16(), w, 0, bias, res.bfloat16() if has_res else None, Co, k, pad, (D, H, W))
+    assert y16.dtype == torch.bfloat16
+    assert torch.equal(y16.float(), _q(y32)), (y16.float() - _q(y32)).abs().max().item()
+    # weight gradient: fp32 output, identical arithmetic -> bit-identical
+    if Ci % 32 == 0 and Co % 8 == 0:
+        dy = _q(rnd(B, D, H, W, Co, seed=64)).cuda()
+        L = F_.rt.lib()
+        ws = F_.workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd), x.device)
+        dw32, dw16 = torch.empty_like(w), torch.empty_like(w)
+        F_.rt.check(L.hupr_conv3x3_wgrad_halo_bf16(F_.rt.ptr(x), F_.rt.ptr(dy), F_.rt.ptr(dw32), B, D, H, W, Ci, Ci, Co, Co,
+                                                   kd, F_.rt.ptr(ws), ws.numel(), F_.rt.stream()))
+        xb, dyb = x.bfloat16(), dy.bfloat16()
+        F_.rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(F_.rt.ptr(xb), F_.rt.ptr(dyb), F_.rt.ptr(dw16), B, D, H, W, Ci, Ci, Co,
+                                                      Co, kd, F_.rt.ptr(ws), ws.numel(), F_.rt.stream()))
+        assert torch.equal(dw16, dw32)
+
+
+def test_conv_autograd_bf16_activations(bf16_math):
+    """ConvFn on bf16 tensors (fwd, dgrad, wgrad, bias grad) against fp64 on the same rounded operands."""
+    from hupr_amd import functional as F_
+    B, Ci, Co, D, H, W = 2, 64, 64, 4, 16, 16
+    x = _q(rnd(B, Ci, D, H, W, seed=70))
+    w = rnd(Co, Ci, 3, 3, 3, seed=71, scale=(Ci * 27) ** -0.5)
+    b = rnd(Co, seed=72)
+    gy = _q(rnd(B, Co, D, H, W, seed=73))
+    wq = _bf16_round(w)
+    xr, wr, br = x.double().requires_grad_(True), wq.clone().requires_grad_(True), b.double().requires_grad_(True)
+    F.conv3d(xr, wr, br, 1, 1).backward(gy.double())
+    xg = cl(x).cuda().bfloat16().requires_grad_(True)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = F_.conv(xg, wg, bg, None, (1, 1, 1))
+    assert y.dtype == torch.bfloat16
+    close(ncdhw(y.float()), F.conv3d(x.double(), wq, b.double(), 1, 1), 6e-3, "bf16act conv fwd (one bf16 store rounding)")
+    y.backward(cl(gy).cuda().bfloat16())
+    assert xg.grad.dtype == torch.bfloat16
+    close(ncdhw(xg.grad.float()), xr.grad, 6e-3, "bf16act dgrad")
+    close(wg.grad, wr.grad, 5e-5, "bf16act wgrad")
+    close(bg.grad, br.grad, 1e-5, "bf16act bias grad")
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_block_tail_bf16_activations(training):
+    """BNActFn / BNAddBNReLUFn on bf16 storage == the fp32-storage kernels on the same (bf16-representable) data,
+    up to the single rounding of each stored output."""
+    from hupr_amd import functional as F_
+    C, vox = 64, (2, 4, 8, 8)
+    x1, x2 = _q(rnd(*vox, C, seed=80) * 2 + 0.5).cuda(), _q(rnd(*vox, C, seed=81)).cuda()
+    gy = _q(rnd(*vox, C, seed=82)).cuda()
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        bn1, bn2 = torch.nn.BatchNorm3d(C).cuda(), torch.nn.BatchNorm3d(C).cuda()
+        with torch.no_grad():
+            for i, bn in enumerate((bn1, bn2)):
+                bn.weight.copy_(rnd(C, seed=83 + i).cuda() * 0.3 + 1)
+                bn.bias.copy_(rnd(C, seed=85 + i).cuda() * 0.2)
+                bn.running_mean.copy_(rnd(C, seed=87 + i).cuda() * 0.1)
+                bn.running_var.copy_(rnd(C, seed=89 + i).cuda().abs() + 0.5)
+        a, b_ = x1.detach().to(dt).requires_grad_(True), x2.detach().to(dt).requires_grad_(True)
+        h = F_.BNActFn.apply(a, bn1.weight, bn1.bias, bn1, training, True)
+        y = F_.BNAddBNReLUFn.apply(h, bn2.weight, bn2.bias, bn2, b_, bn1.weight, bn1.bias, bn1, training)
+        y.backward(gy.to(dt))
+        outs[dt] = [t.detach().float() for t in (h, y, a.grad, b_.grad, bn1.weight.grad, bn2.bias.grad, bn1.running_var)]
+        assert y.dtype == dt and a.grad.dtype == dt
+    names = ["bn+relu", "block tail", "dx1", "dx2", "dgamma", "dbeta", "running_var"]
+    for n, r, g in zip(names, outs[torch.float32], outs[torch.bfloat16]):
+        # chained bf16 roundings h -> y -> grads; a rounding can flip a ReLU mask bit at y ~ 0, so gate the L2 error
+        rel = ((g - r).double().norm() / r.double().norm()).item()
+        assert rel <= 1.5e-2, "bf16act BN %s: rel-L2 %.3e" % (n, rel)
+    close(outs[torch.bfloat16][0], outs[torch.float32][0], 4e-3, "bf16act BN first output: one rounding")
+
+
+def test_interp_mnet_cast_bf16_activations():
+    from hupr_amd import functional as F_
+    x = _q(rnd(2, 8, 16, 16, 64, seed=90)).cuda()
+    gy = _q(rnd(2, 4, 8, 8, 64, seed=91)).cuda()
+    r = {}
+    for dt in (torch.float32, torch.bfloat16):
+        xi = x.detach().to(dt).requires_grad_(True)
+        y = F_.interp(xi, (4, 8, 8))
+        y.backward(gy.to(dt))
+        assert y.dtype == dt and xi.grad.dtype == dt
+        r[dt] = (y.detach().float(), xi.grad.float())
+    assert torch.equal(r[torch.bfloat16][0], _q(r[torch.float32][0]))
+    assert torch.equal(r[torch.bfloat16][1], _q(r[torch.float32][1]))
+    # casts round-trip exactly on bf16-representable data and carry the gradient back in the input dtype
+    xc = x.clone().requires_grad_(True)
+    yb = F_.cast(xc, torch.bfloat16)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb.float(), x)
+    back = F_.cast(yb, torch.float32)
+    back.backward(torch.ones_like(back))
+    assert xc.grad.dtype == torch.float32 and torch.equal(xc.grad, torch.ones_like(x))
+    # MNet front end writing bf16 / reading a bf16 gradient
+    vin = rnd(2, 8, 8, 2, 16, 16, 8, seed=92).cuda()
+    w, b = (rnd(32, 2, 2, 1, 1, seed=93) * 0.5).cuda(), rnd(32, seed=94).cuda()
+    gm = _q(rnd(2, 8, 16, 16, 32, seed=95)).cuda()
+    m = {}
+    for dt in (torch.float32, torch.bfloat16):
+        wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        o = F_.MNetFn.apply(vin, wi, bi, dt)
+        o.backward(gm.to(dt))
+        m[dt] = (o.detach().float(), wi.grad, bi.grad)
+    assert torch.equal(m[torch.bfloat16][0], _q(m[torch.float32][0]))
+    assert torch.equal(m[torch.bfloat16][1], m[torch.float32][1]) and torch.equal(m[torch.bfloat16][2], m[torch.float32][2])
