@@ -9,13 +9,42 @@
 
 namespace hupr {
 
-constexpr int kStatBlocks = 256;
+constexpr int kStatBlocks = 512;
+
+// V consecutive channels per thread as one 16-byte access: 4 fp32 or 8 bf16
+template <typename T> struct ActVec;
+template <> struct ActVec<float> {
+    static constexpr int V = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct ActVec<__bf16> {
+    static constexpr int V = 8;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void load(const __bf16* p, float* v) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+    }
+    static __device__ __forceinline__ void store(__bf16* p, const float* v) {
+        bf16x8 t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (__bf16)v[k];
+        *reinterpret_cast<bf16x8*>(p) = t;
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // column statistics: for every channel c: S1 = sum_r f(r,c), S2 = sum_r g(r,c)
 //   MODE 0 (forward) : f = x,             g = x*x
 //   MODE 1 (backward): f = dy',           g = dy' * xhat      dy' = dy * [y > 0] if y given
-// partial[blk][2][C] doubles
+// partial[blk][2][C] doubles.  A thread owns V channels and walks rows with four 16-byte loads per
+// operand in flight (the kernel is latency-, not bandwidth-limited otherwise).
 // ------------------------------------------------------------------------------------------
 template <int MODE, typename T>
 __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, const T* __restrict__ dy,
@@ -23,49 +52,64 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, 
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, long M, int C,
                                                        double* __restrict__ partial) {
+    constexpr int V = ActVec<T>::V, U = 4;
     extern __shared__ double sh[];   // [2][C]
     const int tid = threadIdx.x;
-    const int c4n = C >> 2;                      // float4 per row
-    const int rows_per_pass = 256 / c4n;         // C <= 1024
-    const int c4 = tid % c4n, rsub = tid / c4n;
+    const int cvn = C / V;                       // channel groups per row
+    const int rows_per_pass = 256 / cvn;         // C / V <= 256
+    const int cv = tid % cvn, rsub = tid / cvn;
     for (int i = tid; i < 2 * C; i += 256) sh[i] = 0.0;
     __syncthreads();
     const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+    float s1[V], s2[V], mu[V], is[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; is[k] = 1.f; }
     if (MODE == 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { mu[k] = mean[c4 * 4 + k]; is[k] = invstd[c4 * 4 + k]; }
+        for (int k = 0; k < V; ++k) { mu[k] = mean[cv * V + k]; is[k] = invstd[cv * V + k]; }
     }
     if (rsub < rows_per_pass) {
-        for (long r = r0 + rsub; r < r1; r += rows_per_pass) {
-            const float4 xv = ld_act4(x + r * C + c4 * 4);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            if (MODE == 0) {
+        for (long r = r0 + rsub; r < r1; r += (long)U * rows_per_pass) {
+            float xs[U][V], gs[U][V], ys[U][V];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { s1[k] += xs[k]; s2[k] = fmaf(xs[k], xs[k], s2[k]); }
-            } else {
-                const float4 gv = ld_act4(dy + r * C + c4 * 4);
-                float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-                if (y) {
-                    const float4 yv = ld_act4(y + r * C + c4 * 4);
-                    const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
+            for (int u = 0; u < U; ++u) {
+                const long ru = r + (long)u * rows_per_pass;
+                if (ru < r1) {
+                    ActVec<T>::load(x + ru * C + cv * V, xs[u]);
+                    if (MODE == 1) {
+                        ActVec<T>::load(dy + ru * C + cv * V, gs[u]);
+                        if (y) ActVec<T>::load(y + ru * C + cv * V, ys[u]);
+                    }
+                } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) gs[k] = ys[k] > 0.f ? gs[k] : 0.f;
+                    for (int k = 0; k < V; ++k) { xs[u][k] = 0.f; gs[u][k] = 0.f; ys[u][k] = 1.f; }
+                    if (MODE == 1) {
+#pragma unroll
+                        for (int k = 0; k < V; ++k) xs[u][k] = mu[k];
+                    }
                 }
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s1[k] += gs[k];
-                    s2[k] = fmaf(gs[k], (xs[k] - mu[k]) * is[k], s2[k]);
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    if (MODE == 0) {
+                        s1[k] += xs[u][k];
+                        s2[k] = fmaf(xs[u][k], xs[u][k], s2[k]);
+                    } else {
+                        const float g = (y && !(ys[u][k] > 0.f)) ? 0.f : gs[u][k];
+                        s1[k] += g;
+                        s2[k] = fmaf(g, (xs[u][k] - mu[k]) * is[k], s2[k]);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            atomicAdd(&sh[c4 * 4 + k], (double)s1[k]);
-            atomicAdd(&sh[C + c4 * 4 + k], (double)s2[k]);
+        for (int k = 0; k < V; ++k) {
+            atomicAdd(&sh[cv * V + k], (double)s1[k]);
+            atomicAdd(&sh[C + cv * V + k], (double)s2[k]);
         }
     }
     __syncthreads();
@@ -73,15 +117,16 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, 
 }
 
 
-// sum partial[b][2][C] over b for channel c; 256 threads = 4 row-groups x 64 channels per block
+// sum partial[b][2][C] over b for channel c; 256 threads = 16 row-groups x 16 channels per block
 __device__ __forceinline__ bool reduce_partials(const double* __restrict__ partial, int nblk, int C, int& c,
                                                 double& s1, double& s2) {
-    __shared__ double sh1[4][64], sh2[4][64];
-    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
-    c = blockIdx.x * 64 + cl;
+    __shared__ double sh1[16][17], sh2[16][17];
+    const int g = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    c = blockIdx.x * 16 + cl;
     double a = 0.0, b2 = 0.0;
     if (c < C) {
-        for (int b = g; b < nblk; b += 4) {
+#pragma unroll 4
+        for (int b = g; b < nblk; b += 16) {
             a += partial[(long)b * 2 * C + c];
             b2 += partial[(long)b * 2 * C + C + c];
         }
@@ -89,10 +134,13 @@ __device__ __forceinline__ bool reduce_partials(const double* __restrict__ parti
     sh1[g][cl] = a;
     sh2[g][cl] = b2;
     __syncthreads();
-    s1 = (sh1[0][cl] + sh1[1][cl]) + (sh1[2][cl] + sh1[3][cl]);
-    s2 = (sh2[0][cl] + sh2[1][cl]) + (sh2[2][cl] + sh2[3][cl]);
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s1 += sh1[k][cl]; s2 += sh2[k][cl]; }
     return g == 0 && c < C;
 }
+constexpr int kFinalizeCh = 16;     // channels per finalize workgroup
 
 // forward finalize: batch mean / biased var -> save_mean, save_invstd, scale, shift; running stats
 __global__ void hupr_k_bn_finalize_fwd(const double* __restrict__ partial, int nblk, long M, int C,
@@ -131,6 +179,17 @@ __global__ void hupr_k_bn_eval_params(const float* __restrict__ gamma, const flo
     shift[c] = beta[c] - rm[c] * sc;
 }
 
+// per-thread channel coefficients: when the grid stride is a multiple of C the V channels of a thread never
+// change, so the coefficient vectors are loaded once instead of once per element group
+template <int V>
+__device__ __forceinline__ void load_coef(const float* __restrict__ a, int c, float* v) {
+#pragma unroll
+    for (int k = 0; k < V; k += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(a + c + k);
+        v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+    }
+}
+
 // y = act(x1*s1 + t1 (+ x2*s2 + t2)) ; act: 0 none, 1 relu
 template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_scale_shift_act(const T* __restrict__ x1,
@@ -139,73 +198,82 @@ __global__ __launch_bounds__(256) void hupr_k_scale_shift_act(const T* __restric
                                                               const T* __restrict__ x2,
                                                               const float* __restrict__ s2,
                                                               const float* __restrict__ t2,
-                                                              T* __restrict__ y, long n4, int C, int act) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        float4 v = ld_act4(x1 + i * 4);
-        const float4 a = *reinterpret_cast<const float4*>(s1 + c), b = *reinterpret_cast<const float4*>(t1 + c);
-        v.x = fmaf(v.x, a.x, b.x); v.y = fmaf(v.y, a.y, b.y);
-        v.z = fmaf(v.z, a.z, b.z); v.w = fmaf(v.w, a.w, b.w);
-        if (x2) {
-            const float4 u = ld_act4(x2 + i * 4);
-            const float4 a2 = *reinterpret_cast<const float4*>(s2 + c), b2 = *reinterpret_cast<const float4*>(t2 + c);
-            v.x += fmaf(u.x, a2.x, b2.x); v.y += fmaf(u.y, a2.y, b2.y);
-            v.z += fmaf(u.z, a2.z, b2.z); v.w += fmaf(u.w, a2.w, b2.w);
+                                                              T* __restrict__ y, long nv, int C, int act) {
+    constexpr int V = ActVec<T>::V;
+    const long stride = (long)gridDim.x * 256;
+    const bool fixed = (stride * V) % C == 0;
+    float a[V], b[V], a2[V], b2[V];
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int c = (int)((i * V) % C);
+    if (fixed) {
+        load_coef<V>(s1, c, a); load_coef<V>(t1, c, b);
+        if (x2) { load_coef<V>(s2, c, a2); load_coef<V>(t2, c, b2); }
+    }
+    for (; i < nv; i += stride) {
+        if (!fixed) {
+            c = (int)((i * V) % C);
+            load_coef<V>(s1, c, a); load_coef<V>(t1, c, b);
+            if (x2) { load_coef<V>(s2, c, a2); load_coef<V>(t2, c, b2); }
         }
-        if (act == 1) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        float v[V], u[V];
+        ActVec<T>::load(x1 + i * V, v);
+        if (x2) ActVec<T>::load(x2 + i * V, u);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            v[k] = fmaf(v[k], a[k], b[k]);
+            if (x2) v[k] += fmaf(u[k], a2[k], b2[k]);
+            if (act == 1) v[k] = fmaxf(v[k], 0.f);
         }
-        st_act4(y + i * 4, v);
+        ActVec<T>::store(y + i * V, v);
     }
 }
 
-// backward finalize + apply:
-//   dgamma = S2, dbeta = S1,  dx = gamma*invstd*(dy' - S1/M - xhat*S2/M)       (train)
-//   dx = gamma*invstd*dy'                                                      (eval)
+// backward finalize: dgamma = S2, dbeta = S1 and the per-channel coefficients of the apply pass
+//   train: dx = w*(g' - S1/M - xhat*S2/M) = cA*g' + cB*(x - mean) + cD,  cA = w, cB = -w*invstd*S2/M, cD = -w*S1/M
+//   eval : dx = w*g'                                                      cB = cD = 0          (w = gamma*invstd)
 __global__ void hupr_k_bn_finalize_bwd(const double* __restrict__ partial, int nblk, int C,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ sums /* [2][C] floats */) {
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd, float inv_m,
+                                       int train, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef /* [3][C] floats */) {
     int c;
     double s1, s2;
     if (!reduce_partials(partial, nblk, C, c, s1, s2)) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
-    sums[c] = (float)s1;
-    sums[C + c] = (float)s2;
+    const float is = invstd[c], w = gamma[c] * is;
+    coef[c] = w;
+    coef[C + c] = train ? -w * is * ((float)s2 * inv_m) : 0.f;
+    coef[2 * C + c] = train ? -w * ((float)s1 * inv_m) : 0.f;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ y,
                                                            const T* __restrict__ x,
                                                            const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, float inv_m,
-                                                           T* __restrict__ dx, long n4, int C, int train) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        const float4 gv = ld_act4(dy + i * 4);
-        const float4 xv = ld_act4(x + i * 4);
-        float g[4] = {gv.x, gv.y, gv.z, gv.w};
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        if (y) {
-            const float4 yv = ld_act4(y + i * 4);
-            const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = ys[k] > 0.f ? g[k] : 0.f;
+                                                           const float* __restrict__ coef,
+                                                           T* __restrict__ dx, long nv, int C) {
+    constexpr int V = ActVec<T>::V;
+    const long stride = (long)gridDim.x * 256;
+    const bool fixed = (stride * V) % C == 0;
+    float cA[V], cB[V], cD[V], mu[V];
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int c = (int)((i * V) % C);
+    if (fixed) { load_coef<V>(coef, c, cA); load_coef<V>(coef + C, c, cB); load_coef<V>(coef + 2 * C, c, cD); load_coef<V>(mean, c, mu); }
+    for (; i < nv; i += stride) {
+        if (!fixed) {
+            c = (int)((i * V) % C);
+            load_coef<V>(coef, c, cA); load_coef<V>(coef + C, c, cB); load_coef<V>(coef + 2 * C, c, cD); load_coef<V>(mean, c, mu);
         }
-        float o[4];
+        float g[V], xs[V], ys[V], o[V];
+        ActVec<T>::load(dy + i * V, g);
+        ActVec<T>::load(x + i * V, xs);
+        if (y) ActVec<T>::load(y + i * V, ys);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float is = invstd[c + k], w = gamma[c + k] * is;
-            if (train) {
-                const float xh = (xs[k] - mean[c + k]) * is;
-                o[k] = w * (g[k] - sums[c + k] * inv_m - xh * sums[C + c + k] * inv_m);
-            } else {
-                o[k] = w * g[k];
-            }
+        for (int k = 0; k < V; ++k) {
+            const float gm = (y && !(ys[k] > 0.f)) ? 0.f : g[k];
+            o[k] = fmaf(cA[k], gm, fmaf(cB[k], xs[k] - mu[k], cD[k]));
         }
-        st_act4(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        ActVec<T>::store(dx + i * V, o);
     }
 }
 
@@ -263,15 +331,16 @@ __global__ void hupr_k_colsum_final(const double* __restrict__ partial, int nblk
 }
 
 static inline int ew_grid(long n4) { return (int)min((long)4096, (n4 + 255) / 256); }
+template <typename T> static inline int act_v() { return sizeof(T) == 2 ? 8 : 4; }
 
 }  // namespace hupr
 
 using namespace hupr;
 
-extern "C" size_t hupr_bn_ws_bytes(int C) { return (size_t)kStatBlocks * 2 * C * sizeof(double) + 2 * C * sizeof(float); }
+extern "C" size_t hupr_bn_ws_bytes(int C) { return (size_t)kStatBlocks * 2 * C * sizeof(double) + 4 * C * sizeof(float); }
 
-static int bn_check(const char* who, long M, int C) {
-    HUPR_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024, "%s: unsupported shape M=%ld C=%d", who, M, C);
+static int bn_check(const char* who, long M, int C, int V = 4) {
+    HUPR_REQUIRE(M > 0 && C > 0 && C % V == 0 && C <= 1024, "%s: unsupported shape M=%ld C=%d (C must be a multiple of %d)", who, M, C, V);
     return HUPR_OK;
 }
 
@@ -282,7 +351,7 @@ static int bn_train_stats(const char* who, const T* x, long M, int C, const floa
                           float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                           float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes, hupr_stream_t stream) {
     HUPR_REQUIRE(x && gamma && beta && save_mean && save_invstd && scale && shift && ws, "%s: null pointer", who);
-    int rc = bn_check(who, M, C);
+    int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
     if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
@@ -291,7 +360,7 @@ static int bn_train_stats(const char* who, const T* x, long M, int C, const floa
     hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
                        (const T*)nullptr, nullptr, nullptr, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, M, C, gamma,
+    hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, M, C, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd");
     return HUPR_OK;
@@ -328,11 +397,11 @@ static int scale_shift_act(const char* who, const T* x1, const float* scale1, co
                            const float* scale2, const float* shift2, T* y, long M, int C, int act, hupr_stream_t stream) {
     HUPR_REQUIRE(x1 && scale1 && shift1 && y, "%s: null pointer", who);
     HUPR_REQUIRE(!x2 || (scale2 && shift2), "%s: second branch needs scale/shift", who);
-    int rc = bn_check(who, M, C);
+    int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
-    const long n4 = M * C / 4;
-    hipLaunchKernelGGL(hupr_k_scale_shift_act<T>, dim3(ew_grid(n4)), dim3(256), 0, as_stream(stream), x1, scale1, shift1,
-                       x2, scale2, shift2, y, n4, C, act);
+    const long nv = M * C / act_v<T>();
+    hipLaunchKernelGGL(hupr_k_scale_shift_act<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x1, scale1, shift1,
+                       x2, scale2, shift2, y, nv, C, act);
     HUPR_LAUNCH_OK("hupr_k_scale_shift_act");
     return HUPR_OK;
 }
@@ -354,21 +423,21 @@ static int bn_bwd(const char* who, const T* dy, const T* y_mask, const T* x, con
                   const float* save_invstd, const float* gamma, T* dx, float* dgamma, float* dbeta, long M, int C,
                   int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
     HUPR_REQUIRE(dy && x && save_mean && save_invstd && gamma && dx && dgamma && dbeta && ws, "%s: null pointer", who);
-    int rc = bn_check(who, M, C);
+    int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
     if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
-    float* sums = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 2 * C * sizeof(double));
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 2 * C * sizeof(double));
     hipLaunchKernelGGL((hupr_k_colstats<1, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, dy, y_mask, save_mean,
                        save_invstd, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<1>");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C,
+                       gamma, save_invstd, 1.0f / (float)M, train, dgamma, dbeta, coef);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd");
-    const long n4 = M * C / 4;
-    hipLaunchKernelGGL(hupr_k_bn_bwd_apply<T>, dim3(ew_grid(n4)), dim3(256), 0, s, dy, y_mask, x, save_mean, save_invstd,
-                       gamma, sums, 1.0f / (float)M, dx, n4, C, train);
+    const long nv = M * C / act_v<T>();
+    hipLaunchKernelGGL(hupr_k_bn_bwd_apply<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x, save_mean, coef, dx, nv, C);
     HUPR_LAUNCH_OK("hupr_k_bn_bwd_apply");
     return HUPR_OK;
 }
@@ -413,7 +482,7 @@ extern "C" int hupr_prelu_bwd_f32(const float* dy, const float* x, const float* 
 template <typename T>
 static int colsum(const char* who, const T* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream) {
     HUPR_REQUIRE(x && out && ws, "%s: null pointer", who);
-    int rc = bn_check(who, M, C);
+    int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
     if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
@@ -422,7 +491,7 @@ static int colsum(const char* who, const T* x, long M, int C, float* out, void* 
     hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
                        (const T*)nullptr, nullptr, nullptr, M, C, partial);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
-    hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + 63) / 64), dim3(256), 0, s, partial, nblk, C, out);
+    hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, out);
     HUPR_LAUNCH_OK("hupr_k_colsum_final");
     return HUPR_OK;
 }
