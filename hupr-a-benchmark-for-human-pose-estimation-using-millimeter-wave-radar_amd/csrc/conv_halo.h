@@ -23,6 +23,7 @@ struct HaloArgs {
     int nd, nh, nw;          // tiles per axis
     int n_co_tiles;
     int ablate;              // profiling only: bit0 skip halo fill, bit1 skip MFMA stages, bit2 skip epilogue stores
+    unsigned long long* trace;  // profiling only: s_memtime stamps of workgroup 0 / wave 0 (scripts/halo_trace.py) or null
 };
 
 // 256-voxel persistent variant; returns false when the geometry is not supported

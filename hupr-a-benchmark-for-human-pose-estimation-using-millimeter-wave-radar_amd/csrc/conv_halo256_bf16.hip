@@ -115,6 +115,15 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         }                                                                                                           \
     }
 
+    // profiling: 8 s_memtime stamps per tile from wave 0 of workgroup 0 (all branches below are wave-uniform)
+    const bool tracing = p.trace != nullptr && blockIdx.x == 0 && wave == 0;
+    int tslot = 0;
+#define HUPR_STAMP()                                                                            \
+    if (tracing) {                                                                              \
+        const unsigned long long t__ = __builtin_amdgcn_s_memtime();                            \
+        if (lane == 0 && tslot < 4096) p.trace[tslot] = t__;                                    \
+        ++tslot;                                                                                \
+    }
     int pb = 0, pd0 = 0, ph0 = 0, pw0 = 0, pn0 = 0;            // previous tile (its accumulators are still live)
     bool have_prev = false;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -131,7 +140,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         const __bf16* wbase = p.wp + (long)n0 * T * p.Ci;
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int c0 = ch * KC;
+            HUPR_STAMP()                                          // 0: tile/chunk start
             HUPR_HALO_ISSUE(0)                                    // first half of the halo loads in flight ...
+            HUPR_STAMP()                                          // 1: halo loads issued
             if (ch == 0) {
                 if (have_prev) HUPR_STORE_TILE(pb, pd0, ph0, pw0, pn0)   // ... while the previous tile is written out
 #pragma unroll
@@ -141,16 +152,20 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const u32x4*>(wbase + wsrc[j] + (long)wt[j] * p.Ci + c0);
+            HUPR_STAMP()                                          // 2: previous tile stored, stage-0 weights issued
             __syncthreads();                                     // every wave is done with Hs / Bs of the previous chunk
+            HUPR_STAMP()                                          // 3: barrier passed
             HUPR_HALO_COMMIT()
             if constexpr (!ABF) {
                 HUPR_HALO_ISSUE(NH)
                 HUPR_HALO_COMMIT()
             }
+            HUPR_STAMP()                                          // 4: halo committed to LDS
             for (int st_ = 0; st_ < n_stage; ++st_) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(&Bs[wt[j]][wdst[j]]) = rb[j];
                 __syncthreads();
+                if (st_ == 0) { HUPR_STAMP() }                    // 5: first weight stage visible
                 if (st_ + 1 < n_stage) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
@@ -179,12 +194,15 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                     }
                 }
                 __syncthreads();
+                if (st_ == 0) { HUPR_STAMP() }                    // 6: first stage computed
             }
+            HUPR_STAMP()                                          // 7: all stages done
         }
         pb = b; pd0 = d0; ph0 = h0; pw0 = w0; pn0 = n0;
         have_prev = true;
     }
     if (have_prev) HUPR_STORE_TILE(pb, pd0, ph0, pw0, pn0)
+#undef HUPR_STAMP
 #undef HUPR_HALO_ISSUE
 #undef HUPR_HALO_COMMIT
 #undef HUPR_STORE_TILE

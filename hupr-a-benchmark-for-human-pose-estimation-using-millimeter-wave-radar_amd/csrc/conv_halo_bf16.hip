@@ -255,6 +255,8 @@ extern "C" int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co
 
 static int g_halo_ablate = 0;
 static int g_halo_variant = 0;      // 0 auto, 1 force the 128-voxel kernel (A/B comparisons)
+static unsigned long long* g_halo_trace = nullptr;
+extern "C" void hupr_debug_halo_trace(void* buf) { g_halo_trace = reinterpret_cast<unsigned long long*>(buf); }
 extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
 extern "C" void hupr_debug_halo_variant(int v) { g_halo_variant = v; }
 
@@ -280,6 +282,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.out_ld = out_ld; a.res_ld = res_ld;
     a.kd = kd;
     a.ablate = g_halo_ablate;
+    a.trace = g_halo_trace;
     if (g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {
         HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16");
         return HUPR_OK;
