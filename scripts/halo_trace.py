@@ -16,11 +16,12 @@ L.hupr_debug_halo_trace(F_.rt.ptr(buf))
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record(); F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W)); e.record()
 torch.cuda.synchronize(); L.hupr_debug_halo_trace(None)
-t = buf.cpu().numpy(); n = int((t != 0).sum()) // 8
-t = t[:n * 8].reshape(n, 8).astype(np.float64)
-names = ["halo issue", "store prev + weights issue", "barrier", "halo commit (wait)", "first weights -> LDS + barrier", "stage 0 MFMA", "stages 1..8", "loop back"]
-d = np.diff(np.concatenate([t, np.roll(t[:, :1], -1, 0)], 1), axis=1)[:-1]      # per tile, 8 intervals (last = to next tile start)
+t = buf.cpu().numpy(); NS = 6
+n = int((t != 0).sum()) // NS
+t = t[:n * NS].reshape(n, NS).astype(np.float64)
+names = ["stage 0 issue work (weights, next halo)", "stage 0 MFMA + barrier", "stages 1..8", "epilogue stores", "next halo -> LDS + barrier", "loop back"]
+d = np.diff(np.concatenate([t, np.roll(t[:, :1], -1, 0)], 1), axis=1)[:-1]      # per tile, NS intervals (last = to next tile start)
 tot = (t[-1, 0] - t[0, 0]) / (n - 1)
 print("kernel %.1f us, %d tiles on workgroup 0, %.0f ticks/tile" % (s.elapsed_time(e) * 1e3, n, tot))
-for k in range(8):
+for k in range(NS):
     print("  %-34s mean %8.0f ticks  (%.1f %%)   min %6.0f max %6.0f" % (names[k], d[:, k].mean(), 100 * d[:, k].mean() / tot, d[:, k].min(), d[:, k].max()))
