@@ -32,30 +32,34 @@ struct WgradHaloArgs {
     int n_ci_tiles, n_co_tiles, groups, n_spatial;
 };
 
-constexpr int kWgHaloVox = 2 * 10 * 10;      // td plane of the 2x8x8 tile; the 1x8x16 tile needs 1*10*18 = 180
 constexpr int kRowB = 128;                   // bytes per LDS row: 64 bf16 channels
 
-__device__ __forceinline__ bf16x8 tr_pair(const __bf16* base, int off0, int off1) {
-    // two transpose-reads (4 rows each) -> 8 consecutive K values for this lane's column
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(reinterpret_cast<const char*>(base) + off0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(reinterpret_cast<const char*>(base) + off1));
+// one transpose-read pair (4 rows each) -> 8 consecutive K values (voxels) of this lane's column
+__device__ __forceinline__ bf16x8 tr_pair(const char* base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
     union { struct { s16x4 a, b; } s; bf16x8 v; } u;
     u.s.a = lo;
     u.s.b = hi;
     return u.v;
 }
 
-template <bool ABF>
-__global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
-    __shared__ __attribute__((aligned(16))) __bf16 Xh[kWgHaloVox * 64];
-    __shared__ __attribute__((aligned(16))) __bf16 DYs[128 * 64];
+// LDS images are row-major [voxel][64 channels] with the 64-byte half of a row XOR-swapped by bit 1 of the row index:
+// a 16-lane transpose-read group touches four consecutive rows x one 32-byte segment, and rows r, r + 2 (128-byte
+// pitch, 64 banks x 4 B) would otherwise land on the same banks (measured: 44 % of the LDS cycles were conflicts).
+__device__ __forceinline__ int swz_col(int row, int col_bytes) { return col_bytes ^ (((row >> 1) & 1) << 6); }
+
+template <bool ABF, bool IS3D>
+__global__ __launch_bounds__(256, 2) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {   // 2 workgroups per CU: <= 112 VGPRs + 144 accumulators
+    constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, LOG2TW = IS3D ? 3 : 4;
+    constexpr int HH = 10, HW = TW + 2;
+    constexpr int NVOX = TD * HH * HW;               // x halo of ONE depth-tap plane: 200 (3-D) / 180 (2-D) voxels
+    constexpr int ITEMS_X = NVOX * 8, ITEMS = ITEMS_X + 128 * 8;
+    __shared__ __attribute__((aligned(16))) char Xh[NVOX * kRowB];
+    __shared__ __attribute__((aligned(16))) char DYs[128 * kRowB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;        // 32-row (co) / 32-col (ci) quadrant of the 64x64 tile
-    const int TW = 1 << p.log2TW, TD = p.TD;
-    const int HH = 10, HW = TW + 2;
     const int pd = p.kd >> 1;
     const int T = p.kd * 9;
 
@@ -69,6 +73,21 @@ __global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
     const int kh_ = g >> 1;                           // K half served by this lane (== lane >> 5)
     const int colb = (16 * (g & 1) + 4 * (s & 3)) * 2;   // byte offset of the 4-column segment inside a 32-col half
     const int rsub = s >> 2;                          // row (0..3) inside the 4-row group
+    // Per-lane LDS byte offsets; everything that depends on (K-step, tap) is a compile-time immediate on top of them.
+    //   dy rows: tile voxel v = 16 ks + c_t,  c_t = 8 kh + 4 t + rsub
+    //   x rows : halo voxel R = lane_row(c_t) + kx + [ks rows + ky HW], whose swizzle bit is f(lane_row + kx) ^ par
+    int dyb[2], xb[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = 8 * kh_ + 4 * t + rsub;
+        dyb[t] = c * kRowB + swz_col(c, wm * 64 + colb);
+        const int lrow = IS3D ? ((c >> 3) * HW + (c & 7)) : c;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+                xb[kx][par][t] = (lrow + kx) * kRowB + ((wn * 64 + colb) ^ (((((lrow + kx) >> 1) & 1) ^ par) << 6));
+    }
 
     f32x16 acc[9];
 #pragma unroll
@@ -76,7 +95,8 @@ __global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int nvox_h = TD * HH * HW;
+    constexpr int NI = (ITEMS + 255) / 256;          // 11 (3-D) / 10 (2-D) 8-channel items per thread per tile
+    constexpr int NB = (NI + 1) / 2;                // two batches: a single 11-item batch costs 135 VGPRs + 144 accumulators (one wave/SIMD)
     for (int st = group; st < p.n_spatial; st += p.groups) {
         int q = st;
         const int twi = q % p.nw; q /= p.nw;
@@ -86,87 +106,91 @@ __global__ __launch_bounds__(256) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p) {
         const int d0 = tdi * TD, h0 = thi * 8, w0 = twi * TW;
 
         __syncthreads();                               // previous tile's fragments are consumed
-        // ---- stage x halo (td plane) and dy tile, fp32 -> bf16, batched loads -----------------------------
-        const int items_x = nvox_h * 8, items = items_x + 128 * 8;
-        constexpr int NB = ABF ? 6 : 4;                // 16-byte (bf16) / 32-byte (fp32) items in flight per thread
-        for (int it0 = tid; it0 < items; it0 += NB * 256) {
+        // ---- stage the x halo (this td plane) and the dy tile: branch-free clamped loads, zero-select, swizzled rows ----
+#pragma unroll
+        for (int ub = 0; ub < NI; ub += NB) {
             float4 va[ABF ? 1 : NB], vc[ABF ? 1 : NB];
             u32x4 vb[ABF ? NB : 1];
-            int dst[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const int it = it0 + u * 256;
-                if constexpr (ABF) vb[u] = (u32x4){0u, 0u, 0u, 0u};
-                else { va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vc[u] = va[u]; }
-                dst[u] = -1;
-                long off = -1;
-                bool is_x = true;
-                if (it < items_x) {
+                const int it = tid + (ub + u) * 256;
+                int off = 0;                             // element offsets fit 31 bits (checked by the launcher)
+                bool ok = false, is_x = true;
+                if (it < ITEMS_X) {
                     const int vox = it >> 3, c8 = it & 7;
                     const int hx = vox % HW;
                     const int t2 = vox / HW;
                     const int hy = t2 % HH, hz = t2 / HH;
                     const int d = d0 + hz + td - pd, h = h0 + hy - 1, w = w0 + hx - 1;
-                    dst[u] = vox * 64 + c8 * 8;
-                    if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W &&
-                        ci0 + c8 * 8 < p.Ci)       // Cin = 32 layers: the upper half of the 64-wide tile is zero
-                        off = ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + ci0 + c8 * 8;
-                } else if (it < items) {
-                    const int j = it - items_x;
+                    ok = (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W &&
+                         ci0 + c8 * 8 < p.Ci;       // Cin = 32 layers: the upper half of the 64-wide tile is zero
+                    off = (((b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + ci0 + c8 * 8;
+                } else if (it < ITEMS) {
+                    const int j = it - ITEMS_X;
                     const int v = j >> 3, c8 = j & 7;
-                    const int wx = v & (TW - 1), hy = (v >> p.log2TW) & 7, dz = v >> (p.log2TW + 3);
-                    dst[u] = 0x40000000 | (v * 64 + c8 * 8);
+                    const int wx = v & (TW - 1), hy = (v >> LOG2TW) & 7, dz = v >> (LOG2TW + 3);
                     is_x = false;
-                    if (co0 + c8 * 8 < p.Co)
-                        off = ((((long)b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx) * p.dy_ld + co0 + c8 * 8;
+                    ok = co0 + c8 * 8 < p.Co;
+                    off = (((b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx) * p.dy_ld + co0 + c8 * 8;
                 }
-                if (off >= 0) {
-                    if constexpr (ABF) {
-                        vb[u] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(is_x ? p.x : p.dy) + off);
-                    } else {
-                        const float* src = static_cast<const float*>(is_x ? p.x : p.dy) + off;
-                        va[u] = *reinterpret_cast<const float4*>(src);
-                        vc[u] = *reinterpret_cast<const float4*>(src + 4);
-                    }
+                if (!ok) off = 0;                      // any valid address; the value is replaced by zeros below
+                if constexpr (ABF) {
+                    const u32x4 ld = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(is_x ? p.x : p.dy) + off);
+                    vb[u] = ok ? ld : (u32x4){0u, 0u, 0u, 0u};
+                } else {
+                    const float* src = static_cast<const float*>(is_x ? p.x : p.dy) + off;
+                    const float4 l0 = *reinterpret_cast<const float4*>(src), l1 = *reinterpret_cast<const float4*>(src + 4);
+                    va[u] = ok ? l0 : make_float4(0.f, 0.f, 0.f, 0.f);
+                    vc[u] = ok ? l1 : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                if (dst[u] >= 0) {
-                    __bf16* base = (dst[u] & 0x40000000) ? DYs : Xh;
+                const int it = tid + (ub + u) * 256;
+                if (it < ITEMS) {
+                    const int row = (it < ITEMS_X) ? (it >> 3) : ((it - ITEMS_X) >> 3);
+                    char* dstp = ((it < ITEMS_X) ? Xh : DYs) + row * kRowB + swz_col(row, (it & 7) * 16);
                     if constexpr (ABF) {
-                        *reinterpret_cast<u32x4*>(&base[dst[u] & 0x3fffffff]) = vb[u];
+                        *reinterpret_cast<u32x4*>(dstp) = vb[u];
                     } else {
                         bf16x8 v;
                         v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;
                         v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;
-                        *reinterpret_cast<bf16x8*>(&base[dst[u] & 0x3fffffff]) = v;
+                        *reinterpret_cast<bf16x8*>(dstp) = v;
                     }
                 }
             }
         }
         __syncthreads();
 
-        // ---- 8 K-steps of 16 voxels; the dy fragment is shared by the 9 taps -------------------------------
-#pragma unroll 1
-        for (int ks = 0; ks < 8; ++ks) {
-            // rows supplied by this lane for the two transpose-reads: tile voxels v = 16 ks + 8 kh + 4 t + rsub
-            int vrow[2], xrow[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int v = 16 * ks + 8 * kh_ + 4 * t + rsub;
-                const int wx = v & (TW - 1), hy = (v >> p.log2TW) & 7, dz = v >> (p.log2TW + 3);
-                vrow[t] = v * kRowB;
-                xrow[t] = ((dz * HH + hy) * HW + wx) * kRowB;
-            }
-            const bf16x8 a = tr_pair(DYs, vrow[0] + wm * 64 + colb, vrow[1] + wm * 64 + colb);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int toff = ((tap / 3) * HW + (tap % 3)) * kRowB;
-                const bf16x8 bq = tr_pair(Xh, xrow[0] + toff + wn * 64 + colb, xrow[1] + toff + wn * 64 + colb);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[tap], 0, 0, 0);
-            }
+        // ---- 8 K-steps of 16 voxels x 9 taps, as 24 groups of three taps (one ky row); the fragments of group j + 1
+        // are read while group j multiplies; the dy fragment of a K-step is shared by its 9 taps --------------------
+        bf16x8 a[2], xq[2][3];
+#define HUPR_WG_LOAD(SET_, J_)                                                                                      \
+        {                                                                                                           \
+            constexpr int ks_ = (J_) / 3, ky_ = (J_) % 3;                                                           \
+            constexpr int rows_ = (IS3D ? ((ks_ >> 2) * HH * HW + 2 * (ks_ & 3) * HW) : ks_ * HW) + ky_ * HW;       \
+            constexpr int par_ = IS3D ? (ky_ & 1) : ((ks_ + ky_) & 1);                                              \
+            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                        \
+                xq[SET_][kx] = tr_pair(Xh + rows_ * kRowB, xb[kx][par_][0], xb[kx][par_][1]);                       \
+            if (ky_ == 0) a[ks_ & 1] = tr_pair(DYs + ks_ * 16 * kRowB, dyb[0], dyb[1]);                             \
         }
+#define HUPR_WG_STEP(J_)                                                                                            \
+        {                                                                                                           \
+            if ((J_) + 1 < 24) { HUPR_WG_LOAD(((J_) + 1) & 1, ((J_) + 1 < 24 ? (J_) + 1 : 0)) }                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                        \
+                acc[((J_) % 3) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((J_) / 3) & 1], xq[(J_) & 1][kx], \
+                                                                                   acc[((J_) % 3) * 3 + kx], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }
+        HUPR_WG_LOAD(0, 0)
+        HUPR_WG_STEP(0) HUPR_WG_STEP(1) HUPR_WG_STEP(2) HUPR_WG_STEP(3) HUPR_WG_STEP(4) HUPR_WG_STEP(5)
+        HUPR_WG_STEP(6) HUPR_WG_STEP(7) HUPR_WG_STEP(8) HUPR_WG_STEP(9) HUPR_WG_STEP(10) HUPR_WG_STEP(11)
+        HUPR_WG_STEP(12) HUPR_WG_STEP(13) HUPR_WG_STEP(14) HUPR_WG_STEP(15) HUPR_WG_STEP(16) HUPR_WG_STEP(17)
+        HUPR_WG_STEP(18) HUPR_WG_STEP(19) HUPR_WG_STEP(20) HUPR_WG_STEP(21) HUPR_WG_STEP(22) HUPR_WG_STEP(23)
+#undef HUPR_WG_LOAD
+#undef HUPR_WG_STEP
     }
 
     // ---- partial[group][co][tap][ci]; D layout: col = lane&31 (ci), row = (r&3)+8*(r>>2)+4*(lane>>5) (co) ------
@@ -205,6 +229,7 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
                  "%s: unsupported channels Ci=%d Co=%d", who, Ci, Co);
     HUPR_REQUIRE(H % 8 == 0 && ((kd == 3 && D % 2 == 0 && W % 8 == 0) || (kd == 1 && D == 1 && W % 16 == 0)),
                  "%s: unsupported geometry", who);
+    HUPR_REQUIRE((long)Bn * D * H * W * (in_ld > dy_ld ? in_ld : dy_ld) < (1L << 31), "%s: tensor too large for 32-bit offsets", who);
     WgradHaloArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws);
     a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.dy_ld = dy_ld;
@@ -223,8 +248,13 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     a.groups = groups;
     hipStream_t s = as_stream(stream);
     const dim3 grid(groups, kd, a.n_ci_tiles * a.n_co_tiles);
-    if (abf) hipLaunchKernelGGL(hupr_k_wgrad_halo_bf16<true>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(hupr_k_wgrad_halo_bf16<false>, grid, dim3(256), 0, s, a);
+    if (kd == 3) {
+        if (abf) hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<true, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<false, true>), grid, dim3(256), 0, s, a);
+    } else {
+        if (abf) hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<true, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<false, false>), grid, dim3(256), 0, s, a);
+    }
     HUPR_LAUNCH_OK("hupr_k_wgrad_halo_bf16");
     const long n = (long)Co * kd * 9 * Ci;
     launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, groups, n, kd * 9, Ci, s);
