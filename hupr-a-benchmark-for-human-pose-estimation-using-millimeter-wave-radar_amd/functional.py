@@ -53,6 +53,29 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Direct gradient sink (installed by tools.distributed.GradientBuckets): parameter gradients are written by the kernels
+# straight into the flat-bucket views, the autograd Functions return None for them, and the 165 per-parameter
+# AccumulateGrad add kernels of a step disappear.  Without a sink every Function returns ordinary gradient tensors.
+GRAD_SINK = None
+
+
+def _pgrad(param):
+    """-> (tensor the kernel writes the gradient of ``param`` into, direct?)."""
+    if GRAD_SINK is not None and param is not None:
+        v = GRAD_SINK.take(param)
+        if v is not None:
+            return v, True
+    return torch.empty_like(param), False
+
+
+def _pret(param, g, direct):
+    """Value a backward() returns for ``param``: None after a direct write (the sink is told the gradient landed)."""
+    if direct:
+        GRAD_SINK.done(param)
+        return None
+    return g
+
+
 def _vox(x):
     """(B, D, H, W) extents and channel count of a channels-last 5-D tensor."""
     assert x.dim() == 5 and x.dtype in (torch.float32, torch.bfloat16), (x.shape, x.dtype)
@@ -139,6 +162,7 @@ class ConvFn(torch.autograd.Function):
         out_extent = (Di + 2 * pad[0] - k[0] + 1, Hi + 2 * pad[1] - k[1] + 1, Wi + 2 * pad[2] - k[2] + 1)
         y = _conv_raw(x, weight, 0, bias, _c(res) if res is not None else None, weight.shape[0], k, pad, out_extent)
         ctx.save_for_backward(x, weight)
+        ctx.bias_ref = bias                       # only its identity/shape is needed (gradient destination)
         ctx.pad, ctx.k, ctx.has_bias, ctx.has_res = pad, k, bias is not None, res is not None
         return y
 
@@ -152,6 +176,7 @@ class ConvFn(torch.autograd.Function):
         _, Do, Ho, Wo, Co = _vox(dy)
         L = rt.lib()
         dx = dw = db = None
+        dw_direct = db_direct = False
         if ctx.needs_input_grad[0]:
             co_pad = Co
             dyp, wsrc = dy, weight
@@ -163,8 +188,9 @@ class ConvFn(torch.autograd.Function):
                 wsrc[:Co] = weight
             dpad = (k[0] - 1 - pad[0], k[1] - 1 - pad[1], k[2] - 1 - pad[2])
             dx = _conv_raw(dyp, wsrc, 1, None, None, Ci, k, dpad, (Di, Hi, Wi))      # packs [Ci][taps reversed][Co]
+        if ctx.needs_input_grad[1]:
+            dw, dw_direct = _pgrad(weight)
         if ctx.needs_input_grad[1] and _halo_ok(x, k, pad) and Ci % 32 == 0 and Co % 8 == 0:
-            dw = torch.empty_like(weight)
             ws = workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, k[0]), x.device)
             fn = L.hupr_conv3x3_wgrad_halo_bf16act if x.dtype == torch.bfloat16 else L.hupr_conv3x3_wgrad_halo_bf16
             rt.check(fn(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Co, Co, k[0],
@@ -172,19 +198,18 @@ class ConvFn(torch.autograd.Function):
         elif ctx.needs_input_grad[1] and x.dtype == torch.bfloat16:
             raise rt.HuprError("no bf16-activation weight-gradient kernel for shape %r" % (tuple(x.shape),))
         elif ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
             nbytes = L.hupr_conv_wgrad_ws_bytes(B, Do, Ho, Wo, Ci, Co, k[0], k[1], k[2])
             ws = workspace(nbytes, x.device)
             rt.check(_fn("conv_wgrad")(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, Di, Hi, Wi, Ci, Ci, Do, Ho, Wo,
                                            Co, Co, k[0], k[1], k[2], pad[0], pad[1], pad[2], rt.ptr(ws),
                                            ws.numel(), rt.stream()))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(Co, dtype=torch.float32, device=dy.device)
+            db, db_direct = _pgrad(ctx.bias_ref)
             ws = workspace(L.hupr_bn_ws_bytes(Co), dy.device)
             rt.check(_act("colsum", dy)(rt.ptr(dy), B * Do * Ho * Wo, Co, rt.ptr(db), rt.ptr(ws), ws.numel(),
                                         rt.stream()))
         dres = dy if ctx.has_res else None
-        return dx, dw, db, dres, None
+        return dx, _pret(weight, dw, dw_direct), _pret(ctx.bias_ref, db, db_direct), dres, None
 
 
 def conv(x, weight, bias=None, res=None, pad=(0, 0, 0)):
@@ -223,19 +248,20 @@ def _bn_params(x, bn, training):
     return scale, shift, mean, invstd
 
 
-def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training):
+def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training, beta=None):
+    """-> (dx, dgamma, dbeta) as backward() return values (None for parameters written through the gradient sink)."""
     L = rt.lib()
     C = x.shape[-1]
     M = x.numel() // C
     dx = torch.empty_like(x)
-    dg = torch.empty(C, dtype=torch.float32, device=x.device)
-    db = torch.empty_like(dg)
+    dg, dg_direct = _pgrad(gamma)
+    db, db_direct = _pgrad(beta) if beta is not None else (torch.empty_like(gamma), False)
     ws = workspace(L.hupr_bn_ws_bytes(C), x.device)
     assert dy.dtype == x.dtype and (y_mask is None or y_mask.dtype == x.dtype)
     rt.check(_act("bn_bwd", x)(rt.ptr(dy), rt.ptr(y_mask) if y_mask is not None else None, rt.ptr(x), rt.ptr(mean),
                                rt.ptr(invstd), rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C,
                                1 if training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
-    return dx, dg, db
+    return dx, _pret(gamma, dg, dg_direct), _pret(beta, db, db_direct)
 
 
 class BNActFn(torch.autograd.Function):
@@ -250,13 +276,14 @@ class BNActFn(torch.autograd.Function):
         rt.check(_act("scale_shift_act", x)(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
                                             rt.ptr(y), x.numel() // C, C, 1 if relu else 0, rt.stream()))
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        ctx.beta_ref = beta
         ctx.training = training
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, invstd, gamma = ctx.saved_tensors
-        dx, dg, db = _bn_bwd(_c(dy), y, x, mean, invstd, gamma, ctx.training)
+        dx, dg, db = _bn_bwd(_c(dy), y, x, mean, invstd, gamma, ctx.training, ctx.beta_ref)
         return dx, dg, db, None, None, None
 
 
@@ -274,6 +301,7 @@ class BNAddBNReLUFn(torch.autograd.Function):
         rt.check(_act("scale_shift_act", x1)(rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(x2), rt.ptr(s2),
                                              rt.ptr(t2), rt.ptr(y), x1.numel() // C, C, 1, rt.stream()))
         ctx.save_for_backward(x1, x2, y, m1, i1, g1, m2, i2, g2)
+        ctx.beta_refs = (b1, b2)
         ctx.training = training
         return y
 
@@ -281,8 +309,8 @@ class BNAddBNReLUFn(torch.autograd.Function):
     def backward(ctx, dy):
         x1, x2, y, m1, i1, g1, m2, i2, g2 = ctx.saved_tensors
         dy = _c(dy)
-        dx1, dg1, db1 = _bn_bwd(dy, y, x1, m1, i1, g1, ctx.training)
-        dx2, dg2, db2 = _bn_bwd(dy, y, x2, m2, i2, g2, ctx.training)
+        dx1, dg1, db1 = _bn_bwd(dy, y, x1, m1, i1, g1, ctx.training, ctx.beta_refs[0])
+        dx2, dg2, db2 = _bn_bwd(dy, y, x2, m2, i2, g2, ctx.training, ctx.beta_refs[1])
         return dx1, dg1, db1, None, dx2, dg2, db2, None, None
 
 
@@ -300,11 +328,11 @@ class PReLUFn(torch.autograd.Function):
         x, alpha = ctx.saved_tensors
         L = rt.lib()
         dx = torch.empty_like(x)
-        da = torch.empty(1, dtype=torch.float32, device=x.device)
+        da, da_direct = _pgrad(alpha)
         ws = workspace(L.hupr_prelu_ws_bytes(), x.device)
         rt.check(L.hupr_prelu_bwd_f32(rt.ptr(_c(dy)), rt.ptr(x), rt.ptr(alpha), rt.ptr(dx), rt.ptr(da), x.numel(),
                                       rt.ptr(ws), ws.numel(), rt.stream()))
-        return dx, da
+        return dx, _pret(alpha, da, da_direct)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -328,13 +356,13 @@ class MNetFn(torch.autograd.Function):
         x, weight, bias = ctx.saved_tensors
         L = rt.lib()
         B, G, F, two, R, A, E = x.shape
-        dw = torch.empty_like(weight)
-        db = torch.empty_like(bias)
+        dw, dw_direct = _pgrad(weight)
+        db, db_direct = _pgrad(bias)
         ws = workspace(L.hupr_mnet_bwd_ws_bytes(), x.device)
         dy = _c(dy)
         rt.check(_act("mnet_bwd", dy)(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(dy), rt.ptr(dw), rt.ptr(db),
                                       B * G, R * A, rt.ptr(ws), ws.numel(), rt.stream()))
-        return None, dw, db, None
+        return None, _pret(weight, dw, dw_direct), _pret(bias, db, db_direct), None
 
 
 class InterpFn(torch.autograd.Function):

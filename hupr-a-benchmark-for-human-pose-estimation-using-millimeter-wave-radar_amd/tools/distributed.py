@@ -7,9 +7,10 @@ the new part BASELINE.json asks for.  Design:
   * parameters and gradients live in a few flat fp32 buckets (reverse registration order ==
     roughly the order backward produces gradients: GCN -> decoder -> encoders -> MNets), so one
     collective moves tens of MB instead of 165 small tensors;
-  * ``p.grad`` is a *view* into its bucket; autograd accumulates in place; a
-    post-accumulate hook counts arrivals and launches the bucket's all-reduce on the
-    communication stream the moment its last gradient lands;
+  * ``p.grad`` is a *view* into its bucket; the operator kernels write weight/bias gradients straight
+    into those views (``functional.GRAD_SINK``: no per-parameter AccumulateGrad add kernels), anything
+    autograd still accumulates itself lands in place; either way an arrival counter launches the
+    bucket's all-reduce on the communication stream the moment its last gradient lands;
   * ``finish()`` makes the compute stream wait for the collectives; the optimiser then runs one
     fused Adam launch per bucket with grad_scale = 1/world_size (sum -> mean);
   * BatchNorm statistics stay per rank (the reference is single-device, no SyncBN).
@@ -67,21 +68,47 @@ class GradientBuckets:
         if cur:
             self.buckets.append(_Bucket(cur, self.device))
         self._owner = {}
+        self._by_ptr = {}                       # parameter storage address -> (bucket, index): the direct-write sink
         for b in self.buckets:
-            for p in b.params:
+            for i, p in enumerate(b.params):
                 self._owner[id(p)] = b
+                self._by_ptr[p.data_ptr()] = (b, i)
                 p.register_post_accumulate_grad_hook(self._hook)
+        self.direct = self.device.type == "cuda"
         self.prepare()
+
+    # -- direct gradient sink (functional.GRAD_SINK protocol) -----------------------------------
+    def take(self, param):
+        """View the kernel should write ``param``'s gradient into, or None (unknown tensor / sink inactive)."""
+        ent = self._by_ptr.get(param.data_ptr()) if self._armed else None
+        if ent is None:
+            return None
+        b, i = ent
+        if b.written[i]:
+            raise RuntimeError("parameter received two direct gradient writes in one backward pass "
+                               "(shared parameters are not supported by the gradient sink)")
+        b.written[i] = True
+        return b.views[i]
+
+    def done(self, param):
+        b, _ = self._by_ptr[param.data_ptr()]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
 
     # -- per-iteration protocol ---------------------------------------------------------------
     def prepare(self):
         """Zero the flat gradients and (re)install the views; call before every backward."""
+        from .. import functional as F_
         for b in self.buckets:
             b.flat_grad.zero_()
             b.pending = len(b.params)
+            b.written = [False] * len(b.params)
             b.work = None
             for p, v in zip(b.params, b.views):
                 p.grad = v
+        self._armed = self.direct
+        F_.GRAD_SINK = self if self.direct else None
 
     def _hook(self, p):
         b = self._owner[id(p)]
@@ -108,6 +135,10 @@ class GradientBuckets:
 
     def finish(self):
         """Block the compute stream on outstanding collectives (call after backward)."""
+        from .. import functional as F_
+        self._armed = False
+        if F_.GRAD_SINK is self:
+            F_.GRAD_SINK = None
         for b in self.buckets:
             if b.pending != 0 and (self.world_size > 1 or self.force_collective):
                 # a parameter received no gradient this iteration: reduce what we have
