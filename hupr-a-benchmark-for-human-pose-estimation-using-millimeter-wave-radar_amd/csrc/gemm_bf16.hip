@@ -410,10 +410,10 @@ extern "C" int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, 
     const int bm = (Co <= 64) ? 64 : 128;
     const long tiles = (long)((Co + bm - 1) / bm) * ((a.N + 127) / 128);
     const int ktiles = (int)((Mv + BKH - 1) / BKH);
-    int splits = (int)((1024 + tiles - 1) / tiles);
-    splits = max(1, min(min(splits, 64), ktiles));
-    a.ksplit = splits;
     a.split_stride = (long)a.M * a.N;
+    int splits = wgrad_splits(tiles, ktiles, (size_t)a.split_stride * sizeof(float));
+    while (splits > 1 && (size_t)splits * a.split_stride * sizeof(float) > ws_bytes) splits >>= 1;
+    a.ksplit = splits;
     if (ws_bytes < (size_t)splits * a.split_stride * sizeof(float))
         return fail(HUPR_ERR_WORKSPACE, "hupr_conv_wgrad_bf16: workspace %zu < %zu", ws_bytes,
                     (size_t)splits * a.split_stride * sizeof(float));

@@ -59,6 +59,15 @@ inline int check_geom(const char* who, int Bn, const ConvGeom& g, int Co, int ci
 }
 
 // split-K partial reduction + optional [Co][taps][Ci] -> (Co,Ci,taps) relayout (gemm_f32.hip)
+// Voxel-axis slices of the GEMM-form weight gradient: enough workgroups for ~4 per CU, at most 256 slices and at most
+// 256 MiB of partials (a 64x64 1x1 weight over 131k voxels used to run on 64 workgroups: a quarter of the chip).
+inline int wgrad_splits(long tiles, long ktiles, size_t one_bytes) {
+    long s = (1024 + tiles - 1) / tiles;
+    if (s > 256) s = 256;
+    if (s > ktiles) s = ktiles;
+    while (s > 1 && (size_t)s * one_bytes > ((size_t)256 << 20)) s >>= 1;
+    return (int)(s < 1 ? 1 : s);
+}
 void launch_splitk_reduce(const float* part, float* out, long n, int splits, long split_stride, int taps, int ci,
                           hipStream_t s);
 

@@ -515,8 +515,12 @@ extern "C" int hupr_conv_fwd_f32(const float* x, const float* wp, const float* b
 
 extern "C" size_t hupr_conv_wgrad_ws_bytes(int Bn, int Do, int Ho, int Wo, int Ci, int Co, int kd, int kh,
                                            int kw) {
-    // worst case number of voxel-axis slices (see hupr_conv_wgrad_f32) x one partial weight tensor
-    return (size_t)64 * Co * kd * kh * kw * Ci * sizeof(float);
+    // number of voxel-axis slices (see wgrad_splits; the bf16 engine's 64-deep K tiles give the smaller tile count,
+    // the fp32 engine's 32-deep ones the larger: take the larger slice count) x one partial weight tensor
+    const size_t one = (size_t)Co * kd * kh * kw * Ci * sizeof(float);
+    const long Mv = (long)Bn * Do * Ho * Wo;
+    const long tiles = (long)((Co + ((Co <= 64) ? 64 : 128) - 1) / ((Co <= 64) ? 64 : 128)) * (((long)kd * kh * kw * Ci + 127) / 128);
+    return (size_t)wgrad_splits(tiles, (Mv + 31) / 32, one) * one;
 }
 
 // dw (Co, Ci, kd, kh, kw) = sum over output voxels of dy[m][co] * x[m shifted by tap][ci]
@@ -541,10 +545,10 @@ extern "C" int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, i
     const int bm = (Co <= 64) ? 64 : 128;
     const long tiles = (long)((Co + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     const int ktiles = (int)((Mv + BK - 1) / BK);
-    int splits = (int)((1024 + tiles - 1) / tiles);
-    splits = max(1, min(min(splits, 64), ktiles));
-    a.ksplit = splits;
     a.split_stride = (long)a.M * a.N;
+    int splits = wgrad_splits(tiles, ktiles, (size_t)a.split_stride * sizeof(float));
+    while (splits > 1 && (size_t)splits * a.split_stride * sizeof(float) > ws_bytes) splits >>= 1;
+    a.ksplit = splits;
     if (ws_bytes < (size_t)splits * a.split_stride * sizeof(float))
         return fail(HUPR_ERR_WORKSPACE, "hupr_conv_wgrad_f32: workspace %zu < %zu", ws_bytes,
                     (size_t)splits * a.split_stride * sizeof(float));
@@ -552,9 +556,7 @@ extern "C" int hupr_conv_wgrad_f32(const float* x, const float* dy, float* dw, i
     if (bm == 64) launch<64, 128, 1, 4, A_KM, B_CONVK>(a, 1, s);
     else launch<128, 128, 2, 2, A_KM, B_CONVK>(a, 1, s);
     HUPR_LAUNCH_OK("hupr_k_gemm_f32<wgrad>");
-    const long n = a.split_stride;
-    hipLaunchKernelGGL(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s,
-                       reinterpret_cast<const float*>(ws), dw, n, splits, a.split_stride, taps, Ci);
+    launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, a.split_stride, splits, a.split_stride, taps, Ci, s);
     HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
     return HUPR_OK;
 }
