@@ -29,41 +29,62 @@ struct Img {   // row-major bf16 LDS image [rows][D] with XOR-swizzled 16-byte c
     static __device__ __forceinline__ int off(int row, int chunk) { return row * D + ((chunk ^ key(row)) << 3); }   // bf16 elements
 };
 
-// stage ROWS x D fp32 rows (row stride ld) into a swizzled bf16 image; rows >= n_valid are zero
-template <int D, int ROWS>
-__device__ __forceinline__ void stage_rows(__bf16* img, const float* __restrict__ src, long ld, int tid) {
+typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+
+// stage ROWS x D rows (fp32, rounded here, or already-bf16; row stride ld elements) into a swizzled bf16 image
+template <int D, int ROWS, typename TI>
+__device__ __forceinline__ void stage_rows(__bf16* img, const TI* __restrict__ src, long ld, int tid) {
     constexpr int CH = D / 8, ITEMS = ROWS * CH, PER = ITEMS / 256;
     static_assert(ITEMS % 256 == 0, "tile must split over 256 threads");
-    float4 a[PER], c[PER];
+    if constexpr (sizeof(TI) == 2) {
+        u32x4a a[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int it = tid + 256 * i, row = it / CH, ch = it % CH;
-        const float* s = src + (long)row * ld + ch * 8;
-        a[i] = *reinterpret_cast<const float4*>(s);
-        c[i] = *reinterpret_cast<const float4*>(s + 4);
-    }
+        for (int i = 0; i < PER; ++i) {
+            const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+            a[i] = *reinterpret_cast<const u32x4a*>(src + (long)row * ld + ch * 8);
+        }
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int it = tid + 256 * i, row = it / CH, ch = it % CH;
-        bf16x8 v;
-        v[0] = (__bf16)a[i].x; v[1] = (__bf16)a[i].y; v[2] = (__bf16)a[i].z; v[3] = (__bf16)a[i].w;
-        v[4] = (__bf16)c[i].x; v[5] = (__bf16)c[i].y; v[6] = (__bf16)c[i].z; v[7] = (__bf16)c[i].w;
-        *reinterpret_cast<bf16x8*>(&img[Img<D>::off(row, ch)]) = v;
+        for (int i = 0; i < PER; ++i) {
+            const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+            *reinterpret_cast<u32x4a*>(&img[Img<D>::off(row, ch)]) = a[i];
+        }
+    } else {
+        float4 a[PER], c[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+            const float* s = reinterpret_cast<const float*>(src) + (long)row * ld + ch * 8;
+            a[i] = *reinterpret_cast<const float4*>(s);
+            c[i] = *reinterpret_cast<const float4*>(s + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+            bf16x8 v;
+            v[0] = (__bf16)a[i].x; v[1] = (__bf16)a[i].y; v[2] = (__bf16)a[i].z; v[3] = (__bf16)a[i].w;
+            v[4] = (__bf16)c[i].x; v[5] = (__bf16)c[i].y; v[6] = (__bf16)c[i].z; v[7] = (__bf16)c[i].w;
+            *reinterpret_cast<bf16x8*>(&img[Img<D>::off(row, ch)]) = v;
+        }
     }
 }
 
-// B-operand fragments (cols = token of this lane, K = channels) straight from global fp32: frag[ks] covers
+// B-operand fragments (cols = token of this lane, K = channels) straight from global: frag[ks] covers
 // channels 16 ks + 8 h .. +7 of row `tok`
-template <int D>
-__device__ __forceinline__ void load_frags(bf16x8* frag, const float* __restrict__ rowp, int lh) {
+template <int D, typename TI>
+__device__ __forceinline__ void load_frags(bf16x8* frag, const TI* __restrict__ rowp, int lh) {
 #pragma unroll
     for (int ks = 0; ks < D / 16; ++ks) {
-        const float4 a = *reinterpret_cast<const float4*>(rowp + ks * 16 + lh * 8);
-        const float4 c = *reinterpret_cast<const float4*>(rowp + ks * 16 + lh * 8 + 4);
-        bf16x8 v;
-        v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
-        v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
-        frag[ks] = v;
+        if constexpr (sizeof(TI) == 2) {
+            frag[ks] = *reinterpret_cast<const bf16x8*>(rowp + ks * 16 + lh * 8);
+        } else {
+            const float* rp = reinterpret_cast<const float*>(rowp);
+            const float4 a = *reinterpret_cast<const float4*>(rp + ks * 16 + lh * 8);
+            const float4 c = *reinterpret_cast<const float4*>(rp + ks * 16 + lh * 8 + 4);
+            bf16x8 v;
+            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+            v[4] = (__bf16)c.x; v[5] = (__bf16)c.y; v[6] = (__bf16)c.z; v[7] = (__bf16)c.w;
+            frag[ks] = v;
+        }
     }
 }
 
@@ -137,17 +158,20 @@ __device__ __forceinline__ void store_ct(float* __restrict__ dst_row, const f32x
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void hupr_k_attn_fwd(const float* __restrict__ K, const float* __restrict__ Q,
-                                                       const float* __restrict__ V, float* __restrict__ out,
-                                                       float* __restrict__ lse, int N, int residual) {
+// TI = float (operands rounded to bf16 while staged) or __bf16 (pre-rounded copies: every workgroup re-reads all of K
+// and V, so halving those bytes and dropping the per-tile conversions is worth one cast pass); Vres = fp32 V for the
+// residual epilogue (exact), or null.
+template <int D, typename TI>
+__global__ __launch_bounds__(256) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
+                                                       const TI* __restrict__ V, const float* __restrict__ Vres,
+                                                       float* __restrict__ out, float* __restrict__ lse, int N) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const long base = (long)blockIdx.y * N * D;
     const int q = blockIdx.x * 128 + wave * 32 + lr;         // this lane's query
     bf16x8 qf[D / 16];
-    load_frags<D>(qf, Q + base + (long)q * D, lh);
+    load_frags<D, TI>(qf, Q + base + (long)q * D, lh);
     f32x16 o[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -156,8 +180,8 @@ __global__ __launch_bounds__(256) void hupr_k_attn_fwd(const float* __restrict__
     float m_run = -INFINITY, l_run = 0.f;
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
-        stage_rows<D, 64>(Ks, K + base + (long)j0 * D, D, tid);
-        stage_rows<D, 64>(Vs, V + base + (long)j0 * D, D, tid);
+        stage_rows<D, 64, TI>(Ks, K + base + (long)j0 * D, D, tid);
+        stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
         __syncthreads();
         f32x16 st[2];
         mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T tile: rows = keys, this lane's column = its query
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_fwd(const float* __restrict__
         mma_tr_x_tile<D>(o, Vs, st, lane);                    // O^T += V^T P^T
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, residual ? V + base + (long)q * D : nullptr, lh);
+    store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     if (lh == 0) lse[(long)blockIdx.y * N + q] = m_run + __logf(l_tot);
 }
 
@@ -221,9 +245,9 @@ __global__ __launch_bounds__(256) void hupr_k_attn_prep(const float* __restrict_
 // ------------------------------------------------------------------------------------------------------
 // backward, dQ: same walk as the forward
 // ------------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const float* __restrict__ K, const float* __restrict__ Q,
-                                                          const float* __restrict__ V, const float* __restrict__ dO,
+template <int D, typename TI>
+__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
+                                                          const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
                                                           float* __restrict__ dQ, int N) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
@@ -232,8 +256,8 @@ __global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const float* __restric
     const long base = (long)blockIdx.y * N * D;
     const int q = blockIdx.x * 128 + wave * 32 + lr;
     bf16x8 qf[D / 16], gf[D / 16];
-    load_frags<D>(qf, Q + base + (long)q * D, lh);
-    load_frags<D>(gf, dO + base + (long)q * D, lh);
+    load_frags<D, TI>(qf, Q + base + (long)q * D, lh);
+    load_frags<D, TI>(gf, dO + base + (long)q * D, lh);
     const float lse_q = lse[(long)blockIdx.y * N + q], d_q = Dq[(long)blockIdx.y * N + q];
     f32x16 dq[D / 32];
 #pragma unroll
@@ -242,8 +266,8 @@ __global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const float* __restric
         for (int r = 0; r < 16; ++r) dq[ct][r] = 0.f;
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
-        stage_rows<D, 64>(Ks, K + base + (long)j0 * D, D, tid);
-        stage_rows<D, 64>(Vs, V + base + (long)j0 * D, D, tid);
+        stage_rows<D, 64, TI>(Ks, K + base + (long)j0 * D, D, tid);
+        stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
         __syncthreads();
         f32x16 st[2], dp[2];
         mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T
@@ -260,12 +284,12 @@ __global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const float* __restric
 // ------------------------------------------------------------------------------------------------------
 // backward, dK / dV: a workgroup owns 128 keys (32 per wave) and streams 64-query tiles
 // ------------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dkv(const float* __restrict__ K, const float* __restrict__ Q,
-                                                           const float* __restrict__ V, const float* __restrict__ dO,
+template <int D, typename TI>
+__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dkv(const TI* __restrict__ K, const TI* __restrict__ Q,
+                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
+                                                           const float* __restrict__ dOres,
                                                            const float* __restrict__ lse, const float* __restrict__ Dq,
-                                                           float* __restrict__ dK, float* __restrict__ dV, int N,
-                                                           int residual) {
+                                                           float* __restrict__ dK, float* __restrict__ dV, int N) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[64 * D];
     __shared__ float s_lse[64], s_d[64];
@@ -273,8 +297,8 @@ __global__ __launch_bounds__(256) void hupr_k_attn_bwd_dkv(const float* __restri
     const long base = (long)blockIdx.y * N * D;
     const int key = blockIdx.x * 128 + wave * 32 + lr;        // this lane's key
     bf16x8 kf[D / 16], vf[D / 16];
-    load_frags<D>(kf, K + base + (long)key * D, lh);
-    load_frags<D>(vf, V + base + (long)key * D, lh);
+    load_frags<D, TI>(kf, K + base + (long)key * D, lh);
+    load_frags<D, TI>(vf, V + base + (long)key * D, lh);
     f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -282,8 +306,8 @@ __global__ __launch_bounds__(256) void hupr_k_attn_bwd_dkv(const float* __restri
         for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.f; dv[ct][r] = 0.f; }
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
-        stage_rows<D, 64>(Qs, Q + base + (long)q0 * D, D, tid);
-        stage_rows<D, 64>(Gs, dO + base + (long)q0 * D, D, tid);
+        stage_rows<D, 64, TI>(Qs, Q + base + (long)q0 * D, D, tid);
+        stage_rows<D, 64, TI>(Gs, dO + base + (long)q0 * D, D, tid);
         if (tid < 64) {
             s_lse[tid] = lse[(long)blockIdx.y * N + q0 + tid];
             s_d[tid] = Dq[(long)blockIdx.y * N + q0 + tid];
@@ -305,7 +329,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_bwd_dkv(const float* __restri
         mma_tr_x_tile<D>(dk, Qs, dp, lane);                   // dK^T += Q^T dS
     }
     store_ct<D>(dK + base + (long)key * D, dk, 1.f, nullptr, lh);
-    store_ct<D>(dV + base + (long)key * D, dv, 1.f, residual ? dO + base + (long)key * D : nullptr, lh);
+    store_ct<D>(dV + base + (long)key * D, dv, 1.f, dOres ? dOres + base + (long)key * D : nullptr, lh);
 }
 
 }  // namespace hupr
@@ -314,36 +338,64 @@ using namespace hupr;
 
 extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C == 128) && N % 128 == 0 && N >= 128) ? 1 : 0; }
 
-// out (B,N,C) = softmax_keys(K Q^T)-weighted V (+V); lse (B,N) saved for the backward
-extern "C" int hupr_attn_fwd_bf16(const float* K, const float* Q, const float* V, float* out, float* lse, int Bn, int N, int C,
-                                  int residual, hupr_stream_t stream) {
-    HUPR_REQUIRE(K && Q && V && out && lse && Bn > 0, "hupr_attn_fwd_bf16: bad argument");
-    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "hupr_attn_fwd_bf16: unsupported shape N=%d C=%d", N, C);
+template <typename TI>
+static int attn_fwd(const char* who, const TI* K, const TI* Q, const TI* V, const float* Vres, float* out, float* lse, int Bn,
+                    int N, int C, hupr_stream_t stream) {
+    HUPR_REQUIRE(K && Q && V && out && lse && Bn > 0, "%s: bad argument", who);
+    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
     dim3 grid(N / 128, Bn);
-    if (C == 64) hipLaunchKernelGGL(hupr_k_attn_fwd<64>, grid, dim3(256), 0, as_stream(stream), K, Q, V, out, lse, N, residual);
-    else hipLaunchKernelGGL(hupr_k_attn_fwd<128>, grid, dim3(256), 0, as_stream(stream), K, Q, V, out, lse, N, residual);
+    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N);
+    else hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N);
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
 
-// dK, dQ, dV (B,N,C) from dout; Dq: scratch (B,N) floats
-extern "C" int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const float* out, const float* dout,
-                                  const float* lse, float* dK, float* dQ, float* dV, float* Dq, int Bn, int N, int C,
+// out (B,N,C) = softmax_keys(K Q^T)-weighted V (+V); lse (B,N) saved for the backward
+extern "C" int hupr_attn_fwd_bf16(const float* K, const float* Q, const float* V, float* out, float* lse, int Bn, int N, int C,
                                   int residual, hupr_stream_t stream) {
-    HUPR_REQUIRE(K && Q && V && out && dout && lse && dK && dQ && dV && Dq && Bn > 0, "hupr_attn_bwd_bf16: bad argument");
-    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "hupr_attn_bwd_bf16: unsupported shape N=%d C=%d", N, C);
+    return attn_fwd("hupr_attn_fwd_bf16", K, Q, V, residual ? V : nullptr, out, lse, Bn, N, C, stream);
+}
+// same with K, Q, V given as pre-rounded bf16 copies (hupr_cast_f32_to_bf16); Vres: fp32 V for the residual, or null
+extern "C" int hupr_attn_fwd_bf16in(const void* K, const void* Q, const void* V, const float* Vres, float* out, float* lse,
+                                    int Bn, int N, int C, hupr_stream_t stream) {
+    return attn_fwd("hupr_attn_fwd_bf16in", static_cast<const __bf16*>(K), static_cast<const __bf16*>(Q),
+                    static_cast<const __bf16*>(V), Vres, out, lse, Bn, N, C, stream);
+}
+
+// dK, dQ, dV (B,N,C) from dout; Dq: scratch (B,N) floats.  V32 / out / dout32: fp32 tensors of the exact row-sum
+// D = rowsum(dO o (out - V)) and the residual epilogue; K, Q, V, dO: the MFMA operands (fp32 or bf16 copies).
+template <typename TI>
+static int attn_bwd(const char* who, const TI* K, const TI* Q, const TI* V, const TI* dO, const float* V32, const float* out,
+                    const float* dout32, const float* lse, float* dK, float* dQ, float* dV, float* Dq, int Bn, int N, int C,
+                    int residual, hupr_stream_t stream) {
+    HUPR_REQUIRE(K && Q && V && dO && V32 && out && dout32 && lse && dK && dQ && dV && Dq && Bn > 0, "%s: bad argument", who);
+    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
     hipStream_t s = as_stream(stream);
     const long rows = (long)Bn * N;
     dim3 grid(N / 128, Bn);
+    const float* dres = residual ? dout32 : nullptr;
     if (C == 64) {
-        hipLaunchKernelGGL(hupr_k_attn_prep<64>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout, out, V, Dq, rows, residual);
-        hipLaunchKernelGGL(hupr_k_attn_bwd_dq<64>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dQ, N);
-        hipLaunchKernelGGL(hupr_k_attn_bwd_dkv<64>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dK, dV, N, residual);
+        hipLaunchKernelGGL(hupr_k_attn_prep<64>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout32, out, V32, Dq, rows, residual);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dres, lse, Dq, dK, dV, N);
     } else {
-        hipLaunchKernelGGL(hupr_k_attn_prep<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout, out, V, Dq, rows, residual);
-        hipLaunchKernelGGL(hupr_k_attn_bwd_dq<128>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dQ, N);
-        hipLaunchKernelGGL(hupr_k_attn_bwd_dkv<128>, grid, dim3(256), 0, s, K, Q, V, dout, lse, Dq, dK, dV, N, residual);
+        hipLaunchKernelGGL(hupr_k_attn_prep<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout32, out, V32, Dq, rows, residual);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dres, lse, Dq, dK, dV, N);
     }
     HUPR_LAUNCH_OK("hupr_k_attn_bwd");
     return HUPR_OK;
+}
+
+extern "C" int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const float* out, const float* dout,
+                                  const float* lse, float* dK, float* dQ, float* dV, float* Dq, int Bn, int N, int C,
+                                  int residual, hupr_stream_t stream) {
+    return attn_bwd("hupr_attn_bwd_bf16", K, Q, V, dout, V, out, dout, lse, dK, dQ, dV, Dq, Bn, N, C, residual, stream);
+}
+extern "C" int hupr_attn_bwd_bf16in(const void* K, const void* Q, const void* V, const void* dO, const float* V32,
+                                    const float* out, const float* dout32, const float* lse, float* dK, float* dQ, float* dV,
+                                    float* Dq, int Bn, int N, int C, int residual, hupr_stream_t stream) {
+    return attn_bwd("hupr_attn_bwd_bf16in", static_cast<const __bf16*>(K), static_cast<const __bf16*>(Q),
+                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), V32, out, dout32, lse, dK, dQ, dV, Dq, Bn, N,
+                    C, residual, stream);
 }

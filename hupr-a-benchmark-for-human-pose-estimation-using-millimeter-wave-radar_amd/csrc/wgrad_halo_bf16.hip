@@ -209,14 +209,167 @@ __global__ __launch_bounds__(256, 2) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16-activation variant with LDS-DMA staging.  The register-staged kernel above is VGPR-capped (144 accumulators +
+// 2 waves/SIMD leave no room to prefetch a tile), so its fill is a synchronous round trip per 128 voxels.  Here:
+//   * x halo and dy tile travel global -> LDS by buffer_load_dwordx4 ... lds (no VGPRs, out-of-range lanes deposit
+//     zeros = the conv padding; probe: scripts/probes/glds_probe.hip) into the idle half of a double-buffered image
+//     while the MFMAs run on the other half; one barrier per tile;
+//   * the row swizzle is applied on the SOURCE side (LDS slot = base + lane * 16 is fixed): slot (row, c') is filled
+//     with channel chunk c' ^ (4 * bit1(row));
+//   * 512 threads: waves 0-3 multiply K-steps 0..3 of the tile, waves 4-7 K-steps 4..7, each half keeping its own
+//     9 x (32x32) accumulators and writing its own partial tensor (partial index 2 * group + half).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool IS3D>
+__global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
+    constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, LOG2TW = IS3D ? 3 : 4;
+    constexpr int HH = 10, HW = TW + 2;
+    constexpr int NVOX = TD * HH * HW;               // 200 (3-D) / 180 (2-D) halo voxels of one depth-tap plane
+    constexpr int NVOXP = (NVOX + 7) / 8 * 8;        // x rows padded to whole 1 KiB DMA pieces (8 rows)
+    constexpr int ITEMS_X = NVOXP * 8, ITEMS = ITEMS_X + 128 * 8;
+    constexpr int IMG = (NVOXP + 128) * kRowB;       // one staged tile: x halo rows, then the dy rows
+    __shared__ __attribute__((aligned(1024))) char buf[2][IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = wave >> 2;                         // K half of this wave
+    const int wm = (wave >> 1) & 1, wn = wave & 1;    // 32-row (co) / 32-col (ci) quadrant of the 64x64 tile
+    const int pd = p.kd >> 1;
+    const int T = p.kd * 9;
+    const int group = blockIdx.x;
+    const int td = blockIdx.y;
+    const int cot = blockIdx.z / p.n_ci_tiles, cit = blockIdx.z % p.n_ci_tiles;
+    const int co0 = cot * 64, ci0 = cit * 64;
+
+    const int g = lane >> 4, s = lane & 15;
+    const int kh_ = g >> 1;
+    const int colb = (16 * (g & 1) + 4 * (s & 3)) * 2;
+    const int rsub = s >> 2;
+    int dyb[2], xb[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = 8 * kh_ + 4 * t + rsub;
+        dyb[t] = NVOXP * kRowB + c * kRowB + swz_col(c, wm * 64 + colb);
+        const int lrow = IS3D ? ((c >> 3) * HW + (c & 7)) : c;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+                xb[kx][par][t] = (lrow + kx) * kRowB + ((wn * 64 + colb) ^ (((((lrow + kx) >> 1) & 1) ^ par) << 6));
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const long x_bytes = (long)p.Bn * p.D * p.H * p.W * p.in_ld * 2, dy_bytes = (long)p.Bn * p.D * p.H * p.W * p.dy_ld * 2;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)dy_bytes, 0x00020000);
+    constexpr int kOOB = 0x7ffffff0;                 // beyond num_records: the DMA deposits zeros
+
+    // LDS-DMA of spatial tile ST_ into image BUF_: 41 (3-D) one-KiB pieces spread over the 8 waves
+#define HUPR_WG_FILL(ST_, BUF_)                                                                                     \
+    {                                                                                                               \
+        int q_ = (ST_);                                                                                             \
+        const int twi_ = q_ % p.nw; q_ /= p.nw;                                                                     \
+        const int thi_ = q_ % p.nh; q_ /= p.nh;                                                                     \
+        const int tdi_ = q_ % p.nd;                                                                                 \
+        const int b_ = q_ / p.nd;                                                                                   \
+        const int d0_ = tdi_ * TD, h0_ = thi_ * 8, w0_ = twi_ * TW;                                                 \
+        _Pragma("unroll") for (int u = 0; u < (ITEMS + 511) / 512; ++u) {                                           \
+            const int it = tid + u * 512;                                                                           \
+            if (it < ITEMS) {                                    /* wave-uniform: ITEMS and ITEMS_X are multiples of 64 */ \
+                char* dst_ = (BUF_) + (it - lane) * 16;                                                             \
+                if (it < ITEMS_X) {                                                                                 \
+                    const int vox = it >> 3, c8 = (it & 7) ^ (((vox >> 1) & 1) << 2);                               \
+                    const int hx = vox % HW;                                                                        \
+                    const int t2 = vox / HW;                                                                        \
+                    const int hy = t2 % HH, hz = t2 / HH;                                                           \
+                    const int d = d0_ + hz + td - pd, h = h0_ + hy - 1, w = w0_ + hx - 1;                           \
+                    const bool ok = vox < NVOX && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&     \
+                                    (unsigned)w < (unsigned)p.W && ci0 + c8 * 8 < p.Ci;                             \
+                    const int off = ((((b_ * p.D + d) * p.H + h) * p.W + w) * p.in_ld + ci0 + c8 * 8) * 2;          \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst_, 16, \
+                                                             ok ? off : kOOB, 0, 0, 0);                             \
+                } else {                                                                                            \
+                    const int j = it - ITEMS_X;                                                                     \
+                    const int v = j >> 3, c8 = (j & 7) ^ (((v >> 1) & 1) << 2);                                     \
+                    const int wx = v & (TW - 1), hy = (v >> LOG2TW) & 7, dz = v >> (LOG2TW + 3);                    \
+                    const bool ok = co0 + c8 * 8 < p.Co;                                                            \
+                    const int off = ((((b_ * p.D + d0_ + dz) * p.H + h0_ + hy) * p.W + w0_ + wx) * p.dy_ld + co0 + c8 * 8) * 2; \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst_, 16, \
+                                                             ok ? off : kOOB, 0, 0, 0);                             \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+
+    bf16x8 a[2], xq[2][3];
+    // K-steps KS0_ .. KS0_+3 of the staged tile IMG_ as 12 groups of three taps, fragments one group ahead
+#define HUPR_WG2_LOAD(IMG_, SET_, KS0_, J_)                                                                         \
+    {                                                                                                               \
+        constexpr int ks_ = (KS0_) + (J_) / 3, ky_ = (J_) % 3;                                                      \
+        constexpr int rows_ = (IS3D ? ((ks_ >> 2) * HH * HW + 2 * (ks_ & 3) * HW) : ks_ * HW) + ky_ * HW;           \
+        constexpr int par_ = IS3D ? (ky_ & 1) : ((ks_ + ky_) & 1);                                                  \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
+            xq[SET_][kx] = tr_pair((IMG_) + rows_ * kRowB, xb[kx][par_][0], xb[kx][par_][1]);                       \
+        if (ky_ == 0) a[ks_ & 1] = tr_pair((IMG_) + ks_ * 16 * kRowB, dyb[0], dyb[1]);                              \
+    }
+#define HUPR_WG2_STEP(IMG_, KS0_, J_)                                                                               \
+    {                                                                                                               \
+        if ((J_) + 1 < 12) { HUPR_WG2_LOAD(IMG_, ((J_) + 1) & 1, KS0_, ((J_) + 1 < 12 ? (J_) + 1 : 0)) }            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
+            acc[((J_) % 3) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((KS0_) + (J_) / 3) & 1], xq[(J_) & 1][kx], \
+                                                                               acc[((J_) % 3) * 3 + kx], 0, 0, 0);  \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }
+#define HUPR_WG2_TILE(IMG_, KS0_)                                                                                   \
+    HUPR_WG2_LOAD(IMG_, 0, KS0_, 0)                                                                                 \
+    HUPR_WG2_STEP(IMG_, KS0_, 0) HUPR_WG2_STEP(IMG_, KS0_, 1) HUPR_WG2_STEP(IMG_, KS0_, 2) HUPR_WG2_STEP(IMG_, KS0_, 3)  \
+    HUPR_WG2_STEP(IMG_, KS0_, 4) HUPR_WG2_STEP(IMG_, KS0_, 5) HUPR_WG2_STEP(IMG_, KS0_, 6) HUPR_WG2_STEP(IMG_, KS0_, 7)  \
+    HUPR_WG2_STEP(IMG_, KS0_, 8) HUPR_WG2_STEP(IMG_, KS0_, 9) HUPR_WG2_STEP(IMG_, KS0_, 10) HUPR_WG2_STEP(IMG_, KS0_, 11)
+
+    int cur = 0;
+    if (group < p.n_spatial) HUPR_WG_FILL(group, buf[0])
+    for (int st = group; st < p.n_spatial; st += p.groups) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile st have landed ...
+        __builtin_amdgcn_s_barrier();                           // ... everyone's have, and everyone left the other image
+        asm volatile("" ::: "memory");
+        if (st + p.groups < p.n_spatial) HUPR_WG_FILL(st + p.groups, buf[cur ^ 1])
+        const char* img = buf[cur];
+        if (kq == 0) { HUPR_WG2_TILE(img, 0) } else { HUPR_WG2_TILE(img, 4) }
+        cur ^= 1;
+    }
+#undef HUPR_WG_FILL
+#undef HUPR_WG2_LOAD
+#undef HUPR_WG2_STEP
+#undef HUPR_WG2_TILE
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ci = ci0 + wn * 32 + lr;
+    float* part = p.part + (long)(group * 2 + kq) * p.Co * T * p.Ci;
+    if (ci < p.Ci) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Co) part[((long)co * T + td * 9 + tap) * p.Ci + ci] = acc[tap][r];
+            }
+        }
+    }
+}
+
 }  // namespace hupr
 
 using namespace hupr;
 
 extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
-    // at most 256 groups, but never more than 128 MiB of partials
+    // at most 256 partial tensors, but never more than 128 MiB of them
     const size_t one = (size_t)Co * kd * 9 * Ci * sizeof(float);
-    size_t groups = 128;
+    size_t groups = 256;
     while (groups > 1 && groups * one > ((size_t)128 << 20)) groups >>= 1;
     return groups * one;
 }
@@ -245,8 +398,24 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     groups = min(groups, a.n_spatial);
     while (groups > 1 && (size_t)groups * one > ws_bytes) groups >>= 1;
     if ((size_t)groups * one > ws_bytes) return fail(HUPR_ERR_WORKSPACE, "hupr_conv3x3_wgrad_halo_bf16: workspace too small");
-    a.groups = groups;
     hipStream_t s = as_stream(stream);
+    const long n = (long)Co * kd * 9 * Ci;
+    const long max_bytes = (long)Bn * D * H * W * (in_ld > dy_ld ? in_ld : dy_ld) * 2;
+    if (abf && kd == 3 && max_bytes < 0x7ffffff0L) {
+        // LDS-DMA kernel: one 512-thread workgroup per CU, two partial tensors (K halves) per workgroup
+        int gw = max(1, min(128, 256 / pairs));
+        gw = min(gw, a.n_spatial);
+        while (gw > 1 && (size_t)gw * 2 * one > ws_bytes) gw >>= 1;
+        if ((size_t)gw * 2 * one <= ws_bytes) {
+            a.groups = gw;
+            hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<true>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
+            HUPR_LAUNCH_OK("hupr_k_wgrad_halo_glds");
+            launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw * 2, n, kd * 9, Ci, s);
+            HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
+            return HUPR_OK;
+        }
+    }
+    a.groups = groups;
     const dim3 grid(groups, kd, a.n_ci_tiles * a.n_co_tiles);
     if (kd == 3) {
         if (abf) hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<true, true>), grid, dim3(256), 0, s, a);
@@ -256,7 +425,6 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
         else hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<false, false>), grid, dim3(256), 0, s, a);
     }
     HUPR_LAUNCH_OK("hupr_k_wgrad_halo_bf16");
-    const long n = (long)Co * kd * 9 * Ci;
     launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, groups, n, kd * 9, Ci, s);
     HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
     return HUPR_OK;

@@ -446,9 +446,12 @@ class AttentionFn(torch.autograd.Function):
         if ctx.flash:
             out = torch.empty_like(v)
             lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
-            rt.check(L.hupr_attn_fwd_bf16(rt.ptr(k), rt.ptr(q), rt.ptr(v), rt.ptr(out), rt.ptr(lse), B, N, C,
-                                          1 if residual else 0, rt.stream()))
-            ctx.save_for_backward(k, q, v, out, lse)
+            # bf16 copies of the MFMA operands: each is re-read by every workgroup (N / 128 times), and the kernels
+            # would round them to bf16 per tile anyway — same bits, half the traffic, also half the saved activations
+            kb, qb, vb = _cast(k, torch.bfloat16), _cast(q, torch.bfloat16), _cast(v, torch.bfloat16)
+            rt.check(L.hupr_attn_fwd_bf16in(rt.ptr(kb), rt.ptr(qb), rt.ptr(vb), rt.ptr(v) if residual else None,
+                                            rt.ptr(out), rt.ptr(lse), B, N, C, rt.stream()))
+            ctx.save_for_backward(kb, qb, vb, v, out, lse)
             ctx.residual = residual
             return out
         # St[kq][j] = q . k  -> softmax over j is a row softmax
@@ -462,14 +465,15 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         if ctx.flash:
-            k, q, v, out, lse = ctx.saved_tensors
+            kb, qb, vb, v, out, lse = ctx.saved_tensors
             dout = _c(dout)
             B, N, C = v.shape
-            dk, dq, dv = torch.empty_like(k), torch.empty_like(q), torch.empty_like(v)
+            dk, dq, dv = torch.empty_like(v), torch.empty_like(v), torch.empty_like(v)
             dq_scr = torch.empty((B, N), dtype=torch.float32, device=v.device)
-            rt.check(rt.lib().hupr_attn_bwd_bf16(rt.ptr(k), rt.ptr(q), rt.ptr(v), rt.ptr(out), rt.ptr(dout), rt.ptr(lse),
-                                                rt.ptr(dk), rt.ptr(dq), rt.ptr(dv), rt.ptr(dq_scr), B, N, C,
-                                                1 if ctx.residual else 0, rt.stream()))
+            gb = _cast(dout, torch.bfloat16)
+            rt.check(rt.lib().hupr_attn_bwd_bf16in(rt.ptr(kb), rt.ptr(qb), rt.ptr(vb), rt.ptr(gb), rt.ptr(v), rt.ptr(out),
+                                                  rt.ptr(dout), rt.ptr(lse), rt.ptr(dk), rt.ptr(dq), rt.ptr(dv),
+                                                  rt.ptr(dq_scr), B, N, C, 1 if ctx.residual else 0, rt.stream()))
             return dk, dq, dv, None
         k, q, v, P = ctx.saved_tensors
         dout = _c(dout)

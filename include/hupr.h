@@ -187,6 +187,15 @@ int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const flo
                        const float* lse, float* dK, float* dQ, float* dV, float* Dq_scratch, int Bn, int N, int C,
                        int residual, hupr_stream_t stream);
 
+/* Same kernels fed with pre-rounded bf16 copies of the MFMA operands (hupr_cast_f32_to_bf16): every workgroup re-reads
+ * all of K/V (or Q/dO), so the copies halve that traffic and drop the per-tile fp32->bf16 conversions; results are
+ * bit-identical to the fp32-input entry points.  Vres / V32 / dout32: the fp32 tensors of the exact residual terms. */
+int hupr_attn_fwd_bf16in(const void* K, const void* Q, const void* V, const float* Vres, float* out, float* lse, int Bn,
+                         int N, int C, hupr_stream_t stream);
+int hupr_attn_bwd_bf16in(const void* K, const void* Q, const void* V, const void* dO, const float* V32, const float* out,
+                         const float* dout32, const float* lse, float* dK, float* dQ, float* dV, float* Dq_scratch,
+                         int Bn, int N, int C, int residual, hupr_stream_t stream);
+
 /* (a7) PRGCN: y = act(t . A + bias) with t = W . x computed by hupr_gemm_f32 (gcn_networks.py:23-29,53-58) */
 int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,
                          int ld, int relu, hupr_stream_t stream);

@@ -488,7 +488,8 @@ def test_conv_halo_bf16_activations(case, bf16_math):
     y16 = F_._conv_raw(x.bfloat16(), w, 0, bias, res.bfloat16() if has_res else None, Co, k, pad, (D, H, W))
     assert y16.dtype == torch.bfloat16
     assert torch.equal(y16.float(), _q(y32)), (y16.float() - _q(y32)).abs().max().item()
-    # weight gradient: fp32 output, identical arithmetic -> bit-identical
+    # weight gradient: fp32 output, identical products; only the fp32 summation order over voxel slices differs
+    # (LDS-DMA kernel: two K halves per workgroup, other slice count)
     if Ci % 32 == 0 and Co % 8 == 0:
         dy = _q(rnd(B, D, H, W, Co, seed=64)).cuda()
         L = F_.rt.lib()
@@ -499,7 +500,7 @@ def test_conv_halo_bf16_activations(case, bf16_math):
         xb, dyb = x.bfloat16(), dy.bfloat16()
         F_.rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(F_.rt.ptr(xb), F_.rt.ptr(dyb), F_.rt.ptr(dw16), B, D, H, W, Ci, Ci, Co,
                                                       Co, kd, F_.rt.ptr(ws), ws.numel(), F_.rt.stream()))
-        assert torch.equal(dw16, dw32)
+        close(dw16, dw32, 2e-6, "bf16act wgrad vs fp32-stored wgrad")
 
 
 def test_conv_autograd_bf16_activations(bf16_math):
