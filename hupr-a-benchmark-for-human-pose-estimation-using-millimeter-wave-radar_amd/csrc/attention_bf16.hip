@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_prep(const float* __restrict_
 // backward, dQ: same walk as the forward
 // ------------------------------------------------------------------------------------------------------
 template <int D, typename TI>
-__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
                                                           float* __restrict__ dQ, int N) {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_bwd_dq(const TI* __restrict__
 // backward, dK / dV: a workgroup owns 128 keys (32 per wave) and streams 64-query tiles
 // ------------------------------------------------------------------------------------------------------
 template <int D, typename TI>
-__global__ __launch_bounds__(256) void hupr_k_attn_bwd_dkv(const TI* __restrict__ K, const TI* __restrict__ Q,
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                            const TI* __restrict__ V, const TI* __restrict__ dO,
                                                            const float* __restrict__ dOres,
                                                            const float* __restrict__ lse, const float* __restrict__ Dq,
