@@ -232,6 +232,26 @@ __global__ __launch_bounds__(256) void hupr_k_adam(float* __restrict__ p, const 
     }
 }
 
+// same update with the learning rate and the step count read from device memory (state = {lr, step}): the launch
+// arguments of a captured hipGraph are frozen, the bias corrections must not be
+__global__ __launch_bounds__(256) void hupr_k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, const float* __restrict__ state, float b1,
+                                                       float b2, float eps, float wd, float gscale) {
+    const float lr = state[0];
+    const double step = (double)state[1];
+    const float bc1 = (float)(1.0 - pow((double)b1, step)), bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pv = p[i];
+        const float gr = fmaf(wd, pv, g[i] * gscale);
+        const float mv = fmaf(b1, m[i], (1.f - b1) * gr);
+        const float vv = fmaf(b2, v[i], (1.f - b2) * gr * gr);
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = pv - (lr / bc1) * (mv / denom);
+    }
+}
+
 static inline int grid1d(long n, int bs = 256, long cap = 4096) { return (int)min(cap, (n + bs - 1) / bs); }
 
 }  // namespace hupr
@@ -330,5 +350,17 @@ extern "C" int hupr_adam_step_f32(float* p, const float* g, float* exp_avg, floa
     hipLaunchKernelGGL(hupr_k_adam, dim3(grid1d(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), gscale);
     HUPR_LAUNCH_OK("hupr_k_adam");
+    return HUPR_OK;
+}
+
+// Same as hupr_adam_step_f32 with {lr, step} in device memory (dev_state[0] = learning rate, dev_state[1] = step count,
+// both float): usable inside a captured hipGraph whose launch arguments are frozen.
+extern "C" int hupr_adam_step_dev_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n,
+                                      const float* dev_state, float beta1, float beta2, float eps, float weight_decay,
+                                      float gscale, hupr_stream_t stream) {
+    HUPR_REQUIRE(p && g && exp_avg && exp_avg_sq && dev_state && n > 0, "hupr_adam_step_dev_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_adam_dev, dim3(grid1d(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n,
+                       dev_state, beta1, beta2, eps, weight_decay, gscale);
+    HUPR_LAUNCH_OK("hupr_k_adam_dev");
     return HUPR_OK;
 }

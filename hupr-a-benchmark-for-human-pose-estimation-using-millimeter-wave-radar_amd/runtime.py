@@ -75,6 +75,7 @@ SIGNATURES = {
     "hupr_gaussian_targets_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_float, c_void_p]),
     "hupr_argmax_rows_f32": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
     "hupr_adam_step_f32": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 5 + [c_int, c_float, c_void_p]),
+    "hupr_adam_step_dev_f32": (c_int, [c_void_p] * 4 + [c_long, c_void_p] + [c_float] * 5 + [c_void_p]),
     # bf16-activation variants (same argument lists as their fp32-activation counterparts)
     "hupr_conv3x3_halo_bf16act": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     "hupr_conv3x3_wgrad_halo_bf16act": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),

@@ -27,6 +27,7 @@ class TrainEngine:
         self.optimizer.grad_scale = 1.0 / self.world_size
         self.G = cfg.DATASET.numGroupFrames
         self._fft_ws = None
+        self._graph = None
 
     # -- data -------------------------------------------------------------------------------------
     def preprocess(self, adc_hori, adc_vert):
@@ -49,8 +50,45 @@ class TrainEngine:
         return loss, loss2
 
     def train_step_from_adc(self, adc_hori, adc_vert, joints):
+        if self._graph is not None:
+            return self._replay(adc_hori, adc_vert, joints)
         h, v = self.preprocess(adc_hori, adc_vert)
         return self.train_step(h, v, joints)
+
+    # -- hipGraph capture of the whole step (single-GPU) --------------------------------------------------------
+    def capture(self, adc_hori, adc_vert, joints, warmup=2):
+        """Capture preprocess + forward + loss + backward + Adam as ONE hipGraph and replay it from then on
+        (``train_step_from_adc``).  ~1000 kernel launches per step otherwise cost ~24 ms of host time, which bounds the
+        step once the kernels are faster than that.  Requirements: fixed shapes (the static input buffers are refilled
+        by copy), world size 1 (the RCCL all-reduce stays on the eager path), ``sync_lr()`` after LR changes.  The
+        ``warmup`` eager steps are real optimisation steps."""
+        if self.world_size != 1:
+            raise RuntimeError("graph capture is only wired for single-GPU runs")
+        self.optimizer.use_device_state()
+        self._g_in = (adc_hori.clone(), adc_vert.clone(), joints.clone())
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                h, v = self.preprocess(self._g_in[0], self._g_in[1])
+                self.train_step(h, v, self._g_in[2])
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            h, v = self.preprocess(self._g_in[0], self._g_in[1])
+            self._g_out = self.train_step(h, v, self._g_in[2])
+        self._graph = g
+
+    def sync_lr(self):
+        self.optimizer.sync_lr()
+
+    def _replay(self, adc_hori, adc_vert, joints):
+        for dst, src in zip(self._g_in, (adc_hori, adc_vert, joints)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._g_out
 
     @torch.no_grad()
     def infer(self, hori, vert):

@@ -22,6 +22,21 @@ class FusedAdam(torch.optim.Optimizer):
         """buckets: list of (flat_param, flat_grad) fp32 GPU tensors covering all parameters in order."""
         self._flat = buckets
         self._flat_state = [dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p, _ in buckets]
+        self._dev_state = None           # {lr, step} on the device: set by use_device_state() for graph-captured steps
+
+    def use_device_state(self):
+        """Keep the learning rate and the step count in device memory (needed when step() is captured in a hipGraph:
+        launch arguments are frozen at capture, the bias corrections and LR schedule must keep moving)."""
+        dev = self._flat[0][0].device
+        self._dev_state = torch.tensor([self.param_groups[0]["lr"], float(self._flat_state[0]["step"])], dtype=torch.float32,
+                                       device=dev)
+        self._dev_lr = self.param_groups[0]["lr"]
+
+    def sync_lr(self):
+        """Push a changed param_groups lr to the device state (call outside graph replay, e.g. once per epoch)."""
+        if self._dev_state is not None and self.param_groups[0]["lr"] != self._dev_lr:
+            self._dev_lr = self.param_groups[0]["lr"]
+            self._dev_state[0] = self._dev_lr
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -34,6 +49,14 @@ class FusedAdam(torch.optim.Optimizer):
         if self._flat is not None:
             g0 = self.param_groups[0]
             b1, b2 = g0["betas"]
+            if self._dev_state is not None:
+                self._dev_state[1] += 1          # device-side step count (captured as a graph node)
+                for (p, g), st in zip(self._flat, self._flat_state):
+                    st["step"] += 1              # host mirror (checkpoints); during replay only the device copy advances
+                    rt.check(L.hupr_adam_step_dev_f32(rt.ptr(p), rt.ptr(g), rt.ptr(st["exp_avg"]), rt.ptr(st["exp_avg_sq"]),
+                                                      p.numel(), rt.ptr(self._dev_state), b1, b2, g0["eps"],
+                                                      g0["weight_decay"], self.grad_scale, s))
+                return loss
             for (p, g), st in zip(self._flat, self._flat_state):
                 st["step"] += 1
                 rt.check(L.hupr_adam_step_f32(rt.ptr(p), rt.ptr(g), rt.ptr(st["exp_avg"]), rt.ptr(st["exp_avg_sq"]),

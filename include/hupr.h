@@ -219,6 +219,9 @@ int hupr_argmax_rows_f32(const float* p, long rows, int n, int* idx, float* maxv
 /* (a10) Adam with coupled L2 weight decay (tools/base.py:47), one flat launch */
 int hupr_adam_step_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int step, float gscale, hupr_stream_t stream);
+/* same, {learning rate, step count} read from device memory (2 floats): for steps replayed from a captured hipGraph */
+int hupr_adam_step_dev_f32(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long n, const float* dev_state,
+                           float beta1, float beta2, float eps, float weight_decay, float gscale, hupr_stream_t stream);
 
 /* ---- bf16-activation variants ("bf16act") -------------------------------------------------------------
  * Same operators with the ACTIVATION tensors (x, y, dy, dx, residual) stored as bf16 in HBM; parameters,

@@ -124,3 +124,38 @@ def test_bf16_and_f32_pipes_agree_at_batch32():
     agree = (outs["f32"][1].reshape(32, 14, -1).argmax(-1) == outs["bf16"][1].reshape(32, 14, -1).argmax(-1)).float().mean().item()
     print("bf16 vs f32 at B=32: max-abs %.3e / %.3e, argmax agreement %.4f" % (e1, e2, agree))
     assert e1 <= 2e-2 and e2 <= 2e-2 and agree >= 0.9
+
+
+def test_graph_replay_matches_eager_steps():
+    """TrainEngine.capture(): the whole step (FFT loader, forward, loss, backward, Adam with device-side step count) as
+    one hipGraph.  Five optimisation steps taken eagerly and taken as 2 eager + 1 capture warm-up + 2 replays must land
+    on the same parameters (same kernels, same order; only the Adam bias corrections are evaluated on the device)."""
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    try:
+        F_.set_math("bf16")
+        cfg = load_config()
+        dev = torch.device("cuda", 0)
+        B, G = 4, cfg.DATASET.numGroupFrames
+        adc_h = torch.from_numpy(synth.adc_cube_int16(31, sensor=0, nframes=B * G)).to(dev)
+        adc_v = torch.from_numpy(synth.adc_cube_int16(31, sensor=1, nframes=B * G)).to(dev)
+        joints = torch.from_numpy(synth.keypoints(B, 32)).to(dev)
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        for _ in range(5):
+            l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)
+        e2 = TrainEngine(cfg, device=dev, seed=0)
+        for _ in range(2):
+            e2.train_step_from_adc(adc_h, adc_v, joints)
+        e2.capture(adc_h, adc_v, joints, warmup=1)
+        for _ in range(2):
+            l2, _ = e2.train_step_from_adc(adc_h, adc_v, joints)
+        torch.cuda.synchronize()
+        p1 = torch.cat([p.detach().flatten() for p in e1.model.parameters()])
+        p2 = torch.cat([p.detach().flatten() for p in e2.model.parameters()])
+        assert torch.isfinite(p2).all()
+        rel = ((p1 - p2).norm() / p1.norm()).item()
+        assert rel <= 1e-5, rel
+        assert abs(float(l1.detach()) - float(l2.detach())) <= 1e-4 * abs(float(l1.detach()))
+    finally:
+        F_.set_math("f32")
