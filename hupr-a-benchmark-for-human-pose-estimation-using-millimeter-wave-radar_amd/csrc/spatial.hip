@@ -29,7 +29,7 @@ __device__ __forceinline__ void mnet_load_means(const float* __restrict__ x, lon
 template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, T* __restrict__ out,
-                                                       long n_bg, int pixels) {
+                                                       float* __restrict__ means, long n_bg, int pixels) {
     __shared__ float sw[kNF * 4 + kNF];
     for (int i = threadIdx.x; i < kNF * 4 + kNF; i += 256) sw[i] = (i < kNF * 4) ? w[i] : bias[i - kNF * 4];
     __syncthreads();
@@ -39,6 +39,11 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__
         const float* xb = x + bg * 16 * (long)pixels * 8;
         float m[16];
         mnet_load_means(xb, (long)pixels * 8, pix, m);
+        if (means) {                                   // 16 elevation means per pixel: all the backward pass needs of x (1/8 of its bytes)
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                *reinterpret_cast<float4*>(means + idx * 16 + j) = make_float4(m[j], m[j + 1], m[j + 2], m[j + 3]);
+        }
         T* o = out + idx * kNF;
 #pragma unroll
         for (int c4 = 0; c4 < kNF / 4; ++c4) {
@@ -69,7 +74,8 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const T* __restrict__ dy,
-                                                       long n_bg, int pixels, float* __restrict__ partial) {
+                                                       const float* __restrict__ means, long n_bg, int pixels,
+                                                       float* __restrict__ partial) {
     __shared__ float sw[kNF * 4 + kNF];
     __shared__ float red[4][kNF * 5];
     for (int i = threadIdx.x; i < kNF * 4 + kNF; i += 256) sw[i] = (i < kNF * 4) ? w[i] : bias[i - kNF * 4];
@@ -82,7 +88,15 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__
         const long bg = idx / pixels, pix = idx - bg * pixels;
         const float* xb = x + bg * 16 * (long)pixels * 8;
         float m[16];
-        mnet_load_means(xb, (long)pixels * 8, pix, m);
+        if (means) {
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(means + idx * 16 + j);
+                m[j] = t.x; m[j + 1] = t.y; m[j + 2] = t.z; m[j + 3] = t.w;
+            }
+        } else {
+            mnet_load_means(xb, (long)pixels * 8, pix, m);
+        }
         const T* g4 = dy + idx * kNF;
 #pragma unroll
         for (int c4 = 0; c4 < kNF / 4; ++c4) {
@@ -268,49 +282,51 @@ using namespace hupr;
 // (a3) MNet forward.  x: (n_bg = B*G, F=8, 2, pixels = R*A, E=8) fp32;  w: (32,2,2,1,1); bias: (32)
 // out: (n_bg, pixels, 32) channels-last, fp32 or (bf16act) bf16
 template <typename T>
-static int mnet_fwd(const char* who, const float* x, const float* w, const float* bias, T* out, long n_bg, int pixels,
-                    hupr_stream_t stream) {
+static int mnet_fwd(const char* who, const float* x, const float* w, const float* bias, T* out, float* means, long n_bg,
+                    int pixels, hupr_stream_t stream) {
     HUPR_REQUIRE(x && w && bias && out && n_bg > 0 && pixels > 0, "%s: bad argument", who);
     const long total = n_bg * pixels;
     const int grid = (int)min((long)8192, (total + 255) / 256);
-    hipLaunchKernelGGL(hupr_k_mnet_fwd<T>, dim3(grid), dim3(256), 0, as_stream(stream), x, w, bias, out, n_bg, pixels);
+    hipLaunchKernelGGL(hupr_k_mnet_fwd<T>, dim3(grid), dim3(256), 0, as_stream(stream), x, w, bias, out, means, n_bg, pixels);
     HUPR_LAUNCH_OK("hupr_k_mnet_fwd");
     return HUPR_OK;
 }
-extern "C" int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, long n_bg, int pixels,
-                                 hupr_stream_t stream) {
-    return mnet_fwd("hupr_mnet_fwd_f32", x, w, bias, out, n_bg, pixels, stream);
+extern "C" int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, float* means_or_null,
+                                 long n_bg, int pixels, hupr_stream_t stream) {
+    return mnet_fwd("hupr_mnet_fwd_f32", x, w, bias, out, means_or_null, n_bg, pixels, stream);
 }
-extern "C" int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, long n_bg, int pixels,
-                                     hupr_stream_t stream) {
-    return mnet_fwd("hupr_mnet_fwd_bf16act", x, w, bias, static_cast<__bf16*>(out), n_bg, pixels, stream);
+extern "C" int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, float* means_or_null,
+                                     long n_bg, int pixels, hupr_stream_t stream) {
+    return mnet_fwd("hupr_mnet_fwd_bf16act", x, w, bias, static_cast<__bf16*>(out), means_or_null, n_bg, pixels, stream);
 }
 
 extern "C" size_t hupr_mnet_bwd_ws_bytes(void) { return (size_t)1024 * kNF * 5 * sizeof(float); }
 
 template <typename T>
-static int mnet_bwd(const char* who, const float* x, const float* w, const float* bias, const T* dy, float* dw,
-                    float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(x && w && bias && dy && dw && dbias && ws && n_bg > 0 && pixels > 0, "%s: bad argument", who);
+static int mnet_bwd(const char* who, const float* x, const float* means, const float* w, const float* bias, const T* dy,
+                    float* dw, float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE((x || means) && w && bias && dy && dw && dbias && ws && n_bg > 0 && pixels > 0, "%s: bad argument", who);
     if (ws_bytes < hupr_mnet_bwd_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     const long total = n_bg * pixels;
     const int grid = (int)min((long)1024, (total + 255) / 256);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(hupr_k_mnet_bwd<T>, dim3(grid), dim3(256), 0, s, x, w, bias, dy, n_bg, pixels,
+    hipLaunchKernelGGL(hupr_k_mnet_bwd<T>, dim3(grid), dim3(256), 0, s, x, w, bias, dy, means, n_bg, pixels,
                        reinterpret_cast<float*>(ws));
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd");
     hipLaunchKernelGGL(hupr_k_mnet_bwd_final, dim3(kNF * 5), dim3(256), 0, s, reinterpret_cast<const float*>(ws), grid, dw, dbias);
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd_final");
     return HUPR_OK;
 }
-extern "C" int hupr_mnet_bwd_f32(const float* x, const float* w, const float* bias, const float* dy, float* dw,
-                                 float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    return mnet_bwd("hupr_mnet_bwd_f32", x, w, bias, dy, dw, dbias, n_bg, pixels, ws, ws_bytes, stream);
+extern "C" int hupr_mnet_bwd_f32(const float* x_or_null, const float* means_or_null, const float* w, const float* bias,
+                                 const float* dy, float* dw, float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes,
+                                 hupr_stream_t stream) {
+    return mnet_bwd("hupr_mnet_bwd_f32", x_or_null, means_or_null, w, bias, dy, dw, dbias, n_bg, pixels, ws, ws_bytes, stream);
 }
-extern "C" int hupr_mnet_bwd_bf16act(const float* x, const float* w, const float* bias, const void* dy, float* dw,
-                                     float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    return mnet_bwd("hupr_mnet_bwd_bf16act", x, w, bias, static_cast<const __bf16*>(dy), dw, dbias, n_bg, pixels, ws,
-                    ws_bytes, stream);
+extern "C" int hupr_mnet_bwd_bf16act(const float* x_or_null, const float* means_or_null, const float* w, const float* bias,
+                                     const void* dy, float* dw, float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes,
+                                     hupr_stream_t stream) {
+    return mnet_bwd("hupr_mnet_bwd_bf16act", x_or_null, means_or_null, w, bias, static_cast<const __bf16*>(dy), dw, dbias, n_bg,
+                    pixels, ws, ws_bytes, stream);
 }
 
 static int interp_check(const char* who, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int in_ld,

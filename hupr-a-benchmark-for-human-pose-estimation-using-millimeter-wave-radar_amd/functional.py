@@ -346,21 +346,25 @@ class MNetFn(torch.autograd.Function):
         if (F, two, E) != (8, 2, 8) or weight.shape != (32, 2, 2, 1, 1):
             raise ValueError("MNet kernel is specialised for F=8, 2 (re/im), E=8, 32 filters")
         out = torch.empty((B, G, R, A, 32), dtype=out_dtype, device=x.device)
-        rt.check(_act("mnet_fwd", out)(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(out), B * G, R * A,
-                                       rt.stream()))
-        ctx.save_for_backward(x, weight, bias)
+        # training: keep the 16 elevation means per pixel (1/8 of x) — the backward pass recomputes everything from them
+        need = weight.requires_grad or bias.requires_grad
+        means = torch.empty((B * G, R * A, 16), dtype=torch.float32, device=x.device) if need else None
+        rt.check(_act("mnet_fwd", out)(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(out),
+                                       rt.ptr(means) if need else None, B * G, R * A, rt.stream()))
+        ctx.save_for_backward(means, weight, bias)
+        ctx.geom = (B, G, R, A)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, bias = ctx.saved_tensors
+        means, weight, bias = ctx.saved_tensors
         L = rt.lib()
-        B, G, F, two, R, A, E = x.shape
+        B, G, R, A = ctx.geom
         dw, dw_direct = _pgrad(weight)
         db, db_direct = _pgrad(bias)
-        ws = workspace(L.hupr_mnet_bwd_ws_bytes(), x.device)
+        ws = workspace(L.hupr_mnet_bwd_ws_bytes(), dy.device)
         dy = _c(dy)
-        rt.check(_act("mnet_bwd", dy)(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(dy), rt.ptr(dw), rt.ptr(db),
+        rt.check(_act("mnet_bwd", dy)(None, rt.ptr(means), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(dy), rt.ptr(dw), rt.ptr(db),
                                       B * G, R * A, rt.ptr(ws), ws.numel(), rt.stream()))
         return None, _pret(weight, dw, dw_direct), _pret(bias, db, db_direct), None
 

@@ -53,9 +53,9 @@ SIGNATURES = {
     "hupr_prelu_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_prelu_ws_bytes": (c_size_t, []),
     "hupr_prelu_bwd_f32": (c_int, [c_void_p] * 5 + [c_long, c_void_p, c_size_t, c_void_p]),
-    "hupr_mnet_fwd_f32": (c_int, [c_void_p] * 4 + [c_long, c_int, c_void_p]),
+    "hupr_mnet_fwd_f32": (c_int, [c_void_p] * 5 + [c_long, c_int, c_void_p]),
     "hupr_mnet_bwd_ws_bytes": (c_size_t, []),
-    "hupr_mnet_bwd_f32": (c_int, [c_void_p] * 6 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_mnet_bwd_f32": (c_int, [c_void_p] * 7 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_interp_linear_fwd_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_interp_linear_bwd_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_attn_flash_supported": (c_int, [c_int, c_int]),
@@ -84,8 +84,8 @@ SIGNATURES = {
     "hupr_scale_shift_act_bf16act": (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_void_p]),
     "hupr_bn_bwd_bf16act": (c_int, [c_void_p] * 9 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_colsum_bf16act": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "hupr_mnet_fwd_bf16act": (c_int, [c_void_p] * 4 + [c_long, c_int, c_void_p]),
-    "hupr_mnet_bwd_bf16act": (c_int, [c_void_p] * 6 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_mnet_fwd_bf16act": (c_int, [c_void_p] * 5 + [c_long, c_int, c_void_p]),
+    "hupr_mnet_bwd_bf16act": (c_int, [c_void_p] * 7 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_interp_linear_fwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_interp_linear_bwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),

@@ -161,12 +161,15 @@ int hupr_prelu_bwd_f32(const float* dy, const float* x, const float* alpha, floa
 
 /* (a3) MNet front end — replaces HuPRNet.forward_chirp + MNet.forward (models/networks.py:23-33,
  * models/chirp_networks.py:17-21): elevation mean, the (F,2)->(2,F) .view, Conv3d(2->32,(2,1,1),s(2,1,1)),
- * MaxPool3d((4,1,1)).  x: (n_bg=B*G, 8, 2, pixels=R*A, 8) fp32; out: (n_bg, pixels, 32) channels-last. */
-int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, long n_bg, int pixels,
-                      hupr_stream_t stream);
+ * MaxPool3d((4,1,1)).  x: (n_bg=B*G, 8, 2, pixels=R*A, 8) fp32; out: (n_bg, pixels, 32) channels-last.
+ * means_or_null: (n_bg, pixels, 16) fp32 — the 16 elevation means per pixel; they are all the backward pass needs of
+ * x (1/8 of its bytes), so a training forward saves them and the backward takes them instead of x. */
+int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bias, float* out, float* means_or_null, long n_bg,
+                      int pixels, hupr_stream_t stream);
 size_t hupr_mnet_bwd_ws_bytes(void);
-int hupr_mnet_bwd_f32(const float* x, const float* w, const float* bias, const float* dy, float* dw, float* dbias,
-                      long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_mnet_bwd_f32(const float* x_or_null, const float* means_or_null, const float* w, const float* bias,
+                      const float* dy, float* dw, float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes,
+                      hupr_stream_t stream);
 
 /* tri-/bilinear align_corners=True resampling (models/layers.py:84,89,199,204; gcn_networks.py:49,63) */
 int hupr_interp_linear_fwd_f32(const float* x, float* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
@@ -246,10 +249,11 @@ int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const void* x, const
                         const float* save_invstd, const float* gamma, void* dx, float* dgamma, float* dbeta, long M,
                         int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_colsum_bf16act(const void* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
-int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, long n_bg, int pixels,
+int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, float* means_or_null, long n_bg,
+                          int pixels, hupr_stream_t stream);
+int hupr_mnet_bwd_bf16act(const float* x_or_null, const float* means_or_null, const float* w, const float* bias,
+                          const void* dy, float* dw, float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes,
                           hupr_stream_t stream);
-int hupr_mnet_bwd_bf16act(const float* x, const float* w, const float* bias, const void* dy, float* dw, float* dbias,
-                          long n_bg, int pixels, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_interp_linear_fwd_bf16act(const void* x, void* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                                    int C, int in_ld, int out_ld, hupr_stream_t stream);
 int hupr_interp_linear_bwd_bf16act(const void* dy, void* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
