@@ -238,9 +238,52 @@ __global__ void hupr_k_pack_weights_bf16(const float* __restrict__ w, __bf16* __
     }
 }
 
+// Table-driven repack of MANY convolution weights in one launch (both layouts of every entry): a training step otherwise
+// issues ~160 six-microsecond pack launches.  One thread per source element; the entry is found by binary search.
+struct PackDesc {          // mirrors the packed struct built in functional.py (little-endian, 48 bytes)
+    const float* w;        // (Co, Ci, taps) parameter
+    void* wp0;             // [Co][tap][Ci]
+    void* wp1;             // [Ci][taps-1-tap][Co]
+    long first;            // index of this entry's first element in the concatenated element space
+    int co, ci, taps, kind;   // kind 0: fp32 outputs, 1: bf16 outputs
+};
+__global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restrict__ descs, int n, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].first <= i) lo = mid; else hi = mid - 1;
+        }
+        const PackDesc d = descs[lo];
+        const long l = i - d.first;
+        const int tap = (int)(l % d.taps);
+        const long t = l / d.taps;
+        const int ci = (int)(t % d.ci), co = (int)(t / d.ci);
+        const float v = d.w[l];
+        const long i0 = ((long)co * d.taps + tap) * d.ci + ci;
+        const long i1 = ((long)ci * d.taps + (d.taps - 1 - tap)) * d.co + co;
+        if (d.kind == 1) {
+            static_cast<__bf16*>(d.wp0)[i0] = (__bf16)v;
+            static_cast<__bf16*>(d.wp1)[i1] = (__bf16)v;
+        } else {
+            static_cast<float*>(d.wp0)[i0] = v;
+            static_cast<float*>(d.wp1)[i1] = v;
+        }
+    }
+}
+
 }  // namespace hupr
 
 using namespace hupr;
+
+extern "C" int hupr_pack_conv_weights_table(const void* descs_dev, int n, long total, hupr_stream_t stream) {
+    HUPR_REQUIRE(descs_dev && n > 0 && total > 0, "hupr_pack_conv_weights_table: bad argument");
+    static_assert(sizeof(PackDesc) == 48, "PackDesc layout is part of the ABI");
+    hipLaunchKernelGGL(hupr_k_pack_table, dim3((unsigned)min((long)8192, (total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const PackDesc*>(descs_dev), n, total);
+    HUPR_LAUNCH_OK("hupr_k_pack_table");
+    return HUPR_OK;
+}
 
 extern "C" int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
                                            hupr_stream_t stream) {

@@ -6,6 +6,8 @@ kernels happens on device each call (35.5 M floats, negligible next to the convo
 
 Nothing here computes with torch ops except allocation, views and gradient bookkeeping.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -98,6 +100,88 @@ def pack_weights_bf16(w, mode):
     return wp
 
 
+# ---- packed-weight cache -------------------------------------------------------------------------------------
+# Parameters (leaf tensors that require grad) keep both packed layouts cached; the cache is stamped with PACK_EPOCH
+# (bumped by optimisers that update weights through the C ABI, i.e. behind torch's version counter) and the tensor's
+# own ``_version``.  The first stale hit of a step refreshes EVERY registered weight with one table-driven launch
+# (hupr_pack_conv_weights_table) instead of ~160 small pack launches per training step.
+import weakref
+
+PACK_EPOCH = 0
+PACK_CACHE = os.environ.get("HUPR_NO_PACK_CACHE", "0") != "1"      # debugging aid: repack on every call
+_pack_entries = {}      # (storage address, kind) -> entry
+_pack_table = None      # (device uint8 tensor, n, total) or None when dirty
+
+
+def invalidate_packed():
+    """Call after changing parameters behind torch's back (FusedAdam does)."""
+    global PACK_EPOCH
+    PACK_EPOCH += 1
+
+
+class _PackEntry:
+    __slots__ = ("wref", "ptr", "kind", "shape", "wp", "stamp")
+
+
+def _pack_refresh_all(dev):
+    global _pack_table
+    L = rt.lib()
+    live = []
+    for key in list(_pack_entries):
+        e = _pack_entries[key]
+        w = e.wref()
+        if w is None or w.data_ptr() != e.ptr or w.device != dev:
+            if w is None:
+                del _pack_entries[key]
+            continue
+        live.append((e, w))
+    if not live:
+        return
+    if _pack_table is None or _pack_table[3] != tuple(id(e) for e, _ in live):
+        rec = np.zeros(len(live), dtype=np.dtype([("w", "<u8"), ("wp0", "<u8"), ("wp1", "<u8"), ("first", "<i8"), ("co", "<i4"),
+                                                   ("ci", "<i4"), ("taps", "<i4"), ("kind", "<i4")]))
+        first = 0
+        for i, (e, w) in enumerate(live):
+            co, ci = w.shape[0], w.shape[1]
+            taps = int(np.prod(w.shape[2:]))
+            rec[i] = (w.data_ptr(), e.wp[0].data_ptr(), e.wp[1].data_ptr(), first, co, ci, taps, e.kind)
+            first += co * ci * taps
+        tab = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        _pack_table = (tab, len(live), first, tuple(id(e) for e, _ in live))
+    tab, n, total, _ = _pack_table
+    rt.check(L.hupr_pack_conv_weights_table(rt.ptr(tab), n, total, rt.stream()))
+    for e, w in live:
+        e.stamp = (PACK_EPOCH, w._version)
+
+
+def _packed(weight, mode, kind):
+    """Packed layout ``mode`` (0 forward, 1 input gradient) of ``weight`` as fp32 (kind 0) or bf16 (kind 1)."""
+    global _pack_table
+    if not (PACK_CACHE and weight.is_leaf and weight.requires_grad and weight.is_contiguous()) or \
+            torch.cuda.is_current_stream_capturing():
+        return pack_weights_bf16(weight, mode) if kind else pack_weights(weight, mode)
+    key = (weight.data_ptr(), kind)
+    e = _pack_entries.get(key)
+    if e is not None and (e.wref() is None or e.shape != tuple(weight.shape)):     # the address was recycled by another tensor
+        e = None
+    if e is None:
+        e = _PackEntry()
+        e.wref, e.ptr, e.kind, e.shape = weakref.ref(weight), weight.data_ptr(), kind, tuple(weight.shape)
+        pk = pack_weights_bf16 if kind else pack_weights
+        e.wp = (pk(weight, 0), pk(weight, 1))
+        e.stamp = (PACK_EPOCH, weight._version)
+        _pack_entries[key] = e
+        _pack_table = None
+    elif e.stamp != (PACK_EPOCH, weight._version):
+        _pack_refresh_all(weight.device)
+        if e.stamp != (PACK_EPOCH, weight._version):          # not covered by the table pass (should not happen)
+            pk = pack_weights_bf16 if kind else pack_weights
+            e.wp = (pk(weight, 0), pk(weight, 1))
+            e.stamp = (PACK_EPOCH, weight._version)
+            _pack_table = None
+    return e.wp[mode]
+
+
 USE_FLASH = True       # bf16 mode: fused attention kernels where supported (C in {64,128}, N % 128 == 0)
 USE_HALO = True        # bf16 mode: LDS halo-tiled kernel for 3x3(x3) "same" convolutions
 
@@ -120,7 +204,7 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent):
     abf = x.dtype == torch.bfloat16
     if _halo_ok(x, k, pad, co):
         assert res is None or res.dtype == x.dtype
-        wp = pack_weights_bf16(weight, mode)
+        wp = _packed(weight, mode, 1)
         if ev is not None:
             ev[0].record()
         fn = rt.lib().hupr_conv3x3_halo_bf16act if abf else rt.lib().hupr_conv3x3_halo_bf16
@@ -132,7 +216,7 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent):
     if abf:
         raise rt.HuprError("bf16-stored activations are only supported by the halo-tiled 3x3 convolutions "
                            "(shape %r, kernel %r); cast to fp32 first" % (tuple(x.shape), k))
-    wp = pack_weights(weight, mode)
+    wp = _packed(weight, mode, 0)
     if ev is not None:
         ev[0].record()
     rt.check(_fn("conv_fwd")(

@@ -46,6 +46,8 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         L = rt.lib()
         s = rt.stream()
+        from .. import functional as F_
+        F_.invalidate_packed()             # parameters change below without bumping torch's version counters
         if self._flat is not None:
             g0 = self.param_groups[0]
             b1, b2 = g0["betas"]
