@@ -278,33 +278,39 @@ __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const T* __restrict__
 }
 
 // ---- PReLU with one shared slope (nn.PReLU() default) --------------------------------------
-__global__ __launch_bounds__(256) void hupr_k_prelu_fwd(const float* __restrict__ x, const float* __restrict__ alpha,
-                                                        float* __restrict__ y, long n4) {
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_prelu_fwd(const T* __restrict__ x, const float* __restrict__ alpha,
+                                                        T* __restrict__ y, long nv) {
+    constexpr int V = ActVec<T>::V;
     const float a = alpha[0];
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        float4 v = reinterpret_cast<const float4*>(x)[i];
-        v.x = v.x > 0.f ? v.x : a * v.x; v.y = v.y > 0.f ? v.y : a * v.y;
-        v.z = v.z > 0.f ? v.z : a * v.z; v.w = v.w > 0.f ? v.w : a * v.w;
-        reinterpret_cast<float4*>(y)[i] = v;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float v[V];
+        ActVec<T>::load(x + i * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = v[k] > 0.f ? v[k] : a * v[k];
+        ActVec<T>::store(y + i * V, v);
     }
 }
 
 // dx = dy * (x > 0 ? 1 : alpha);  partial[blk] = sum dy * x * [x <= 0]
-__global__ __launch_bounds__(256) void hupr_k_prelu_bwd(const float* __restrict__ dy, const float* __restrict__ x,
-                                                        const float* __restrict__ alpha, float* __restrict__ dx,
-                                                        long n4, double* __restrict__ partial) {
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_prelu_bwd(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const float* __restrict__ alpha, T* __restrict__ dx,
+                                                        long nv, double* __restrict__ partial) {
+    constexpr int V = ActVec<T>::V;
     __shared__ double red[4];
     const float a = alpha[0];
     float acc = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const float4 g = reinterpret_cast<const float4*>(dy)[i];
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        float4 o;
-        o.x = v.x > 0.f ? g.x : a * g.x; o.y = v.y > 0.f ? g.y : a * g.y;
-        o.z = v.z > 0.f ? g.z : a * g.z; o.w = v.w > 0.f ? g.w : a * g.w;
-        acc += (v.x > 0.f ? 0.f : g.x * v.x) + (v.y > 0.f ? 0.f : g.y * v.y) +
-               (v.z > 0.f ? 0.f : g.z * v.z) + (v.w > 0.f ? 0.f : g.w * v.w);
-        reinterpret_cast<float4*>(dx)[i] = o;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float g[V], v[V], o[V];
+        ActVec<T>::load(dy + i * V, g);
+        ActVec<T>::load(x + i * V, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            o[k] = v[k] > 0.f ? g[k] : a * g[k];
+            acc += v[k] > 0.f ? 0.f : g[k] * v[k];
+        }
+        ActVec<T>::store(dx + i * V, o);
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)acc;
@@ -455,27 +461,46 @@ extern "C" int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const voi
                   M, C, train, ws, ws_bytes, stream);
 }
 
-extern "C" int hupr_prelu_fwd_f32(const float* x, const float* alpha, float* y, long n, hupr_stream_t stream) {
-    HUPR_REQUIRE(x && alpha && y && n > 0 && n % 4 == 0, "hupr_prelu_fwd_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_prelu_fwd, dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), x, alpha, y, n / 4);
+template <typename T>
+static int prelu_fwd(const char* who, const T* x, const float* alpha, T* y, long n, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && alpha && y && n > 0 && n % act_v<T>() == 0, "%s: bad argument", who);
+    const long nv = n / act_v<T>();
+    hipLaunchKernelGGL(hupr_k_prelu_fwd<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x, alpha, y, nv);
     HUPR_LAUNCH_OK("hupr_k_prelu_fwd");
     return HUPR_OK;
+}
+extern "C" int hupr_prelu_fwd_f32(const float* x, const float* alpha, float* y, long n, hupr_stream_t stream) {
+    return prelu_fwd("hupr_prelu_fwd_f32", x, alpha, y, n, stream);
+}
+extern "C" int hupr_prelu_fwd_bf16act(const void* x, const float* alpha, void* y, long n, hupr_stream_t stream) {
+    return prelu_fwd("hupr_prelu_fwd_bf16act", static_cast<const __bf16*>(x), alpha, static_cast<__bf16*>(y), n, stream);
 }
 
 extern "C" size_t hupr_prelu_ws_bytes(void) { return 4096 * sizeof(double); }
 
-extern "C" int hupr_prelu_bwd_f32(const float* dy, const float* x, const float* alpha, float* dx, float* dalpha,
-                                  long n, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(dy && x && alpha && dx && dalpha && ws && n > 0 && n % 4 == 0, "hupr_prelu_bwd_f32: bad argument");
-    if (ws_bytes < hupr_prelu_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_prelu_bwd_f32: workspace too small");
+template <typename T>
+static int prelu_bwd(const char* who, const T* dy, const T* x, const float* alpha, T* dx, float* dalpha, long n, void* ws,
+                     size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && x && alpha && dx && dalpha && ws && n > 0 && n % act_v<T>() == 0, "%s: bad argument", who);
+    if (ws_bytes < hupr_prelu_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
-    const int grid = ew_grid(n / 4);
+    const long nv = n / act_v<T>();
+    const int grid = ew_grid(nv);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(hupr_k_prelu_bwd, dim3(grid), dim3(256), 0, s, dy, x, alpha, dx, n / 4, partial);
+    hipLaunchKernelGGL(hupr_k_prelu_bwd<T>, dim3(grid), dim3(256), 0, s, dy, x, alpha, dx, nv, partial);
     HUPR_LAUNCH_OK("hupr_k_prelu_bwd");
     hipLaunchKernelGGL(hupr_k_sum_partials, dim3(1), dim3(256), 0, s, partial, grid, dalpha);
     HUPR_LAUNCH_OK("hupr_k_sum_partials");
     return HUPR_OK;
+}
+extern "C" int hupr_prelu_bwd_f32(const float* dy, const float* x, const float* alpha, float* dx, float* dalpha,
+                                  long n, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return prelu_bwd("hupr_prelu_bwd_f32", dy, x, alpha, dx, dalpha, n, ws, ws_bytes, stream);
+}
+extern "C" int hupr_prelu_bwd_bf16act(const void* dy, const void* x, const float* alpha, void* dx, float* dalpha, long n,
+                                      void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return prelu_bwd("hupr_prelu_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(x), alpha,
+                     static_cast<__bf16*>(dx), dalpha, n, ws, ws_bytes, stream);
 }
 
 // out[c] = sum over rows of x[row][c]   (bias gradient of a convolution)

@@ -17,6 +17,7 @@ _ws_cache = {}
 CONV_PROBE = None      # bench.py installs a callable(x, co, k) -> (start_event, end_event) | None
 MATH = "f32"           # matrix-pipe arithmetic of the GEMM-shaped ops: "f32" (parity path) or "bf16"
 ACT_BF16 = True        # bf16 mode only: the 3-D encoders keep their activations in HBM as bf16 ("bf16act" kernels)
+ACT_BF16_DECODER = os.environ.get("HUPR_DECODER_F32", "0") != "1"      # ... and so do the BasicBlock2D decoder stacks
 
 
 def set_math(mode):
@@ -403,7 +404,7 @@ class PReLUFn(torch.autograd.Function):
     def forward(ctx, x, alpha):
         x = _c(x)
         y = torch.empty_like(x)
-        rt.check(rt.lib().hupr_prelu_fwd_f32(rt.ptr(x), rt.ptr(alpha), rt.ptr(y), x.numel(), rt.stream()))
+        rt.check(_act("prelu_fwd", x)(rt.ptr(x), rt.ptr(alpha), rt.ptr(y), x.numel(), rt.stream()))
         ctx.save_for_backward(x, alpha)
         return y
 
@@ -414,7 +415,9 @@ class PReLUFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         da, da_direct = _pgrad(alpha)
         ws = workspace(L.hupr_prelu_ws_bytes(), x.device)
-        rt.check(L.hupr_prelu_bwd_f32(rt.ptr(_c(dy)), rt.ptr(x), rt.ptr(alpha), rt.ptr(dx), rt.ptr(da), x.numel(),
+        dy = _c(dy)
+        assert dy.dtype == x.dtype
+        rt.check(_act("prelu_bwd", x)(rt.ptr(dy), rt.ptr(x), rt.ptr(alpha), rt.ptr(dx), rt.ptr(da), x.numel(),
                                       rt.ptr(ws), ws.numel(), rt.stream()))
         return dx, _pret(alpha, da, da_direct)
 

@@ -146,10 +146,14 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
                 self.attention(k_c_v, q_c_h, re, residual=True), self.attention(k_v, q_v, re)]
 
     def forward(self, ral1maps, ral2maps, ramaps, rel1maps, rel2maps, remaps):
-        maps = self.decoderLayer3(torch.cat(self._level(0, ramaps, remaps), 4))
-        maps = self.decoderLayer2(torch.cat([maps] + self._level(1, ral2maps, rel2maps), 4))
-        x = torch.cat([maps] + self._level(2, ral1maps, rel1maps), 4)
-        x = self.decoderLayer1[1](self.decoderLayer1[0](x))
+        # with bf16 activations (F_.act_bf16()) the BasicBlock2D stacks (3x3 convolutions, PReLU, up-sampling) read and
+        # write bf16 too; the attention outputs are cast once on the way in, the 1x1 head gets fp32 back
+        act = torch.bfloat16 if (F_.act_bf16() and F_.ACT_BF16_DECODER) else torch.float32
+        lvl = lambda i, ra, re: [F_.cast(t, act) for t in self._level(i, ra, re)]
+        maps = self.decoderLayer3(torch.cat(lvl(0, ramaps, remaps), 4))
+        maps = self.decoderLayer2(torch.cat([maps] + lvl(1, ral2maps, rel2maps), 4))
+        x = torch.cat([maps] + lvl(2, ral1maps, rel1maps), 4)
+        x = F_.cast(self.decoderLayer1[1](self.decoderLayer1[0](x)), torch.float32)
         # 1x1 head with the 14 output channels zero-padded to 16 so later kernels stay float4-aligned
         head = self.decoderLayer1[2]
         w16 = torch.nn.functional.pad(head.weight, (0, 0, 0, 0, 0, 0, 0, 16 - self.numKeypoints))

@@ -85,6 +85,8 @@ SIGNATURES = {
     "hupr_scale_shift_act_bf16act": (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_void_p]),
     "hupr_bn_bwd_bf16act": (c_int, [c_void_p] * 9 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_colsum_bf16act": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_prelu_fwd_bf16act": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "hupr_prelu_bwd_bf16act": (c_int, [c_void_p] * 5 + [c_long, c_void_p, c_size_t, c_void_p]),
     "hupr_mnet_fwd_bf16act": (c_int, [c_void_p] * 5 + [c_long, c_int, c_void_p]),
     "hupr_mnet_bwd_bf16act": (c_int, [c_void_p] * 7 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_interp_linear_fwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),

@@ -253,6 +253,9 @@ int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const void* x, const
                         const float* save_invstd, const float* gamma, void* dx, float* dgamma, float* dbeta, long M,
                         int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_colsum_bf16act(const void* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_prelu_fwd_bf16act(const void* x, const float* alpha, void* y, long n, hupr_stream_t stream);
+int hupr_prelu_bwd_bf16act(const void* dy, const void* x, const float* alpha, void* dx, float* dalpha, long n, void* ws,
+                           size_t ws_bytes, hupr_stream_t stream);
 int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, float* means_or_null, long n_bg,
                           int pixels, hupr_stream_t stream);
 int hupr_mnet_bwd_bf16act(const float* x_or_null, const float* means_or_null, const float* w, const float* bias,
