@@ -17,35 +17,33 @@ namespace hupr {
 
 
 
-constexpr int kHaloMaxVox = 4 * 10 * 10;     // (2+2) x (8+2) x (8+2); the 2-D tile needs 1 x 10 x 18 = 180
-
-template <int BN, int KC, bool ABF>
-__global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
+// Tile geometry (compile time): 3-D layers 2 x 8 x 8 voxels with a 4 x 10 x 10 halo and 27 taps; 2-D maps 1 x 8 x 16 with a
+// 1 x 10 x 18 halo and 9 taps.  A stage = the three ky taps of one (kz, kx) column, so that a lane whose two output rows
+// are neighbours in y reads the four halo rows hy .. hy+3 once for all six (row, ky) products (see conv_halo256_bf16.hip).
+template <int BN, int KC, bool ABF, bool IS3D>
+__global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {      // two workgroups per CU (LDS <= 75 KB each)
     // KC = 64: unpadded 128-byte rows whose 16-byte chunks are XOR-swizzled — halo rows by
-    //   key = ((hx >> 1) & 3) | ((hy & 1) << 2), weight rows by key = (n >> 1) & 7 — which makes every
-    //   ds_read_b128 lane group (rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of the 32-row fragment) hit 16
-    //   distinct slots for all 27 tap shifts (a padded pitch cannot: the shifted halo rows are 3-way conflicted).
-    // KC = 32 (only the Cin = 32 stem): padded 80-byte rows.
+    //   key = ((hx >> 1) & 3) | (((hy >> 1) & 1) << 2), weight rows by key = (n >> 1) & 7 — which makes every
+    //   ds_read_b128 lane group hit all 64 banks for every tap shift.  KC = 32 (only the Cin = 32 stem): padded 80-byte rows.
     constexpr bool SWZ = (KC == 64);
     constexpr int LDK = SWZ ? KC : KC + 8;            // bf16 elements per LDS row
     constexpr int WN = (BN == 64) ? 2 : 1, WM = 4 / WN;
-    constexpr int WTM = 128 / WM;                     // rows per wave: 64 (BN=64) or 32 (BN=32)
-    constexpr int TM = WTM / 32;
+    constexpr int TM = (128 / WM) / 32;               // 32-voxel accumulator tiles per wave: 2 (BN = 64) or 1 (BN = 32)
     constexpr int C8 = KC / 8;                        // 8-channel groups per row
-    constexpr int B_LD = (BN * C8) / 256;             // 16-byte weight loads per thread per tap
-    static_assert((BN * C8) % 256 == 0 || BN * C8 == 128, "weight tile must split evenly over the threads");
+    constexpr int TS = 3;
+    constexpr int B_LD = (TS * BN * C8 + 255) / 256;  // 16-byte weight loads per thread per stage
+    constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, KD = IS3D ? 3 : 1;
+    constexpr int HD = TD + KD - 1, HH = 10, HW = TW + 2;
+    constexpr int NVOX = HD * HH * HW;                // 400 (3-D) / 180 (2-D)
+    constexpr int T = KD * 9, NSTAGE = KD * 3;
+    constexpr int NI = (NVOX * C8 + 255) / 256;       // halo items (8 channels of one voxel) per thread
 
-    constexpr int TS = 3;                             // taps per stage: one kernel row (kw = 0,1,2)
-    __shared__ __attribute__((aligned(16))) __bf16 Hs[kHaloMaxVox * LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[TS][BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
-    const int TW = 1 << p.log2TW, TD = p.TD;
-    const int pd = p.kd >> 1;
-    const int HD = TD + p.kd - 1, HH = 10, HW = TW + 2;
-    const int T = p.kd * 9;
 
     // block -> (spatial tile, co tile); co fastest so consecutive workgroups reuse the same halo via L2
     // XCD-aware order: workgroup b runs on XCD b % 8, so each XCD gets a contiguous run of tiles and spatial
@@ -64,17 +62,15 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
     const int d0 = tdi * TD, h0 = thi * 8, w0 = twi * TW;
     const int n0 = cot * BN;
 
-    // A fragment rows of this lane: tile voxel -> halo index of its (0,0,0) tap
-    int abase[TM], awx[TM], ahy[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wm * WTM + i * 32 + lr;
-        const int wx = row & (TW - 1), hy = (row >> p.log2TW) & 7, dz = row >> (p.log2TW + 3);
-        abase[i] = ((dz * HH + hy) * HW + wx) * LDK;
-        awx[i] = wx;
-        ahy[i] = hy;
-    }
-    const int bkey = ((wn * 32 + lr) >> 1) & 7;       // weight row swizzle key of this lane's B fragment row
+    // MFMA column lr of accumulator tile i <-> output voxel (dz, hy0 + i, wx):
+    //   TM = 2: 3-D  dz = wm,      hy0 = 2 (lr >> 3),            wx = lr & 7      2-D  hy0 = 4 wm + 2 (lr >> 4), wx = lr & 15
+    //   TM = 1: 3-D  dz = wm >> 1, hy0 = 4 (wm & 1) + (lr >> 3), wx = lr & 7      2-D  hy0 = 2 wm + (lr >> 4),   wx = lr & 15
+    const int wx = IS3D ? (lr & 7) : (lr & 15);
+    const int eb = IS3D ? (lr >> 3) : (lr >> 4);
+    const int dz = IS3D ? (TM == 2 ? wm : (wm >> 1)) : 0;
+    const int hy0 = (TM == 2) ? ((IS3D ? 0 : 4 * wm) + 2 * eb) : (IS3D ? 4 * (wm & 1) + eb : 2 * wm + eb);
+    const int abase = ((dz * HH + hy0) * HW + wx) * LDK;       // halo element of tap (0,0,0) of accumulator tile 0
+    const int bkey = ((wn * 32 + lr) >> 1) & 7;               // weight row swizzle key of this lane's B fragment row
 
     f32x16 acc[TM];
 #pragma unroll
@@ -82,126 +78,121 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    constexpr int B_LD_ = (B_LD > 0) ? B_LD : 1;     // 32x32 tile: 128 loads, threads 128..255 duplicate
-    // Branch-free on purpose (rows past Co are clamped, their columns are never stored): with straight-line
-    // loads hipcc emits counted s_waitcnt vmcnt(N) and the prefetch really stays in flight.
-    const __bf16* bsrc[B_LD_];
-    int bdst[B_LD_];
+    // weight-stage loads of this thread: item f = tid + 256 j over [ky t][row n][chunk c8]; rows past Co are clamped
+    // (their output columns are never stored) so that the loads stay branch-free and hipcc keeps counted vmcnt waits
+    const __bf16* bsrc[B_LD];
+    int bdst[B_LD];
 #pragma unroll
-    for (int i = 0; i < B_LD_; ++i) {
-        const int f = (tid + 256 * i) % (BN * C8);
-        const int n = min(n0 + f / C8, p.Co - 1);
-        bsrc[i] = p.wp + (long)n * T * p.Ci + (f % C8) * 8;
-        bdst[i] = (f / C8) * LDK + (SWZ ? (((f % C8) ^ ((f / C8) >> 1)) & 7) : (f % C8)) * 8;
+    for (int j = 0; j < B_LD; ++j) {
+        const int f = (tid + 256 * j) % (TS * BN * C8);
+        const int t = f / (BN * C8), r = f % (BN * C8), n = r / C8, c8 = r % C8;
+        bsrc[j] = p.wp + (long)min(n0 + n, p.Co - 1) * T * p.Ci + (long)t * 3 * p.Ci + c8 * 8;     // tap = (kz*3 + ky)*3 + kx
+        bdst[j] = t * (BN * LDK) + n * LDK + (SWZ ? (((c8 ^ (n >> 1)) & 7) << 3) : c8 * 8);
     }
-    u32x4 rb[TS * B_LD_];                             // next stage's weight tiles, in flight during the MFMAs
+    u32x4 rb[B_LD];                                   // next stage's weight tiles, in flight during the MFMAs
+    __bf16* const Bflat = &Bs[0][0];
 
-    auto compute_tap = [&](int tap, const __bf16* Bt) {
-        const int tw_ = tap % 3, tt = tap / 3;
-        const int th_ = tt % 3, td_ = tt / 3;
-        const int toff = ((td_ * HH + th_) * HW + tw_) * LDK;
-        int akey[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) akey[i] = (((awx[i] + tw_) >> 1) & 3) | (((ahy[i] + th_) & 1) << 2);
-#pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-            const int cw = ks * 2 + lh;                 // 16-byte chunk wanted by this lane half
-            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(&Bt[(wn * 32 + lr) * LDK + (SWZ ? (cw ^ bkey) : cw) * 8]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&Hs[abase[i] + toff + (SWZ ? (cw ^ akey[i]) : cw) * 8]);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, afrag, acc[i], 0, 0, 0);   // D'[channel][voxel]
-            }
-        }
-    };
-
-    const int nvox = HD * HH * HW;
-    const int n_stage = T / TS;                       // 9 (3-D) or 3 (2-D)
-    constexpr int NI = (kHaloMaxVox * C8 + 255) / 256;   // halo items (8 channels of one voxel) per thread
     for (int c0 = 0; c0 < p.Ci; c0 += KC) {
-        // weights of stage 0
 #pragma unroll
-        for (int t = 0; t < TS; ++t)
-#pragma unroll
-            for (int i = 0; i < B_LD_; ++i) rb[t * B_LD_ + i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (long)t * p.Ci + c0);
+        for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const u32x4*>(bsrc[j] + c0);      // stage 0: kz = kx = 0
         if (c0 > 0) __syncthreads();            // previous chunk's readers are done with Hs / Bs
-        // ---- halo chunk: global fp32 -> bf16 LDS, zero outside the tensor.  ALL of this thread's loads are issued
-        // before any is converted/stored, so the fill costs about one memory round trip. -----------------------------
+        // ---- halo chunk: global -> bf16 LDS, zero outside the tensor.  ALL of this thread's loads are issued before any
+        // is stored, so the fill costs about one memory round trip. ---------------------------------------------------
         if (!(p.ablate & 1)) {
-            if constexpr (ABF) {
-                u32x4 va[NI];
-                int dst[NI];
+            constexpr int NB_ = IS3D ? (NI + 1) / 2 : NI;      // 3-D halo (13 items): two batches keep the kernel at 2 workgroups / CU
 #pragma unroll
-                for (int u = 0; u < NI; ++u) {
-                    const int it = tid + u * 256;
-                    va[u] = (u32x4){0u, 0u, 0u, 0u};
-                    dst[u] = -1;
-                    if (it < nvox * C8) {
+            for (int ub = 0; ub < NI; ub += NB_) {
+                u32x4 vb[ABF ? NB_ : 1];
+                float4 va[ABF ? 1 : NB_], vc[ABF ? 1 : NB_];
+#pragma unroll
+                for (int u = 0; u < NB_; ++u) {
+                    const int it = tid + (ub + u) * 256;
+                    if constexpr (ABF) vb[u] = (u32x4){0u, 0u, 0u, 0u};
+                    else { va[u] = make_float4(0.f, 0.f, 0.f, 0.f); vc[u] = va[u]; }
+                    if (it < NVOX * C8) {
                         const int vox = it / C8, c8 = it - vox * C8;
                         const int hx = vox % HW;
                         const int t = vox / HW;
                         const int hy = t % HH, hz = t / HH;
-                        const int d = d0 + hz - pd, h = h0 + hy - 1, w = w0 + hx - 1;
-                        dst[u] = vox * LDK + (SWZ ? (c8 ^ (((hx >> 1) & 3) | ((hy & 1) << 2))) : c8) * 8;
-                        if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
-                            va[u] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.x) +
-                                        ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8);
+                        const int d = d0 + hz - (KD >> 1), h = h0 + hy - 1, w = w0 + hx - 1;
+                        if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+                            const long off = ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8;
+                            if constexpr (ABF) {
+                                vb[u] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.x) + off);
+                            } else {
+                                const float* src = static_cast<const float*>(p.x) + off;
+                                va[u] = *reinterpret_cast<const float4*>(src);
+                                vc[u] = *reinterpret_cast<const float4*>(src + 4);
+                            }
+                        }
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < NI; ++u)
-                    if (dst[u] >= 0) *reinterpret_cast<u32x4*>(&Hs[dst[u]]) = va[u];
-            } else {
-            float4 va[NI], vc[NI];
-            int dst[NI];
-#pragma unroll
-            for (int u = 0; u < NI; ++u) {
-                const int it = tid + u * 256;
-                va[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                vc[u] = va[u];
-                dst[u] = -1;
-                if (it < nvox * C8) {
-                    const int vox = it / C8, c8 = it - vox * C8;
-                    const int hx = vox % HW;
-                    const int t = vox / HW;
-                    const int hy = t % HH, hz = t / HH;
-                    const int d = d0 + hz - pd, h = h0 + hy - 1, w = w0 + hx - 1;
-                    dst[u] = vox * LDK + (SWZ ? (c8 ^ (((hx >> 1) & 3) | ((hy & 1) << 2))) : c8) * 8;
-                    if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
-                        const float* src = static_cast<const float*>(p.x) + ((((long)b * p.D + d) * p.H + h) * p.W + w) * p.in_ld + c0 + c8 * 8;
-                        va[u] = *reinterpret_cast<const float4*>(src);
-                        vc[u] = *reinterpret_cast<const float4*>(src + 4);
+                for (int u = 0; u < NB_; ++u) {
+                    const int it = tid + (ub + u) * 256;
+                    if (it < NVOX * C8) {
+                        const int vox = it / C8, c8 = it - vox * C8;
+                        const int hx = vox % HW, hy = (vox / HW) % HH;
+                        __bf16* dstp = &Hs[vox * LDK + (SWZ ? (c8 ^ (((hx >> 1) & 3) | (((hy >> 1) & 1) << 2))) : c8) * 8];
+                        if constexpr (ABF) {
+                            *reinterpret_cast<u32x4*>(dstp) = vb[u];
+                        } else {
+                            bf16x8 v;
+                            v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;
+                            v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;
+                            *reinterpret_cast<bf16x8*>(dstp) = v;
+                        }
                     }
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < NI; ++u) {
-                if (dst[u] >= 0) {
-                    bf16x8 v;
-                    v[0] = (__bf16)va[u].x; v[1] = (__bf16)va[u].y; v[2] = (__bf16)va[u].z; v[3] = (__bf16)va[u].w;
-                    v[4] = (__bf16)vc[u].x; v[5] = (__bf16)vc[u].y; v[6] = (__bf16)vc[u].z; v[7] = (__bf16)vc[u].w;
-                    *reinterpret_cast<bf16x8*>(&Hs[dst[u]]) = v;
-                }
-            }
             }
         }
-        // ---- stages of three taps: compute from Bs while the next stage's weights travel to registers ---------------
-        for (int st_ = 0; st_ < n_stage; ++st_) {
+        // ---- stages: compute from Bs while the next stage's weights travel to registers -------------------------------
+        // (kz is a real loop — unrolling all nine 3-D stages costs ~60 VGPRs and spills at two workgroups per CU)
+#pragma unroll 1
+        for (int kz = 0; kz < KD; ++kz)
 #pragma unroll
-            for (int t = 0; t < TS; ++t)
+        for (int kx = 0; kx < 3; ++kx) {
+            const int st_ = kz * 3 + kx;
 #pragma unroll
-                for (int i = 0; i < B_LD_; ++i) *reinterpret_cast<u32x4*>(&Bs[t][bdst[i]]) = rb[t * B_LD_ + i];
+            for (int j = 0; j < B_LD; ++j)
+                if (B_LD * 256 == TS * BN * C8 || tid + 256 * j < TS * BN * C8) *reinterpret_cast<u32x4*>(&Bflat[bdst[j]]) = rb[j];
             __syncthreads();
-            if (st_ + 1 < n_stage) {
+            if (st_ + 1 < NSTAGE) {
+                const long soff = (long)(((st_ + 1) / 3) * 9 + ((st_ + 1) % 3)) * p.Ci + c0;     // tap (kz, ky = 0, kx) of the next stage
 #pragma unroll
-                for (int t = 0; t < TS; ++t)
-#pragma unroll
-                    for (int i = 0; i < B_LD_; ++i)
-                        rb[t * B_LD_ + i] = *reinterpret_cast<const u32x4*>(bsrc[i] + (long)((st_ + 1) * TS + t) * p.Ci + c0);
+                for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const u32x4*>(bsrc[j] + soff);
             }
-            if (!(p.ablate & 2)) {
+            {
+                const int toff = (kz * HH * HW + kx) * LDK;
+                const int xkey = ((wx + kx) >> 1) & 3;
+                constexpr int NA = TM + 2;                     // halo rows hy0 .. hy0 + TM + 1 of this lane's column
+                bf16x8 af[2][NA], bq[2][TS];                   // two fragment sets: K-step ks + 1 is read while ks multiplies
+#define HUPR_FRAGS(SET_, KS_)                                                                                       \
+                {                                                                                                   \
+                    const int cw_ = (KS_) * 2 + lh;                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < NA; ++r)                                                  \
+                        af[SET_][r] = *reinterpret_cast<const bf16x8*>(                                             \
+                            &Hs[abase + toff + r * (HW * LDK) +                                                     \
+                                (SWZ ? (cw_ ^ (xkey | ((((hy0 + r) >> 1) & 1) << 2))) : cw_) * 8]);                  \
+                    _Pragma("unroll") for (int t = 0; t < TS; ++t)                                                  \
+                        bq[SET_][t] = *reinterpret_cast<const bf16x8*>(                                             \
+                            &Bs[t][(wn * 32 + lr) * LDK + (SWZ ? (cw_ ^ bkey) : cw_) * 8]);                          \
+                }
+                HUPR_FRAGS(0, 0)
 #pragma unroll
-                for (int t = 0; t < TS; ++t) compute_tap(st_ * TS + t, Bs[t]);
+                for (int ks = 0; ks < KC / 16; ++ks) {
+                    if (ks + 1 < KC / 16) {
+                        if (ks & 1) { HUPR_FRAGS(0, ks + 1) } else { HUPR_FRAGS(1, ks + 1) }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // keep the prefetch reads ahead of the MFMAs (see conv_halo256_bf16.hip)
+#pragma unroll
+                    for (int t = 0; t < TS; ++t)               // ky;  D'[channel][voxel]
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t + i], acc[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef HUPR_FRAGS
             }
             __syncthreads();                      // all waves are done with Bs (and, on the last stage, with Hs)
         }
@@ -211,9 +202,7 @@ __global__ __launch_bounds__(256) void hupr_k_conv_halo_bf16(HaloArgs p) {
     if (!(p.ablate & 4)) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int row = wm * WTM + i * 32 + lr;
-            const int wx = row & (TW - 1), hy = (row >> p.log2TW) & 7, dz = row >> (p.log2TW + 3);
-            const long m = (((long)b * p.D + d0 + dz) * p.H + h0 + hy) * p.W + w0 + wx;
+            const long m = (((long)b * p.D + d0 + dz) * p.H + h0 + hy0 + i) * p.W + w0 + wx;
             halo_store_voxel<ABF>(p, acc[i], m, n0 + wn * 32 + 4 * lh);
         }
     }
@@ -340,8 +329,13 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     hipStream_t s = as_stream(stream);
 #define HUPR_HALO_LAUNCH(BN_, KC_)                                                                                       \
     do {                                                                                                                 \
-        if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);     \
+        if (kd == 3) {                                                                                                   \
+            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);   \
+            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);      \
+        } else {                                                                                                         \
+            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);  \
+            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);     \
+        }                                                                                                                \
     } while (0)
     if (Ci % 64 == 0) {
         if (n32) HUPR_HALO_LAUNCH(32, 64); else HUPR_HALO_LAUNCH(64, 64);
