@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
-                    help="matrix-pipe arithmetic of the GEMM-shaped ops (tensors stay fp32 in HBM; accumulate fp32)")
+                    help="matrix-pipe arithmetic of the GEMM-shaped ops (fp32 accumulate either way); bf16 also stores the "
+                         "encoder/decoder activations as bf16 in HBM, f32 is the bit-faithful parity path")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,10 +151,11 @@ def main():
         if ms:
             avg = float(np.mean(ms)) * 1e-3
             ach = kflop / avg / 1e12
-            kname = "hupr_k_conv_halo_bf16<64,64>" if args.dtype == "bf16" else "hupr_k_gemm_f32<128,64,2,2,A_CONV,B_NK>"
+            kname = "hupr_k_conv_halo256_bf16<bf16 activations>" if args.dtype == "bf16" else "hupr_k_gemm_f32<128,64,2,2,A_CONV,B_NK>"
             roof = {"bound": "mfma", "kernel": kname + " (Encoder3D.layer1 64->64 3x3x3, fwd+dgrad launches)",
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": pmc.get("traffic_bytes_per_launch") if B == 32 else None,
+                    "algorithmic_bytes": pmc.get("algorithmic_bytes_per_launch") if B == 32 else None,
                     "traffic_note": "HBM bytes/launch from rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_pmc_dominant_kernels.md",
                     "launches": len(ms), "avg_ms": round(avg * 1e3, 4), "flop_per_launch": kflop}
         out = {

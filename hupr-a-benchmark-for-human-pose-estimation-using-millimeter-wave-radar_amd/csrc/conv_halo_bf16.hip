@@ -237,7 +237,11 @@ struct PackDesc {          // mirrors the packed struct built in functional.py (
     int co, ci, taps, kind;   // kind 0: fp32 outputs, 1: bf16 outputs
 };
 __global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restrict__ descs, int n, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    // index space [0, 2 total): first half = DESTINATION elements of layout 0, second half of layout 1, so the writes are
+    // coalesced (2- or 4-byte scattered writes made the first, source-indexed version as slow as the launches it replaced)
+    for (long i2 = (long)blockIdx.x * 256 + threadIdx.x; i2 < 2 * total; i2 += (long)gridDim.x * 256) {
+        const int layout = i2 >= total;
+        const long i = layout ? i2 - total : i2;
         int lo = 0, hi = n - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -245,19 +249,22 @@ __global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restr
         }
         const PackDesc d = descs[lo];
         const long l = i - d.first;
-        const int tap = (int)(l % d.taps);
-        const long t = l / d.taps;
-        const int ci = (int)(t % d.ci), co = (int)(t / d.ci);
-        const float v = d.w[l];
-        const long i0 = ((long)co * d.taps + tap) * d.ci + ci;
-        const long i1 = ((long)ci * d.taps + (d.taps - 1 - tap)) * d.co + co;
-        if (d.kind == 1) {
-            static_cast<__bf16*>(d.wp0)[i0] = (__bf16)v;
-            static_cast<__bf16*>(d.wp1)[i1] = (__bf16)v;
-        } else {
-            static_cast<float*>(d.wp0)[i0] = v;
-            static_cast<float*>(d.wp1)[i1] = v;
+        long src;
+        if (layout == 0) {                              // [co][tap][ci]
+            const int ci = (int)(l % d.ci);
+            const long t = l / d.ci;
+            const int tap = (int)(t % d.taps), co = (int)(t / d.taps);
+            src = ((long)co * d.ci + ci) * d.taps + tap;
+        } else {                                        // [ci][taps-1-tap][co]
+            const int co = (int)(l % d.co);
+            const long t = l / d.co;
+            const int tapf = (int)(t % d.taps), ci = (int)(t / d.taps);
+            src = ((long)co * d.ci + ci) * d.taps + (d.taps - 1 - tapf);
         }
+        const float v = d.w[src];
+        void* dst = layout ? d.wp1 : d.wp0;
+        if (d.kind == 1) static_cast<__bf16*>(dst)[l] = (__bf16)v;
+        else static_cast<float*>(dst)[l] = v;
     }
 }
 
@@ -268,7 +275,7 @@ using namespace hupr;
 extern "C" int hupr_pack_conv_weights_table(const void* descs_dev, int n, long total, hupr_stream_t stream) {
     HUPR_REQUIRE(descs_dev && n > 0 && total > 0, "hupr_pack_conv_weights_table: bad argument");
     static_assert(sizeof(PackDesc) == 48, "PackDesc layout is part of the ABI");
-    hipLaunchKernelGGL(hupr_k_pack_table, dim3((unsigned)min((long)8192, (total + 255) / 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(hupr_k_pack_table, dim3((unsigned)min((long)16384, (2 * total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const PackDesc*>(descs_dev), n, total);
     HUPR_LAUNCH_OK("hupr_k_pack_table");
     return HUPR_OK;
