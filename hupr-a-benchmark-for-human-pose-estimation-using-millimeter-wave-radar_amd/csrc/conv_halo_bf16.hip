@@ -236,21 +236,19 @@ struct PackDesc {          // mirrors the packed struct built in functional.py (
     long first;            // index of this entry's first element in the concatenated element space
     int co, ci, taps, kind;   // kind 0: fp32 outputs, 1: bf16 outputs
 };
-__global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restrict__ descs, int n, long total) {
-    // index space [0, 2 total): first half = DESTINATION elements of layout 0, second half of layout 1, so the writes are
-    // coalesced (2- or 4-byte scattered writes made the first, source-indexed version as slow as the launches it replaced)
-    for (long i2 = (long)blockIdx.x * 256 + threadIdx.x; i2 < 2 * total; i2 += (long)gridDim.x * 256) {
-        const int layout = i2 >= total;
-        const long i = layout ? i2 - total : i2;
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (descs[mid].first <= i) lo = mid; else hi = mid - 1;
-        }
-        const PackDesc d = descs[lo];
-        const long l = i - d.first;
+// One workgroup = 2048 consecutive DESTINATION elements of one layout of one entry (coalesced writes, no per-element
+// search): blocks[b] = {entry, layout, first destination element}.
+struct PackBlock { int entry, layout; long start; };
+__global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restrict__ descs, const PackBlock* __restrict__ blocks) {
+    const PackBlock pb = blocks[blockIdx.x];
+    const PackDesc d = descs[pb.entry];
+    const long count = (long)d.co * d.ci * d.taps;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long l = pb.start + threadIdx.x + 256 * u;
+        if (l >= count) break;
         long src;
-        if (layout == 0) {                              // [co][tap][ci]
+        if (pb.layout == 0) {                           // [co][tap][ci]
             const int ci = (int)(l % d.ci);
             const long t = l / d.ci;
             const int tap = (int)(t % d.taps), co = (int)(t / d.taps);
@@ -262,7 +260,7 @@ __global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restr
             src = ((long)co * d.ci + ci) * d.taps + (d.taps - 1 - tapf);
         }
         const float v = d.w[src];
-        void* dst = layout ? d.wp1 : d.wp0;
+        void* dst = pb.layout ? d.wp1 : d.wp0;
         if (d.kind == 1) static_cast<__bf16*>(dst)[l] = (__bf16)v;
         else static_cast<float*>(dst)[l] = v;
     }
@@ -272,11 +270,11 @@ __global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restr
 
 using namespace hupr;
 
-extern "C" int hupr_pack_conv_weights_table(const void* descs_dev, int n, long total, hupr_stream_t stream) {
-    HUPR_REQUIRE(descs_dev && n > 0 && total > 0, "hupr_pack_conv_weights_table: bad argument");
-    static_assert(sizeof(PackDesc) == 48, "PackDesc layout is part of the ABI");
-    hipLaunchKernelGGL(hupr_k_pack_table, dim3((unsigned)min((long)16384, (2 * total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const PackDesc*>(descs_dev), n, total);
+extern "C" int hupr_pack_conv_weights_table(const void* descs_dev, const void* blocks_dev, int n_blocks, hupr_stream_t stream) {
+    HUPR_REQUIRE(descs_dev && blocks_dev && n_blocks > 0, "hupr_pack_conv_weights_table: bad argument");
+    static_assert(sizeof(PackDesc) == 48 && sizeof(PackBlock) == 16, "PackDesc / PackBlock layouts are part of the ABI");
+    hipLaunchKernelGGL(hupr_k_pack_table, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const PackDesc*>(descs_dev), reinterpret_cast<const PackBlock*>(blocks_dev));
     HUPR_LAUNCH_OK("hupr_k_pack_table");
     return HUPR_OK;
 }

@@ -142,15 +142,22 @@ def _pack_refresh_all(dev):
         rec = np.zeros(len(live), dtype=np.dtype([("w", "<u8"), ("wp0", "<u8"), ("wp1", "<u8"), ("first", "<i8"), ("co", "<i4"),
                                                    ("ci", "<i4"), ("taps", "<i4"), ("kind", "<i4")]))
         first = 0
+        blocks = []
         for i, (e, w) in enumerate(live):
             co, ci = w.shape[0], w.shape[1]
             taps = int(np.prod(w.shape[2:]))
             rec[i] = (w.data_ptr(), e.wp[0].data_ptr(), e.wp[1].data_ptr(), first, co, ci, taps, e.kind)
-            first += co * ci * taps
+            cnt = co * ci * taps
+            first += cnt
+            for layout in (0, 1):
+                blocks.extend((i, layout, st) for st in range(0, cnt, 2048))
+        blk = np.zeros(len(blocks), dtype=np.dtype([("entry", "<i4"), ("layout", "<i4"), ("start", "<i8")]))
+        blk["entry"], blk["layout"], blk["start"] = zip(*blocks)
         tab = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
-        _pack_table = (tab, len(live), first, tuple(id(e) for e, _ in live))
-    tab, n, total, _ = _pack_table
-    rt.check(L.hupr_pack_conv_weights_table(rt.ptr(tab), n, total, rt.stream()))
+        btab = torch.from_numpy(blk.view(np.uint8).copy()).to(dev)
+        _pack_table = (tab, btab, len(blocks), tuple(id(e) for e, _ in live))
+    tab, btab, n_blocks, _ = _pack_table
+    rt.check(L.hupr_pack_conv_weights_table(rt.ptr(tab), rt.ptr(btab), n_blocks, rt.stream()))
     for e, w in live:
         e.stamp = (PACK_EPOCH, w._version)
 

@@ -35,7 +35,7 @@ SIGNATURES = {
     "hupr_conv_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int] * 19 + [c_void_p]),
     "hupr_conv_wgrad_bf16": (c_int, [c_void_p] * 3 + [c_int] * 17 + [c_void_p, c_size_t, c_void_p]),
     "hupr_pack_conv_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "hupr_pack_conv_weights_table": (c_int, [c_void_p, c_int, c_long, c_void_p]),
+    "hupr_pack_conv_weights_table": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hupr_debug_halo_ablate": (None, [c_int]),
     "hupr_debug_halo_variant": (None, [c_int]),
     "hupr_debug_halo_trace": (None, [c_void_p]),

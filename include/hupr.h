@@ -119,10 +119,11 @@ int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int
  * run from LDS.  wp_bf16 from hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci] bf16). */
 int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
                                 hupr_stream_t stream);
-/* Repack many weights (both layouts each) in ONE launch.  descs_dev: device array of n 48-byte records
+/* Repack many weights (both layouts each) in ONE launch.  descs_dev: device array of 48-byte records
  * { const float* w; void* wp0; void* wp1; int64 first; int32 co, ci, taps, kind } with kind 0 = fp32 layouts
- * (hupr_pack_conv_weights_f32 modes 0 and 1), 1 = bf16 layouts; `first` = running element offset, total = sum co*ci*taps. */
-int hupr_pack_conv_weights_table(const void* descs_dev, int n, long total, hupr_stream_t stream);
+ * (hupr_pack_conv_weights_f32 modes 0 and 1), 1 = bf16 layouts.  blocks_dev: one 16-byte record per workgroup
+ * { int32 entry, layout; int64 start }: the workgroup writes destination elements [start, start + 2048) of that layout. */
+int hupr_pack_conv_weights_table(const void* descs_dev, const void* blocks_dev, int n_blocks, hupr_stream_t stream);
 void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel */
 void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */
 void hupr_debug_halo_trace(void* device_u64_4096); /* profiling aid: per-tile s_memtime stamps of workgroup 0 (null = off) */
