@@ -8,7 +8,7 @@
 //        - 256-pt range FFT per chirp: LDS-staged radix-4 DIF, one wave per chirp
 //        - only the 64 kept range bins (94..31) are scattered into an LDS Doppler tile
 //        - clutter removal (chirp mean) + 64-pt Doppler FFT (radix-4, 16 lanes per FFT)
-//        - only the 16 kept Doppler bins are written: RD[sf][i][r][12 antennas]  (98 KB / sf)
+//        - only the 16 kept Doppler bins are written: RD[sf][12 antennas][i][r]  (98 KB / sf)
 //   K2 hupr_k_angle           one workgroup per (sensor-frame, Doppler bin)
 //        - the zero-padded 8x64 angle FFT has <= 12 non-zero inputs, so it is evaluated as a
 //          pruned DFT:  out[e',a'] = P[a'] + w8^e' Q[a'] + [e'=0] R[a']
@@ -38,7 +38,7 @@ constexpr int kRx = 4, kChirps = 192, kSamples = 256;
 constexpr int kVant = 12;            // 8 azimuth + 4 elevation virtual antennas
 constexpr int kRange = 64, kDop = 16, kAz = 64, kEl = 8;
 constexpr int kRangeHi = 94;         // kept range bins 94,93,...,31
-constexpr int kDopStride = 65;       // padded LDS row (float2) for the Doppler tile
+constexpr int kDopStride = 68;       // LDS row pitch (float2) of the Doppler tile: 8 rows x 4 lanes of a quad-per-FFT read cover all 64 banks
 
 __device__ __forceinline__ int pad32(int p) { return p + (p >> 5); }
 
@@ -52,6 +52,25 @@ __device__ __forceinline__ void r4(float2& x0, float2& x1, float2& x2, float2& x
     x3 = csub(a1, b3);
 }
 
+// 16-point forward DFT in registers: two radix-4 DIF stages.  In: x[n] natural order; out: X[g + 4 q] at x[4 g + q].
+__device__ __forceinline__ void fft16(float2 (&x)[16]) {
+    // W_16^m, m = 0..9 (only products j*q with j, q in 0..3 occur)
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+    const float2 w16[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f},
+                            {-c1, s1}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r4(x[j], x[j + 4], x[j + 8], x[j + 12]);
+        if (j > 0) {
+            x[j + 4] = cmul(x[j + 4], w16[j]);
+            x[j + 8] = cmul(x[j + 8], w16[2 * j]);
+            x[j + 12] = cmul(x[j + 12], w16[3 * j]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: range FFT + crop + clutter removal + Doppler FFT + crop
 // grid = n_sf * 12, block = 256
@@ -59,7 +78,7 @@ __device__ __forceinline__ void r4(float2& x0, float2& x1, float2& x2, float2& x
 __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __restrict__ iq,
                                                             float2* __restrict__ rd) {
     __shared__ float2 tw[256];                       // W_256^t
-    __shared__ float2 rbuf[4][256 + 8];              // one range-FFT scratch per wave
+    __shared__ float2 rbuf_x[16 * 273];              // one 16 x 17 transpose tile per (wave, chirp slot)
     __shared__ float2 dop[kRange * kDopStride];      // [range bin][chirp loop]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,126 +93,98 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
     // each int32 holds one (I,Q) sample
     const int32_t* src = reinterpret_cast<const int32_t*>(iq) +
                          ((size_t)(sf * kRx + rx) * kChirps) * kSamples;
-    float2* buf = rbuf[wave];
-
+    // 256-point range FFT = 16 x 16 (n = 16 n1 + n2, k = k1 + 16 k2): sixteen lanes per chirp, four chirps per wave at
+    // a time.  Lane n2 holds x[16 n1 + n2] (n1 = 0..15), does the 16-point DFT over n1 in registers, applies
+    // W_256^{n2 k1}, the 16 x 16 tile is transposed through LDS ONCE, and lane k1 finishes with the DFT over n2 —
+    // one LDS exchange per chirp instead of three radix-4 exchanges (two of which were 2- and 4-way bank-conflicted).
+    const int l16 = lane & 15, cs = lane >> 4;
     // All 16 chirps of this wave are requested up front (64 VGPRs): one HBM round trip (~2 us) is several times longer
     // than a 256-point FFT, so a one-chirp-ahead prefetch leaves every FFT waiting on its loads.
-    int32_t raw[16][4];
+    int32_t raw[4][16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int32_t* row = src + (size_t)(3 * (wave * 16 + j) + tx) * kSamples;
+    for (int ps = 0; ps < 4; ++ps) {
+        const int32_t* row = src + (size_t)(3 * (wave * 16 + ps * 4 + cs) + tx) * kSamples + l16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) raw[j][q] = row[lane + 64 * q];
+        for (int n1 = 0; n1 < 16; ++n1) raw[ps][n1] = row[16 * n1];
     }
+    // per-lane twiddles W_256^{n2 k1}, k1 = 1..15 (independent of the chirp: read once)
+    float2 twl[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int cc = wave * 16 + j;
-        float2 x[4];
+    for (int k1 = 0; k1 < 16; ++k1) twl[k1] = tw[(l16 * k1) & 255];
+    float2* xch = rbuf_x + (wave * 4 + cs) * 273;   // 16 x 17 transpose tile of this lane's chirp slot (+1: bank offset between slots)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            x[q] = make_float2((float)(int16_t)(raw[j][q] & 0xffff), (float)(raw[j][q] >> 16));
-        // stage 0 (span 64) straight from registers
-        r4(x[0], x[1], x[2], x[3]);
-        x[1] = cmul(x[1], tw[lane]);
-        x[2] = cmul(x[2], tw[(2 * lane) & 255]);
-        x[3] = cmul(x[3], tw[(3 * lane) & 255]);
+    for (int ps = 0; ps < 4; ++ps) {
+        const int cc = wave * 16 + ps * 4 + cs;
+        float2 x[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) buf[pad32(lane + 64 * q)] = x[q];
-        wave_lds_fence();
-        // stage 1 (span 16)
-        {
-            const int n = lane & 15, base = (lane >> 4) * 64 + n;
+        for (int n1 = 0; n1 < 16; ++n1)
+            x[n1] = make_float2((float)(int16_t)(raw[ps][n1] & 0xffff), (float)(raw[ps][n1] >> 16));
+        fft16(x);                                        // Y[k1 = g + 4 q] at x[4 g + q]
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = buf[pad32(base + 16 * q)];
-            r4(x[0], x[1], x[2], x[3]);
-            x[1] = cmul(x[1], tw[(4 * n) & 255]);
-            x[2] = cmul(x[2], tw[(8 * n) & 255]);
-            x[3] = cmul(x[3], tw[(12 * n) & 255]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) buf[pad32(base + 16 * q)] = x[q];
-        }
-        wave_lds_fence();
-        // stage 2 (span 4)
-        {
-            const int n = lane & 3, base = (lane >> 2) * 16 + n;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = buf[pad32(base + 4 * q)];
-            r4(x[0], x[1], x[2], x[3]);
-            x[1] = cmul(x[1], tw[(16 * n) & 255]);
-            x[2] = cmul(x[2], tw[(32 * n) & 255]);
-            x[3] = cmul(x[3], tw[(48 * n) & 255]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) buf[pad32(base + 4 * q)] = x[q];
-        }
-        wave_lds_fence();
-        // stage 3 (span 1), results stay in registers; position p = 4*lane+q holds bin
-        // k = digit-reverse_4(p) = (lane>>4) + 4*((lane>>2)&3) + 16*(lane&3) + 64*q
-        {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = buf[pad32(4 * lane + q)];
-            r4(x[0], x[1], x[2], x[3]);
-            const int kb = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = kRangeHi - (kb + 64 * q);
-                if (r >= 0 && r < kRange) dop[r * kDopStride + cc] = x[q];
+                const int k1 = g + 4 * q;
+                xch[k1 * 17 + l16] = (k1 == 0) ? x[4 * g + q] : cmul(x[4 * g + q], twl[k1]);
             }
-        }
-        wave_lds_fence();   // rbuf is reused by the same wave for its next chirp
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) x[n2] = xch[l16 * 17 + n2];     // lane k1 = l16 gathers its row
+        wave_lds_fence();                                // the tile is rewritten by the next pass
+        fft16(x);                                        // X[k1 + 16 k2], k2 = g + 4 q at x[4 g + q]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = l16 + 16 * (g + 4 * q);
+                const int r = kRangeHi - k;
+                if (r >= 0 && r < kRange) dop[r * kDopStride + cc] = x[4 * g + q];
+            }
     }
     __syncthreads();       // every wave's columns of the Doppler tile are in place
 
-    // Doppler: 64 FFTs of 64 points, 16 lanes each -> 16 FFTs per pass
-    const int n = tid & 15;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int r = pass * 16 + (tid >> 4);
-        float2* row = dop + r * kDopStride;
-        float2 x[4];
+    // Doppler: 64 FFTs (one per kept range bin) of 64 points = 16 x 4 (n = 4 n1 + n2, k = k1 + 16 k2), four lanes per FFT:
+    // lane n2 does the 16-point DFT over n1 in registers and applies W_64^{n2 k1}; the remaining 4-point DFT over n2 is a
+    // sum across the quad (DPP), and only k2 = 0 (bins 0..7) and k2 = 3 (bins 56..63, factor i^{n2}) are kept — no LDS
+    // exchange at all (the radix-4 version needed two, both bank-conflicted).
+    {
+        const int n2 = tid & 3, r = tid >> 2;
+        const float2* row = dop + r * kDopStride;
+        float2 x[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) x[q] = row[n + 16 * q];
+        for (int n1 = 0; n1 < 16; ++n1) x[n1] = row[4 * n1 + n2];
         // static clutter removal (reference :122-128): subtract the mean over the 64 chirp loops
-        float sx = (x[0].x + x[1].x) + (x[2].x + x[3].x);
-        float sy = (x[0].y + x[1].y) + (x[2].y + x[3].y);
+        float sx = 0.f, sy = 0.f;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            sx += __shfl_xor(sx, o, 16);
-            sy += __shfl_xor(sy, o, 16);
-        }
+        for (int n1 = 0; n1 < 16; ++n1) { sx += x[n1].x; sy += x[n1].y; }
+        sx += __shfl_xor(sx, 1, 64); sy += __shfl_xor(sy, 1, 64);
+        sx += __shfl_xor(sx, 2, 64); sy += __shfl_xor(sy, 2, 64);
         sx *= (1.0f / 64.0f);
         sy *= (1.0f / 64.0f);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { x[q].x -= sx; x[q].y -= sy; }
-        // stage 0 (span 16): W_64^{nq} = W_256^{4nq}
-        r4(x[0], x[1], x[2], x[3]);
-        x[1] = cmul(x[1], tw[(4 * n) & 255]);
-        x[2] = cmul(x[2], tw[(8 * n) & 255]);
-        x[3] = cmul(x[3], tw[(12 * n) & 255]);
+        for (int n1 = 0; n1 < 16; ++n1) { x[n1].x -= sx; x[n1].y -= sy; }
+        fft16(x);                                        // Y[k1 = g + 4 q] at x[4 g + q]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) row[n + 16 * q] = x[q];
-        wave_lds_fence();
-        {   // stage 1 (span 4)
-            const int m = n & 3, base = (n >> 2) * 16 + m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = row[base + 4 * q];
-            r4(x[0], x[1], x[2], x[3]);
-            x[1] = cmul(x[1], tw[(16 * m) & 255]);
-            x[2] = cmul(x[2], tw[(32 * m) & 255]);
-            x[3] = cmul(x[3], tw[(48 * m) & 255]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) row[base + 4 * q] = x[q];
-        }
-        wave_lds_fence();
-        {   // stage 2 (span 1); position 4n+q holds Doppler bin d = (n>>2) + 4*(n&3) + 16*q
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = row[4 * n + q];
-            r4(x[0], x[1], x[2], x[3]);
-            const int db = (n >> 2) + 4 * (n & 3);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = (db + 16 * q + 8) & 63;   // fftshift + keep 24..39 -> i = 0..15
-                if (i < kDop) rd[((size_t)(sf * kDop + i) * kRange + r) * kVant + vant] = x[q];
+                const int k1 = g + 4 * q;
+                float2 y = x[4 * g + q];
+                if (k1 > 0) y = cmul(y, tw[(4 * n2 * k1) & 255]);          // W_64^{n2 k1}
+                if (k1 >= 8) {                                             // k2 = 3: W_4^{3 n2} = i^{n2}
+                    const float2 t = y;
+                    if (n2 == 1) y = make_float2(-t.y, t.x);
+                    else if (n2 == 2) y = make_float2(-t.x, -t.y);
+                    else if (n2 == 3) y = make_float2(t.y, -t.x);
+                }
+                y.x += __shfl_xor(y.x, 1, 64); y.y += __shfl_xor(y.y, 1, 64);
+                y.x += __shfl_xor(y.x, 2, 64); y.y += __shfl_xor(y.y, 2, 64);
+                // Doppler bin d = k1 (k1 < 8) or k1 + 48; fftshift + keep 24..39 -> i = (d + 8) & 63 = 0..15
+                const int i = (k1 < 8) ? k1 + 8 : k1 - 8;
+                // RD[sf][antenna][doppler][range]: a workgroup's 64 range bins form a 512-byte run (antenna-innermost
+                // made every 8-byte store its own partial line: 4x write amplification in the counters)
+                if ((k1 & 3) == n2) rd[(((size_t)sf * kVant + vant) * kDop + i) * kRange + r] = y;
             }
-        }
     }
 }
 
@@ -243,8 +234,11 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
     const int sf = blockIdx.x / kPlanes, pl = blockIdx.x % kPlanes;
     const int i = LOADER ? pl + 4 : pl;         // loader keeps Doppler indices 4..11 (dataset.py:145)
 
-    const float2* src = rd + (size_t)(sf * kDop + i) * kRange * kVant;
-    for (int t = tid; t < kRange * kVant; t += 256) cells[t] = src[t];
+    // RD[sf][antenna][doppler][range] -> cells[range][antenna]: twelve 512-byte runs
+    for (int t = tid; t < kRange * kVant; t += 256) {
+        const int v = t >> 6, r = t & 63;
+        cells[r * kVant + v] = rd[(((size_t)sf * kVant + v) * kDop + i) * kRange + r];
+    }
     if (tid < 64) tw64[tid] = kTw256[4 * tid];
     __syncthreads();
 
