@@ -91,16 +91,24 @@ __device__ __forceinline__ void load_frags(bf16x8* frag, const TI* __restrict__ 
 // acc[t] (t = 0,1: image rows 32t..32t+31) = img(64 rows x D) . frags  ->  tile [image row][lane token]
 template <int D>
 __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img, const bf16x8* frag, int lr, int lh) {
+    // all A fragments of the 64 x D image rows are read before the first MFMA (hipcc otherwise issues each read right in
+    // front of its MFMA and every MFMA waits out the LDS latency)
+    bf16x8 a[2][D / 16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks)
+            a[t][ks] = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, ks * 2 + lh)]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, ks * 2 + lh)]);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[ks], acc[t], 0, 0, 0);
-        }
     }
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][ks], frag[ks], acc[t], 0, 0, 0);
 }
 
 // out[ct] (channels 32ct..) += img^T (channels x 64 image rows) . W, where W is a [64 image rows][lane token] tile
