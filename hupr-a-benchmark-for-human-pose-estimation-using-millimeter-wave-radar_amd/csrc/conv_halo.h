@@ -34,6 +34,34 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
 // out as 16-byte (fp32) or 8-byte (bf16) vector stores with a single voxel address per accumulator tile.
 template <bool ABF>
 __device__ __forceinline__ void halo_store_voxel(const HaloArgs& p, const f32x16& acc, long m, int chb) {
+    if constexpr (ABF) {
+        // bf16 output without a residual: lanes l and l + 32 hold the two 4-channel halves of the same voxel's 8-channel
+        // groups; one v_permlane32_swap per dword gives each of them a full 16-byte run (two stores per tile instead of
+        // four 8-byte ones — the epilogue is store-issue bound)
+        if (!p.res && (p.Co & 7) == 0 && (p.out_ld & 7) == 0) {
+            const int lh = (chb >> 2) & 1, cb = chb - 4 * lh;
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4n v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                const int ch = chb + 8 * g;
+                if (p.bias && ch < p.Co) v += (f32x4n){p.bias[ch], p.bias[ch + 1], p.bias[ch + 2], p.bias[ch + 3]};
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const bf16x2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+                pk[g][0] = __builtin_bit_cast(unsigned, lo);
+                pk[g][1] = __builtin_bit_cast(unsigned, hi);
+            }
+#pragma unroll
+            for (int gp = 0; gp < 4; gp += 2) {
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pk[gp][0], pk[gp + 1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pk[gp][1], pk[gp + 1][1], false, false);
+                const int ch = cb + 8 * (gp + lh);            // lower half-wave: group gp, upper: group gp + 1
+                if (ch < p.Co)
+                    *reinterpret_cast<u32x4*>(static_cast<__bf16*>(p.y) + m * p.out_ld + ch) = (u32x4){r0[0], r1[0], r0[1], r1[1]};
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int ch = chb + 8 * g;

@@ -57,26 +57,32 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     // halo row swizzle: 16-byte chunk c8 of halo voxel (hy, hx) lives at chunk c8 ^ (((hx >> 1) & 3) | (((hy >> 1) & 1) << 2));
     // with the lane -> voxel map above every 16-lane ds_read_b128 group covers all 64 banks for all 27 tap shifts.
     // ISSUE: global -> registers for halo items [U0, U0 + NH) of the tile at (B_, D0_, H0_, W0_), channel chunk C0_.
+    // bf16 sources: branch-free raw buffer loads (offsets beyond num_records return zeros = the padding); fp32 sources
+    // (the secondary path) keep guarded flat loads
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.x), 0, ABF ? (int)((long)p.Bn * p.D * p.H * p.W * p.in_ld * 2) : 0, 0x00020000);
 #define HUPR_HALO_ISSUE(U0, B_, D0_, H0_, W0_, C0_)                                                                \
     _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
         const int it = tid + (u + (U0)) * 512;                                                                      \
-        if constexpr (ABF) vb[u] = (u32x4){0u, 0u, 0u, 0u};                                                         \
-        else { va[u] = (f32x4n){0.f, 0.f, 0.f, 0.f}; vc[u] = va[u]; }                                               \
-        if (it < NVOX * C8 && !(p.ablate & 1)) {                                                                    \
-            const int vox = it >> 3, c8 = it & 7;                                                                   \
-            const int hx = vox % HW;                                                                                \
-            const int t_ = vox / HW;                                                                                \
-            const int hy = t_ % HH, hz = t_ / HH;                                                                   \
-            const int d = (D0_) + hz - 1, h = (H0_) + hy - 1, w = (W0_) + hx - 1;                                   \
-            if ((unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {        \
-                const long off = ((((long)(B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8;         \
-                if constexpr (ABF) {                                                                                \
-                    vb[u] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.x) + off);                 \
-                } else {                                                                                            \
-                    const float* src = static_cast<const float*>(p.x) + off;                                        \
-                    va[u] = *reinterpret_cast<const f32x4n*>(src);                                                  \
-                    vc[u] = *reinterpret_cast<const f32x4n*>(src + 4);                                              \
-                }                                                                                                   \
+        const int vox = it >> 3, c8 = it & 7;                                                                       \
+        const int hx = vox % HW;                                                                                    \
+        const int t_ = vox / HW;                                                                                    \
+        const int hy = t_ % HH, hz = t_ / HH;                                                                       \
+        const int d = (D0_) + hz - 1, h = (H0_) + hy - 1, w = (W0_) + hx - 1;                                       \
+        const bool ok = it < NVOX * C8 && !(p.ablate & 1) && (unsigned)d < (unsigned)p.D &&                         \
+                        (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;                                 \
+        if constexpr (ABF) {                                                                                        \
+            const int off = (((((B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8) * 2;              \
+            const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : 0x7ffffff0, 0, 0);              \
+            vb[u] = (u32x4){ld_[0], ld_[1], ld_[2], ld_[3]};                                                        \
+        } else {                                                                                                    \
+            va[u] = (f32x4n){0.f, 0.f, 0.f, 0.f};                                                                   \
+            vc[u] = va[u];                                                                                          \
+            if (ok) {                                                                                               \
+                const float* src = static_cast<const float*>(p.x) +                                                 \
+                                   ((((long)(B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8;       \
+                va[u] = *reinterpret_cast<const f32x4n*>(src);                                                      \
+                vc[u] = *reinterpret_cast<const f32x4n*>(src + 4);                                                  \
             }                                                                                                       \
         }                                                                                                           \
     }
@@ -264,6 +270,7 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     a.n_co_tiles = a.Co / 64;
     const long tiles = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
     if (tiles >= (1L << 31) || tiles < 256) return false;          // small problems: the 128-voxel kernel fills the chip better
+    if (abf && (long)Bn * a.D * a.H * a.W * a.in_ld * 2 >= 0x7ffffff0L) return false;   // 32-bit buffer offsets
     // one persistent workgroup per CU
     if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(256), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<false>, dim3(256), dim3(512), 0, s, a);
