@@ -159,3 +159,32 @@ def test_graph_replay_matches_eager_steps():
         assert abs(float(l1.detach()) - float(l2.detach())) <= 1e-4 * abs(float(l1.detach()))
     finally:
         F_.set_math("f32")
+
+
+def test_bf16_path_argmax_agreement_b32():
+    """SURVEY 8(d) bf16 gate at scale (2 heads x 448 joints, eval, B = 32): the bf16 path (bf16 matrix pipe + bf16-stored
+    activations) against the fp32 parity path on the same weights/inputs.  The random-weight fixture has flat heat-maps
+    (values within a few 1e-3 of each other around the peak), so some arg-max flips are unavoidable: every flip must be a
+    proven near-tie (the fp32 map at the bf16 arg-max is within 2e-3 of its own maximum, i.e. inside the bf16 heat-map
+    error), the agreement rate must stay >= 95 %, and the heat-maps themselves within 1e-2."""
+    from hupr_amd import functional as F_
+    try:
+        _, net = _net("f32")
+        net.eval()
+        h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(32, 77))
+        out = {}
+        for m in ("f32", "bf16"):
+            F_.set_math(m)
+            with torch.no_grad():
+                p1, p2 = net(h, v)
+            out[m] = (p1.reshape(32, 14, -1).float(), p2.reshape(32, 14, -1).float())
+        for hd in (0, 1):
+            a, b = out["f32"][hd], out["bf16"][hd]
+            assert (a - b).abs().max().item() <= 1e-2
+            ia, ib = a.argmax(-1), b.argmax(-1)
+            same = ia == ib
+            assert same.float().mean().item() >= 0.95, same.float().mean().item()
+            gap = (a.max(-1).values - a.gather(-1, ib[..., None])[..., 0])[~same]
+            assert gap.numel() == 0 or gap.max().item() <= 2e-3, gap.max().item()
+    finally:
+        F_.set_math("f32")
