@@ -145,3 +145,22 @@ def test_dca1000_ingest_bit_exact(tmp_path):
     assert preprocessing.dca1000_frames(torch.zeros(0, dtype=torch.int16, device="cuda")).shape[0] == 0
     cube = preprocessing.fft_chain(dev)
     assert cube.shape == (3, 16, 64, 64, 8) and torch.isfinite(torch.view_as_real(cube)).all()
+
+
+def test_sequence_fft_cache_matches_uncached_loader():
+    """Windows assembled from the per-sequence cache == the un-cached loader on the gathered ADC frames, incl. the
+    sequence-edge clamping of the reference (datasets/dataset.py:120-139)."""
+    from hupr_amd import preprocessing, synth
+    from hupr_amd.datasets import SequenceFFTCache, window_indices
+    dur, G = 12, 8
+    adc_h = torch.from_numpy(synth.adc_cube_int16(40, sensor=0, nframes=dur)).cuda()
+    adc_v = torch.from_numpy(synth.adc_cube_int16(40, sensor=1, nframes=dur)).cuda()
+    cache = SequenceFFTCache(adc_h, adc_v, G)
+    hb, vb = cache.batch([0, 5, dur - 1])
+    for k, index in enumerate((0, 5, dur - 1)):
+        idx = torch.tensor(window_indices(index, dur, G)).cuda()
+        ref_h = preprocessing.fft_chain_loader(adc_h.index_select(0, idx))
+        ref_v = preprocessing.fft_chain_loader(adc_v.index_select(0, idx))
+        h, v = cache.window(index)
+        assert torch.equal(h, ref_h) and torch.equal(v, ref_v)
+        assert torch.equal(hb[k], ref_h) and torch.equal(vb[k], ref_v)
