@@ -228,7 +228,12 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     constexpr int NVOXP = (NVOX + 7) / 8 * 8;        // x rows padded to whole 1 KiB DMA pieces (8 rows)
     constexpr int ITEMS_X = NVOXP * 8, ITEMS = ITEMS_X + 128 * 8;
     constexpr int IMG = (NVOXP + 128) * kRowB;       // one staged tile: x halo rows, then the dy rows
-    __shared__ __attribute__((aligned(1024))) char buf[2][IMG];
+    // THREE DISTINCT LDS objects with static roles in a by-3 unrolled loop: hipcc's waitcnt pass then proves that the image
+    // being read is not the target of a pending LDS-DMA and emits counted vmcnt(N) instead of vmcnt(0) in front of the
+    // first ds_read after an issue (with one array and a rotating index every tile waited for the DMA it had just issued)
+    __shared__ __attribute__((aligned(1024))) char bufA[IMG];
+    __shared__ __attribute__((aligned(1024))) char bufB[IMG];
+    __shared__ __attribute__((aligned(1024))) char bufC[IMG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = wave >> 2;                         // K half of this wave
@@ -268,39 +273,59 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)dy_bytes, 0x00020000);
     constexpr int kOOB = 0x7ffffff0;                 // beyond num_records: the DMA deposits zeros
 
-    // LDS-DMA of spatial tile ST_ into image BUF_: 41 (3-D) one-KiB pieces spread over the 8 waves
+    // LDS-DMA pieces of this wave: piece pc = 8 u + wave moves 64 items (8 rows x 128 B) to image offset pc KiB.  What
+    // does not depend on the tile is computed once: the byte offset of the lane's 16 bytes relative to the tile origin
+    // (rel) and which tile borders would put it outside the tensor (msk; bit 6 = always outside: row padding / channel
+    // tail).  Per tile a piece then costs an add, a mask test and a select.
+    constexpr int NP = (ITEMS / 64 + 7) / 8;          // 6 pieces for the first wave(s), 5 for the others (3-D)
+    constexpr int NLAST = ITEMS / 64 - (NP - 1) * 8;  // waves that own a piece in the last round
+    constexpr int PX = ITEMS_X / 64;                  // pieces [0, PX) are x halo rows, the rest dy rows
+    int rel[NP], msk[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int it = tid + u * 512;
+        rel[u] = 0;
+        msk[u] = 64;
+        if (it < ITEMS_X) {
+            const int vox = it >> 3, c8 = (it & 7) ^ (((vox >> 1) & 1) << 2);
+            const int hx = vox % HW;
+            const int t2 = vox / HW;
+            const int hy = t2 % HH, hz = t2 / HH;
+            const int dzr = hz + td - pd, hyr = hy - 1, hxr = hx - 1;
+            rel[u] = (((dzr * p.H + hyr) * p.W + hxr) * p.in_ld + ci0 + c8 * 8) * 2;
+            msk[u] = (dzr < 0 ? 1 : 0) | (dzr >= TD ? 2 : 0) | (hyr < 0 ? 4 : 0) | (hyr >= 8 ? 8 : 0) | (hxr < 0 ? 16 : 0) |
+                     (hxr >= TW ? 32 : 0) | ((vox >= NVOX || ci0 + c8 * 8 >= p.Ci) ? 64 : 0);
+        } else if (it < ITEMS) {
+            const int j = it - ITEMS_X;
+            const int v = j >> 3, c8 = (j & 7) ^ (((v >> 1) & 1) << 2);
+            const int wx = v & (TW - 1), hy = (v >> LOG2TW) & 7, dz = v >> (LOG2TW + 3);
+            rel[u] = (((dz * p.H + hy) * p.W + wx) * p.dy_ld + co0 + c8 * 8) * 2;
+            msk[u] = (co0 + c8 * 8 >= p.Co) ? 64 : 0;
+        }
+    }
+    // The fill is UNCONDITIONAL (past the last tile it re-fetches the last one): hipcc can only count how many younger
+    // memory operations are guaranteed to be in flight, and a conditional fill would turn every wait in front of an LDS
+    // read that may alias an older DMA into vmcnt(0).
 #define HUPR_WG_FILL(ST_, BUF_)                                                                                     \
     {                                                                                                               \
-        int q_ = (ST_);                                                                                             \
+        int q_ = min((ST_), last_tile);                                                                             \
         const int twi_ = q_ % p.nw; q_ /= p.nw;                                                                     \
         const int thi_ = q_ % p.nh; q_ /= p.nh;                                                                     \
         const int tdi_ = q_ % p.nd;                                                                                 \
         const int b_ = q_ / p.nd;                                                                                   \
         const int d0_ = tdi_ * TD, h0_ = thi_ * 8, w0_ = twi_ * TW;                                                 \
-        _Pragma("unroll") for (int u = 0; u < (ITEMS + 511) / 512; ++u) {                                           \
-            const int it = tid + u * 512;                                                                           \
-            if (it < ITEMS) {                                    /* wave-uniform: ITEMS and ITEMS_X are multiples of 64 */ \
-                char* dst_ = (BUF_) + (it - lane) * 16;                                                             \
-                if (it < ITEMS_X) {                                                                                 \
-                    const int vox = it >> 3, c8 = (it & 7) ^ (((vox >> 1) & 1) << 2);                               \
-                    const int hx = vox % HW;                                                                        \
-                    const int t2 = vox / HW;                                                                        \
-                    const int hy = t2 % HH, hz = t2 / HH;                                                           \
-                    const int d = d0_ + hz + td - pd, h = h0_ + hy - 1, w = w0_ + hx - 1;                           \
-                    const bool ok = vox < NVOX && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&     \
-                                    (unsigned)w < (unsigned)p.W && ci0 + c8 * 8 < p.Ci;                             \
-                    const int off = ((((b_ * p.D + d) * p.H + h) * p.W + w) * p.in_ld + ci0 + c8 * 8) * 2;          \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)dst_, 16, \
-                                                             ok ? off : kOOB, 0, 0, 0);                             \
-                } else {                                                                                            \
-                    const int j = it - ITEMS_X;                                                                     \
-                    const int v = j >> 3, c8 = (j & 7) ^ (((v >> 1) & 1) << 2);                                     \
-                    const int wx = v & (TW - 1), hy = (v >> LOG2TW) & 7, dz = v >> (LOG2TW + 3);                    \
-                    const bool ok = co0 + c8 * 8 < p.Co;                                                            \
-                    const int off = ((((b_ * p.D + d0_ + dz) * p.H + h0_ + hy) * p.W + w0_ + wx) * p.dy_ld + co0 + c8 * 8) * 2; \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)dst_, 16, \
-                                                             ok ? off : kOOB, 0, 0, 0);                             \
-                }                                                                                                   \
+        const int org_ = ((b_ * p.D + d0_) * p.H + h0_) * p.W + w0_;                                                \
+        const int bx_ = org_ * p.in_ld * 2, bdy_ = org_ * p.dy_ld * 2;                                              \
+        const int flags_ = 64 | (d0_ == 0 ? 1 : 0) | (d0_ + TD == p.D ? 2 : 0) | (h0_ == 0 ? 4 : 0) |               \
+                           (h0_ + 8 == p.H ? 8 : 0) | (w0_ == 0 ? 16 : 0) | (w0_ + TW == p.W ? 32 : 0);             \
+        _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                            \
+            const int pc_ = u * 8 + wave;                        /* wave-uniform */                                 \
+            if (u < NP - 1 || wave < NLAST) {                                                                       \
+                const bool isx_ = pc_ < PX;                                                                         \
+                const int voff_ = (msk[u] & flags_) ? kOOB : (isx_ ? bx_ : bdy_) + rel[u];                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(isx_ ? rx : rdy,                                           \
+                                                         (__attribute__((address_space(3))) void*)((BUF_) + pc_ * 1024), \
+                                                         16, voff_, 0, 0, 0);                                       \
             }                                                                                                       \
         }                                                                                                           \
     }
@@ -331,17 +356,33 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     HUPR_WG2_STEP(IMG_, KS0_, 4) HUPR_WG2_STEP(IMG_, KS0_, 5) HUPR_WG2_STEP(IMG_, KS0_, 6) HUPR_WG2_STEP(IMG_, KS0_, 7)  \
     HUPR_WG2_STEP(IMG_, KS0_, 8) HUPR_WG2_STEP(IMG_, KS0_, 9) HUPR_WG2_STEP(IMG_, KS0_, 10) HUPR_WG2_STEP(IMG_, KS0_, 11)
 
-    int cur = 0;
-    if (group < p.n_spatial) HUPR_WG_FILL(group, buf[0])
-    for (int st = group; st < p.n_spatial; st += p.groups) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile st have landed ...
-        __builtin_amdgcn_s_barrier();                           // ... everyone's have, and everyone left the other image
-        asm volatile("" ::: "memory");
-        if (st + p.groups < p.n_spatial) HUPR_WG_FILL(st + p.groups, buf[cur ^ 1])
-        const char* img = buf[cur];
-        if (kq == 0) { HUPR_WG2_TILE(img, 0) } else { HUPR_WG2_TILE(img, 4) }
-        cur ^= 1;
+    // The DMA runs two tiles ahead.  Per tile: wait until this wave's pieces of tile st have landed while leaving its
+    // pieces of tile st + 1 in flight (counted vmcnt — the builtin, so that hipcc's own bookkeeping sees it), barrier,
+    // issue tile st + 2 into the image everyone has just left, multiply tile st.  The loop starts two (virtual) tiles early
+    // with the multiply switched off, so every LDS-DMA of the kernel is issued from the three in-loop sites.
+    const int last_tile = group + ((p.n_spatial - 1 - group) / p.groups) * p.groups;      // last tile of this workgroup
+#define HUPR_WG_ITER(CUR_, FILL_)                                                                                   \
+    {                                                                                                               \
+        if (st >= p.n_spatial) break;                                                                               \
+        if (wave < NLAST) __builtin_amdgcn_s_waitcnt(0x0F70 | NP);                                                  \
+        else __builtin_amdgcn_s_waitcnt(0x0F70 | (NP - 1));                                                         \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("" ::: "memory");                                                                              \
+        HUPR_WG_FILL(st + 2 * p.groups, FILL_)                                                                      \
+        if (st >= 0) {                                                                                              \
+            if (kq == 0) { HUPR_WG2_TILE(CUR_, 0) } else { HUPR_WG2_TILE(CUR_, 4) }                                 \
+        }                                                                                                           \
+        st += p.groups;                                                                                             \
     }
+    if (group >= p.n_spatial) return;
+    int st = group - 2 * p.groups;
+    for (;;) {
+        HUPR_WG_ITER(bufB, bufA)
+        HUPR_WG_ITER(bufC, bufB)
+        HUPR_WG_ITER(bufA, bufC)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // the two re-fetches past the last tile must land before the LDS is released
+#undef HUPR_WG_ITER
 #undef HUPR_WG_FILL
 #undef HUPR_WG2_LOAD
 #undef HUPR_WG2_STEP
