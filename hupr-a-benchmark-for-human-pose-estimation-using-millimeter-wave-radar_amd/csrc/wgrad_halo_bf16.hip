@@ -442,14 +442,15 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     hipStream_t s = as_stream(stream);
     const long n = (long)Co * kd * 9 * Ci;
     const long max_bytes = (long)Bn * D * H * W * (in_ld > dy_ld ? in_ld : dy_ld) * 2;
-    if (abf && kd == 3 && max_bytes < 0x7ffffff0L) {
+    if (abf && max_bytes < 0x7ffffff0L) {
         // LDS-DMA kernel: one 512-thread workgroup per CU, two partial tensors (K halves) per workgroup
         int gw = max(1, min(128, 256 / pairs));
         gw = min(gw, a.n_spatial);
         while (gw > 1 && (size_t)gw * 2 * one > ws_bytes) gw >>= 1;
         if ((size_t)gw * 2 * one <= ws_bytes) {
             a.groups = gw;
-            hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<true>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
+            if (kd == 3) hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<true>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<false>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
             HUPR_LAUNCH_OK("hupr_k_wgrad_halo_glds");
             launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw * 2, n, kd * 9, Ci, s);
             HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
