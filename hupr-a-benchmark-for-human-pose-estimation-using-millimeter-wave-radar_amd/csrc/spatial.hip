@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__
 }
 
 // backward: recompute the arg-max chirp step, accumulate dW[co][ch2][kt] and dbias[co]
-// partial[blk][160]
+// partial[blk][160].  A thread owns one pixel x 8 output channels (four threads per pixel): 40 accumulators instead of
+// 160 keeps the kernel at full occupancy — the one-pixel-x-32-channels version ran at 0.66 TB/s on 134 MB.
 template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const T* __restrict__ dy,
@@ -79,14 +80,14 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__
     __shared__ float sw[kNF * 4 + kNF];
     __shared__ float red[4][kNF * 5];
     for (int i = threadIdx.x; i < kNF * 4 + kNF; i += 256) sw[i] = (i < kNF * 4) ? w[i] : bias[i - kNF * 4];
+    for (int i = threadIdx.x; i < 4 * kNF * 5; i += 256) (&red[0][0])[i] = 0.f;
     __syncthreads();
-    float acc[kNF * 5];
+    const int cg = threadIdx.x & 3;                   // channel group: channels 8 cg .. 8 cg + 7
+    float acc[40];
 #pragma unroll
-    for (int i = 0; i < kNF * 5; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 40; ++i) acc[i] = 0.f;
     const long total = n_bg * pixels;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long bg = idx / pixels, pix = idx - bg * pixels;
-        const float* xb = x + bg * 16 * (long)pixels * 8;
+    for (long idx = (long)blockIdx.x * 64 + (threadIdx.x >> 2); idx < total; idx += (long)gridDim.x * 64) {
         float m[16];
         if (means) {
 #pragma unroll
@@ -95,16 +96,17 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__
                 m[j] = t.x; m[j + 1] = t.y; m[j + 2] = t.z; m[j + 3] = t.w;
             }
         } else {
-            mnet_load_means(xb, (long)pixels * 8, pix, m);
+            const long bg = idx / pixels, pix = idx - bg * pixels;
+            mnet_load_means(x + bg * 16 * (long)pixels * 8, (long)pixels * 8, pix, m);
         }
-        const T* g4 = dy + idx * kNF;
+        const T* g4 = dy + idx * kNF + cg * 8;
 #pragma unroll
-        for (int c4 = 0; c4 < kNF / 4; ++c4) {
+        for (int c4 = 0; c4 < 2; ++c4) {
             const float4 gv = ld_act4(g4 + c4 * 4);
             const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int co = c4 * 4 + k;
+                const int cl = c4 * 4 + k, co = cg * 8 + cl;
                 const float w00 = sw[co * 4 + 0], w01 = sw[co * 4 + 1], w10 = sw[co * 4 + 2], w11 = sw[co * 4 + 3];
                 float best = -INFINITY, a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
 #pragma unroll
@@ -119,19 +121,25 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_bwd(const float* __restrict__
                         a0 = m[2 * t2]; a1 = m[2 * t2 + 1]; b0 = m[8 + 2 * t2]; b1 = m[8 + 2 * t2 + 1];
                     }
                 }
-                acc[co * 4 + 0] = fmaf(gs[k], a0, acc[co * 4 + 0]);
-                acc[co * 4 + 1] = fmaf(gs[k], a1, acc[co * 4 + 1]);
-                acc[co * 4 + 2] = fmaf(gs[k], b0, acc[co * 4 + 2]);
-                acc[co * 4 + 3] = fmaf(gs[k], b1, acc[co * 4 + 3]);
-                acc[kNF * 4 + co] += gs[k];
+                acc[cl * 5 + 0] = fmaf(gs[k], a0, acc[cl * 5 + 0]);
+                acc[cl * 5 + 1] = fmaf(gs[k], a1, acc[cl * 5 + 1]);
+                acc[cl * 5 + 2] = fmaf(gs[k], b0, acc[cl * 5 + 2]);
+                acc[cl * 5 + 3] = fmaf(gs[k], b1, acc[cl * 5 + 3]);
+                acc[cl * 5 + 4] += gs[k];
             }
         }
     }
+    // reduce over the 16 pixels of a wave that share a channel group (lanes l, l+4, ...), then over the 4 waves
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < kNF * 5; ++i) {
-        const float s = wave_sum(acc[i]);
-        if (lane == 0) red[wave][i] = s;
+    for (int i = 0; i < 40; ++i) {
+        float s = acc[i];
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane < 4) {
+            const int cl = i / 5, q = i - cl * 5, co = cg * 8 + cl;
+            red[wave][(q < 4) ? co * 4 + q : kNF * 4 + co] = s;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kNF * 5; i += 256)
@@ -308,7 +316,7 @@ static int mnet_bwd(const char* who, const float* x, const float* means, const f
     HUPR_REQUIRE((x || means) && w && bias && dy && dw && dbias && ws && n_bg > 0 && pixels > 0, "%s: bad argument", who);
     if (ws_bytes < hupr_mnet_bwd_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     const long total = n_bg * pixels;
-    const int grid = (int)min((long)1024, (total + 255) / 256);
+    const int grid = (int)min((long)1024, (total + 63) / 64);      // 64 pixels per workgroup pass; partial[grid][160]
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(hupr_k_mnet_bwd<T>, dim3(grid), dim3(256), 0, s, x, w, bias, dy, means, n_bg, pixels,
                        reinterpret_cast<float*>(ws));
