@@ -277,6 +277,147 @@ __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-branch variant for the BasicBlock3D tail y = relu(bn_a(x1) + bn_b(x2)): both branches share dy and the ReLU mask,
+// so one statistics pass (S1 = sum dy', S2a = sum dy' xhat1, S2b = sum dy' xhat2; partial[blk][3][C]) and one apply pass
+// (dx1, dx2) replace two of each — 4 + 6 tensor reads/writes instead of 6 + 8.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_colstats2(const T* __restrict__ x1, const T* __restrict__ x2,
+                                                        const T* __restrict__ dy, const T* __restrict__ y,
+                                                        const float* __restrict__ mean1, const float* __restrict__ invstd1,
+                                                        const float* __restrict__ mean2, const float* __restrict__ invstd2,
+                                                        long M, int C, double* __restrict__ partial) {
+    constexpr int V = ActVec<T>::V, U = 2;
+    extern __shared__ double sh[];   // [3][C]
+    const int tid = threadIdx.x;
+    const int cvn = C / V;
+    const int rows_per_pass = 256 / cvn;
+    const int cv = tid % cvn, rsub = tid / cvn;
+    for (int i = tid; i < 3 * C; i += 256) sh[i] = 0.0;
+    __syncthreads();
+    const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    float s1[V], sa[V], sb[V], mu1[V], is1[V], mu2[V], is2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        s1[k] = sa[k] = sb[k] = 0.f;
+        mu1[k] = mean1[cv * V + k]; is1[k] = invstd1[cv * V + k];
+        mu2[k] = mean2[cv * V + k]; is2[k] = invstd2[cv * V + k];
+    }
+    if (rsub < rows_per_pass) {
+        for (long r = r0 + rsub; r < r1; r += (long)U * rows_per_pass) {
+            float xa[U][V], xb[U][V], gs[U][V], ys[U][V];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long ru = r + (long)u * rows_per_pass;
+                if (ru < r1) {
+                    ActVec<T>::load(x1 + ru * C + cv * V, xa[u]);
+                    ActVec<T>::load(x2 + ru * C + cv * V, xb[u]);
+                    ActVec<T>::load(dy + ru * C + cv * V, gs[u]);
+                    ActVec<T>::load(y + ru * C + cv * V, ys[u]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) { xa[u][k] = mu1[k]; xb[u][k] = mu2[k]; gs[u][k] = 0.f; ys[u][k] = 1.f; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float g = (ys[u][k] > 0.f) ? gs[u][k] : 0.f;
+                    s1[k] += g;
+                    sa[k] = fmaf(g, (xa[u][k] - mu1[k]) * is1[k], sa[k]);
+                    sb[k] = fmaf(g, (xb[u][k] - mu2[k]) * is2[k], sb[k]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            atomicAdd(&sh[cv * V + k], (double)s1[k]);
+            atomicAdd(&sh[C + cv * V + k], (double)sa[k]);
+            atomicAdd(&sh[2 * C + cv * V + k], (double)sb[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * C; i += 256) partial[(long)blockIdx.x * 3 * C + i] = sh[i];
+}
+
+// coef[6][C]: {cA, cB, cD} of branch 1, then of branch 2 (see hupr_k_bn_finalize_bwd)
+__global__ void hupr_k_bn_finalize_bwd2(const double* __restrict__ partial, int nblk, int C, const float* __restrict__ gamma1,
+                                        const float* __restrict__ invstd1, const float* __restrict__ gamma2,
+                                        const float* __restrict__ invstd2, float inv_m, int train, float* __restrict__ dgamma1,
+                                        float* __restrict__ dbeta1, float* __restrict__ dgamma2, float* __restrict__ dbeta2,
+                                        float* __restrict__ coef) {
+    __shared__ double sh[3][16][17];
+    const int g = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0, d = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = g; k < nblk; k += 16) {
+            a += partial[(long)k * 3 * C + c];
+            b += partial[(long)k * 3 * C + C + c];
+            d += partial[(long)k * 3 * C + 2 * C + c];
+        }
+    }
+    sh[0][g][cl] = a; sh[1][g][cl] = b; sh[2][g][cl] = d;
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    double s1 = 0.0, sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s1 += sh[0][k][cl]; sa += sh[1][k][cl]; sb += sh[2][k][cl]; }
+    dbeta1[c] = (float)s1;
+    dbeta2[c] = (float)s1;
+    dgamma1[c] = (float)sa;
+    dgamma2[c] = (float)sb;
+    const float i1 = invstd1[c], w1 = gamma1[c] * i1, i2 = invstd2[c], w2 = gamma2[c] * i2;
+    coef[c] = w1;
+    coef[C + c] = train ? -w1 * i1 * ((float)sa * inv_m) : 0.f;
+    coef[2 * C + c] = train ? -w1 * ((float)s1 * inv_m) : 0.f;
+    coef[3 * C + c] = w2;
+    coef[4 * C + c] = train ? -w2 * i2 * ((float)sb * inv_m) : 0.f;
+    coef[5 * C + c] = train ? -w2 * ((float)s1 * inv_m) : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply2(const T* __restrict__ dy, const T* __restrict__ y,
+                                                            const T* __restrict__ x1, const T* __restrict__ x2,
+                                                            const float* __restrict__ mean1, const float* __restrict__ mean2,
+                                                            const float* __restrict__ coef, T* __restrict__ dx1,
+                                                            T* __restrict__ dx2, long nv, int C) {
+    constexpr int V = ActVec<T>::V;
+    const long stride = (long)gridDim.x * 256;
+    const bool fixed = (stride * V) % C == 0;
+    float a1[V], b1[V], d1[V], m1[V], a2[V], b2[V], d2[V], m2[V];
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int c = (int)((i * V) % C);
+#define HUPR_LOAD_COEFS()                                                                                           \
+    load_coef<V>(coef, c, a1); load_coef<V>(coef + C, c, b1); load_coef<V>(coef + 2 * C, c, d1); load_coef<V>(mean1, c, m1); \
+    load_coef<V>(coef + 3 * C, c, a2); load_coef<V>(coef + 4 * C, c, b2); load_coef<V>(coef + 5 * C, c, d2); load_coef<V>(mean2, c, m2);
+    if (fixed) { HUPR_LOAD_COEFS() }
+    for (; i < nv; i += stride) {
+        if (!fixed) {
+            c = (int)((i * V) % C);
+            HUPR_LOAD_COEFS()
+        }
+        float g[V], xa[V], xb[V], ys[V], o1[V], o2[V];
+        ActVec<T>::load(dy + i * V, g);
+        ActVec<T>::load(y + i * V, ys);
+        ActVec<T>::load(x1 + i * V, xa);
+        ActVec<T>::load(x2 + i * V, xb);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float gm = (ys[k] > 0.f) ? g[k] : 0.f;
+            o1[k] = fmaf(a1[k], gm, fmaf(b1[k], xa[k] - m1[k], d1[k]));
+            o2[k] = fmaf(a2[k], gm, fmaf(b2[k], xb[k] - m2[k], d2[k]));
+        }
+        ActVec<T>::store(dx1 + i * V, o1);
+        ActVec<T>::store(dx2 + i * V, o2);
+    }
+#undef HUPR_LOAD_COEFS
+}
+
 // ---- PReLU with one shared slope (nn.PReLU() default) --------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void hupr_k_prelu_fwd(const T* __restrict__ x, const float* __restrict__ alpha,
@@ -343,7 +484,7 @@ template <typename T> static inline int act_v() { return sizeof(T) == 2 ? 8 : 4;
 
 using namespace hupr;
 
-extern "C" size_t hupr_bn_ws_bytes(int C) { return (size_t)kStatBlocks * 2 * C * sizeof(double) + 4 * C * sizeof(float); }
+extern "C" size_t hupr_bn_ws_bytes(int C) { return (size_t)kStatBlocks * 3 * C * sizeof(double) + 8 * C * sizeof(float); }
 
 static int bn_check(const char* who, long M, int C, int V = 4) {
     HUPR_REQUIRE(M > 0 && C > 0 && C % V == 0 && C <= 1024, "%s: unsupported shape M=%ld C=%d (C must be a multiple of %d)", who, M, C, V);
@@ -459,6 +600,50 @@ extern "C" int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const voi
     return bn_bwd("hupr_bn_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y_mask),
                   static_cast<const __bf16*>(x), save_mean, save_invstd, gamma, static_cast<__bf16*>(dx), dgamma, dbeta,
                   M, C, train, ws, ws_bytes, stream);
+}
+
+// BatchNorm backward of y = relu(bn_a(x1) + bn_b(x2)) for both branches at once (shared dy and ReLU mask y).
+template <typename T>
+static int bn_bwd2(const char* who, const T* dy, const T* y_mask, const T* x1, const float* mean1, const float* invstd1,
+                   const float* gamma1, const T* x2, const float* mean2, const float* invstd2, const float* gamma2, T* dx1,
+                   T* dx2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, long M, int C, int train, void* ws,
+                   size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && y_mask && x1 && x2 && mean1 && invstd1 && gamma1 && mean2 && invstd2 && gamma2 && dx1 && dx2 && dgamma1 &&
+                 dbeta1 && dgamma2 && dbeta2 && ws, "%s: null pointer", who);
+    int rc = bn_check(who, M, C, act_v<T>());
+    if (rc) return rc;
+    if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
+    hipStream_t s = as_stream(stream);
+    const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
+    double* partial = reinterpret_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 3 * C * sizeof(double));
+    hipLaunchKernelGGL(hupr_k_colstats2<T>, dim3(nblk), dim3(256), 3 * C * sizeof(double), s, x1, x2, dy, y_mask, mean1, invstd1,
+                       mean2, invstd2, M, C, partial);
+    HUPR_LAUNCH_OK("hupr_k_colstats2");
+    hipLaunchKernelGGL(hupr_k_bn_finalize_bwd2, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, gamma1,
+                       invstd1, gamma2, invstd2, 1.0f / (float)M, train, dgamma1, dbeta1, dgamma2, dbeta2, coef);
+    HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd2");
+    const long nv = M * C / act_v<T>();
+    hipLaunchKernelGGL(hupr_k_bn_bwd_apply2<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x1, x2, mean1, mean2, coef, dx1, dx2,
+                       nv, C);
+    HUPR_LAUNCH_OK("hupr_k_bn_bwd_apply2");
+    return HUPR_OK;
+}
+extern "C" int hupr_bn_bwd2_f32(const float* dy, const float* y_mask, const float* x1, const float* mean1, const float* invstd1,
+                                const float* gamma1, const float* x2, const float* mean2, const float* invstd2,
+                                const float* gamma2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                                float* dbeta2, long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return bn_bwd2("hupr_bn_bwd2_f32", dy, y_mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, dx1, dx2, dgamma1,
+                   dbeta1, dgamma2, dbeta2, M, C, train, ws, ws_bytes, stream);
+}
+extern "C" int hupr_bn_bwd2_bf16act(const void* dy, const void* y_mask, const void* x1, const float* mean1, const float* invstd1,
+                                    const float* gamma1, const void* x2, const float* mean2, const float* invstd2,
+                                    const float* gamma2, void* dx1, void* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                                    float* dbeta2, long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return bn_bwd2("hupr_bn_bwd2_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y_mask),
+                   static_cast<const __bf16*>(x1), mean1, invstd1, gamma1, static_cast<const __bf16*>(x2), mean2, invstd2, gamma2,
+                   static_cast<__bf16*>(dx1), static_cast<__bf16*>(dx2), dgamma1, dbeta1, dgamma2, dbeta2, M, C, train, ws,
+                   ws_bytes, stream);
 }
 
 template <typename T>

@@ -401,9 +401,23 @@ class BNAddBNReLUFn(torch.autograd.Function):
     def backward(ctx, dy):
         x1, x2, y, m1, i1, g1, m2, i2, g2 = ctx.saved_tensors
         dy = _c(dy)
-        dx1, dg1, db1 = _bn_bwd(dy, y, x1, m1, i1, g1, ctx.training, ctx.beta_refs[0])
-        dx2, dg2, db2 = _bn_bwd(dy, y, x2, m2, i2, g2, ctx.training, ctx.beta_refs[1])
-        return dx1, dg1, db1, None, dx2, dg2, db2, None, None
+        # both branches share dy and the ReLU mask: one statistics pass + one apply pass for the pair
+        L = rt.lib()
+        C = x1.shape[-1]
+        M = x1.numel() // C
+        assert dy.dtype == x1.dtype == x2.dtype == y.dtype
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        b1, b2 = ctx.beta_refs
+        dg1, dg1_d = _pgrad(g1)
+        db1, db1_d = _pgrad(b1)
+        dg2, dg2_d = _pgrad(g2)
+        db2, db2_d = _pgrad(b2)
+        ws = workspace(L.hupr_bn_ws_bytes(C), x1.device)
+        rt.check(_act("bn_bwd2", x1)(rt.ptr(dy), rt.ptr(y), rt.ptr(x1), rt.ptr(m1), rt.ptr(i1), rt.ptr(g1), rt.ptr(x2), rt.ptr(m2),
+                                     rt.ptr(i2), rt.ptr(g2), rt.ptr(dx1), rt.ptr(dx2), rt.ptr(dg1), rt.ptr(db1), rt.ptr(dg2),
+                                     rt.ptr(db2), M, C, 1 if ctx.training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
+        return (dx1, _pret(g1, dg1, dg1_d), _pret(b1, db1, db1_d), None, dx2, _pret(g2, dg2, dg2_d), _pret(b2, db2, db2_d),
+                None, None)
 
 
 class PReLUFn(torch.autograd.Function):

@@ -156,6 +156,11 @@ int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float* x, const 
                     int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
 
 /* out[c] = sum_rows x[row][c] — bias gradient of Encoder3D.layer1.0 (models/layers.py:195); ws as hupr_bn_ws_bytes */
+/* both branches of y = relu(bn_a(x1) + bn_b(x2)) (BasicBlock3D tail) in one statistics pass + one apply pass */
+int hupr_bn_bwd2_f32(const float* dy, const float* y_mask, const float* x1, const float* mean1, const float* invstd1,
+                     const float* gamma1, const float* x2, const float* mean2, const float* invstd2, const float* gamma2,
+                     float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, long M, int C,
+                     int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_colsum_f32(const float* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
 
 /* (a6) nn.PReLU() with one shared slope (models/layers.py:26,32) */
@@ -253,6 +258,10 @@ int hupr_scale_shift_act_bf16act(const void* x1, const float* scale1, const floa
 int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const void* x, const float* save_mean,
                         const float* save_invstd, const float* gamma, void* dx, float* dgamma, float* dbeta, long M,
                         int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_bn_bwd2_bf16act(const void* dy, const void* y_mask, const void* x1, const float* mean1, const float* invstd1,
+                         const float* gamma1, const void* x2, const float* mean2, const float* invstd2, const float* gamma2,
+                         void* dx1, void* dx2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, long M, int C,
+                         int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_colsum_bf16act(const void* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_prelu_fwd_bf16act(const void* x, const float* alpha, void* y, long n, hupr_stream_t stream);
 int hupr_prelu_bwd_bf16act(const void* dy, const void* x, const float* alpha, void* dx, float* dalpha, long n, void* ws,
