@@ -43,6 +43,20 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ src, int i, int 
     return v;
 }
 
+// eight / four bf16 values stored in HBM -> fp32 registers (exact: a bf16 is the top half of an fp32)
+__device__ __forceinline__ void ld8_bf16(const void* src, float4& v0, float4& v1) {
+    const uint4 t = *reinterpret_cast<const uint4*>(src);
+    v0 = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                     __uint_as_float(t.y & 0xffff0000u));
+    v1 = make_float4(__uint_as_float(t.z << 16), __uint_as_float(t.z & 0xffff0000u), __uint_as_float(t.w << 16),
+                     __uint_as_float(t.w & 0xffff0000u));
+}
+__device__ __forceinline__ float4 ld4_bf16(const void* src) {
+    const uint2 t = *reinterpret_cast<const uint2*>(src);
+    return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                       __uint_as_float(t.y & 0xffff0000u));
+}
+
 struct VoxDec {
     int b, od, oh, ow;
 };
@@ -161,9 +175,13 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_bf16(GemmArgs p) {
                     const int ih = ((a_vox[i] >> 10) & 1023) + th_ - g.ph;
                     const int iw = (a_vox[i] & 1023) + tw_ - g.pw;
                     if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
-                        const float* src = Ag + (a_off[i] + ((long)id * g.Hi + ih) * g.Wi + iw) * g.in_ld + ci;
-                        v0 = *reinterpret_cast<const float4*>(src);
-                        v1 = *reinterpret_cast<const float4*>(src + 4);
+                        const long e = (a_off[i] + ((long)id * g.Hi + ih) * g.Wi + iw) * g.in_ld + ci;
+                        if (p.flags & GEMM_A_BF16) {
+                            ld8_bf16(reinterpret_cast<const __bf16*>(Ag) + e, v0, v1);
+                        } else {
+                            v0 = *reinterpret_cast<const float4*>(Ag + e);
+                            v1 = *reinterpret_cast<const float4*>(Ag + e + 4);
+                        }
                     }
                 }
                 ra[2 * i] = v0;
@@ -218,8 +236,11 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_bf16(GemmArgs p) {
                 if (k < p.K && n < p.N) {
                     const VoxDec d = decode_vox(k, g);
                     const int id = d.od + td_ - g.pd, ih = d.oh + th_ - g.ph, iw = d.ow + tw_ - g.pw;
-                    if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi)
-                        v = *reinterpret_cast<const float4*>(Bg + ((((long)d.b * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.in_ld + ci);
+                    if ((unsigned)id < (unsigned)g.Di && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi) {
+                        const long e = ((((long)d.b * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.in_ld + ci;
+                        if (p.flags & GEMM_B_BF16) v = ld4_bf16(reinterpret_cast<const __bf16*>(Bg) + e);
+                        else v = *reinterpret_cast<const float4*>(Bg + e);
+                    }
                 }
                 rb[j] = v;
             }
@@ -316,9 +337,13 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_bf16(GemmArgs p) {
                 if (row < p.M) {
                     float v = acc[i][j][r] + bv;
                     if (resg) v += resg[(long)row * p.res_ld + col];
-                    float* dst = Cg + (long)row * p.ldc + col;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
+                    if (p.flags & GEMM_C_BF16) {            // bf16-stored output (batch strides in elements)
+                        reinterpret_cast<__bf16*>(p.C)[z0 * p.c_bs0 + z1 * p.c_bs1 + (long)row * p.ldc + col] = (__bf16)v;
+                    } else {
+                        float* dst = Cg + (long)row * p.ldc + col;
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                    }
                 }
             }
         }
@@ -368,33 +393,74 @@ extern "C" int hupr_gemm_bf16(int ta, int tb, const float* A, const float* B, fl
     return HUPR_OK;
 }
 
-extern "C" int hupr_conv_fwd_bf16(const float* x, const float* wp, const float* bias, const float* res, float* y, int Bn,
-                                  int Di, int Hi, int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int out_ld,
-                                  int res_ld, int kd, int kh, int kw, int pd, int ph, int pw, int accumulate,
-                                  hupr_stream_t stream) {
-    HUPR_REQUIRE(x && wp && y, "hupr_conv_fwd_bf16: null pointer");
+static int conv_fwd_h(const char* who, const void* x, const float* wp, const float* bias, const float* res, void* y,
+                      int Bn, int Di, int Hi, int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int out_ld,
+                      int res_ld, int kd, int kh, int kw, int pd, int ph, int pw, int accumulate, int flags,
+                      hupr_stream_t stream) {
+    HUPR_REQUIRE(x && wp && y, "%s: null pointer", who);
     GemmArgs a;
     fill_common(a);
     a.g = ConvGeom{Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, kd, kh, kw, pd, ph, pw};
-    int rc = check_geom("hupr_conv_fwd_bf16", Bn, a.g, Co, 8);
+    int rc = check_geom(who, Bn, a.g, Co, 8);
     if (rc) return rc;
     HUPR_REQUIRE(Do == Di + 2 * pd - kd + 1 && Ho == Hi + 2 * ph - kh + 1 && Wo == Wi + 2 * pw - kw + 1,
-                 "hupr_conv_fwd_bf16: output extent does not match stride-1 convolution");
+                 "%s: output extent does not match stride-1 convolution", who);
+    HUPR_REQUIRE(!(flags & GEMM_C_BF16) || (!accumulate && !res), "%s: bf16 output excludes accumulate/residual", who);
     const long M = (long)Bn * Do * Ho * Wo;
-    HUPR_REQUIRE(M < (1L << 31), "hupr_conv_fwd_bf16: too many output voxels");
-    a.A = x; a.B = wp; a.C = y;
+    HUPR_REQUIRE(M < (1L << 31), "%s: too many output voxels", who);
+    a.A = reinterpret_cast<const float*>(x); a.B = wp; a.C = reinterpret_cast<float*>(y);
     a.M = (int)M; a.N = Co; a.K = kd * kh * kw * Ci;
     a.lda = 0; a.ldb = a.K; a.ldc = out_ld;
     a.bias = bias; a.res = res; a.res_ld = res_ld;
     a.accumulate = accumulate;
+    a.flags = flags;
     dispatch_h<A_CONV, B_NK>(a, 1, as_stream(stream));
     HUPR_LAUNCH_OK("hupr_k_gemm_bf16<conv>");
     return HUPR_OK;
 }
 
-extern "C" int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int Di, int Hi, int Wi, int Ci,
-                                    int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
-                                    int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+extern "C" int hupr_conv_fwd_bf16(const float* x, const float* wp, const float* bias, const float* res, float* y, int Bn,
+                                  int Di, int Hi, int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int out_ld,
+                                  int res_ld, int kd, int kh, int kw, int pd, int ph, int pw, int accumulate,
+                                  hupr_stream_t stream) {
+    return conv_fwd_h("hupr_conv_fwd_bf16", x, wp, bias, res, y, Bn, Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, Co, out_ld, res_ld,
+                      kd, kh, kw, pd, ph, pw, accumulate, 0, stream);
+}
+
+extern "C" int hupr_conv_fwd_bf16_mixed(const void* x, int x_bf16, const float* wp, const float* bias, void* y, int y_bf16,
+                                        int Bn, int Di, int Hi, int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co,
+                                        int out_ld, int kd, int kh, int kw, int pd, int ph, int pw, hupr_stream_t stream) {
+    return conv_fwd_h("hupr_conv_fwd_bf16_mixed", x, wp, bias, nullptr, y, Bn, Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, Co, out_ld,
+                      0, kd, kh, kw, pd, ph, pw, 0, (x_bf16 ? GEMM_A_BF16 : 0) | (y_bf16 ? GEMM_C_BF16 : 0), stream);
+}
+
+// Input gradient of a temporal merge (kernel (G,1,1), no padding, one output slice): every input slice d sees exactly
+// one tap, so instead of an implicit GEMM over G zero-padded taps this is G*Bn plain GEMMs
+// dx[b, d] (HW x Ci) = dy[b] (HW x Co) . W_d (Co x Ci), batched over z = (b, d).  wp1: mode-1 packed weights
+// [Ci][taps reversed][Co] (fp32); dx is stored as bf16 when dx_bf16.
+extern "C" int hupr_tmerge_dgrad_bf16(const float* dy, const float* wp1, void* dx, int dx_bf16, int Bn, int G, int HW,
+                                      int Ci, int Co, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && wp1 && dx, "hupr_tmerge_dgrad_bf16: null pointer");
+    HUPR_REQUIRE(Bn > 0 && G > 0 && HW > 0 && Ci > 0 && Co > 0 && (long)Bn * G <= 65535,
+                 "hupr_tmerge_dgrad_bf16: bad shape %d %d %d %d %d", Bn, G, HW, Ci, Co);
+    GemmArgs a;
+    fill_common(a);
+    a.A = dy; a.B = wp1 + (long)(G - 1) * Co; a.C = reinterpret_cast<float*>(dx);
+    a.M = HW; a.N = Ci; a.K = Co;
+    a.lda = Co; a.ldb = (long)G * Co; a.ldc = Ci;
+    a.zdiv = G;
+    a.a_bs0 = (long)HW * Co; a.a_bs1 = 0;
+    a.b_bs0 = 0; a.b_bs1 = -(long)Co;
+    a.c_bs0 = (long)G * HW * Ci; a.c_bs1 = (long)HW * Ci;
+    a.flags = dx_bf16 ? GEMM_C_BF16 : 0;
+    dispatch_h<A_ROWK, B_NK>(a, Bn * G, as_stream(stream));
+    HUPR_LAUNCH_OK("hupr_k_gemm_bf16<tmerge dgrad>");
+    return HUPR_OK;
+}
+
+static int conv_wgrad_h(const void* x, int x_bf16, const float* dy, float* dw, int Bn, int Di, int Hi, int Wi, int Ci,
+                        int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
+                        int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream) {
     HUPR_REQUIRE(x && dy && dw && ws, "hupr_conv_wgrad_bf16: null pointer");
     GemmArgs a;
     fill_common(a);
@@ -404,7 +470,8 @@ extern "C" int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, 
     const long Mv = (long)Bn * Do * Ho * Wo;
     HUPR_REQUIRE(Mv < (1L << 31), "hupr_conv_wgrad_bf16: too many output voxels");
     const int taps = kd * kh * kw;
-    a.A = dy; a.B = x; a.C = reinterpret_cast<float*>(ws);
+    a.A = dy; a.B = reinterpret_cast<const float*>(x); a.C = reinterpret_cast<float*>(ws);
+    a.flags = x_bf16 ? GEMM_B_BF16 : 0;
     a.M = Co; a.N = taps * Ci; a.K = (int)Mv;
     a.lda = dy_ld; a.ldb = 0; a.ldc = a.N;
     const int bm = (Co <= 64) ? 64 : 128;
@@ -424,4 +491,19 @@ extern "C" int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, 
     launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, a.split_stride, splits, a.split_stride, taps, Ci, s);
     HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
     return HUPR_OK;
+}
+
+extern "C" int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int Di, int Hi, int Wi, int Ci,
+                                    int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
+                                    int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return conv_wgrad_h(x, 0, dy, dw, Bn, Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, Co, dy_ld, kd, kh, kw, pd, ph, pw, ws, ws_bytes,
+                        stream);
+}
+
+extern "C" int hupr_conv_wgrad_bf16_mixed(const void* x, int x_bf16, const float* dy, float* dw, int Bn, int Di, int Hi,
+                                          int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd,
+                                          int kh, int kw, int pd, int ph, int pw, void* ws, size_t ws_bytes,
+                                          hupr_stream_t stream) {
+    return conv_wgrad_h(x, x_bf16, dy, dw, Bn, Di, Hi, Wi, Ci, in_ld, Do, Ho, Wo, Co, dy_ld, kd, kh, kw, pd, ph, pw, ws,
+                        ws_bytes, stream);
 }

@@ -33,7 +33,9 @@ struct GemmArgs {
     int ksplit;               // >1: grid.y slices K, partial tiles go to C + slice*M*ldc... (see host)
     long split_stride;        // floats between partial outputs
     int accumulate;           // 1: C += result (read-modify-write; not with ksplit)
+    int flags;                // bf16 engine only: GEMM_A_BF16 / GEMM_B_BF16 / GEMM_C_BF16 (tensor stored as bf16 in HBM)
 };
+enum { GEMM_A_BF16 = 1, GEMM_B_BF16 = 2, GEMM_C_BF16 = 4 };
 
 
 inline void fill_common(GemmArgs& a) {
@@ -45,6 +47,7 @@ inline void fill_common(GemmArgs& a) {
     a.ksplit = 1;
     a.split_stride = 0;
     a.accumulate = 0;
+    a.flags = 0;
     a.g = ConvGeom{};
 }
 

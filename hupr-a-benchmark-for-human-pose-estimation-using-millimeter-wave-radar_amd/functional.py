@@ -308,6 +308,59 @@ def conv(x, weight, bias=None, res=None, pad=(0, 0, 0)):
     return ConvFn.apply(x, weight, bias, res, tuple(pad))
 
 
+class TemporalMergeFn(torch.autograd.Function):
+    """Frame-axis merge: Conv3d with kernel (G,1,1), no padding and no bias on a (B,G,H,W,C) map (the
+    l1temporalMerge / l2temporalMerge / temporalMerge of the reference, models/layers.py:195-197,218-220), taking
+    the bf16-stored feature maps of the bf16-activation encoder directly: bf16 in, fp32 merged map out; the
+    input gradient (G*B batched GEMMs — every frame slice sees exactly one tap) is written as bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = _c(x)
+        B, G, H, W, Ci = _vox(x)
+        Co = weight.shape[0]
+        assert tuple(weight.shape[1:]) == (Ci, G, 1, 1), (weight.shape, x.shape)
+        y = torch.empty((B, 1, H, W, Co), dtype=torch.float32, device=x.device)
+        rt.check(rt.lib().hupr_conv_fwd_bf16_mixed(
+            rt.ptr(x), int(x.dtype == torch.bfloat16), rt.ptr(_packed(weight, 0, 0)), None, rt.ptr(y), 0,
+            B, G, H, W, Ci, Ci, 1, H, W, Co, Co, G, 1, 1, 0, 0, 0, rt.stream()))
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _c(dy)
+        B, G, H, W, Ci = _vox(x)
+        Co = weight.shape[0]
+        L = rt.lib()
+        xbf = int(x.dtype == torch.bfloat16)
+        dx = dw = None
+        direct = False
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            rt.check(L.hupr_tmerge_dgrad_bf16(rt.ptr(dy), rt.ptr(_packed(weight, 1, 0)), rt.ptr(dx), xbf, B, G, H * W,
+                                              Ci, Co, rt.stream()))
+        if ctx.needs_input_grad[1]:
+            dw, direct = _pgrad(weight)
+            ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, Ci, Co, G, 1, 1), x.device)
+            rt.check(L.hupr_conv_wgrad_bf16_mixed(rt.ptr(x), xbf, rt.ptr(dy), rt.ptr(dw), B, G, H, W, Ci, Ci, 1, H, W,
+                                                  Co, Co, G, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
+        return dx, _pret(weight, dw, direct)
+
+
+def temporal_merge(x, weight):
+    """(B,G,H,W,C) -> (B,1,H,W,Co) fp32.  bf16-stored maps go through the mixed-storage kernels (bf16 math only);
+    fp32 maps through the generic convolution."""
+    if x.dtype == torch.bfloat16 and os.environ.get("HUPR_TMERGE_CAST", "0") == "1":      # A/B aid: cast + generic conv
+        x = cast(x, torch.float32)
+    if x.dtype == torch.bfloat16:
+        if MATH != "bf16":
+            raise rt.HuprError("bf16-stored activations need the bf16 math mode")
+        return TemporalMergeFn.apply(x, weight)
+    return ConvFn.apply(x, weight, None, None, (0, 0, 0))
+
+
 # ----------------------------------------------------------------------------------------------
 # BatchNorm (+ReLU), and the BasicBlock3D tail  relu(bn_a(x1) + bn_b(x2))
 # ----------------------------------------------------------------------------------------------

@@ -190,11 +190,11 @@ class Encoder3D(nn.Module):
         """maps: channels-last (B, G, R, A, nf) -> three channels-last (B,1,h,w,c) fp32 feature maps.
 
         With bf16 activations (F_.act_bf16()) everything up to the temporal merges — the 3x3x3 convolutions,
-        BatchNorms and resamplings that dominate the step — reads and writes bf16 tensors; the merges and the
-        decoder stay fp32, with one cast per scale at the boundary."""
+        BatchNorms and resamplings that dominate the step — reads and writes bf16 tensors; the merges read those
+        bf16 maps directly and emit fp32 (F_.temporal_merge)."""
         l1maps = self.layer1[1](_conv(maps, self.layer1[0]))
         l2maps = self.layer2(l1maps)
         l3maps = self.layer3(l2maps)
-        f32 = torch.float32
-        return (_conv(F_.cast(l1maps, f32), self.l1temporalMerge), _conv(F_.cast(l2maps, f32), self.l2temporalMerge),
-                _conv(F_.cast(l3maps, f32), self.temporalMerge))
+        return (F_.temporal_merge(l1maps, self.l1temporalMerge.weight),
+                F_.temporal_merge(l2maps, self.l2temporalMerge.weight),
+                F_.temporal_merge(l3maps, self.temporalMerge.weight))

@@ -34,6 +34,10 @@ SIGNATURES = {
                                c_long, c_int, c_long, c_long, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "hupr_conv_fwd_bf16": (c_int, [c_void_p] * 5 + [c_int] * 19 + [c_void_p]),
     "hupr_conv_wgrad_bf16": (c_int, [c_void_p] * 3 + [c_int] * 17 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_conv_fwd_bf16_mixed": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 17 + [c_void_p]),
+    "hupr_conv_wgrad_bf16_mixed": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 17
+                                   + [c_void_p, c_size_t, c_void_p]),
+    "hupr_tmerge_dgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 5 + [c_void_p]),
     "hupr_pack_conv_weights_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "hupr_pack_conv_weights_table": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hupr_debug_halo_ablate": (None, [c_int]),

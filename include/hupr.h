@@ -114,6 +114,22 @@ int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int
                          int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
                          int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream);
 
+/* Mixed-storage variants for the temporal merges of Encoder3D (reference models/layers.py:195-197: Conv3d with
+ * kernel (G,1,1) collapsing the frame axis): the feature maps arrive bf16-stored from the bf16-activation encoder,
+ * the merged maps and all gradients of the parameters stay fp32.  x_bf16 / y_bf16 / dx_bf16 select the HBM storage
+ * type of that tensor (0: fp32, 1: bf16); everything else as in the entry points above.
+ * hupr_tmerge_dgrad_bf16: input gradient of such a merge (one output slice, no padding) as Bn*G batched GEMMs
+ * dx[b,d] = dy[b] . W_d  with wp1 the mode-1 packed fp32 weights ([Ci][taps reversed][Co]). */
+int hupr_conv_fwd_bf16_mixed(const void* x, int x_bf16, const float* wp, const float* bias, void* y, int y_bf16,
+                             int Bn, int Di, int Hi, int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co,
+                             int out_ld, int kd, int kh, int kw, int pd, int ph, int pw, hupr_stream_t stream);
+int hupr_conv_wgrad_bf16_mixed(const void* x, int x_bf16, const float* dy, float* dw, int Bn, int Di, int Hi,
+                               int Wi, int Ci, int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd,
+                               int kh, int kw, int pd, int ph, int pw, void* ws, size_t ws_bytes,
+                               hupr_stream_t stream);
+int hupr_tmerge_dgrad_bf16(const float* dy, const float* wp1, void* dx, int dx_bf16, int Bn, int G, int HW,
+                           int Ci, int Co, hupr_stream_t stream);
+
 /* LDS halo-tiled 3x3x3 / 1x3x3 "same" convolution on the bf16 matrix pipe (forward, and input gradient
  * with mode-1 packed weights): the input halo of a 128-voxel tile is staged once as bf16 and all taps
  * run from LDS.  wp_bf16 from hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci] bf16). */

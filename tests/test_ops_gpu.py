@@ -526,6 +526,38 @@ def test_conv_autograd_bf16_activations(bf16_math):
     close(bg.grad, br.grad, 1e-5, "bf16act bias grad")
 
 
+@pytest.mark.parametrize("B,G,H,W,C", [(2, 8, 16, 16, 64), (3, 4, 8, 8, 128), (2, 2, 16, 16, 256)])
+def test_temporal_merge_bf16_activations(B, G, H, W, C, bf16_math):
+    """F_.temporal_merge on a bf16-stored map (mixed-storage GEMM kernels: bf16 source, fp32 merged map, bf16 input
+    gradient from G*B batched GEMMs) against (a) fp64 on the same rounded operands and (b) the generic ConvFn on the
+    fp32 copy of the same map — same products, same accumulation order, so (b) is an exact comparison."""
+    from hupr_amd import functional as F_
+    x = _q(rnd(B, C, G, H, W, seed=80))
+    w = rnd(C, C, G, 1, 1, seed=81, scale=(C * G) ** -0.5)
+    gy = rnd(B, C, 1, H, W, seed=82)
+    wq = _bf16_round(w)
+    xr, wr = x.double().requires_grad_(True), wq.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr)
+    yr.backward(_bf16_round(gy))
+    xg = cl(x).cuda().bfloat16().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    y = F_.temporal_merge(xg, wg)
+    assert y.dtype == torch.float32 and tuple(y.shape) == (B, 1, H, W, C)
+    close(ncdhw(y), yr, 2e-5, "temporal merge fwd")
+    y.backward(cl(gy).cuda())
+    assert xg.grad.dtype == torch.bfloat16
+    close(ncdhw(xg.grad.float()), xr.grad, 6e-3, "temporal merge dgrad (one bf16 store rounding)")
+    close(wg.grad, wr.grad, 5e-5, "temporal merge wgrad")
+    # generic path on the fp32 copy
+    x32 = cl(x).cuda().requires_grad_(True)
+    w32 = w.cuda().requires_grad_(True)
+    y32 = F_.conv(x32, w32, None, None, (0, 0, 0))
+    y32.backward(cl(gy).cuda())
+    assert torch.equal(y, y32)
+    close(xg.grad.float(), x32.grad, 4e-3, "dgrad vs generic")
+    close(wg.grad, w32.grad, 2e-6, "wgrad vs generic")
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_block_tail_bf16_activations(training):
     """BNActFn / BNAddBNReLUFn on bf16 storage == the fp32-storage kernels on the same (bf16-representable) data,
