@@ -388,9 +388,35 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
 #undef HUPR_WG2_STEP
 #undef HUPR_WG2_TILE
 
+    // Merge the two K halves through the (now dead) images: the kq = 1 waves park their accumulators, six taps and then
+    // three, the kq = 0 waves add them — one partial tensor per workgroup instead of two halves what the workgroups
+    // write at the very end of the kernel and what the split-K reduction reads back.
+    {
+        const int t256 = tid & 255;
+        float* const red[3] = {reinterpret_cast<float*>(bufA), reinterpret_cast<float*>(bufB), reinterpret_cast<float*>(bufC)};
+        __syncthreads();
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if (round) __syncthreads();
+            if (kq == 1) {
+#pragma unroll
+                for (int tap = round * 6; tap < (round ? 9 : 6); ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((tap - round * 6) >> 1)][(((tap & 1) * 16 + r) << 8) + t256] = acc[tap][r];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int tap = round * 6; tap < (round ? 9 : 6); ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r] += red[((tap - round * 6) >> 1)][(((tap & 1) * 16 + r) << 8) + t256];
+            }
+        }
+    }
+    if (kq != 0) return;
     const int lr = lane & 31, lh = lane >> 5;
     const int ci = ci0 + wn * 32 + lr;
-    float* part = p.part + (long)(group * 2 + kq) * p.Co * T * p.Ci;
+    float* part = p.part + (long)group * p.Co * T * p.Ci;
     if (ci < p.Ci) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -443,16 +469,16 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     const long n = (long)Co * kd * 9 * Ci;
     const long max_bytes = (long)Bn * D * H * W * (in_ld > dy_ld ? in_ld : dy_ld) * 2;
     if (abf && max_bytes < 0x7ffffff0L) {
-        // LDS-DMA kernel: one 512-thread workgroup per CU, two partial tensors (K halves) per workgroup
+        // LDS-DMA kernel: one 512-thread workgroup per CU (two K halves, merged in LDS), one partial tensor per workgroup
         int gw = max(1, min(128, 256 / pairs));
         gw = min(gw, a.n_spatial);
-        while (gw > 1 && (size_t)gw * 2 * one > ws_bytes) gw >>= 1;
-        if ((size_t)gw * 2 * one <= ws_bytes) {
+        while (gw > 1 && (size_t)gw * one > ws_bytes) gw >>= 1;
+        if ((size_t)gw * one <= ws_bytes) {
             a.groups = gw;
             if (kd == 3) hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<true>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
             else hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<false>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
             HUPR_LAUNCH_OK("hupr_k_wgrad_halo_glds");
-            launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw * 2, n, kd * 9, Ci, s);
+            launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw, n, kd * 9, Ci, s);
             HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
             return HUPR_OK;
         }

@@ -130,8 +130,14 @@ def check(rc):
         raise HuprError("hupr error %d: %s" % (rc, lib().hupr_last_error().decode()))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
-    """Current torch HIP stream as a raw hipStream_t."""
+    """Current torch HIP stream (of the current device) as a raw hipStream_t.  Called once per kernel launch
+    (~1400 times per training step), hence the private fast accessor when this torch build has it."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
