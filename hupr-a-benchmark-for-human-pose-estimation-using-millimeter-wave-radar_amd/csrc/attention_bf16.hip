@@ -19,6 +19,8 @@
 
 namespace hupr {
 
+constexpr float kLog2e = 1.4426950408889634f;
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -170,7 +172,7 @@ __device__ __forceinline__ void store_ct(float* __restrict__ dst_row, const f32x
 // and V, so halving those bytes and dropping the per-tile conversions is worth one cast pass); Vres = fp32 V for the
 // residual epilogue (exact), or null.
 template <int D, typename TI>
-__global__ __launch_bounds__(256) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
+__global__ __launch_bounds__(256, 2) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
                                                        float* __restrict__ out, float* __restrict__ lse, int N) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
@@ -200,22 +202,25 @@ __global__ __launch_bounds__(256) void hupr_k_attn_fwd(const TI* __restrict__ K,
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other half-wave holds the other 32 keys
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
+        const float nm = -m_new * kLog2e;                   // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __expf(st[t][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][r], kLog2e, nm));
                 st[t][r] = pv;
                 sum += pv;
             }
         l_run = l_run * alpha + sum;
         m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {     // after the first tiles the running maxima rarely move
 #pragma unroll
-        for (int ct = 0; ct < D / 32; ++ct)
+            for (int ct = 0; ct < D / 32; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        }
         mma_tr_x_tile<D>(o, Vs, st, lane);                    // O^T += V^T P^T
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
     bf16x8 qf[D / 16], gf[D / 16];
     load_frags<D, TI>(qf, Q + base + (long)q * D, lh);
     load_frags<D, TI>(gf, dO + base + (long)q * D, lh);
-    const float lse_q = lse[(long)blockIdx.y * N + q], d_q = Dq[(long)blockIdx.y * N + q];
+    const float nlse_q = -lse[(long)blockIdx.y * N + q] * kLog2e, d_q = Dq[(long)blockIdx.y * N + q];
     f32x16 dq[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[t][r] = __expf(st[t][r] - lse_q) * (dp[t][r] - d_q);   // dS^T
+            for (int r = 0; r < 16; ++r) st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], kLog2e, nlse_q)) * (dp[t][r] - d_q);   // dS^T
         mma_tr_x_tile<D>(dq, Ks, st, lane);                   // dQ^T += K^T dS^T
     }
     store_ct<D>(dQ + base + (long)q * D, dq, 1.f, nullptr, lh);
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         stage_rows<D, 64, TI>(Qs, Q + base + (long)q0 * D, D, tid);
         stage_rows<D, 64, TI>(Gs, dO + base + (long)q0 * D, D, tid);
         if (tid < 64) {
-            s_lse[tid] = lse[(long)blockIdx.y * N + q0 + tid];
+            s_lse[tid] = -lse[(long)blockIdx.y * N + q0 + tid] * kLog2e;      // pre-scaled for the exp2 form
             s_d[tid] = Dq[(long)blockIdx.y * N + q0 + tid];
         }
         __syncthreads();
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float pv = __expf(s[t][r] - s_lse[qi]);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], kLog2e, s_lse[qi]));
                 dp[t][r] = pv * (dp[t][r] - s_d[qi]);          // dS
                 s[t][r] = pv;                                   // P
             }
