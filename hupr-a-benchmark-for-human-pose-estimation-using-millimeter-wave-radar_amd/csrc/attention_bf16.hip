@@ -70,6 +70,45 @@ __device__ __forceinline__ void stage_rows(__bf16* img, const TI* __restrict__ s
     }
 }
 
+// The same staging split in two so that the global loads of tile i + 1 are in flight while tile i is multiplied:
+// load() right after the tile barrier, store() after the next one.
+template <int D, int ROWS, typename TI>
+struct StageRegs {
+    static constexpr int CH = D / 8, ITEMS = ROWS * CH, PER = ITEMS / 256;
+    static_assert(ITEMS % 256 == 0, "tile must split over 256 threads");
+    u32x4a v[PER * (sizeof(TI) == 2 ? 1 : 2)];
+    __device__ __forceinline__ void load(const TI* __restrict__ src, long ld, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+            if constexpr (sizeof(TI) == 2) {
+                v[i] = *reinterpret_cast<const u32x4a*>(src + (long)row * ld + ch * 8);
+            } else {
+                const float* sp = reinterpret_cast<const float*>(src) + (long)row * ld + ch * 8;
+                v[2 * i] = *reinterpret_cast<const u32x4a*>(sp);
+                v[2 * i + 1] = *reinterpret_cast<const u32x4a*>(sp + 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int it = tid + 256 * i, row = it / CH, ch = it % CH;
+            if constexpr (sizeof(TI) == 2) {
+                *reinterpret_cast<u32x4a*>(&img[Img<D>::off(row, ch)]) = v[i];
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)__uint_as_float(v[2 * i][e]);
+                    o[4 + e] = (__bf16)__uint_as_float(v[2 * i + 1][e]);
+                }
+                *reinterpret_cast<bf16x8*>(&img[Img<D>::off(row, ch)]) = o;
+            }
+        }
+    }
+};
+
 // B-operand fragments (cols = token of this lane, K = channels) straight from global: frag[ks] covers
 // channels 16 ks + 8 h .. +7 of row `tok`
 template <int D, typename TI>
@@ -172,7 +211,7 @@ __device__ __forceinline__ void store_ct(float* __restrict__ dst_row, const f32x
 // and V, so halving those bytes and dropping the per-tile conversions is worth one cast pass); Vres = fp32 V for the
 // residual epilogue (exact), or null.
 template <int D, typename TI>
-__global__ __launch_bounds__(256, 2) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
                                                        float* __restrict__ out, float* __restrict__ lse, int N) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
@@ -188,11 +227,18 @@ __global__ __launch_bounds__(256, 2) void hupr_k_attn_fwd(const TI* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    StageRegs<D, 64, TI> kr, vr;
+    kr.load(K + base, D, tid);
+    vr.load(V + base, D, tid);
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
-        stage_rows<D, 64, TI>(Ks, K + base + (long)j0 * D, D, tid);
-        stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
+        kr.store(Ks, tid);
+        vr.store(Vs, tid);
         __syncthreads();
+        if (j0 + 64 < N) {                                    // next tile's rows travel while this one is multiplied
+            kr.load(K + base + (long)(j0 + 64) * D, D, tid);
+            vr.load(V + base + (long)(j0 + 64) * D, D, tid);
+        }
         f32x16 st[2];
         mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T tile: rows = keys, this lane's column = its query
         float mx = -INFINITY;
@@ -277,11 +323,18 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
     for (int ct = 0; ct < D / 32; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[ct][r] = 0.f;
+    StageRegs<D, 64, TI> kr, vr;
+    kr.load(K + base, D, tid);
+    vr.load(V + base, D, tid);
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
-        stage_rows<D, 64, TI>(Ks, K + base + (long)j0 * D, D, tid);
-        stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
+        kr.store(Ks, tid);
+        vr.store(Vs, tid);
         __syncthreads();
+        if (j0 + 64 < N) {
+            kr.load(K + base + (long)(j0 + 64) * D, D, tid);
+            vr.load(V + base + (long)(j0 + 64) * D, D, tid);
+        }
         f32x16 st[2], dp[2];
         mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T
         mma_rows_x_frags<D>(dp, Vs, gf, lr, lh);              // dP^T = V dO^T
@@ -317,15 +370,26 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     for (int ct = 0; ct < D / 32; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.f; dv[ct][r] = 0.f; }
+    // register prefetch of the next tile: both arrays at D = 128 (one wave per SIMD, 512 registers); at D = 64 the
+    // kernel sits at the 256-register limit of two waves per SIMD and only the query rows fit
+    constexpr bool PFG = (D == 128);
+    StageRegs<D, 64, TI> qr, gr;
+    qr.load(Q + base, D, tid);
+    if (PFG) gr.load(dO + base, D, tid);
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
-        stage_rows<D, 64, TI>(Qs, Q + base + (long)q0 * D, D, tid);
-        stage_rows<D, 64, TI>(Gs, dO + base + (long)q0 * D, D, tid);
+        qr.store(Qs, tid);
+        if (PFG) gr.store(Gs, tid);
+        else stage_rows<D, 64, TI>(Gs, dO + base + (long)q0 * D, D, tid);
         if (tid < 64) {
             s_lse[tid] = -lse[(long)blockIdx.y * N + q0 + tid] * kLog2e;      // pre-scaled for the exp2 form
             s_d[tid] = Dq[(long)blockIdx.y * N + q0 + tid];
         }
         __syncthreads();
+        if (q0 + 64 < N) {
+            qr.load(Q + base + (long)(q0 + 64) * D, D, tid);
+            if (PFG) gr.load(dO + base + (long)(q0 + 64) * D, D, tid);
+        }
         f32x16 s[2], dp[2];
         mma_rows_x_frags<D>(s, Qs, kf, lr, lh);               // S tile: rows = queries, this lane's column = its key
         mma_rows_x_frags<D>(dp, Gs, vf, lr, lh);              // dP = dO V^T
