@@ -186,8 +186,8 @@ __device__ __forceinline__ void mma_tr_x_tile(f32x16* out, const __bf16* img, co
 
 // write an accumulator tile set acc[ct] ([channel][lane token]) to dst[token][channel] (+ scale, + optional add)
 template <int D>
-__device__ __forceinline__ void store_ct(float* __restrict__ dst_row, const f32x16* acc, float scale,
-                                         const float* __restrict__ add_row, int lh) {
+__device__ __forceinline__ void store_ct(float* dst_row, const f32x16* acc, float scale, const float* add_row, int lh) {
+    // add_row may alias dst_row (gradient accumulation in place): each float4 is read, then written, by one lane
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct) {
 #pragma unroll
@@ -213,14 +213,17 @@ __device__ __forceinline__ void store_ct(float* __restrict__ dst_row, const f32x
 template <int D, typename TI>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
-                                                       float* __restrict__ out, float* __restrict__ lse, int N) {
+                                                       float* __restrict__ out, float* __restrict__ lse, int N, int ldk,
+                                                       int ldq) {
+    // ldk / ldq: row strides (elements) of K and Q — the projections of one map may sit side by side in one tensor
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const long base = (long)blockIdx.y * N * D;
     const int q = blockIdx.x * 128 + wave * 32 + lr;         // this lane's query
+    K += (long)blockIdx.y * N * ldk;
     bf16x8 qf[D / 16];
-    load_frags<D, TI>(qf, Q + base + (long)q * D, lh);
+    load_frags<D, TI>(qf, Q + ((long)blockIdx.y * N + q) * ldq, lh);
     f32x16 o[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     StageRegs<D, 64, TI> kr, vr;
-    kr.load(K + base, D, tid);
+    kr.load(K, ldk, tid);
     vr.load(V + base, D, tid);
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
         vr.store(Vs, tid);
         __syncthreads();
         if (j0 + 64 < N) {                                    // next tile's rows travel while this one is multiplied
-            kr.load(K + base + (long)(j0 + 64) * D, D, tid);
+            kr.load(K + (long)(j0 + 64) * ldk, ldk, tid);
             vr.load(V + base + (long)(j0 + 64) * D, D, tid);
         }
         f32x16 st[2];
@@ -308,14 +311,15 @@ template <int D, typename TI>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
-                                                          float* __restrict__ dQ, int N) {
+                                                          float* __restrict__ dQ, int N, int ldk, int ldq, int lddq) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const long base = (long)blockIdx.y * N * D;
     const int q = blockIdx.x * 128 + wave * 32 + lr;
+    K += (long)blockIdx.y * N * ldk;
     bf16x8 qf[D / 16], gf[D / 16];
-    load_frags<D, TI>(qf, Q + base + (long)q * D, lh);
+    load_frags<D, TI>(qf, Q + ((long)blockIdx.y * N + q) * ldq, lh);
     load_frags<D, TI>(gf, dO + base + (long)q * D, lh);
     const float nlse_q = -lse[(long)blockIdx.y * N + q] * kLog2e, d_q = Dq[(long)blockIdx.y * N + q];
     f32x16 dq[D / 32];
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[ct][r] = 0.f;
     StageRegs<D, 64, TI> kr, vr;
-    kr.load(K + base, D, tid);
+    kr.load(K, ldk, tid);
     vr.load(V + base, D, tid);
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
         vr.store(Vs, tid);
         __syncthreads();
         if (j0 + 64 < N) {
-            kr.load(K + base + (long)(j0 + 64) * D, D, tid);
+            kr.load(K + (long)(j0 + 64) * ldk, ldk, tid);
             vr.load(V + base + (long)(j0 + 64) * D, D, tid);
         }
         f32x16 st[2], dp[2];
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
             for (int r = 0; r < 16; ++r) st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], kLog2e, nlse_q)) * (dp[t][r] - d_q);   // dS^T
         mma_tr_x_tile<D>(dq, Ks, st, lane);                   // dQ^T += K^T dS^T
     }
-    store_ct<D>(dQ + base + (long)q * D, dq, 1.f, nullptr, lh);
+    store_ct<D>(dQ + ((long)blockIdx.y * N + q) * lddq, dq, 1.f, nullptr, lh);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -353,9 +357,10 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
 template <int D, typename TI>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                            const TI* __restrict__ V, const TI* __restrict__ dO,
-                                                           const float* __restrict__ dOres,
+                                                           const float* dVadd,
                                                            const float* __restrict__ lse, const float* __restrict__ Dq,
-                                                           float* __restrict__ dK, float* __restrict__ dV, int N) {
+                                                           float* __restrict__ dK, float* dV, int N, int ldk,
+                                                           int ldq, int lddk) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[64 * D];
     __shared__ float s_lse[64], s_d[64];
@@ -363,8 +368,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     const long base = (long)blockIdx.y * N * D;
     const int key = blockIdx.x * 128 + wave * 32 + lr;        // this lane's key
     bf16x8 kf[D / 16], vf[D / 16];
-    load_frags<D, TI>(kf, K + base + (long)key * D, lh);
+    load_frags<D, TI>(kf, K + ((long)blockIdx.y * N + key) * ldk, lh);
     load_frags<D, TI>(vf, V + base + (long)key * D, lh);
+    Q += (long)blockIdx.y * N * ldq;
     f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     // kernel sits at the 256-register limit of two waves per SIMD and only the query rows fit
     constexpr bool PFG = (D == 128);
     StageRegs<D, 64, TI> qr, gr;
-    qr.load(Q + base, D, tid);
+    qr.load(Q, ldq, tid);
     if (PFG) gr.load(dO + base, D, tid);
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         }
         __syncthreads();
         if (q0 + 64 < N) {
-            qr.load(Q + base + (long)(q0 + 64) * D, D, tid);
+            qr.load(Q + (long)(q0 + 64) * ldq, ldq, tid);
             if (PFG) gr.load(dO + base + (long)(q0 + 64) * D, D, tid);
         }
         f32x16 s[2], dp[2];
@@ -405,8 +411,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         mma_tr_x_tile<D>(dv, Gs, s, lane);                    // dV^T += dO^T P
         mma_tr_x_tile<D>(dk, Qs, dp, lane);                   // dK^T += Q^T dS
     }
-    store_ct<D>(dK + base + (long)key * D, dk, 1.f, nullptr, lh);
-    store_ct<D>(dV + base + (long)key * D, dv, 1.f, dOres ? dOres + base + (long)key * D : nullptr, lh);
+    store_ct<D>(dK + ((long)blockIdx.y * N + key) * lddk, dk, 1.f, nullptr, lh);
+    store_ct<D>(dV + base + (long)key * D, dv, 1.f, dVadd ? dVadd + base + (long)key * D : nullptr, lh);
 }
 
 }  // namespace hupr
@@ -416,13 +422,14 @@ using namespace hupr;
 extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C == 128) && N % 128 == 0 && N >= 128) ? 1 : 0; }
 
 template <typename TI>
-static int attn_fwd(const char* who, const TI* K, const TI* Q, const TI* V, const float* Vres, float* out, float* lse, int Bn,
-                    int N, int C, hupr_stream_t stream) {
+static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const float* Vres, float* out,
+                    float* lse, int Bn, int N, int C, hupr_stream_t stream) {
     HUPR_REQUIRE(K && Q && V && out && lse && Bn > 0, "%s: bad argument", who);
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
+    HUPR_REQUIRE(ldk >= C && ldq >= C && ldk % 8 == 0 && ldq % 8 == 0, "%s: bad row strides %d %d", who, ldk, ldq);
     dim3 grid(N / 128, Bn);
-    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N);
-    else hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N);
+    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq);
+    else hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq);
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
@@ -430,35 +437,45 @@ static int attn_fwd(const char* who, const TI* K, const TI* Q, const TI* V, cons
 // out (B,N,C) = softmax_keys(K Q^T)-weighted V (+V); lse (B,N) saved for the backward
 extern "C" int hupr_attn_fwd_bf16(const float* K, const float* Q, const float* V, float* out, float* lse, int Bn, int N, int C,
                                   int residual, hupr_stream_t stream) {
-    return attn_fwd("hupr_attn_fwd_bf16", K, Q, V, residual ? V : nullptr, out, lse, Bn, N, C, stream);
+    return attn_fwd("hupr_attn_fwd_bf16", K, C, Q, C, V, residual ? V : nullptr, out, lse, Bn, N, C, stream);
 }
 // same with K, Q, V given as pre-rounded bf16 copies (hupr_cast_f32_to_bf16); Vres: fp32 V for the residual, or null
 extern "C" int hupr_attn_fwd_bf16in(const void* K, const void* Q, const void* V, const float* Vres, float* out, float* lse,
                                     int Bn, int N, int C, hupr_stream_t stream) {
-    return attn_fwd("hupr_attn_fwd_bf16in", static_cast<const __bf16*>(K), static_cast<const __bf16*>(Q),
+    return attn_fwd("hupr_attn_fwd_bf16in", static_cast<const __bf16*>(K), C, static_cast<const __bf16*>(Q), C,
+                    static_cast<const __bf16*>(V), Vres, out, lse, Bn, N, C, stream);
+}
+// ... and with row strides ldk / ldq (elements) for K and Q: the key / query projections of one map stored side by side
+// in one (B, N, ld) tensor (MSCSA level: four 1x1 projections of a map computed by one GEMM)
+extern "C" int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres,
+                                       float* out, float* lse, int Bn, int N, int C, hupr_stream_t stream) {
+    return attn_fwd("hupr_attn_fwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
                     static_cast<const __bf16*>(V), Vres, out, lse, Bn, N, C, stream);
 }
 
 // dK, dQ, dV (B,N,C) from dout; Dq: scratch (B,N) floats.  V32 / out / dout32: fp32 tensors of the exact row-sum
 // D = rowsum(dO o (out - V)) and the residual epilogue; K, Q, V, dO: the MFMA operands (fp32 or bf16 copies).
+// ldk / ldq / lddk / lddq: row strides of K, Q, dK, dQ.  dVadd: tensor added to dV in the epilogue (dout32 for the
+// residual form; may be dV itself to accumulate onto what another attention over the same values left there), or null.
 template <typename TI>
-static int attn_bwd(const char* who, const TI* K, const TI* Q, const TI* V, const TI* dO, const float* V32, const float* out,
-                    const float* dout32, const float* lse, float* dK, float* dQ, float* dV, float* Dq, int Bn, int N, int C,
-                    int residual, hupr_stream_t stream) {
+static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const TI* dO, const float* V32,
+                    const float* out, const float* dout32, const float* lse, float* dK, int lddk, float* dQ, int lddq,
+                    float* dV, const float* dVadd, float* Dq, int Bn, int N, int C, int residual, hupr_stream_t stream) {
     HUPR_REQUIRE(K && Q && V && dO && V32 && out && dout32 && lse && dK && dQ && dV && Dq && Bn > 0, "%s: bad argument", who);
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
+    HUPR_REQUIRE(ldk >= C && ldq >= C && lddk >= C && lddq >= C && ldk % 8 == 0 && ldq % 8 == 0 && lddk % 4 == 0 && lddq % 4 == 0,
+                 "%s: bad row strides", who);
     hipStream_t s = as_stream(stream);
     const long rows = (long)Bn * N;
     dim3 grid(N / 128, Bn);
-    const float* dres = residual ? dout32 : nullptr;
     if (C == 64) {
         hipLaunchKernelGGL(hupr_k_attn_prep<64>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout32, out, V32, Dq, rows, residual);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dres, lse, Dq, dK, dV, N);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dVadd, lse, Dq, dK, dV, N, ldk, ldq, lddk);
     } else {
         hipLaunchKernelGGL(hupr_k_attn_prep<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout32, out, V32, Dq, rows, residual);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dres, lse, Dq, dK, dV, N);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq);
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dVadd, lse, Dq, dK, dV, N, ldk, ldq, lddk);
     }
     HUPR_LAUNCH_OK("hupr_k_attn_bwd");
     return HUPR_OK;
@@ -467,12 +484,24 @@ static int attn_bwd(const char* who, const TI* K, const TI* Q, const TI* V, cons
 extern "C" int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const float* out, const float* dout,
                                   const float* lse, float* dK, float* dQ, float* dV, float* Dq, int Bn, int N, int C,
                                   int residual, hupr_stream_t stream) {
-    return attn_bwd("hupr_attn_bwd_bf16", K, Q, V, dout, V, out, dout, lse, dK, dQ, dV, Dq, Bn, N, C, residual, stream);
+    return attn_bwd("hupr_attn_bwd_bf16", K, C, Q, C, V, dout, V, out, dout, lse, dK, C, dQ, C, dV, residual ? dout : nullptr, Dq,
+                    Bn, N, C, residual, stream);
 }
 extern "C" int hupr_attn_bwd_bf16in(const void* K, const void* Q, const void* V, const void* dO, const float* V32,
                                     const float* out, const float* dout32, const float* lse, float* dK, float* dQ, float* dV,
                                     float* Dq, int Bn, int N, int C, int residual, hupr_stream_t stream) {
-    return attn_bwd("hupr_attn_bwd_bf16in", static_cast<const __bf16*>(K), static_cast<const __bf16*>(Q),
-                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), V32, out, dout32, lse, dK, dQ, dV, Dq, Bn, N,
-                    C, residual, stream);
+    return attn_bwd("hupr_attn_bwd_bf16in", static_cast<const __bf16*>(K), C, static_cast<const __bf16*>(Q), C,
+                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), V32, out, dout32, lse, dK, C, dQ, C, dV,
+                    residual ? dout32 : nullptr, Dq, Bn, N, C, residual, stream);
+}
+// strided form (see hupr_attn_fwd_bf16in_ld): dK / dQ land in column blocks of wider gradient tensors; accumulate != 0
+// (non-residual form only) adds the result onto the dV already in place
+extern "C" int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const void* dO,
+                                       const float* V32, const float* out, const float* dout32, const float* lse, float* dK,
+                                       int lddk, float* dQ, int lddq, float* dV, float* Dq, int Bn, int N, int C,
+                                       int residual, int accumulate, hupr_stream_t stream) {
+    HUPR_REQUIRE(!(residual && accumulate), "hupr_attn_bwd_bf16in_ld: accumulate is for the non-residual form");
+    return attn_bwd("hupr_attn_bwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
+                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), V32, out, dout32, lse, dK, lddk, dQ, lddq,
+                    dV, residual ? dout32 : (accumulate ? dV : nullptr), Dq, Bn, N, C, residual, stream);
 }

@@ -654,6 +654,105 @@ class AttentionFn(torch.autograd.Function):
         return dk, dq, dv, None
 
 
+LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
+
+
+def mscsa_level_fused_ok(ra):
+    """One MSCSA level can run as MSCSALevelFn: bf16 math, fused attention kernels available for this (N, C)."""
+    B, _, H, W, C = ra.shape
+    return (LEVEL_FUSION and MATH == "bf16" and USE_FLASH and ra.dtype == torch.float32
+            and bool(rt.lib().hupr_attn_flash_supported(H * W, C)))
+
+
+class MSCSALevelFn(torch.autograd.Function):
+    """One level of the multi-scale cross/self attention (models/layers.py:150-163 of the reference): eight 1x1
+    projections of the two maps and the four attentions they feed, as one autograd node.
+
+        ra . [phi_cross_hori | theta_cross_hori | phi_self_hori | theta_self_hori] -> Ya (B, N, 4C) bf16
+        re . [phi_cross_vert | theta_cross_vert | phi_self_vert | theta_self_vert] -> Ye
+        out1 = attn(K=Ya[0], Q=Ye[1], V=ra) + ra      out2 = attn(K=Ya[2], Q=Ya[3], V=ra)
+        out3 = attn(K=Ye[0], Q=Ya[1], V=re) + re      out4 = attn(K=Ye[2], Q=Ye[3], V=re)
+
+    The four projections of a map are ONE GEMM whose epilogue stores the bf16 operands the attention kernels read (no
+    fp32 projections, no casts); the backward lets the attention kernels write dK / dQ into column blocks of dYa / dYe
+    and accumulate both dV of a map in place, so each map's gradient is one GEMM (K = 4C) with dV as its residual term
+    and each map's four weight gradients are one split-K GEMM — no gradient-accumulation kernels at all.
+    Weights: the eight (C, C, 1, 1) parameters in the order of the two lists above."""
+
+    #            K source/slot, Q source/slot, V map (0: ra, 1: re), residual
+    SPEC = ((0, 0, 1, 1, 0, True), (0, 2, 0, 3, 0, False), (1, 0, 0, 1, 1, True), (1, 2, 1, 3, 1, False))
+
+    @staticmethod
+    def forward(ctx, ra, re, *weights):
+        assert len(weights) == 8
+        ra, re = _c(ra), _c(re)
+        B, _, H, W, C = ra.shape
+        N = H * W
+        L = rt.lib()
+        dev = ra.device
+        bf = torch.bfloat16
+        maps = (ra, re)
+        Wc = (torch.cat([w.reshape(C, C) for w in weights[:4]], 0), torch.cat([w.reshape(C, C) for w in weights[4:]], 0))
+        Y = (torch.empty((B, N, 4 * C), dtype=bf, device=dev), torch.empty((B, N, 4 * C), dtype=bf, device=dev))
+        for x, wc, y in zip(maps, Wc, Y):          # a 1x1 kernel's packed layout IS the parameter layout (Co, Ci)
+            rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(y), 1, B, 1, H, W, C, C, 1, H, W,
+                                                4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.stream()))
+        vb = (_cast(ra, bf), _cast(re, bf))
+        outs = [torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev) for _ in range(4)]
+        lses = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(4)]
+        for (ks, kslot, qs, qslot, vs, residual), out, lse in zip(MSCSALevelFn.SPEC, outs, lses):
+            rt.check(L.hupr_attn_fwd_bf16in_ld(Y[ks].data_ptr() + kslot * C * 2, 4 * C, Y[qs].data_ptr() + qslot * C * 2, 4 * C,
+                                               rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None, rt.ptr(out),
+                                               rt.ptr(lse), B, N, C, rt.stream()))
+        ctx.save_for_backward(ra, re, Wc[0], Wc[1], Y[0], Y[1], vb[0], vb[1], *outs, *lses)
+        ctx.weights = weights
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        t = ctx.saved_tensors
+        maps, Wc, Y, vb, outs, lses = t[0:2], t[2:4], t[4:6], t[6:8], t[8:12], t[12:16]
+        weights = ctx.weights
+        B, _, H, W, C = maps[0].shape
+        N = H * W
+        L = rt.lib()
+        dev = maps[0].device
+        f32 = torch.float32
+        dY = (torch.empty((B, N, 4 * C), dtype=f32, device=dev), torch.empty((B, N, 4 * C), dtype=f32, device=dev))
+        dV = (torch.empty((B, N, C), dtype=f32, device=dev), torch.empty((B, N, C), dtype=f32, device=dev))
+        dq_scr = torch.empty((B, N), dtype=f32, device=dev)
+        for (ks, kslot, qs, qslot, vs, residual), out, lse, dout in zip(MSCSALevelFn.SPEC, outs, lses, douts):
+            dout = _c(dout)
+            gb = _cast(dout, torch.bfloat16)
+            rt.check(L.hupr_attn_bwd_bf16in_ld(
+                Y[ks].data_ptr() + kslot * C * 2, 4 * C, Y[qs].data_ptr() + qslot * C * 2, 4 * C, rt.ptr(vb[vs]), rt.ptr(gb),
+                rt.ptr(maps[vs]), rt.ptr(out), rt.ptr(dout), rt.ptr(lse), dY[ks].data_ptr() + kslot * C * 4, 4 * C,
+                dY[qs].data_ptr() + qslot * C * 4, 4 * C, rt.ptr(dV[vs]), rt.ptr(dq_scr), B, N, C, 1 if residual else 0,
+                0 if residual else 1, rt.stream()))          # SPEC order: the residual attention of a map writes dV, the other adds
+        grads = [None, None]
+        for i in range(2):
+            if ctx.needs_input_grad[i]:
+                dx = torch.empty_like(maps[i])
+                rt.check(L.hupr_gemm_bf16(0, 0, rt.ptr(dY[i]), rt.ptr(Wc[i]), rt.ptr(dx), B * N, C, 4 * C, 4 * C, C, C, 1, 0, 0,
+                                          0, rt.ptr(dV[i]), C, 0, 0, rt.stream()))
+                grads[i] = dx
+        wgrads = [None] * 8
+        for i in range(2):
+            if not any(ctx.needs_input_grad[2 + 4 * i + j] for j in range(4)):
+                continue
+            dWc = torch.empty((4 * C, C), dtype=f32, device=dev)
+            ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, C, 4 * C, 1, 1, 1), dev)
+            rt.check(L.hupr_conv_wgrad_bf16(rt.ptr(maps[i]), rt.ptr(dY[i]), rt.ptr(dWc), B, 1, H, W, C, C, 1, H, W, 4 * C, 4 * C,
+                                            1, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
+            for j in range(4):
+                w = weights[4 * i + j]
+                if ctx.needs_input_grad[2 + 4 * i + j]:
+                    g, direct = _pgrad(w)
+                    g.copy_(dWc[j * C:(j + 1) * C].view_as(w))
+                    wgrads[4 * i + j] = _pret(w, g, direct)
+        return (grads[0], grads[1]) + tuple(wgrads)
+
+
 class GCNLayerFn(torch.autograd.Function):
     """y = act( (W x) A + bias ) == W (x A) + bias  (models/gcn_networks.py:23-29); x, y: (B, F, ld=16)."""
 

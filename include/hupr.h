@@ -224,6 +224,16 @@ int hupr_attn_fwd_bf16in(const void* K, const void* Q, const void* V, const floa
 int hupr_attn_bwd_bf16in(const void* K, const void* Q, const void* V, const void* dO, const float* V32, const float* out,
                          const float* dout32, const float* lse, float* dK, float* dQ, float* dV, float* Dq_scratch,
                          int Bn, int N, int C, int residual, hupr_stream_t stream);
+/* Strided forms for one MSCSA level (models/layers.py:150-163: eight 1x1 projections of the two maps feed four attentions):
+ * the four projections of a map are one GEMM into a (B, N, 4C) bf16 tensor, K / Q point at column blocks of it with
+ * row strides ldk / ldq (elements), and the backward writes dK / dQ into column blocks (lddk / lddq) of the matching
+ * fp32 gradient tensors.  accumulate != 0 (non-residual form) adds onto the dV another attention left in place. */
+int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres, float* out,
+                            float* lse, int Bn, int N, int C, hupr_stream_t stream);
+int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const void* dO,
+                            const float* V32, const float* out, const float* dout32, const float* lse, float* dK,
+                            int lddk, float* dQ, int lddq, float* dV, float* Dq_scratch, int Bn, int N, int C,
+                            int residual, int accumulate, hupr_stream_t stream);
 
 /* (a7) PRGCN: y = act(t . A + bias) with t = W . x computed by hupr_gemm_f32 (gcn_networks.py:23-29,53-58) */
 int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,

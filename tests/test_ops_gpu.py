@@ -558,6 +558,41 @@ def test_temporal_merge_bf16_activations(B, G, H, W, C, bf16_math):
     close(wg.grad, w32.grad, 2e-6, "wgrad vs generic")
 
 
+@pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (64, 32)])
+def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
+    """MSCSALevelFn (one GEMM per map for its four 1x1 projections with bf16 epilogue, strided attention operands,
+    in-place dV accumulation, one dgrad / wgrad GEMM per map) against the same level composed from ConvFn + AttentionFn:
+    the forward is bit-identical (same products, same rounding points), the gradients differ only by summation order."""
+    from hupr_amd import functional as F_
+    B, N = 2, H * H
+    ra, re = rnd(B, 1, H, H, C, seed=90).cuda(), rnd(B, 1, H, H, C, seed=91).cuda()
+    ws = [rnd(C, C, 1, 1, seed=92 + i, scale=C ** -0.5).cuda() for i in range(8)]
+    gs = [rnd(B, 1, H, H, C, seed=110 + i).cuda() for i in range(4)]
+
+    def run(fused):
+        a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        if fused:
+            assert F_.mscsa_level_fused_ok(a)
+            outs = F_.MSCSALevelFn.apply(a, e, *w)
+        else:
+            conv = lambda x, wt: F_.conv(x, wt, None, None, (0, 0, 0))
+            att = lambda k, q, v, res: F_.AttentionFn.apply(k.reshape(B, N, C), q.reshape(B, N, C), v.reshape(B, N, C),
+                                                            res).reshape(B, 1, H, H, C)
+            k_c_h, q_c_h, k_h, q_h = [conv(a, w[i]) for i in range(4)]
+            k_c_v, q_c_v, k_v, q_v = [conv(e, w[4 + i]) for i in range(4)]
+            outs = (att(k_c_h, q_c_v, a, True), att(k_h, q_h, a, False), att(k_c_v, q_c_h, e, True), att(k_v, q_v, e, False))
+        sum((o * g).sum() for o, g in zip(outs, gs)).backward()
+        return [o.detach() for o in outs], [a.grad, e.grad] + [t.grad for t in w]
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    for i, (x, y) in enumerate(zip(o1, o0)):
+        assert torch.equal(x, y), "attention output %d differs" % i
+    for i, (x, y) in enumerate(zip(g1, g0)):
+        close(x, y, 2e-5, "gradient %d (0,1: maps; 2..9: projection weights)" % i)
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_block_tail_bf16_activations(training):
     """BNActFn / BNAddBNReLUFn on bf16 storage == the fp32-storage kernels on the same (bf16-representable) data,
