@@ -35,10 +35,10 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
 template <bool ABF>
 __device__ __forceinline__ void halo_store_voxel(const HaloArgs& p, const f32x16& acc, long m, int chb) {
     if constexpr (ABF) {
-        // bf16 output without a residual: lanes l and l + 32 hold the two 4-channel halves of the same voxel's 8-channel
-        // groups; one v_permlane32_swap per dword gives each of them a full 16-byte run (two stores per tile instead of
-        // four 8-byte ones — the epilogue is store-issue bound)
-        if (!p.res && (p.Co & 7) == 0 && (p.out_ld & 7) == 0) {
+        // bf16 output: lanes l and l + 32 hold the two 4-channel halves of the same voxel's 8-channel groups; one
+        // v_permlane32_swap per dword gives each of them a full 16-byte run (two stores per tile instead of four 8-byte
+        // ones — the epilogue is store-issue bound).  A residual is added to the lane's own channels before the swap.
+        if ((p.Co & 7) == 0 && (p.out_ld & 7) == 0) {
             const int lh = (chb >> 2) & 1, cb = chb - 4 * lh;
             unsigned pk[4][2];
 #pragma unroll
@@ -46,6 +46,10 @@ __device__ __forceinline__ void halo_store_voxel(const HaloArgs& p, const f32x16
                 f32x4n v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                 const int ch = chb + 8 * g;
                 if (p.bias && ch < p.Co) v += (f32x4n){p.bias[ch], p.bias[ch + 1], p.bias[ch + 2], p.bias[ch + 3]};
+                if (p.res && ch < p.Co) {
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.res) + m * p.res_ld + ch);
+                    v += (f32x4n){(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+                }
                 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                 const bf16x2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
                 pk[g][0] = __builtin_bit_cast(unsigned, lo);

@@ -203,11 +203,13 @@ def _halo_ok(x, k, pad, co=4):
     return bool(rt.lib().hupr_conv3x3_halo_supported(Di, Hi, Wi, Ci, k[0], k[1], k[2], pad[0], pad[1], pad[2]))
 
 
-def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent):
-    """weight: parameter-layout tensor (Co', Ci', taps...) packed here (mode 0 forward / 1 input gradient)."""
+def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None):
+    """weight: parameter-layout tensor (Co', Ci', taps...) packed here (mode 0 forward / 1 input gradient).
+    out: write here instead of a fresh tensor (may be ``res`` itself: the epilogue reads a residual element right
+    before the same lane overwrites it)."""
     B, Di, Hi, Wi, Ci = _vox(x)
     Do, Ho, Wo = out_extent
-    y = torch.empty((B, Do, Ho, Wo, co), dtype=x.dtype, device=x.device)
+    y = torch.empty((B, Do, Ho, Wo, co), dtype=x.dtype, device=x.device) if out is None else out
     ev = CONV_PROBE(x, co, k) if CONV_PROBE is not None else None
     abf = x.dtype == torch.bfloat16
     if _halo_ok(x, k, pad, co):
@@ -302,6 +304,60 @@ class ConvFn(torch.autograd.Function):
                                         rt.stream()))
         dres = dy if ctx.has_res else None
         return dx, _pret(weight, dw, dw_direct), _pret(ctx.bias_ref, db, db_direct), dres, None
+
+
+class DualConvFn(torch.autograd.Function):
+    """Two bias-free "same" 3x3(x3) convolutions of one bf16-stored map (the main[0] / downsample[0] pair of a
+    BasicBlock3D, reference models/layers.py:55-65) as one autograd node, so that the two input gradients are summed
+    in the second kernel's residual epilogue instead of by a separate accumulation kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w_a, w_b, pad):
+        x = _c(x)
+        k = _ksize(w_a)
+        B, D, H, W, Ci = _vox(x)
+        co = w_a.shape[0]
+        assert w_b.shape == w_a.shape and _halo_ok(x, k, pad, co)
+        y_a = _conv_raw(x, w_a, 0, None, None, co, k, pad, (D, H, W))
+        y_b = _conv_raw(x, w_b, 0, None, None, co, k, pad, (D, H, W))
+        ctx.save_for_backward(x, w_a, w_b)
+        ctx.k, ctx.pad = k, pad
+        return y_a, y_b
+
+    @staticmethod
+    def backward(ctx, dy_a, dy_b):
+        x, w_a, w_b = ctx.saved_tensors
+        dy = (_c(dy_a), _c(dy_b))
+        k, pad = ctx.k, ctx.pad
+        B, D, H, W, Ci = _vox(x)
+        Co = w_a.shape[0]
+        L = rt.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dpad = (k[0] - 1 - pad[0], k[1] - 1 - pad[1], k[2] - 1 - pad[2])
+            dx = _conv_raw(dy[0], w_a, 1, None, None, Ci, k, dpad, (D, H, W))
+            dx = _conv_raw(dy[1], w_b, 1, None, dx, Ci, k, dpad, (D, H, W), out=dx)
+        grads = []
+        for i, w in enumerate((w_a, w_b)):
+            if not ctx.needs_input_grad[1 + i]:
+                grads.append(None)
+                continue
+            dw, direct = _pgrad(w)
+            ws = workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, k[0]), x.device)
+            fn = L.hupr_conv3x3_wgrad_halo_bf16act if x.dtype == torch.bfloat16 else L.hupr_conv3x3_wgrad_halo_bf16
+            rt.check(fn(rt.ptr(x), rt.ptr(dy[i]), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, k[0], rt.ptr(ws), ws.numel(),
+                        rt.stream()))
+            grads.append(_pret(w, dw, direct))
+        return dx, grads[0], grads[1], None
+
+
+def dual_conv(x, w_a, w_b, pad):
+    """(conv(x, w_a), conv(x, w_b)); fused input-gradient accumulation where the halo kernels apply."""
+    k = _ksize(w_a)
+    if w_a.shape == w_b.shape and _halo_ok(x, k, pad, w_a.shape[0]) and x.shape[-1] % 32 == 0 and w_a.shape[0] % 8 == 0 \
+            and os.environ.get("HUPR_NO_DUAL_CONV", "0") != "1":
+        return DualConvFn.apply(x, w_a, w_b, tuple(pad))
+    return ConvFn.apply(x, w_a, None, None, tuple(pad)), ConvFn.apply(x, w_b, None, None, tuple(pad))
 
 
 def conv(x, weight, bias=None, res=None, pad=(0, 0, 0)):

@@ -66,8 +66,8 @@ class BasicBlock3D(nn.Module):
         self.relu = activation()
 
     def forward(self, x):
-        res = _conv(x, self.downsample[0])
-        out = _conv(x, self.main[0])
+        # the two convolutions of x as one node: their input gradients are summed in the second kernel's epilogue
+        out, res = F_.dual_conv(x, self.main[0].weight, self.downsample[0].weight, tuple(self.main[0].padding))
         bn1 = self.main[1]
         out = F_.BNActFn.apply(out, bn1.weight, bn1.bias, bn1, self.training, True)
         out = _conv(out, self.main[3])

@@ -558,6 +558,33 @@ def test_temporal_merge_bf16_activations(B, G, H, W, C, bf16_math):
     close(wg.grad, w32.grad, 2e-6, "wgrad vs generic")
 
 
+@pytest.mark.parametrize("act", ["bf16", "f32"])
+def test_dual_conv_matches_two_convs(act, bf16_math):
+    """DualConvFn (input gradients of the two convolutions summed in the second kernel's residual epilogue, in place)
+    against two ConvFn nodes whose input gradients autograd adds."""
+    from hupr_amd import functional as F_
+    B, Ci, Co, D, H, W = 2, 64, 128, 4, 16, 16
+    dt = torch.bfloat16 if act == "bf16" else torch.float32
+    x0 = cl(rnd(B, Ci, D, H, W, seed=120)).cuda().to(dt)
+    wa0, wb0 = (rnd(Co, Ci, 3, 3, 3, seed=121 + i, scale=(Ci * 27) ** -0.5).cuda() for i in range(2))
+    ga, gb = (cl(rnd(B, Co, D, H, W, seed=123 + i)).cuda().to(dt) for i in range(2))
+
+    def run(fused):
+        x = x0.clone().requires_grad_(True)
+        wa, wb = wa0.clone().requires_grad_(True), wb0.clone().requires_grad_(True)
+        if fused:
+            ya, yb = F_.DualConvFn.apply(x, wa, wb, (1, 1, 1))
+        else:
+            ya, yb = F_.conv(x, wa, None, None, (1, 1, 1)), F_.conv(x, wb, None, None, (1, 1, 1))
+        torch.autograd.backward([ya, yb], [ga, gb])
+        return ya.detach(), yb.detach(), x.grad, wa.grad, wb.grad
+
+    f, u = run(True), run(False)
+    assert torch.equal(f[0], u[0]) and torch.equal(f[1], u[1])
+    close(f[2].float(), u[2].float(), 1e-2 if act == "bf16" else 1e-6, "summed input gradient")
+    assert torch.equal(f[3], u[3]) and torch.equal(f[4], u[4])
+
+
 @pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (64, 32)])
 def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
     """MSCSALevelFn (one GEMM per map for its four 1x1 projections with bf16 epilogue, strided attention operands,
