@@ -68,6 +68,34 @@ __device__ __forceinline__ void st_act4(__bf16* p, float4 v) {
     *reinterpret_cast<hupr_bf16x4*>(p) = o;
 }
 
+// 16-byte activation vectors: V consecutive channels (4 fp32 / 8 bf16) loaded to / stored from fp32 registers
+template <typename T> struct ActVec;
+template <> struct ActVec<float> {
+    static constexpr int V = 4;
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct ActVec<__bf16> {
+    static constexpr int V = 8;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void load(const __bf16* p, float* v) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
+    }
+    static __device__ __forceinline__ void store(__bf16* p, const float* v) {
+        bf16x8 t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (__bf16)v[k];
+        *reinterpret_cast<bf16x8*>(p) = t;
+    }
+};
+
 static inline hipStream_t as_stream(hupr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -11,34 +11,6 @@ namespace hupr {
 
 constexpr int kStatBlocks = 512;
 
-// V consecutive channels per thread as one 16-byte access: 4 fp32 or 8 bf16
-template <typename T> struct ActVec;
-template <> struct ActVec<float> {
-    static constexpr int V = 4;
-    static __device__ __forceinline__ void load(const float* p, float* v) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
-    static __device__ __forceinline__ void store(float* p, const float* v) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-};
-template <> struct ActVec<__bf16> {
-    static constexpr int V = 8;
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    static __device__ __forceinline__ void load(const __bf16* p, float* v) {
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
-    }
-    static __device__ __forceinline__ void store(__bf16* p, const float* v) {
-        bf16x8 t;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = (__bf16)v[k];
-        *reinterpret_cast<bf16x8*>(p) = t;
-    }
-};
-
 // ------------------------------------------------------------------------------------------
 // column statistics: for every channel c: S1 = sum_r f(r,c), S2 = sum_r g(r,c)
 //   MODE 0 (forward) : f = x,             g = x*x

@@ -199,6 +199,36 @@ __device__ __forceinline__ float lin_weight(int o, int i, int in, int out) {
     if (l.i1 == i) w += l.w1;                            // at the clamped upper edge both taps hit the same voxel
     return w;
 }
+// the same two helpers with the per-axis ratios hoisted out of the voxel loops (scale = (in-1)/(out-1) exactly as
+// lin_coord computes it, inv = (out-1)/(in-1)): the backward kernel evaluates tens of candidate weights per voxel
+struct LinAxis {
+    int in, out;
+    float scale, inv;
+};
+__device__ __forceinline__ LinAxis lin_axis(int in, int out) {
+    LinAxis a;
+    a.in = in; a.out = out;
+    a.scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    a.inv = (in > 1) ? (float)(out - 1) / (float)(in - 1) : 0.f;
+    return a;
+}
+__device__ __forceinline__ void lin_range(int i, const LinAxis& a, int& lo, int& hi) {
+    if (a.out == 1 || a.in == 1) { lo = 0; hi = a.out - 1; return; }
+    // contributors have scale * o in (i - 1, i + 1), i.e. o in ((i-1) inv, (i+1) inv); 1/32 covers the float rounding of
+    // scale, inv and the products for any extent below 2^15 (a zero-weight candidate costs one weight evaluation)
+    lo = max(0, (int)ceilf((float)(i - 1) * a.inv - 0.03125f));
+    hi = min(a.out - 1, (int)floorf((float)(i + 1) * a.inv + 0.03125f));
+}
+__device__ __forceinline__ float lin_weight(int o, int i, const LinAxis& a) {
+    const float src = a.scale * (float)o;
+    const int i0 = (int)src;
+    const int i1 = i0 + ((i0 < a.in - 1) ? 1 : 0);
+    const float w1 = src - (float)i0;
+    float w = 0.f;
+    if (i0 == i) w += 1.f - w1;
+    if (i1 == i) w += w1;
+    return w;
+}
 
 // forward: y[o] = sum over the 8 corner voxels
 template <typename T>
@@ -241,45 +271,57 @@ __global__ __launch_bounds__(256) void hupr_k_interp_fwd(const T* __restrict__ s
     }
 }
 
-// backward, gather form: each thread owns one INPUT voxel (x 4 channels) and sums the output gradients that
-// touched it — deterministic, no atomics, no zero-fill pass.
-template <typename T>
+// backward, gather form: each thread owns one INPUT voxel x VPT 16-byte channel vectors and sums the output gradients
+// that touched it — deterministic, no atomics, no zero-fill pass.  The kernel is VALU-bound on the candidate-weight
+// arithmetic (tens of weights per voxel), so a thread covers as many channels of its voxel as the shape allows and the
+// candidate window per axis is the exact contributor range widened by a rounding margin only.
+template <typename T, int VPT>
 __global__ __launch_bounds__(256) void hupr_k_interp_bwd(const T* __restrict__ dy, T* __restrict__ dx, int Bn,
                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                                                          int in_ld, int out_ld) {
-    const int c4n = C >> 2;
-    const long total = (long)Bn * Di * Hi * Wi * c4n;
+    constexpr int V = ActVec<T>::V, CH = V * VPT;
+    const int cgn = C / CH;
+    const long total = (long)Bn * Di * Hi * Wi * cgn;
+    const LinAxis ad = lin_axis(Di, Do), ah = lin_axis(Hi, Ho), aw = lin_axis(Wi, Wo);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int c4 = idx % c4n;
-        long v = idx / c4n;
+        const int c0 = (int)(idx % cgn) * CH;
+        long v = idx / cgn;
         const int iw = v % Wi; v /= Wi;
         const int ih = v % Hi; v /= Hi;
         const int id = v % Di;
         const int b = v / Di;
         int dlo, dhi, hlo, hhi, wlo, whi;
-        lin_range(id, Di, Do, dlo, dhi);
-        lin_range(ih, Hi, Ho, hlo, hhi);
-        lin_range(iw, Wi, Wo, wlo, whi);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        lin_range(id, ad, dlo, dhi);
+        lin_range(ih, ah, hlo, hhi);
+        lin_range(iw, aw, wlo, whi);
+        float acc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) acc[k] = 0.f;
         for (int od = dlo; od <= dhi; ++od) {
-            const float wd = (Di == 1 && Do == 1) ? 1.f : lin_weight(od, id, Di, Do);
+            const float wd = (Di == 1 && Do == 1) ? 1.f : lin_weight(od, id, ad);
             if (wd == 0.f) continue;
             for (int oh = hlo; oh <= hhi; ++oh) {
-                const float wh = lin_weight(oh, ih, Hi, Ho);
+                const float wh = lin_weight(oh, ih, ah);
                 if (wh == 0.f) continue;
                 for (int ow = wlo; ow <= whi; ++ow) {
-                    const float ww = lin_weight(ow, iw, Wi, Wo);
+                    const float ww = lin_weight(ow, iw, aw);
                     if (ww == 0.f) continue;
                     const float wgt = wd * wh * ww;
                     const long ovox = (((long)b * Do + od) * Ho + oh) * Wo + ow;
-                    const float4 g = ld_act4(dy + ovox * out_ld + c4 * 4);
-                    acc.x = fmaf(wgt, g.x, acc.x); acc.y = fmaf(wgt, g.y, acc.y);
-                    acc.z = fmaf(wgt, g.z, acc.z); acc.w = fmaf(wgt, g.w, acc.w);
+                    const T* src = dy + ovox * out_ld + c0;
+#pragma unroll
+                    for (int u = 0; u < VPT; ++u) {
+                        float g[V];
+                        ActVec<T>::load(src + u * V, g);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) acc[u * V + k] = fmaf(wgt, g[k], acc[u * V + k]);
+                    }
                 }
             }
         }
         const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
-        st_act4(dx + ivox * in_ld + c4 * 4, acc);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) ActVec<T>::store(dx + ivox * in_ld + c0 + u * V, acc + u * V);
     }
 }
 
@@ -374,9 +416,18 @@ static int interp_bwd(const char* who, const T* dy, T* dx, int Bn, int Di, int H
     HUPR_REQUIRE(dy && dx, "%s: null pointer", who);
     int rc = interp_check(who, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     if (rc) return rc;
-    const long total = (long)Bn * Di * Hi * Wi * (C / 4);
-    hipLaunchKernelGGL(hupr_k_interp_bwd<T>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
-                       as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    constexpr int V = ActVec<T>::V;
+    HUPR_REQUIRE(C % V == 0 && in_ld % V == 0 && out_ld % V == 0, "%s: channels / strides must be multiples of %d", who, V);
+    const long voxels = (long)Bn * Di * Hi * Wi;
+    if (C % (4 * V) == 0 && voxels * (C / (4 * V)) >= 256 * 256) {       // 4 vectors per thread while the grid stays full
+        const long total = voxels * (C / (4 * V));
+        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 4>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    } else {
+        const long total = voxels * (C / V);
+        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 1>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    }
     HUPR_LAUNCH_OK("hupr_k_interp_bwd");
     return HUPR_OK;
 }
