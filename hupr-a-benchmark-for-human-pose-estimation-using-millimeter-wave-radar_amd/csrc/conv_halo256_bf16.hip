@@ -28,6 +28,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];     // double-buffered weight stages
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // static issue priority for the second-dispatched half of the workgroup (it loses every arbitration against its older
+    // SIMD partner otherwise): -2% kernel time measured on the layer-1 shape, either half works, no per-segment flips
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int wm = wave >> 1, wn = wave & 1;                   // wave = depth slice dz (4) x 32-channel half (2)
     const int lr = lane & 31, lh = lane >> 5;
     // MFMA column lr of accumulator tile i  <->  output voxel (dz = wm, hy = 2 (lr >> 3) + i, wx = lr & 7)
