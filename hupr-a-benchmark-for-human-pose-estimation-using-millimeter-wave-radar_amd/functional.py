@@ -714,25 +714,27 @@ LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
 
 
 def mscsa_level_fused_ok(ra):
-    """One MSCSA level can run as MSCSALevelFn: bf16 math, fused attention kernels available for this (N, C)."""
+    """One MSCSA level can run as MSCSALevelFn (bf16 math; any (N, C) — shapes without a fused attention kernel keep the
+    GEMM / row-softmax attention core inside the node)."""
     B, _, H, W, C = ra.shape
-    return (LEVEL_FUSION and MATH == "bf16" and USE_FLASH and ra.dtype == torch.float32
-            and bool(rt.lib().hupr_attn_flash_supported(H * W, C)))
+    return LEVEL_FUSION and MATH == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
 
 
 class MSCSALevelFn(torch.autograd.Function):
     """One level of the multi-scale cross/self attention (models/layers.py:150-163 of the reference): eight 1x1
     projections of the two maps and the four attentions they feed, as one autograd node.
 
-        ra . [phi_cross_hori | theta_cross_hori | phi_self_hori | theta_self_hori] -> Ya (B, N, 4C) bf16
+        ra . [phi_cross_hori | theta_cross_hori | phi_self_hori | theta_self_hori] -> Ya (B, N, 4C)
         re . [phi_cross_vert | theta_cross_vert | phi_self_vert | theta_self_vert] -> Ye
         out1 = attn(K=Ya[0], Q=Ye[1], V=ra) + ra      out2 = attn(K=Ya[2], Q=Ya[3], V=ra)
         out3 = attn(K=Ye[0], Q=Ya[1], V=re) + re      out4 = attn(K=Ye[2], Q=Ye[3], V=re)
 
-    The four projections of a map are ONE GEMM whose epilogue stores the bf16 operands the attention kernels read (no
-    fp32 projections, no casts); the backward lets the attention kernels write dK / dQ into column blocks of dYa / dYe
-    and accumulate both dV of a map in place, so each map's gradient is one GEMM (K = 4C) with dV as its residual term
-    and each map's four weight gradients are one split-K GEMM — no gradient-accumulation kernels at all.
+    The four projections of a map are ONE GEMM; the backward writes dK / dQ into column blocks of dYa / dYe and
+    accumulates both dV of a map in place, so each map's gradient is one GEMM (K = 4C) with dV as its residual term and
+    each map's four weight gradients are one split-K GEMM — no gradient-accumulation kernels at all.
+    Attention core: the fused kernels where they exist for (N, C) — the projection epilogue then stores the bf16
+    operands those kernels read, no fp32 projections and no casts — else GEMM + row-softmax on the fp32 projections
+    (the level-0 maps, C = 256), with the same strided operands / outputs.
     Weights: the eight (C, C, 1, 1) parameters in the order of the two lists above."""
 
     #            K source/slot, Q source/slot, V map (0: ra, 1: re), residual
@@ -746,29 +748,47 @@ class MSCSALevelFn(torch.autograd.Function):
         N = H * W
         L = rt.lib()
         dev = ra.device
-        bf = torch.bfloat16
+        flash = USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
+        ydt = torch.bfloat16 if flash else torch.float32
+        esz = 2 if flash else 4
         maps = (ra, re)
         Wc = (torch.cat([w.reshape(C, C) for w in weights[:4]], 0), torch.cat([w.reshape(C, C) for w in weights[4:]], 0))
-        Y = (torch.empty((B, N, 4 * C), dtype=bf, device=dev), torch.empty((B, N, 4 * C), dtype=bf, device=dev))
+        Y = (torch.empty((B, N, 4 * C), dtype=ydt, device=dev), torch.empty((B, N, 4 * C), dtype=ydt, device=dev))
         for x, wc, y in zip(maps, Wc, Y):          # a 1x1 kernel's packed layout IS the parameter layout (Co, Ci)
-            rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(y), 1, B, 1, H, W, C, C, 1, H, W,
-                                                4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.stream()))
-        vb = (_cast(ra, bf), _cast(re, bf))
+            rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(y), 1 if flash else 0, B, 1, H, W, C, C,
+                                                1, H, W, 4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.stream()))
         outs = [torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev) for _ in range(4)]
-        lses = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(4)]
-        for (ks, kslot, qs, qslot, vs, residual), out, lse in zip(MSCSALevelFn.SPEC, outs, lses):
-            rt.check(L.hupr_attn_fwd_bf16in_ld(Y[ks].data_ptr() + kslot * C * 2, 4 * C, Y[qs].data_ptr() + qslot * C * 2, 4 * C,
-                                               rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None, rt.ptr(out),
-                                               rt.ptr(lse), B, N, C, rt.stream()))
-        ctx.save_for_backward(ra, re, Wc[0], Wc[1], Y[0], Y[1], vb[0], vb[1], *outs, *lses)
+        if flash:
+            vb = (_cast(ra, torch.bfloat16), _cast(re, torch.bfloat16))
+            aux = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(4)]          # log-sum-exp per query
+        else:
+            vb = maps
+            aux = [torch.empty((B, N, N), dtype=torch.float32, device=dev) for _ in range(4)]       # P[query][key]
+        for (ks, kslot, qs, qslot, vs, residual), out, a in zip(MSCSALevelFn.SPEC, outs, aux):
+            kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
+            if flash:
+                rt.check(L.hupr_attn_fwd_bf16in_ld(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
+                                                   rt.ptr(out), rt.ptr(a), B, N, C, rt.stream()))
+            else:
+                # P[q][j] = Q[q] . K[j], softmax over the keys j (row softmax), out = P V (+ V)
+                rt.check(L.hupr_gemm_bf16(0, 1, qp, kp, rt.ptr(a), N, N, C, 4 * C, 4 * C, N, B, N * 4 * C, N * 4 * C, N * N,
+                                          None, 0, 0, 0, rt.stream()))
+                rt.check(L.hupr_softmax_rows_f32(rt.ptr(a), B * N, N, rt.stream()))
+                v = maps[vs]
+                rt.check(L.hupr_gemm_bf16(0, 0, rt.ptr(a), rt.ptr(v), rt.ptr(out), N, C, N, N, C, C, B, N * N, N * C, N * C,
+                                          rt.ptr(v) if residual else None, C, N * C if residual else 0, 0, rt.stream()))
+        ctx.save_for_backward(ra, re, Wc[0], Wc[1], Y[0], Y[1], vb[0], vb[1], *outs, *aux)
         ctx.weights = weights
+        ctx.flash = flash
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
         t = ctx.saved_tensors
-        maps, Wc, Y, vb, outs, lses = t[0:2], t[2:4], t[4:6], t[6:8], t[8:12], t[12:16]
+        maps, Wc, Y, vb, outs, aux = t[0:2], t[2:4], t[4:6], t[6:8], t[8:12], t[12:16]
         weights = ctx.weights
+        flash = ctx.flash
+        esz = 2 if flash else 4
         B, _, H, W, C = maps[0].shape
         N = H * W
         L = rt.lib()
@@ -776,15 +796,32 @@ class MSCSALevelFn(torch.autograd.Function):
         f32 = torch.float32
         dY = (torch.empty((B, N, 4 * C), dtype=f32, device=dev), torch.empty((B, N, 4 * C), dtype=f32, device=dev))
         dV = (torch.empty((B, N, C), dtype=f32, device=dev), torch.empty((B, N, C), dtype=f32, device=dev))
-        dq_scr = torch.empty((B, N), dtype=f32, device=dev)
-        for (ks, kslot, qs, qslot, vs, residual), out, lse, dout in zip(MSCSALevelFn.SPEC, outs, lses, douts):
+        scr = torch.empty((B, N), dtype=f32, device=dev) if flash else torch.empty((B, N, N), dtype=f32, device=dev)
+        # SPEC order: the residual attention of a map writes its dV, the other one adds to it
+        for (ks, kslot, qs, qslot, vs, residual), out, a, dout in zip(MSCSALevelFn.SPEC, outs, aux, douts):
             dout = _c(dout)
-            gb = _cast(dout, torch.bfloat16)
-            rt.check(L.hupr_attn_bwd_bf16in_ld(
-                Y[ks].data_ptr() + kslot * C * 2, 4 * C, Y[qs].data_ptr() + qslot * C * 2, 4 * C, rt.ptr(vb[vs]), rt.ptr(gb),
-                rt.ptr(maps[vs]), rt.ptr(out), rt.ptr(dout), rt.ptr(lse), dY[ks].data_ptr() + kslot * C * 4, 4 * C,
-                dY[qs].data_ptr() + qslot * C * 4, 4 * C, rt.ptr(dV[vs]), rt.ptr(dq_scr), B, N, C, 1 if residual else 0,
-                0 if residual else 1, rt.stream()))          # SPEC order: the residual attention of a map writes dV, the other adds
+            kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
+            dkp, dqp = dY[ks].data_ptr() + kslot * C * 4, dY[qs].data_ptr() + qslot * C * 4
+            if flash:
+                gb = _cast(dout, torch.bfloat16)
+                rt.check(L.hupr_attn_bwd_bf16in_ld(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(gb), rt.ptr(maps[vs]),
+                                                   rt.ptr(out), rt.ptr(dout), rt.ptr(a), dkp, 4 * C, dqp, 4 * C, rt.ptr(dV[vs]),
+                                                   rt.ptr(scr), B, N, C, 1 if residual else 0, 0 if residual else 1,
+                                                   rt.stream()))
+                continue
+            v, P, g = maps[vs], a, rt.ptr(dout)
+            # dV[j] = sum_q P[q][j] dout[q]  (+ dout: residual form; else added onto the dV already there)
+            rt.check(L.hupr_gemm_bf16(1, 0, rt.ptr(P), g, rt.ptr(dV[vs]), N, C, N, N, C, C, B, N * N, N * C, N * C,
+                                      g if residual else None, C, N * C if residual else 0, 0 if residual else 1, rt.stream()))
+            # dP[q][j] = dout[q] . V[j]; dS = softmax backward in place
+            rt.check(L.hupr_gemm_bf16(0, 1, g, rt.ptr(v), rt.ptr(scr), N, N, C, C, C, N, B, N * C, N * C, N * N, None, 0, 0, 0,
+                                      rt.stream()))
+            rt.check(L.hupr_softmax_rows_bwd_f32(rt.ptr(P), rt.ptr(scr), B * N, N, rt.stream()))
+            # dQ[q] = sum_j dS[q][j] K[j];  dK[j] = sum_q dS[q][j] Q[q]   (into their column blocks)
+            rt.check(L.hupr_gemm_bf16(0, 0, rt.ptr(scr), kp, dqp, N, C, N, N, 4 * C, 4 * C, B, N * N, N * 4 * C, N * 4 * C,
+                                      None, 0, 0, 0, rt.stream()))
+            rt.check(L.hupr_gemm_bf16(1, 0, rt.ptr(scr), qp, dkp, N, C, N, N, 4 * C, 4 * C, B, N * N, N * 4 * C, N * 4 * C,
+                                      None, 0, 0, 0, rt.stream()))
         grads = [None, None]
         for i in range(2):
             if ctx.needs_input_grad[i]:

@@ -585,7 +585,7 @@ def test_dual_conv_matches_two_convs(act, bf16_math):
     assert torch.equal(f[3], u[3]) and torch.equal(f[4], u[4])
 
 
-@pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (64, 32)])
+@pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (64, 32), (256, 16), (32, 8)])      # the last two: no fused attention kernel
 def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
     """MSCSALevelFn (one GEMM per map for its four 1x1 projections with bf16 epilogue, strided attention operands,
     in-place dV accumulation, one dgrad / wgrad GEMM per map) against the same level composed from ConvFn + AttentionFn:
