@@ -236,16 +236,50 @@ struct PackDesc {          // mirrors the packed struct built in functional.py (
     long first;            // index of this entry's first element in the concatenated element space
     int co, ci, taps, kind;   // kind 0: fp32 outputs, 1: bf16 outputs
 };
-// One workgroup = 2048 consecutive DESTINATION elements of one layout of one entry (coalesced writes, no per-element
-// search): blocks[b] = {entry, layout, first destination element}.
+// Block kinds (blocks[b] = {entry, layout, start}):
+//   layout 0 / 1: 2048 consecutive DESTINATION elements of that layout of the entry, starting at `start` — the generic
+//                 element-wise form (coalesced writes, 4-byte gathers): small or odd-shaped weights, fp32 outputs;
+//   layout 2    : one 32 (co) x 32 (ci) x taps tile of a bf16-output entry with Co % 32 == 0, Ci % 32 == 0, taps <= 27,
+//                 start = co0 << 32 | ci0.  The tile is read as 32 contiguous runs of 32*taps floats, parked in LDS as
+//                 bf16, and leaves as 64-byte runs of BOTH layouts (16 bytes per lane) — the element-wise form spent
+//                 its time on 4-byte gathers strided by Ci*taps for the transposed layout.
 struct PackBlock { int entry, layout; long start; };
+constexpr int kPackTile = 32, kPackMaxTaps = 27;
 __global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restrict__ descs, const PackBlock* __restrict__ blocks) {
+    __shared__ __bf16 tile[kPackTile * (kPackTile * kPackMaxTaps + 2)];
     const PackBlock pb = blocks[blockIdx.x];
     const PackDesc d = descs[pb.entry];
+    const int tid = threadIdx.x;
+    if (pb.layout == 2) {
+        const int co0 = (int)(pb.start >> 32), ci0 = (int)(pb.start & 0xffffffff);
+        const int T = d.taps, run = kPackTile * T, pitch = run + 2;        // [co][ci][tap] with a padded row
+        for (int idx = tid; idx < kPackTile * run; idx += 256) {
+            const int r = idx / run, o = idx - r * run;
+            tile[r * pitch + o] = (__bf16)d.w[((long)(co0 + r) * d.ci + ci0) * T + o];
+        }
+        __syncthreads();
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        __bf16* wp0 = static_cast<__bf16*>(d.wp0);
+        __bf16* wp1 = static_cast<__bf16*>(d.wp1);
+        const int v8 = (tid & 3) * 8;                                      // 8 consecutive ci (layout 0) / co (layout 1)
+        for (int rt = tid >> 2; rt < kPackTile * T; rt += 64) {
+            const int r = rt / T, t = rt - r * T;                          // layout 0: row (co0 + r, tap t), ci0 + v8 ..
+            bf16x8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tile[r * pitch + (v8 + k) * T + t];
+            *reinterpret_cast<bf16x8*>(wp0 + ((long)(co0 + r) * T + t) * d.ci + ci0 + v8) = v;
+            const int i = r, tf = t;                                       // layout 1: row (ci0 + i, flipped tap tf), co0 + v8 ..
+            bf16x8 u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] = tile[(v8 + k) * pitch + i * T + (T - 1 - tf)];
+            *reinterpret_cast<bf16x8*>(wp1 + ((long)(ci0 + i) * T + tf) * d.co + co0 + v8) = u;
+        }
+        return;
+    }
     const long count = (long)d.co * d.ci * d.taps;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const long l = pb.start + threadIdx.x + 256 * u;
+        const long l = pb.start + tid + 256 * u;
         if (l >= count) break;
         long src;
         if (pb.layout == 0) {                           // [co][tap][ci]

@@ -149,8 +149,12 @@ def _pack_refresh_all(dev):
             rec[i] = (w.data_ptr(), e.wp[0].data_ptr(), e.wp[1].data_ptr(), first, co, ci, taps, e.kind)
             cnt = co * ci * taps
             first += cnt
-            for layout in (0, 1):
-                blocks.extend((i, layout, st) for st in range(0, cnt, 2048))
+            if e.kind == 1 and co % 32 == 0 and ci % 32 == 0 and taps <= 27:
+                # 32 x 32 x taps tiles, both layouts per tile through LDS (hupr_k_pack_table, block layout 2)
+                blocks.extend((i, 2, (c0 << 32) | i0) for c0 in range(0, co, 32) for i0 in range(0, ci, 32))
+            else:
+                for layout in (0, 1):
+                    blocks.extend((i, layout, st) for st in range(0, cnt, 2048))
         blk = np.zeros(len(blocks), dtype=np.dtype([("entry", "<i4"), ("layout", "<i4"), ("start", "<i8")]))
         blk["entry"], blk["layout"], blk["start"] = zip(*blocks)
         tab = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)

@@ -558,6 +558,26 @@ def test_temporal_merge_bf16_activations(B, G, H, W, C, bf16_math):
     close(wg.grad, w32.grad, 2e-6, "wgrad vs generic")
 
 
+def test_pack_cache_table_refresh_matches_single_packs(bf16_math):
+    """The packed-weight cache refreshes every registered weight with ONE table-driven launch (32x32xtaps LDS tiles for
+    bf16 halo weights, element-wise blocks for the rest); both layouts of every entry must equal the one-weight pack
+    kernels bit for bit, before and after the parameters change behind torch's version counter."""
+    from hupr_amd import functional as F_
+    shapes = [((64, 64, 3, 3, 3), 1), ((128, 64, 3, 3), 1), ((64, 32, 3, 3, 3), 1), ((32, 96, 3, 3), 1), ((16, 64, 3, 3), 1),
+              ((64, 64, 8, 1, 1), 0), ((256, 1024, 3, 3), 1)]
+    ws = [(torch.nn.Parameter(rnd(*sh, seed=130 + i).cuda()), kind) for i, (sh, kind) in enumerate(shapes)]
+    single = lambda w, mode, kind: F_.pack_weights_bf16(w, mode) if kind else F_.pack_weights(w, mode)
+    for rnd_ in range(2):
+        for w, kind in ws:
+            for mode in (0, 1):
+                got = F_._packed(w, mode, kind)
+                assert torch.equal(got, single(w, mode, kind)), (tuple(w.shape), mode, kind, rnd_)
+        with torch.no_grad():
+            for w, _ in ws:
+                w.mul_(1.5).add_(0.25)
+        F_.invalidate_packed()
+
+
 @pytest.mark.parametrize("act", ["bf16", "f32"])
 def test_dual_conv_matches_two_convs(act, bf16_math):
     """DualConvFn (input gradients of the two convolutions summed in the second kernel's residual epilogue, in place)
