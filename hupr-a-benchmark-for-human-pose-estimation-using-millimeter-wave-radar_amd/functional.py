@@ -60,6 +60,7 @@ def _c(t):
 # straight into the flat-bucket views, the autograd Functions return None for them, and the 165 per-parameter
 # AccumulateGrad add kernels of a step disappear.  Without a sink every Function returns ordinary gradient tensors.
 GRAD_SINK = None
+BN_COUNTER_SINK = None      # list collecting the BatchNorm modules whose num_batches_tracked is due (tools.engine)
 
 
 def _pgrad(param):
@@ -443,7 +444,10 @@ def _bn_params(x, bn, training):
             float(bn.momentum), float(bn.eps), rt.ptr(mean), rt.ptr(invstd), rt.ptr(scale), rt.ptr(shift),
             rt.ptr(ws), ws.numel(), rt.stream()))
         if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            if BN_COUNTER_SINK is not None:
+                BN_COUNTER_SINK.append(bn)          # the engine bumps all counters of a step with one launch
+            else:
+                bn.num_batches_tracked.add_(1)
     else:
         rt.check(L.hupr_bn_eval_params_f32(rt.ptr(bn.weight), rt.ptr(bn.bias), rt.ptr(bn.running_mean),
                                            rt.ptr(bn.running_var), float(bn.eps), C, rt.ptr(scale),

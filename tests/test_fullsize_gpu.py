@@ -157,6 +157,10 @@ def test_graph_replay_matches_eager_steps():
         rel = ((p1 - p2).norm() / p1.norm()).item()
         assert rel <= 1e-5, rel
         assert abs(float(l1.detach()) - float(l2.detach())) <= 1e-4 * abs(float(l1.detach()))
+        # the BatchNorm step counters (bumped by one launch per step, also inside the graph) count all five steps
+        for eng in (e1, e2):
+            nbt = [v for k, v in eng.model.state_dict().items() if k.endswith("num_batches_tracked")]
+            assert len(nbt) == 30 and all(int(v) == 5 for v in nbt), [int(v) for v in nbt]
     finally:
         F_.set_math("f32")
 
