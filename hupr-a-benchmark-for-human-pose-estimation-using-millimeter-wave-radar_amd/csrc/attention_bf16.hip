@@ -204,6 +204,42 @@ __device__ __forceinline__ void store_ct(float* dst_row, const f32x16* acc, floa
     }
 }
 
+// the same tile set stored as bf16 (8-byte runs of 4 channels): the decoder's copy of an attention output
+template <int D>
+__device__ __forceinline__ void store_ct16(__bf16* dst_row, const f32x16* acc, float scale, const float* add_row, int lh) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ct = 0; ct < D / 32; ++ct) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int c = 32 * ct + 8 * q4 + 4 * lh;
+            float4 v = make_float4(acc[ct][4 * q4] * scale, acc[ct][4 * q4 + 1] * scale, acc[ct][4 * q4 + 2] * scale,
+                                   acc[ct][4 * q4 + 3] * scale);
+            if (add_row) {
+                const float4 a = *reinterpret_cast<const float4*>(add_row + c);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+            const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            *reinterpret_cast<bf16x4*>(dst_row + c) = o;
+        }
+    }
+}
+// store_ct with the added tensor given as bf16 (a gradient that arrives bf16-stored)
+template <int D>
+__device__ __forceinline__ void store_ct_add16(float* dst_row, const f32x16* acc, const __bf16* add_row, int lh) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ct = 0; ct < D / 32; ++ct) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int c = 32 * ct + 8 * q4 + 4 * lh;
+            const bf16x4 a = *reinterpret_cast<const bf16x4*>(add_row + c);
+            *reinterpret_cast<float4*>(dst_row + c) = make_float4(acc[ct][4 * q4] + (float)a[0], acc[ct][4 * q4 + 1] + (float)a[1],
+                                                                  acc[ct][4 * q4 + 2] + (float)a[2], acc[ct][4 * q4 + 3] + (float)a[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
@@ -214,8 +250,9 @@ template <int D, typename TI>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
                                                        float* __restrict__ out, float* __restrict__ lse, int N, int ldk,
-                                                       int ldq) {
-    // ldk / ldq: row strides (elements) of K and Q — the projections of one map may sit side by side in one tensor
+                                                       int ldq, __bf16* __restrict__ out16, int ld16) {
+    // ldk / ldq: row strides (elements) of K and Q — the projections of one map may sit side by side in one tensor;
+    // out16 (optional): a bf16 copy of the output with row stride ld16 (a column block of the decoder's input)
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
@@ -274,12 +311,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
+    if (out16)
+        store_ct16<D>(out16 + ((long)blockIdx.y * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     if (lh == 0) lse[(long)blockIdx.y * N + q] = m_run + __logf(l_tot);
 }
 
 // D[q] = sum_c dO[q,c] * (out[q,c] - (residual ? V[q,c] : 0))
-template <int D>
-__global__ __launch_bounds__(256) void hupr_k_attn_prep(const float* __restrict__ dO, const float* __restrict__ out,
+template <int D, typename TG>
+__global__ __launch_bounds__(256) void hupr_k_attn_prep(const TG* __restrict__ dO, int lddo, const float* __restrict__ out,
                                                         const float* __restrict__ V, float* __restrict__ Dq, long rows,
                                                         int residual) {
     // 16 lanes per row (D/16 floats each)
@@ -290,7 +329,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_prep(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < D / 64; ++i) {
             const long o = row * D + (sub + 16 * i) * 4;
-            const float4 g = *reinterpret_cast<const float4*>(dO + o);
+            const float4 g = ld_act4<TG>(dO + row * lddo + (sub + 16 * i) * 4);
             float4 y = *reinterpret_cast<const float4*>(out + o);
             if (residual) {
                 const float4 v = *reinterpret_cast<const float4*>(V + o);
@@ -311,7 +350,7 @@ template <int D, typename TI>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
-                                                          float* __restrict__ dQ, int N, int ldk, int ldq, int lddq) {
+                                                          float* __restrict__ dQ, int N, int ldk, int ldq, int lddq, int lddo) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
@@ -320,7 +359,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
     K += (long)blockIdx.y * N * ldk;
     bf16x8 qf[D / 16], gf[D / 16];
     load_frags<D, TI>(qf, Q + ((long)blockIdx.y * N + q) * ldq, lh);
-    load_frags<D, TI>(gf, dO + base + (long)q * D, lh);
+    load_frags<D, TI>(gf, dO + ((long)blockIdx.y * N + q) * lddo, lh);
     const float nlse_q = -lse[(long)blockIdx.y * N + q] * kLog2e, d_q = Dq[(long)blockIdx.y * N + q];
     f32x16 dq[D / 32];
 #pragma unroll
@@ -360,7 +399,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
                                                            const float* dVadd,
                                                            const float* __restrict__ lse, const float* __restrict__ Dq,
                                                            float* __restrict__ dK, float* dV, int N, int ldk,
-                                                           int ldq, int lddk) {
+                                                           int ldq, int lddk, int lddo, const __bf16* dVadd16, int ldadd16) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[64 * D];
     __shared__ float s_lse[64], s_d[64];
@@ -371,6 +410,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     load_frags<D, TI>(kf, K + ((long)blockIdx.y * N + key) * ldk, lh);
     load_frags<D, TI>(vf, V + base + (long)key * D, lh);
     Q += (long)blockIdx.y * N * ldq;
+    dO += (long)blockIdx.y * N * lddo;
     f32x16 dk[D / 32], dv[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -381,12 +421,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     constexpr bool PFG = (D == 128);
     StageRegs<D, 64, TI> qr, gr;
     qr.load(Q, ldq, tid);
-    if (PFG) gr.load(dO + base, D, tid);
+    if (PFG) gr.load(dO, lddo, tid);
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
         qr.store(Qs, tid);
         if (PFG) gr.store(Gs, tid);
-        else stage_rows<D, 64, TI>(Gs, dO + base + (long)q0 * D, D, tid);
+        else stage_rows<D, 64, TI>(Gs, dO + (long)q0 * lddo, lddo, tid);
         if (tid < 64) {
             s_lse[tid] = -lse[(long)blockIdx.y * N + q0 + tid] * kLog2e;      // pre-scaled for the exp2 form
             s_d[tid] = Dq[(long)blockIdx.y * N + q0 + tid];
@@ -394,7 +434,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         __syncthreads();
         if (q0 + 64 < N) {
             qr.load(Q + (long)(q0 + 64) * ldq, ldq, tid);
-            if (PFG) gr.load(dO + base + (long)(q0 + 64) * D, D, tid);
+            if (PFG) gr.load(dO + (long)(q0 + 64) * lddo, lddo, tid);
         }
         f32x16 s[2], dp[2];
         mma_rows_x_frags<D>(s, Qs, kf, lr, lh);               // S tile: rows = queries, this lane's column = its key
@@ -412,7 +452,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         mma_tr_x_tile<D>(dk, Qs, dp, lane);                   // dK^T += Q^T dS
     }
     store_ct<D>(dK + ((long)blockIdx.y * N + key) * lddk, dk, 1.f, nullptr, lh);
-    store_ct<D>(dV + base + (long)key * D, dv, 1.f, dVadd ? dVadd + base + (long)key * D : nullptr, lh);
+    if (dVadd16) store_ct_add16<D>(dV + base + (long)key * D, dv, dVadd16 + ((long)blockIdx.y * N + key) * ldadd16, lh);
+    else store_ct<D>(dV + base + (long)key * D, dv, 1.f, dVadd ? dVadd + base + (long)key * D : nullptr, lh);
 }
 
 }  // namespace hupr
@@ -423,13 +464,15 @@ extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C =
 
 template <typename TI>
 static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const float* Vres, float* out,
-                    float* lse, int Bn, int N, int C, hupr_stream_t stream) {
+                    float* lse, void* out16, int ld16, int Bn, int N, int C, hupr_stream_t stream) {
     HUPR_REQUIRE(K && Q && V && out && lse && Bn > 0, "%s: bad argument", who);
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
     HUPR_REQUIRE(ldk >= C && ldq >= C && ldk % 8 == 0 && ldq % 8 == 0, "%s: bad row strides %d %d", who, ldk, ldq);
+    HUPR_REQUIRE(!out16 || (ld16 >= C && ld16 % 4 == 0), "%s: bad bf16 output stride %d", who, ld16);
     dim3 grid(N / 128, Bn);
-    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq);
-    else hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq);
+    __bf16* o16 = static_cast<__bf16*>(out16);
+    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
+    else hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
@@ -437,46 +480,55 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
 // out (B,N,C) = softmax_keys(K Q^T)-weighted V (+V); lse (B,N) saved for the backward
 extern "C" int hupr_attn_fwd_bf16(const float* K, const float* Q, const float* V, float* out, float* lse, int Bn, int N, int C,
                                   int residual, hupr_stream_t stream) {
-    return attn_fwd("hupr_attn_fwd_bf16", K, C, Q, C, V, residual ? V : nullptr, out, lse, Bn, N, C, stream);
+    return attn_fwd("hupr_attn_fwd_bf16", K, C, Q, C, V, residual ? V : nullptr, out, lse, nullptr, 0, Bn, N, C, stream);
 }
 // same with K, Q, V given as pre-rounded bf16 copies (hupr_cast_f32_to_bf16); Vres: fp32 V for the residual, or null
 extern "C" int hupr_attn_fwd_bf16in(const void* K, const void* Q, const void* V, const float* Vres, float* out, float* lse,
                                     int Bn, int N, int C, hupr_stream_t stream) {
     return attn_fwd("hupr_attn_fwd_bf16in", static_cast<const __bf16*>(K), C, static_cast<const __bf16*>(Q), C,
-                    static_cast<const __bf16*>(V), Vres, out, lse, Bn, N, C, stream);
+                    static_cast<const __bf16*>(V), Vres, out, lse, nullptr, 0, Bn, N, C, stream);
 }
 // ... and with row strides ldk / ldq (elements) for K and Q: the key / query projections of one map stored side by side
-// in one (B, N, ld) tensor (MSCSA level: four 1x1 projections of a map computed by one GEMM)
+// in one (B, N, ld) tensor (MSCSA level: four 1x1 projections of a map computed by one GEMM); out16 (optional): a bf16
+// copy of the output written with row stride ld16 (a column block of the decoder's concatenated input)
 extern "C" int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres,
-                                       float* out, float* lse, int Bn, int N, int C, hupr_stream_t stream) {
+                                       float* out, float* lse, void* out16, int ld16, int Bn, int N, int C,
+                                       hupr_stream_t stream) {
     return attn_fwd("hupr_attn_fwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
-                    static_cast<const __bf16*>(V), Vres, out, lse, Bn, N, C, stream);
+                    static_cast<const __bf16*>(V), Vres, out, lse, out16, ld16, Bn, N, C, stream);
 }
 
 // dK, dQ, dV (B,N,C) from dout; Dq: scratch (B,N) floats.  V32 / out / dout32: fp32 tensors of the exact row-sum
 // D = rowsum(dO o (out - V)) and the residual epilogue; K, Q, V, dO: the MFMA operands (fp32 or bf16 copies).
-// ldk / ldq / lddk / lddq: row strides of K, Q, dK, dQ.  dVadd: tensor added to dV in the epilogue (dout32 for the
-// residual form; may be dV itself to accumulate onto what another attention over the same values left there), or null.
+// ldk / ldq / lddk / lddq / lddo: row strides of K, Q, dK, dQ, dO.  dVadd: tensor added to dV in the epilogue (dout32 for
+// the residual form; may be dV itself to accumulate onto what another attention over the same values left there), or
+// null.  dout32 == null (bf16 dO only): the gradient arrived bf16-stored, so dO itself is the exact gradient — the
+// row-sum and the residual term read it directly.
 template <typename TI>
-static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const TI* dO, const float* V32,
-                    const float* out, const float* dout32, const float* lse, float* dK, int lddk, float* dQ, int lddq,
-                    float* dV, const float* dVadd, float* Dq, int Bn, int N, int C, int residual, hupr_stream_t stream) {
-    HUPR_REQUIRE(K && Q && V && dO && V32 && out && dout32 && lse && dK && dQ && dV && Dq && Bn > 0, "%s: bad argument", who);
+static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const TI* dO, int lddo,
+                    const float* V32, const float* out, const float* dout32, const float* lse, float* dK, int lddk, float* dQ,
+                    int lddq, float* dV, int accumulate, float* Dq, int Bn, int N, int C, int residual, hupr_stream_t stream) {
+    HUPR_REQUIRE(K && Q && V && dO && V32 && out && lse && dK && dQ && dV && Dq && Bn > 0, "%s: bad argument", who);
+    HUPR_REQUIRE(dout32 || sizeof(TI) == 2, "%s: fp32 operands need the fp32 gradient", who);
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
-    HUPR_REQUIRE(ldk >= C && ldq >= C && lddk >= C && lddq >= C && ldk % 8 == 0 && ldq % 8 == 0 && lddk % 4 == 0 && lddq % 4 == 0,
+    HUPR_REQUIRE(ldk >= C && ldq >= C && lddk >= C && lddq >= C && lddo >= C && ldk % 8 == 0 && ldq % 8 == 0 && lddo % 8 == 0 &&
+                     lddk % 4 == 0 && lddq % 4 == 0,
                  "%s: bad row strides", who);
+    HUPR_REQUIRE(!(residual && accumulate), "%s: accumulate is for the non-residual form", who);
     hipStream_t s = as_stream(stream);
     const long rows = (long)Bn * N;
     dim3 grid(N / 128, Bn);
-    if (C == 64) {
-        hipLaunchKernelGGL(hupr_k_attn_prep<64>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout32, out, V32, Dq, rows, residual);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<64, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dVadd, lse, Dq, dK, dV, N, ldk, ldq, lddk);
-    } else {
-        hipLaunchKernelGGL(hupr_k_attn_prep<128>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, dout32, out, V32, Dq, rows, residual);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dq<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq);
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<128, TI>), grid, dim3(256), 0, s, K, Q, V, dO, dVadd, lse, Dq, dK, dV, N, ldk, ldq, lddk);
-    }
+    const float* add32 = residual ? dout32 : (accumulate ? dV : nullptr);
+    const __bf16* add16 = (residual && !dout32) ? reinterpret_cast<const __bf16*>(dO) : nullptr;
+    const dim3 pgrid((unsigned)((rows + 15) / 16));
+#define HUPR_ATTN_BWD(D_)                                                                                                  \
+    if (dout32) hipLaunchKernelGGL((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
+    else hipLaunchKernelGGL((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
+    hipLaunchKernelGGL((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo);  \
+    hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, dK, dV, N, ldk, ldq,   \
+                       lddk, lddo, add16, lddo);
+    if (C == 64) { HUPR_ATTN_BWD(64) } else { HUPR_ATTN_BWD(128) }
+#undef HUPR_ATTN_BWD
     HUPR_LAUNCH_OK("hupr_k_attn_bwd");
     return HUPR_OK;
 }
@@ -484,24 +536,25 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
 extern "C" int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const float* out, const float* dout,
                                   const float* lse, float* dK, float* dQ, float* dV, float* Dq, int Bn, int N, int C,
                                   int residual, hupr_stream_t stream) {
-    return attn_bwd("hupr_attn_bwd_bf16", K, C, Q, C, V, dout, V, out, dout, lse, dK, C, dQ, C, dV, residual ? dout : nullptr, Dq,
-                    Bn, N, C, residual, stream);
+    return attn_bwd("hupr_attn_bwd_bf16", K, C, Q, C, V, dout, C, V, out, dout, lse, dK, C, dQ, C, dV, 0, Dq, Bn, N, C, residual,
+                    stream);
 }
 extern "C" int hupr_attn_bwd_bf16in(const void* K, const void* Q, const void* V, const void* dO, const float* V32,
                                     const float* out, const float* dout32, const float* lse, float* dK, float* dQ, float* dV,
                                     float* Dq, int Bn, int N, int C, int residual, hupr_stream_t stream) {
+    HUPR_REQUIRE(dout32, "hupr_attn_bwd_bf16in: null pointer");
     return attn_bwd("hupr_attn_bwd_bf16in", static_cast<const __bf16*>(K), C, static_cast<const __bf16*>(Q), C,
-                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), V32, out, dout32, lse, dK, C, dQ, C, dV,
-                    residual ? dout32 : nullptr, Dq, Bn, N, C, residual, stream);
+                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), C, V32, out, dout32, lse, dK, C, dQ, C, dV, 0,
+                    Dq, Bn, N, C, residual, stream);
 }
-// strided form (see hupr_attn_fwd_bf16in_ld): dK / dQ land in column blocks of wider gradient tensors; accumulate != 0
-// (non-residual form only) adds the result onto the dV already in place
-extern "C" int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const void* dO,
+// strided form (see hupr_attn_fwd_bf16in_ld): dK / dQ land in column blocks of wider gradient tensors; dO has row
+// stride lddo (a column block of the gradient of the decoder's concatenated input); dout32 may be null (see above);
+// accumulate != 0 (non-residual form only) adds the result onto the dV already in place
+extern "C" int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const void* dO, int lddo,
                                        const float* V32, const float* out, const float* dout32, const float* lse, float* dK,
                                        int lddk, float* dQ, int lddq, float* dV, float* Dq, int Bn, int N, int C,
                                        int residual, int accumulate, hupr_stream_t stream) {
-    HUPR_REQUIRE(!(residual && accumulate), "hupr_attn_bwd_bf16in_ld: accumulate is for the non-residual form");
     return attn_bwd("hupr_attn_bwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
-                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), V32, out, dout32, lse, dK, lddk, dQ, lddq,
-                    dV, residual ? dout32 : (accumulate ? dV : nullptr), Dq, Bn, N, C, residual, stream);
+                    static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), lddo, V32, out, dout32, lse, dK, lddk, dQ,
+                    lddq, dV, accumulate, Dq, Bn, N, C, residual, stream);
 }

@@ -719,6 +719,7 @@ class AttentionFn(torch.autograd.Function):
 
 
 LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
+CAT_FUSION = os.environ.get("HUPR_NO_CAT_FUSION", "0") != "1"      # fused levels return their maps concatenated as bf16
 
 
 def mscsa_level_fused_ok(ra):
@@ -743,13 +744,17 @@ class MSCSALevelFn(torch.autograd.Function):
     Attention core: the fused kernels where they exist for (N, C) — the projection epilogue then stores the bf16
     operands those kernels read, no fp32 projections and no casts — else GEMM + row-softmax on the fp32 projections
     (the level-0 maps, C = 256), with the same strided operands / outputs.
-    Weights: the eight (C, C, 1, 1) parameters in the order of the two lists above."""
+    Weights: the eight (C, C, 1, 1) parameters in the order of the two lists above.
+    cat_bf16 (fused attention kernels only): return ONE bf16 tensor (B,1,H,W,4C) = cat(out1..out4) — the kernels write
+    the bf16 copy the decoder concatenates next straight from their accumulators, and the backward reads the four
+    column blocks of the incoming (possibly strided: a slice of the concatenation's gradient) bf16 gradient in place: no
+    cast or copy kernels on either side.  Otherwise: the four fp32 outputs."""
 
     #            K source/slot, Q source/slot, V map (0: ra, 1: re), residual
     SPEC = ((0, 0, 1, 1, 0, True), (0, 2, 0, 3, 0, False), (1, 0, 0, 1, 1, True), (1, 2, 1, 3, 1, False))
 
     @staticmethod
-    def forward(ctx, ra, re, *weights):
+    def forward(ctx, ra, re, cat_bf16, *weights):
         assert len(weights) == 8
         ra, re = _c(ra), _c(re)
         B, _, H, W, C = ra.shape
@@ -766,17 +771,20 @@ class MSCSALevelFn(torch.autograd.Function):
             rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(y), 1 if flash else 0, B, 1, H, W, C, C,
                                                 1, H, W, 4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.stream()))
         outs = [torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev) for _ in range(4)]
+        cat_bf16 = bool(cat_bf16) and flash
+        cat = torch.empty((B, 1, H, W, 4 * C), dtype=torch.bfloat16, device=dev) if cat_bf16 else None
         if flash:
             vb = (_cast(ra, torch.bfloat16), _cast(re, torch.bfloat16))
             aux = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(4)]          # log-sum-exp per query
         else:
             vb = maps
             aux = [torch.empty((B, N, N), dtype=torch.float32, device=dev) for _ in range(4)]       # P[query][key]
-        for (ks, kslot, qs, qslot, vs, residual), out, a in zip(MSCSALevelFn.SPEC, outs, aux):
+        for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
             if flash:
                 rt.check(L.hupr_attn_fwd_bf16in_ld(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
-                                                   rt.ptr(out), rt.ptr(a), B, N, C, rt.stream()))
+                                                   rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
+                                                   4 * C, B, N, C, rt.stream()))
             else:
                 # P[q][j] = Q[q] . K[j], softmax over the keys j (row softmax), out = P V (+ V)
                 rt.check(L.hupr_gemm_bf16(0, 1, qp, kp, rt.ptr(a), N, N, C, 4 * C, 4 * C, N, B, N * 4 * C, N * 4 * C, N * N,
@@ -787,7 +795,9 @@ class MSCSALevelFn(torch.autograd.Function):
                                           rt.ptr(v) if residual else None, C, N * C if residual else 0, 0, rt.stream()))
         ctx.save_for_backward(ra, re, Wc[0], Wc[1], Y[0], Y[1], vb[0], vb[1], *outs, *aux)
         ctx.weights = weights
-        ctx.flash = flash
+        ctx.flash, ctx.cat_bf16 = flash, cat_bf16
+        if cat_bf16:
+            return (cat,)
         return tuple(outs)
 
     @staticmethod
@@ -805,18 +815,32 @@ class MSCSALevelFn(torch.autograd.Function):
         dY = (torch.empty((B, N, 4 * C), dtype=f32, device=dev), torch.empty((B, N, 4 * C), dtype=f32, device=dev))
         dV = (torch.empty((B, N, C), dtype=f32, device=dev), torch.empty((B, N, C), dtype=f32, device=dev))
         scr = torch.empty((B, N), dtype=f32, device=dev) if flash else torch.empty((B, N, N), dtype=f32, device=dev)
+        if ctx.cat_bf16:
+            # one bf16 gradient (B,1,H,W,4C), typically a column slice of the decoder input's gradient: read in place
+            dcat = douts[0]
+            ld = dcat.stride(3)
+            if not (dcat.dtype == torch.bfloat16 and dcat.stride(4) == 1 and dcat.stride(2) == W * ld and ld % 8 == 0
+                    and (B == 1 or dcat.stride(0) == N * ld) and dcat.data_ptr() % 16 == 0):
+                dcat = _cast(dcat, torch.bfloat16)
+                ld = 4 * C
+            douts = [None] * 4
         # SPEC order: the residual attention of a map writes its dV, the other one adds to it
-        for (ks, kslot, qs, qslot, vs, residual), out, a, dout in zip(MSCSALevelFn.SPEC, outs, aux, douts):
-            dout = _c(dout)
+        for i, ((ks, kslot, qs, qslot, vs, residual), out, a, dout) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux, douts)):
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
             dkp, dqp = dY[ks].data_ptr() + kslot * C * 4, dY[qs].data_ptr() + qslot * C * 4
             if flash:
-                gb = _cast(dout, torch.bfloat16)
-                rt.check(L.hupr_attn_bwd_bf16in_ld(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(gb), rt.ptr(maps[vs]),
-                                                   rt.ptr(out), rt.ptr(dout), rt.ptr(a), dkp, 4 * C, dqp, 4 * C, rt.ptr(dV[vs]),
+                if ctx.cat_bf16:
+                    gp, ldg, g32 = dcat.data_ptr() + i * C * 2, ld, None
+                else:
+                    dout = _c(dout)
+                    gb = _cast(dout, torch.bfloat16)
+                    gp, ldg, g32 = rt.ptr(gb), C, rt.ptr(dout)
+                rt.check(L.hupr_attn_bwd_bf16in_ld(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), gp, ldg, rt.ptr(maps[vs]),
+                                                   rt.ptr(out), g32, rt.ptr(a), dkp, 4 * C, dqp, 4 * C, rt.ptr(dV[vs]),
                                                    rt.ptr(scr), B, N, C, 1 if residual else 0, 0 if residual else 1,
                                                    rt.stream()))
                 continue
+            dout = _c(dout)
             v, P, g = maps[vs], a, rt.ptr(dout)
             # dV[j] = sum_q P[q][j] dout[q]  (+ dout: residual form; else added onto the dV already there)
             rt.check(L.hupr_gemm_bf16(1, 0, rt.ptr(P), g, rt.ptr(dV[vs]), N, C, N, N, C, C, B, N * N, N * C, N * C,
@@ -839,7 +863,7 @@ class MSCSALevelFn(torch.autograd.Function):
                 grads[i] = dx
         wgrads = [None] * 8
         for i in range(2):
-            if not any(ctx.needs_input_grad[2 + 4 * i + j] for j in range(4)):
+            if not any(ctx.needs_input_grad[3 + 4 * i + j] for j in range(4)):
                 continue
             dWc = torch.empty((4 * C, C), dtype=f32, device=dev)
             ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, C, 4 * C, 1, 1, 1), dev)
@@ -847,11 +871,11 @@ class MSCSALevelFn(torch.autograd.Function):
                                             1, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
             for j in range(4):
                 w = weights[4 * i + j]
-                if ctx.needs_input_grad[2 + 4 * i + j]:
+                if ctx.needs_input_grad[3 + 4 * i + j]:
                     g, direct = _pgrad(w)
                     g.copy_(dWc[j * C:(j + 1) * C].view_as(w))
                     wgrads[4 * i + j] = _pret(w, g, direct)
-        return (grads[0], grads[1]) + tuple(wgrads)
+        return (grads[0], grads[1], None) + tuple(wgrads)
 
 
 class GCNLayerFn(torch.autograd.Function):

@@ -137,11 +137,11 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
                                    residual)
         return out.reshape(B, 1, H, W, C)
 
-    def _level(self, i, ra, re):
+    def _level(self, i, ra, re, cat_bf16=False):
         if F_.mscsa_level_fused_ok(ra):         # bf16 math: projections + attentions of the level as one autograd node
             w = [m[i].weight for m in (self.phi_cross_hori, self.theta_cross_hori, self.phi_self_hori, self.theta_self_hori,
                                        self.phi_cross_vert, self.theta_cross_vert, self.phi_self_vert, self.theta_self_vert)]
-            return list(F_.MSCSALevelFn.apply(ra, re, *w))
+            return list(F_.MSCSALevelFn.apply(ra, re, cat_bf16, *w))
         k_c_h, q_c_v = _conv(ra, self.phi_cross_hori[i]), _conv(re, self.theta_cross_vert[i])
         k_c_v, q_c_h = _conv(re, self.phi_cross_vert[i]), _conv(ra, self.theta_cross_hori[i])
         k_h, q_h = _conv(ra, self.phi_self_hori[i]), _conv(ra, self.theta_self_hori[i])
@@ -153,7 +153,8 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
         # with bf16 activations (F_.act_bf16()) the BasicBlock2D stacks (3x3 convolutions, PReLU, up-sampling) read and
         # write bf16 too; the attention outputs are cast once on the way in, the 1x1 head gets fp32 back
         act = torch.bfloat16 if (F_.act_bf16() and F_.ACT_BF16_DECODER) else torch.float32
-        lvl = lambda i, ra, re: [F_.cast(t, act) for t in self._level(i, ra, re)]
+        # bf16 decoder input: a fused level hands back its four maps already concatenated and cast (one tensor)
+        lvl = lambda i, ra, re: [F_.cast(t, act) for t in self._level(i, ra, re, act == torch.bfloat16 and F_.CAT_FUSION)]
         maps = self.decoderLayer3(torch.cat(lvl(0, ramaps, remaps), 4))
         maps = self.decoderLayer2(torch.cat([maps] + lvl(1, ral2maps, rel2maps), 4))
         x = torch.cat([maps] + lvl(2, ral1maps, rel1maps), 4)

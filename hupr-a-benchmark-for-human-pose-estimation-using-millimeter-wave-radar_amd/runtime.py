@@ -70,9 +70,10 @@ SIGNATURES = {
     "hupr_attn_bwd_bf16": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
     "hupr_attn_fwd_bf16in": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     "hupr_attn_bwd_bf16in": (c_int, [c_void_p] * 12 + [c_int] * 4 + [c_void_p]),
-    "hupr_attn_fwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
-    "hupr_attn_bwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 6 + [c_void_p, c_int, c_void_p, c_int]
-                                + [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "hupr_attn_fwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_void_p, c_int] + [c_int] * 3
+                                + [c_void_p]),
+    "hupr_attn_bwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4
+                                + [c_void_p, c_int, c_void_p, c_int] + [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "hupr_softmax_rows_f32": (c_int, [c_void_p, c_long, c_int, c_void_p]),
     "hupr_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "hupr_gcn_adj_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),

@@ -227,11 +227,13 @@ int hupr_attn_bwd_bf16in(const void* K, const void* Q, const void* V, const void
 /* Strided forms for one MSCSA level (models/layers.py:150-163: eight 1x1 projections of the two maps feed four attentions):
  * the four projections of a map are one GEMM into a (B, N, 4C) bf16 tensor, K / Q point at column blocks of it with
  * row strides ldk / ldq (elements), and the backward writes dK / dQ into column blocks (lddk / lddq) of the matching
- * fp32 gradient tensors.  accumulate != 0 (non-residual form) adds onto the dV another attention left in place. */
+ * fp32 gradient tensors.  accumulate != 0 (non-residual form) adds onto the dV another attention left in place.
+ * out16: optional bf16 copy of the output with row stride ld16 (a column block of the decoder's concatenated input);
+ * dO: bf16, row stride lddo; dout32 null: the gradient arrived bf16-stored and dO is used for the exact terms too. */
 int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres, float* out,
-                            float* lse, int Bn, int N, int C, hupr_stream_t stream);
-int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const void* dO,
-                            const float* V32, const float* out, const float* dout32, const float* lse, float* dK,
+                            float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, hupr_stream_t stream);
+int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const void* dO, int lddo,
+                            const float* V32, const float* out, const float* dout32_or_null, const float* lse, float* dK,
                             int lddk, float* dQ, int lddq, float* dV, float* Dq_scratch, int Bn, int N, int C,
                             int residual, int accumulate, hupr_stream_t stream);
 

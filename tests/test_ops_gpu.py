@@ -578,6 +578,39 @@ def test_pack_cache_table_refresh_matches_single_packs(bf16_math):
         F_.invalidate_packed()
 
 
+@pytest.mark.parametrize("C,H", [(64, 16), (128, 16)])
+def test_mscsa_level_bf16_concatenated_output(C, H, bf16_math):
+    """cat_bf16 form of MSCSALevelFn: the attention kernels also write the bf16 concatenation of the four maps, and the
+    backward reads a bf16 gradient that is a strided column slice of a wider tensor (as torch.cat's backward hands it
+    over).  Must equal the four-output form fed with the same (bf16-representable) gradients, bit for bit."""
+    from hupr_amd import functional as F_
+    B, N = 2, H * H
+    ra, re = rnd(B, 1, H, H, C, seed=140).cuda(), rnd(B, 1, H, H, C, seed=141).cuda()
+    ws = [rnd(C, C, 1, 1, seed=142 + i, scale=C ** -0.5).cuda() for i in range(8)]
+    wide = rnd(B, 1, H, H, 4 * C + 64, seed=150).cuda().bfloat16()          # gradient of a wider concatenation
+    gcat = wide[..., 64:]                                                     # strided view, as CatBackward produces
+    assert not gcat.is_contiguous()
+
+    def run(cat):
+        a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        outs = F_.MSCSALevelFn.apply(a, e, cat, *w)
+        if cat:
+            assert len(outs) == 1 and outs[0].dtype == torch.bfloat16
+            y = outs[0]
+            y.backward(gcat)
+        else:
+            y = torch.cat([o.bfloat16() for o in outs], 4)
+            torch.autograd.backward(list(outs), [gcat[..., i * C:(i + 1) * C].float().contiguous() for i in range(4)])
+        return y.detach(), [a.grad, e.grad] + [t.grad for t in w]
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert torch.equal(y1, y0)
+    for i, (x, y) in enumerate(zip(g1, g0)):
+        assert torch.equal(x, y), "gradient %d differs" % i
+
+
 @pytest.mark.parametrize("act", ["bf16", "f32"])
 def test_dual_conv_matches_two_convs(act, bf16_math):
     """DualConvFn (input gradients of the two convolutions summed in the second kernel's residual epilogue, in place)
@@ -621,7 +654,7 @@ def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
         w = [t.clone().requires_grad_(True) for t in ws]
         if fused:
             assert F_.mscsa_level_fused_ok(a)
-            outs = F_.MSCSALevelFn.apply(a, e, *w)
+            outs = F_.MSCSALevelFn.apply(a, e, False, *w)
         else:
             conv = lambda x, wt: F_.conv(x, wt, None, None, (0, 0, 0))
             att = lambda k, q, v, res: F_.AttentionFn.apply(k.reshape(B, N, C), q.reshape(B, N, C), v.reshape(B, N, C),
