@@ -44,7 +44,7 @@ class _Bucket:
 class GradientBuckets:
     """Flat parameter/gradient buckets with overlapped all-reduce."""
 
-    def __init__(self, module, bucket_bytes=48 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=48 << 20, process_group=None, tail_bytes=8 << 20):
         self.group = process_group
         # HUPR_FORCE_ALLREDUCE=1: run the collectives even with one rank (exercises RCCL + the side stream on a 1-GPU box)
         import os
@@ -56,17 +56,30 @@ class GradientBuckets:
         self.device = params[0].device
         self.use_streams = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_streams else None
-        # reverse registration order, split by size
-        self.buckets = []
+        # reverse registration order, split by size.  The all-reduce of the LAST bucket cannot overlap with anything
+        # (its final gradient is the end of backward), so the trailing parameters get a small bucket of their own
+        # (<= tail_bytes): the exposed collective is then latency- instead of bandwidth-sized.
+        groups = []
         cur, cur_bytes = [], 0
         for p in reversed(params):
             cur.append(p)
             cur_bytes += p.numel() * 4
             if cur_bytes >= bucket_bytes:
-                self.buckets.append(_Bucket(cur, self.device))
+                groups.append(cur)
                 cur, cur_bytes = [], 0
         if cur:
-            self.buckets.append(_Bucket(cur, self.device))
+            groups.append(cur)
+        last = groups[-1]
+        if tail_bytes and sum(p.numel() for p in last) * 4 > tail_bytes and len(last) > 1:
+            n_tail, acc = 0, 0
+            for p in reversed(last):
+                if acc + p.numel() * 4 > tail_bytes and n_tail > 0:
+                    break
+                acc += p.numel() * 4
+                n_tail += 1
+            if 0 < n_tail < len(last):
+                groups[-1:] = [last[:-n_tail], last[-n_tail:]]
+        self.buckets = [_Bucket(g, self.device) for g in groups]
         self._owner = {}
         self._by_ptr = {}                       # parameter storage address -> (bucket, index): the direct-write sink
         for b in self.buckets:
