@@ -141,6 +141,8 @@ def main():
 
     cfg = load_config()
     F_.set_math(args.dtype)
+    if os.environ.get("HUPR_GEMM_SMALL_TILES_OFF", "0") == "1":      # A/B aid
+        F_.rt.lib().hupr_debug_gemm_small_tiles(1)
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     if args.workload == "c2":
         return bench_inference(args, cfg, dev, rank, world, peak)
