@@ -27,7 +27,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int D>
 struct Img {   // row-major bf16 LDS image [rows][D] with XOR-swizzled 16-byte chunks
     static constexpr int CH = D / 8;
-    static __device__ __forceinline__ int key(int row) { return (D == 64) ? ((row >> 1) & 7) : (row & 15); }
+    static __device__ __forceinline__ int key(int row) { return (D == 64) ? ((row >> 1) & 7) : (row & (D / 8 - 1)); }
     static __device__ __forceinline__ int off(int row, int chunk) { return row * D + ((chunk ^ key(row)) << 3); }   // bf16 elements
 };
 
@@ -134,29 +134,36 @@ template <int D>
 __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img, const bf16x8* frag, int lr, int lh) {
     // all A fragments of the 64 x D image rows are read before the first MFMA (hipcc otherwise issues each read right in
     // front of its MFMA and every MFMA waits out the LDS latency)
-    bf16x8 a[2][D / 16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks)
-            a[t][ks] = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, ks * 2 + lh)]);
-    __builtin_amdgcn_sched_barrier(0);
+    // (D = 256: in chunks of four K-steps — sixteen would hold 128 registers of fragments)
+    constexpr int KS = D / 16, CHK = KS > 8 ? 4 : KS;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     }
 #pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks)
+    for (int k0 = 0; k0 < KS; k0 += CHK) {
+        bf16x8 a[2][CHK];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][ks], frag[ks], acc[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < CHK; ++ks)
+                a[t][ks] = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, (k0 + ks) * 2 + lh)]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < CHK; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][ks], frag[k0 + ks], acc[t], 0, 0, 0);
+    }
 }
 
 // out[ct] (channels 32ct..) += img^T (channels x 64 image rows) . W, where W is a [64 image rows][lane token] tile
 // held in accumulator layout w[2][16] (as produced by mma_rows_x_frags).  K slot 8h+i of K-step (t,u) <-> image row
 // 32t + 16u + 8(i>>2) + 4h + (i&3); the A operand rows are fetched with transpose-reads.
-template <int D>
-__device__ __forceinline__ void mma_tr_x_tile(f32x16* out, const __bf16* img, const f32x16* w, int lane) {
+// NCT channel tiles starting at tile ct0 (a channel half of the dK / dV kernel at D = 256; everything otherwise).
+template <int D, int NCT = D / 32>
+__device__ __forceinline__ void mma_tr_x_tile(f32x16* out, const __bf16* img, const f32x16* w, int lane, int ct0 = 0) {
     const int g = lane >> 4, s = lane & 15, h = g >> 1;
     const int col = 16 * (g & 1) + 4 * (s & 3);            // first of the 4 channels this supplier lane addresses
     const int rsub = s >> 2;
@@ -169,8 +176,8 @@ __device__ __forceinline__ void mma_tr_x_tile(f32x16* out, const __bf16* img, co
             for (int i = 0; i < 8; ++i) b[i] = (__bf16)w[t][8 * u + i];
             const int row0 = 32 * t + 16 * u + 4 * h + rsub, row1 = row0 + 8;
 #pragma unroll
-            for (int ct = 0; ct < D / 32; ++ct) {
-                const int c = 32 * ct + col;                   // channel; chunk = c >> 3, 8-byte half = (c >> 2) & 1
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int c = 32 * (ct0 + ct) + col;           // channel; chunk = c >> 3, 8-byte half = (c >> 2) & 1
                 const __bf16* p0 = &img[Img<D>::off(row0, c >> 3) + (c & 4)];
                 const __bf16* p1 = &img[Img<D>::off(row1, c >> 3) + (c & 4)];
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
@@ -267,15 +274,23 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    StageRegs<D, 64, TI> kr, vr;
-    kr.load(K, ldk, tid);
-    vr.load(V + base, D, tid);
+    constexpr bool PF = (D <= 128);                           // D = 256 has no registers to spare for the prefetch
+    StageRegs<PF ? D : 64, 64, TI> kr, vr;
+    if (PF) {
+        kr.load(K, ldk, tid);
+        vr.load(V + base, D, tid);
+    }
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
-        kr.store(Ks, tid);
-        vr.store(Vs, tid);
+        if (PF) {
+            kr.store(Ks, tid);
+            vr.store(Vs, tid);
+        } else {
+            stage_rows<D, 64, TI>(Ks, K + (long)j0 * ldk, ldk, tid);
+            stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
+        }
         __syncthreads();
-        if (j0 + 64 < N) {                                    // next tile's rows travel while this one is multiplied
+        if (PF && j0 + 64 < N) {                              // next tile's rows travel while this one is multiplied
             kr.load(K + (long)(j0 + 64) * ldk, ldk, tid);
             vr.load(V + base + (long)(j0 + 64) * D, D, tid);
         }
@@ -366,15 +381,23 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
     for (int ct = 0; ct < D / 32; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[ct][r] = 0.f;
-    StageRegs<D, 64, TI> kr, vr;
-    kr.load(K, ldk, tid);
-    vr.load(V + base, D, tid);
+    constexpr bool PF = (D <= 128);
+    StageRegs<PF ? D : 64, 64, TI> kr, vr;
+    if (PF) {
+        kr.load(K, ldk, tid);
+        vr.load(V + base, D, tid);
+    }
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();
-        kr.store(Ks, tid);
-        vr.store(Vs, tid);
+        if (PF) {
+            kr.store(Ks, tid);
+            vr.store(Vs, tid);
+        } else {
+            stage_rows<D, 64, TI>(Ks, K + (long)j0 * ldk, ldk, tid);
+            stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
+        }
         __syncthreads();
-        if (j0 + 64 < N) {
+        if (PF && j0 + 64 < N) {
             kr.load(K + (long)(j0 + 64) * ldk, ldk, tid);
             vr.load(V + base + (long)(j0 + 64) * D, D, tid);
         }
@@ -393,7 +416,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
 // ------------------------------------------------------------------------------------------------------
 // backward, dK / dV: a workgroup owns 128 keys (32 per wave) and streams 64-query tiles
 // ------------------------------------------------------------------------------------------------------
-template <int D, typename TI>
+template <int D, typename TI, int NH>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                            const TI* __restrict__ V, const TI* __restrict__ dO,
                                                            const float* dVadd,
@@ -411,20 +434,26 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     load_frags<D, TI>(vf, V + base + (long)key * D, lh);
     Q += (long)blockIdx.y * N * ldq;
     dO += (long)blockIdx.y * N * lddo;
-    f32x16 dk[D / 32], dv[D / 32];
+    // NH = 2 (D = 256): blockIdx.z picks the half of the OUTPUT channels this launch slice accumulates (S, dS are
+    // recomputed per half — the full set of dK, dV accumulators would not fit the register file)
+    constexpr int DV = D / NH;
+    const int c0 = blockIdx.z * DV;
+    f32x16 dk[DV / 32], dv[DV / 32];
 #pragma unroll
-    for (int ct = 0; ct < D / 32; ++ct)
+    for (int ct = 0; ct < DV / 32; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.f; dv[ct][r] = 0.f; }
     // register prefetch of the next tile: both arrays at D = 128 (one wave per SIMD, 512 registers); at D = 64 the
     // kernel sits at the 256-register limit of two waves per SIMD and only the query rows fit
-    constexpr bool PFG = (D == 128);
-    StageRegs<D, 64, TI> qr, gr;
-    qr.load(Q, ldq, tid);
+    constexpr bool PFQ = (D <= 128), PFG = (D == 128);
+    StageRegs<PFQ ? D : 64, 64, TI> qr;
+    StageRegs<PFG ? D : 64, 64, TI> gr;
+    if (PFQ) qr.load(Q, ldq, tid);
     if (PFG) gr.load(dO, lddo, tid);
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
-        qr.store(Qs, tid);
+        if (PFQ) qr.store(Qs, tid);
+        else stage_rows<D, 64, TI>(Qs, Q + (long)q0 * ldq, ldq, tid);
         if (PFG) gr.store(Gs, tid);
         else stage_rows<D, 64, TI>(Gs, dO + (long)q0 * lddo, lddo, tid);
         if (tid < 64) {
@@ -433,7 +462,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         }
         __syncthreads();
         if (q0 + 64 < N) {
-            qr.load(Q + (long)(q0 + 64) * ldq, ldq, tid);
+            if (PFQ) qr.load(Q + (long)(q0 + 64) * ldq, ldq, tid);
             if (PFG) gr.load(dO + (long)(q0 + 64) * lddo, lddo, tid);
         }
         f32x16 s[2], dp[2];
@@ -448,19 +477,19 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
                 dp[t][r] = pv * (dp[t][r] - s_d[qi]);          // dS
                 s[t][r] = pv;                                   // P
             }
-        mma_tr_x_tile<D>(dv, Gs, s, lane);                    // dV^T += dO^T P
-        mma_tr_x_tile<D>(dk, Qs, dp, lane);                   // dK^T += Q^T dS
+        mma_tr_x_tile<D, DV / 32>(dv, Gs, s, lane, c0 / 32);  // dV^T += dO^T P
+        mma_tr_x_tile<D, DV / 32>(dk, Qs, dp, lane, c0 / 32); // dK^T += Q^T dS
     }
-    store_ct<D>(dK + ((long)blockIdx.y * N + key) * lddk, dk, 1.f, nullptr, lh);
-    if (dVadd16) store_ct_add16<D>(dV + base + (long)key * D, dv, dVadd16 + ((long)blockIdx.y * N + key) * ldadd16, lh);
-    else store_ct<D>(dV + base + (long)key * D, dv, 1.f, dVadd ? dVadd + base + (long)key * D : nullptr, lh);
+    store_ct<DV>(dK + ((long)blockIdx.y * N + key) * lddk + c0, dk, 1.f, nullptr, lh);
+    if (dVadd16) store_ct_add16<DV>(dV + base + (long)key * D + c0, dv, dVadd16 + ((long)blockIdx.y * N + key) * ldadd16 + c0, lh);
+    else store_ct<DV>(dV + base + (long)key * D + c0, dv, 1.f, dVadd ? dVadd + base + (long)key * D + c0 : nullptr, lh);
 }
 
 }  // namespace hupr
 
 using namespace hupr;
 
-extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C == 128) && N % 128 == 0 && N >= 128) ? 1 : 0; }
+extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C == 128 || C == 256) && N % 128 == 0 && N >= 128) ? 1 : 0; }
 
 template <typename TI>
 static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const float* Vres, float* out,
@@ -472,7 +501,8 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     dim3 grid(N / 128, Bn);
     __bf16* o16 = static_cast<__bf16*>(out16);
     if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
-    else hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
+    else if (C == 128) hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
+    else hipLaunchKernelGGL((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
@@ -521,13 +551,13 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     const float* add32 = residual ? dout32 : (accumulate ? dV : nullptr);
     const __bf16* add16 = (residual && !dout32) ? reinterpret_cast<const __bf16*>(dO) : nullptr;
     const dim3 pgrid((unsigned)((rows + 15) / 16));
-#define HUPR_ATTN_BWD(D_)                                                                                                  \
+#define HUPR_ATTN_BWD(D_, NH_)                                                                                             \
     if (dout32) hipLaunchKernelGGL((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
     else hipLaunchKernelGGL((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
     hipLaunchKernelGGL((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo);  \
-    hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, dK, dV, N, ldk, ldq,   \
-                       lddk, lddo, add16, lddo);
-    if (C == 64) { HUPR_ATTN_BWD(64) } else { HUPR_ATTN_BWD(128) }
+    hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<D_, TI, NH_>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
+                       dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo);
+    if (C == 64) { HUPR_ATTN_BWD(64, 1) } else if (C == 128) { HUPR_ATTN_BWD(128, 1) } else { HUPR_ATTN_BWD(256, 2) }
 #undef HUPR_ATTN_BWD
     HUPR_LAUNCH_OK("hupr_k_attn_bwd");
     return HUPR_OK;

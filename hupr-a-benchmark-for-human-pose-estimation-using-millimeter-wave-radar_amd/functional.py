@@ -719,6 +719,7 @@ class AttentionFn(torch.autograd.Function):
 
 
 LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
+FLASH256 = os.environ.get("HUPR_NO_FLASH256", "0") != "1"      # A/B aid: level-0 (C = 256) attention on the fused kernels
 CAT_FUSION = os.environ.get("HUPR_NO_CAT_FUSION", "0") != "1"      # fused levels return their maps concatenated as bf16
 
 
@@ -761,7 +762,7 @@ class MSCSALevelFn(torch.autograd.Function):
         N = H * W
         L = rt.lib()
         dev = ra.device
-        flash = USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
+        flash = USE_FLASH and bool(L.hupr_attn_flash_supported(N, C)) and (C != 256 or FLASH256)
         ydt = torch.bfloat16 if flash else torch.float32
         esz = 2 if flash else 4
         maps = (ra, re)

@@ -393,7 +393,8 @@ def test_attention_bf16(bf16_math):
     close(out, ref, 2e-2, "bf16 attention")
 
 
-@pytest.mark.parametrize("N,C,residual", [(256, 64, True), (512, 64, False), (256, 128, True), (4096, 64, False)])
+@pytest.mark.parametrize("N,C,residual", [(256, 64, True), (512, 64, False), (256, 128, True), (4096, 64, False), (256, 256, True),
+                                          (384, 256, False)])
 def test_flash_attention_bf16(N, C, residual, bf16_math):
     """Fused attention kernels (bf16 operands): forward and all three gradients vs an fp64 reference."""
     from hupr_amd import functional as F_
@@ -578,7 +579,7 @@ def test_pack_cache_table_refresh_matches_single_packs(bf16_math):
         F_.invalidate_packed()
 
 
-@pytest.mark.parametrize("C,H", [(64, 16), (128, 16)])
+@pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (256, 16)])
 def test_mscsa_level_bf16_concatenated_output(C, H, bf16_math):
     """cat_bf16 form of MSCSALevelFn: the attention kernels also write the bf16 concatenation of the four maps, and the
     backward reads a bf16 gradient that is a strided column slice of a wider tensor (as torch.cat's backward hands it
@@ -638,7 +639,7 @@ def test_dual_conv_matches_two_convs(act, bf16_math):
     assert torch.equal(f[3], u[3]) and torch.equal(f[4], u[4])
 
 
-@pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (64, 32), (256, 16), (32, 8)])      # the last two: no fused attention kernel
+@pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (64, 32), (256, 16), (32, 8), (96, 16)])      # the last two: no fused attention kernel
 def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
     """MSCSALevelFn (one GEMM per map for its four 1x1 projections with bf16 epilogue, strided attention operands,
     in-place dV accumulation, one dgrad / wgrad GEMM per map) against the same level composed from ConvFn + AttentionFn:
