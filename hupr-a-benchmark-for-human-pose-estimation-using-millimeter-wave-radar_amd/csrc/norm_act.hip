@@ -14,7 +14,9 @@ constexpr int kStatBlocks = 512;
 // ------------------------------------------------------------------------------------------
 // column statistics: for every channel c: S1 = sum_r f(r,c), S2 = sum_r g(r,c)
 //   MODE 0 (forward) : f = x,             g = x*x
-//   MODE 1 (backward): f = dy',           g = dy' * xhat      dy' = dy * [y > 0] if y given
+//   MODE 1 (backward): f = dy',           g = dy' * xhat      dy' = dy * [y > 0] if y given, or — fs / ft given — dy *
+//                      [fs x + ft > 0]: the ReLU mask recomputed from x with the forward pass's scale / shift (the
+//                      very expression hupr_k_scale_shift_act evaluated) instead of read back as a third tensor
 // partial[blk][2][C] doubles.  A thread owns V channels and walks rows with four 16-byte loads per
 // operand in flight (the kernel is latency-, not bandwidth-limited otherwise).
 // ------------------------------------------------------------------------------------------
@@ -23,7 +25,8 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, 
                                                        const T* __restrict__ y,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, long M, int C,
-                                                       double* __restrict__ partial) {
+                                                       double* __restrict__ partial, const float* __restrict__ fs,
+                                                       const float* __restrict__ ft) {
     constexpr int V = ActVec<T>::V, U = 4;
     extern __shared__ double sh[];   // [2][C]
     const int tid = threadIdx.x;
@@ -35,12 +38,16 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, 
     const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    float s1[V], s2[V], mu[V], is[V];
+    float s1[V], s2[V], mu[V], is[V], ma[V], mb[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; is[k] = 1.f; }
+    for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; is[k] = 1.f; ma[k] = 0.f; mb[k] = 1.f; }
     if (MODE == 1) {
 #pragma unroll
         for (int k = 0; k < V; ++k) { mu[k] = mean[cv * V + k]; is[k] = invstd[cv * V + k]; }
+        if (fs) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { ma[k] = fs[cv * V + k]; mb[k] = ft[cv * V + k]; }
+        }
     }
     if (rsub < rows_per_pass) {
         for (long r = r0 + rsub; r < r1; r += (long)U * rows_per_pass) {
@@ -71,7 +78,8 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, 
                         s1[k] += xs[u][k];
                         s2[k] = fmaf(xs[u][k], xs[u][k], s2[k]);
                     } else {
-                        const float g = (y && !(ys[u][k] > 0.f)) ? 0.f : gs[u][k];
+                        float g = (y && !(ys[u][k] > 0.f)) ? 0.f : gs[u][k];
+                        if (fs && !(fmaf(xs[u][k], ma[k], mb[k]) > 0.f)) g = 0.f;
                         s1[k] += g;
                         s2[k] = fmaf(g, (xs[u][k] - mu[k]) * is[k], s2[k]);
                     }
@@ -223,18 +231,24 @@ __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const T* __restrict__
                                                            const T* __restrict__ x,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ coef,
-                                                           T* __restrict__ dx, long nv, int C) {
+                                                           T* __restrict__ dx, long nv, int C,
+                                                           const float* __restrict__ fs, const float* __restrict__ ft) {
     constexpr int V = ActVec<T>::V;
     const long stride = (long)gridDim.x * 256;
     const bool fixed = (stride * V) % C == 0;
-    float cA[V], cB[V], cD[V], mu[V];
+    float cA[V], cB[V], cD[V], mu[V], ma[V], mb[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { ma[k] = 0.f; mb[k] = 1.f; }
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     int c = (int)((i * V) % C);
-    if (fixed) { load_coef<V>(coef, c, cA); load_coef<V>(coef + C, c, cB); load_coef<V>(coef + 2 * C, c, cD); load_coef<V>(mean, c, mu); }
+#define HUPR_LOAD_COEFS()                                                                                           \
+    load_coef<V>(coef, c, cA); load_coef<V>(coef + C, c, cB); load_coef<V>(coef + 2 * C, c, cD); load_coef<V>(mean, c, mu); \
+    if (fs) { load_coef<V>(fs, c, ma); load_coef<V>(ft, c, mb); }
+    if (fixed) { HUPR_LOAD_COEFS() }
     for (; i < nv; i += stride) {
         if (!fixed) {
             c = (int)((i * V) % C);
-            load_coef<V>(coef, c, cA); load_coef<V>(coef + C, c, cB); load_coef<V>(coef + 2 * C, c, cD); load_coef<V>(mean, c, mu);
+            HUPR_LOAD_COEFS()
         }
         float g[V], xs[V], ys[V], o[V];
         ActVec<T>::load(dy + i * V, g);
@@ -242,11 +256,13 @@ __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply(const T* __restrict__
         if (y) ActVec<T>::load(y + i * V, ys);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const float gm = (y && !(ys[k] > 0.f)) ? 0.f : g[k];
+            float gm = (y && !(ys[k] > 0.f)) ? 0.f : g[k];
+            if (fs && !(fmaf(xs[k], ma[k], mb[k]) > 0.f)) gm = 0.f;
             o[k] = fmaf(cA[k], gm, fmaf(cB[k], xs[k] - mu[k], cD[k]));
         }
         ActVec<T>::store(dx + i * V, o);
     }
+#undef HUPR_LOAD_COEFS
 }
 
 // ------------------------------------------------------------------------------------------
@@ -259,7 +275,10 @@ __global__ __launch_bounds__(256) void hupr_k_colstats2(const T* __restrict__ x1
                                                         const T* __restrict__ dy, const T* __restrict__ y,
                                                         const float* __restrict__ mean1, const float* __restrict__ invstd1,
                                                         const float* __restrict__ mean2, const float* __restrict__ invstd2,
-                                                        long M, int C, double* __restrict__ partial) {
+                                                        long M, int C, double* __restrict__ partial,
+                                                        const float* __restrict__ fs1, const float* __restrict__ ft1,
+                                                        const float* __restrict__ fs2, const float* __restrict__ ft2) {
+    // y == null: the ReLU mask is recomputed as [fs1 x1 + ft1 + (fs2 x2 + ft2) > 0], the forward pass's own expression
     constexpr int V = ActVec<T>::V, U = 2;
     extern __shared__ double sh[];   // [3][C]
     const int tid = threadIdx.x;
@@ -271,12 +290,14 @@ __global__ __launch_bounds__(256) void hupr_k_colstats2(const T* __restrict__ x1
     const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
-    float s1[V], sa[V], sb[V], mu1[V], is1[V], mu2[V], is2[V];
+    float s1[V], sa[V], sb[V], mu1[V], is1[V], mu2[V], is2[V], ma1[V], mb1[V], ma2[V], mb2[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         s1[k] = sa[k] = sb[k] = 0.f;
         mu1[k] = mean1[cv * V + k]; is1[k] = invstd1[cv * V + k];
         mu2[k] = mean2[cv * V + k]; is2[k] = invstd2[cv * V + k];
+        ma1[k] = ma2[k] = 0.f; mb1[k] = mb2[k] = 1.f;
+        if (!y) { ma1[k] = fs1[cv * V + k]; mb1[k] = ft1[cv * V + k]; ma2[k] = fs2[cv * V + k]; mb2[k] = ft2[cv * V + k]; }
     }
     if (rsub < rows_per_pass) {
         for (long r = r0 + rsub; r < r1; r += (long)U * rows_per_pass) {
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(256) void hupr_k_colstats2(const T* __restrict__ x1
                     ActVec<T>::load(x1 + ru * C + cv * V, xa[u]);
                     ActVec<T>::load(x2 + ru * C + cv * V, xb[u]);
                     ActVec<T>::load(dy + ru * C + cv * V, gs[u]);
-                    ActVec<T>::load(y + ru * C + cv * V, ys[u]);
+                    if (y) ActVec<T>::load(y + ru * C + cv * V, ys[u]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < V; ++k) { xa[u][k] = mu1[k]; xb[u][k] = mu2[k]; gs[u][k] = 0.f; ys[u][k] = 1.f; }
@@ -298,7 +319,9 @@ __global__ __launch_bounds__(256) void hupr_k_colstats2(const T* __restrict__ x1
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const float g = (ys[u][k] > 0.f) ? gs[u][k] : 0.f;
+                    float act = fmaf(xa[u][k], ma1[k], mb1[k]);
+                    act += fmaf(xb[u][k], ma2[k], mb2[k]);
+                    const float g = ((y ? ys[u][k] : act) > 0.f) ? gs[u][k] : 0.f;
                     s1[k] += g;
                     sa[k] = fmaf(g, (xa[u][k] - mu1[k]) * is1[k], sa[k]);
                     sb[k] = fmaf(g, (xb[u][k] - mu2[k]) * is2[k], sb[k]);
@@ -357,16 +380,21 @@ __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply2(const T* __restrict_
                                                             const T* __restrict__ x1, const T* __restrict__ x2,
                                                             const float* __restrict__ mean1, const float* __restrict__ mean2,
                                                             const float* __restrict__ coef, T* __restrict__ dx1,
-                                                            T* __restrict__ dx2, long nv, int C) {
+                                                            T* __restrict__ dx2, long nv, int C,
+                                                            const float* __restrict__ fs1, const float* __restrict__ ft1,
+                                                            const float* __restrict__ fs2, const float* __restrict__ ft2) {
     constexpr int V = ActVec<T>::V;
     const long stride = (long)gridDim.x * 256;
     const bool fixed = (stride * V) % C == 0;
-    float a1[V], b1[V], d1[V], m1[V], a2[V], b2[V], d2[V], m2[V];
+    float a1[V], b1[V], d1[V], m1[V], a2[V], b2[V], d2[V], m2[V], ma1[V], mb1[V], ma2[V], mb2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { ma1[k] = ma2[k] = 0.f; mb1[k] = mb2[k] = 1.f; }
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     int c = (int)((i * V) % C);
 #define HUPR_LOAD_COEFS()                                                                                           \
     load_coef<V>(coef, c, a1); load_coef<V>(coef + C, c, b1); load_coef<V>(coef + 2 * C, c, d1); load_coef<V>(mean1, c, m1); \
-    load_coef<V>(coef + 3 * C, c, a2); load_coef<V>(coef + 4 * C, c, b2); load_coef<V>(coef + 5 * C, c, d2); load_coef<V>(mean2, c, m2);
+    load_coef<V>(coef + 3 * C, c, a2); load_coef<V>(coef + 4 * C, c, b2); load_coef<V>(coef + 5 * C, c, d2); load_coef<V>(mean2, c, m2); \
+    if (!y) { load_coef<V>(fs1, c, ma1); load_coef<V>(ft1, c, mb1); load_coef<V>(fs2, c, ma2); load_coef<V>(ft2, c, mb2); }
     if (fixed) { HUPR_LOAD_COEFS() }
     for (; i < nv; i += stride) {
         if (!fixed) {
@@ -375,12 +403,14 @@ __global__ __launch_bounds__(256) void hupr_k_bn_bwd_apply2(const T* __restrict_
         }
         float g[V], xa[V], xb[V], ys[V], o1[V], o2[V];
         ActVec<T>::load(dy + i * V, g);
-        ActVec<T>::load(y + i * V, ys);
+        if (y) ActVec<T>::load(y + i * V, ys);
         ActVec<T>::load(x1 + i * V, xa);
         ActVec<T>::load(x2 + i * V, xb);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const float gm = (ys[k] > 0.f) ? g[k] : 0.f;
+            float act = fmaf(xa[k], ma1[k], mb1[k]);
+            act += fmaf(xb[k], ma2[k], mb2[k]);
+            const float gm = ((y ? ys[k] : act) > 0.f) ? g[k] : 0.f;
             o1[k] = fmaf(a1[k], gm, fmaf(b1[k], xa[k] - m1[k], d1[k]));
             o2[k] = fmaf(a2[k], gm, fmaf(b2[k], xb[k] - m2[k], d2[k]));
         }
@@ -477,7 +507,7 @@ static int bn_train_stats(const char* who, const T* x, long M, int C, const floa
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
-                       (const T*)nullptr, nullptr, nullptr, M, C, partial);
+                       (const T*)nullptr, nullptr, nullptr, M, C, partial, (const float*)nullptr, (const float*)nullptr);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
     hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, M, C, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
@@ -538,10 +568,11 @@ extern "C" int hupr_scale_shift_act_bf16act(const void* x1, const float* scale1,
 
 // BatchNorm backward through an optional ReLU mask (y > 0).  train=1: batch-stat formula.
 template <typename T>
-static int bn_bwd(const char* who, const T* dy, const T* y_mask, const T* x, const float* save_mean,
-                  const float* save_invstd, const float* gamma, T* dx, float* dgamma, float* dbeta, long M, int C,
-                  int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+static int bn_bwd(const char* who, const T* dy, const T* y_mask, const float* fs, const float* ft, const T* x,
+                  const float* save_mean, const float* save_invstd, const float* gamma, T* dx, float* dgamma, float* dbeta,
+                  long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
     HUPR_REQUIRE(dy && x && save_mean && save_invstd && gamma && dx && dgamma && dbeta && ws, "%s: null pointer", who);
+    HUPR_REQUIRE((fs == nullptr) == (ft == nullptr) && !(fs && y_mask), "%s: give y_mask OR the forward scale/shift pair", who);
     int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
     if (ws_bytes < hupr_bn_ws_bytes(C)) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
@@ -550,37 +581,60 @@ static int bn_bwd(const char* who, const T* dy, const T* y_mask, const T* x, con
     double* partial = reinterpret_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 2 * C * sizeof(double));
     hipLaunchKernelGGL((hupr_k_colstats<1, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, dy, y_mask, save_mean,
-                       save_invstd, M, C, partial);
+                       save_invstd, M, C, partial, fs, ft);
     HUPR_LAUNCH_OK("hupr_k_colstats<1>");
     hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C,
                        gamma, save_invstd, 1.0f / (float)M, train, dgamma, dbeta, coef);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd");
     const long nv = M * C / act_v<T>();
-    hipLaunchKernelGGL(hupr_k_bn_bwd_apply<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x, save_mean, coef, dx, nv, C);
+    hipLaunchKernelGGL(hupr_k_bn_bwd_apply<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x, save_mean, coef, dx, nv, C, fs, ft);
     HUPR_LAUNCH_OK("hupr_k_bn_bwd_apply");
     return HUPR_OK;
 }
 extern "C" int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float* x, const float* save_mean,
                                const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                                long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    return bn_bwd("hupr_bn_bwd_f32", dy, y_mask, x, save_mean, save_invstd, gamma, dx, dgamma, dbeta, M, C, train, ws,
-                  ws_bytes, stream);
+    return bn_bwd("hupr_bn_bwd_f32", dy, y_mask, nullptr, nullptr, x, save_mean, save_invstd, gamma, dx, dgamma, dbeta, M, C, train,
+                  ws, ws_bytes, stream);
+}
+// ... with the ReLU mask recomputed from x and the forward pass's scale / shift (hupr_bn_train_stats / eval_params) instead
+// of read from the activation: one tensor read less in each of the two passes
+extern "C" int hupr_bn_bwd_remask_f32(const float* dy, const float* fwd_scale, const float* fwd_shift, const float* x,
+                                      const float* save_mean, const float* save_invstd, const float* gamma, float* dx,
+                                      float* dgamma, float* dbeta, long M, int C, int train, void* ws, size_t ws_bytes,
+                                      hupr_stream_t stream) {
+    HUPR_REQUIRE(fwd_scale && fwd_shift, "hupr_bn_bwd_remask_f32: null pointer");
+    return bn_bwd("hupr_bn_bwd_remask_f32", dy, (const float*)nullptr, fwd_scale, fwd_shift, x, save_mean, save_invstd, gamma, dx,
+                  dgamma, dbeta, M, C, train, ws, ws_bytes, stream);
+}
+extern "C" int hupr_bn_bwd_remask_bf16act(const void* dy, const float* fwd_scale, const float* fwd_shift, const void* x,
+                                          const float* save_mean, const float* save_invstd, const float* gamma, void* dx,
+                                          float* dgamma, float* dbeta, long M, int C, int train, void* ws, size_t ws_bytes,
+                                          hupr_stream_t stream) {
+    HUPR_REQUIRE(fwd_scale && fwd_shift, "hupr_bn_bwd_remask_bf16act: null pointer");
+    return bn_bwd("hupr_bn_bwd_remask_bf16act", static_cast<const __bf16*>(dy), (const __bf16*)nullptr, fwd_scale, fwd_shift,
+                  static_cast<const __bf16*>(x), save_mean, save_invstd, gamma, static_cast<__bf16*>(dx), dgamma, dbeta, M, C,
+                  train, ws, ws_bytes, stream);
 }
 extern "C" int hupr_bn_bwd_bf16act(const void* dy, const void* y_mask, const void* x, const float* save_mean,
                                    const float* save_invstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
                                    long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    return bn_bwd("hupr_bn_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y_mask),
+    return bn_bwd("hupr_bn_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y_mask), nullptr, nullptr,
                   static_cast<const __bf16*>(x), save_mean, save_invstd, gamma, static_cast<__bf16*>(dx), dgamma, dbeta,
                   M, C, train, ws, ws_bytes, stream);
 }
 
 // BatchNorm backward of y = relu(bn_a(x1) + bn_b(x2)) for both branches at once (shared dy and ReLU mask y).
 template <typename T>
-static int bn_bwd2(const char* who, const T* dy, const T* y_mask, const T* x1, const float* mean1, const float* invstd1,
+static int bn_bwd2(const char* who, const T* dy, const T* y_mask, const float* const* fwd /* {s1,t1,s2,t2} or null */,
+                   const T* x1, const float* mean1, const float* invstd1,
                    const float* gamma1, const T* x2, const float* mean2, const float* invstd2, const float* gamma2, T* dx1,
                    T* dx2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, long M, int C, int train, void* ws,
                    size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(dy && y_mask && x1 && x2 && mean1 && invstd1 && gamma1 && mean2 && invstd2 && gamma2 && dx1 && dx2 && dgamma1 &&
+    const float* fs1 = fwd ? fwd[0] : nullptr; const float* ft1 = fwd ? fwd[1] : nullptr;
+    const float* fs2 = fwd ? fwd[2] : nullptr; const float* ft2 = fwd ? fwd[3] : nullptr;
+    HUPR_REQUIRE((y_mask != nullptr) != (fs1 && ft1 && fs2 && ft2), "%s: give y_mask OR the two forward scale/shift pairs", who);
+    HUPR_REQUIRE(dy && x1 && x2 && mean1 && invstd1 && gamma1 && mean2 && invstd2 && gamma2 && dx1 && dx2 && dgamma1 &&
                  dbeta1 && dgamma2 && dbeta2 && ws, "%s: null pointer", who);
     int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
@@ -590,14 +644,14 @@ static int bn_bwd2(const char* who, const T* dy, const T* y_mask, const T* x1, c
     double* partial = reinterpret_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 3 * C * sizeof(double));
     hipLaunchKernelGGL(hupr_k_colstats2<T>, dim3(nblk), dim3(256), 3 * C * sizeof(double), s, x1, x2, dy, y_mask, mean1, invstd1,
-                       mean2, invstd2, M, C, partial);
+                       mean2, invstd2, M, C, partial, fs1, ft1, fs2, ft2);
     HUPR_LAUNCH_OK("hupr_k_colstats2");
     hipLaunchKernelGGL(hupr_k_bn_finalize_bwd2, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, gamma1,
                        invstd1, gamma2, invstd2, 1.0f / (float)M, train, dgamma1, dbeta1, dgamma2, dbeta2, coef);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd2");
     const long nv = M * C / act_v<T>();
     hipLaunchKernelGGL(hupr_k_bn_bwd_apply2<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x1, x2, mean1, mean2, coef, dx1, dx2,
-                       nv, C);
+                       nv, C, fs1, ft1, fs2, ft2);
     HUPR_LAUNCH_OK("hupr_k_bn_bwd_apply2");
     return HUPR_OK;
 }
@@ -605,14 +659,38 @@ extern "C" int hupr_bn_bwd2_f32(const float* dy, const float* y_mask, const floa
                                 const float* gamma1, const float* x2, const float* mean2, const float* invstd2,
                                 const float* gamma2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                                 float* dbeta2, long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    return bn_bwd2("hupr_bn_bwd2_f32", dy, y_mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, dx1, dx2, dgamma1,
+    return bn_bwd2("hupr_bn_bwd2_f32", dy, y_mask, nullptr, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, dx1, dx2, dgamma1,
                    dbeta1, dgamma2, dbeta2, M, C, train, ws, ws_bytes, stream);
 }
 extern "C" int hupr_bn_bwd2_bf16act(const void* dy, const void* y_mask, const void* x1, const float* mean1, const float* invstd1,
                                     const float* gamma1, const void* x2, const float* mean2, const float* invstd2,
                                     const float* gamma2, void* dx1, void* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
                                     float* dbeta2, long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    return bn_bwd2("hupr_bn_bwd2_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y_mask),
+    return bn_bwd2("hupr_bn_bwd2_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(y_mask), nullptr,
+                   static_cast<const __bf16*>(x1), mean1, invstd1, gamma1, static_cast<const __bf16*>(x2), mean2, invstd2, gamma2,
+                   static_cast<__bf16*>(dx1), static_cast<__bf16*>(dx2), dgamma1, dbeta1, dgamma2, dbeta2, M, C, train, ws,
+                   ws_bytes, stream);
+}
+
+// two-branch backward with the ReLU mask recomputed from x1, x2 and the forward scale / shift pairs (no y_mask read)
+extern "C" int hupr_bn_bwd2_remask_f32(const float* dy, const float* x1, const float* fwd_scale1, const float* fwd_shift1,
+                                       const float* mean1, const float* invstd1, const float* gamma1, const float* x2,
+                                       const float* fwd_scale2, const float* fwd_shift2, const float* mean2,
+                                       const float* invstd2, const float* gamma2, float* dx1, float* dx2, float* dgamma1,
+                                       float* dbeta1, float* dgamma2, float* dbeta2, long M, int C, int train, void* ws,
+                                       size_t ws_bytes, hupr_stream_t stream) {
+    const float* fwd[4] = {fwd_scale1, fwd_shift1, fwd_scale2, fwd_shift2};
+    return bn_bwd2("hupr_bn_bwd2_remask_f32", dy, (const float*)nullptr, fwd, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2,
+                   dx1, dx2, dgamma1, dbeta1, dgamma2, dbeta2, M, C, train, ws, ws_bytes, stream);
+}
+extern "C" int hupr_bn_bwd2_remask_bf16act(const void* dy, const void* x1, const float* fwd_scale1, const float* fwd_shift1,
+                                           const float* mean1, const float* invstd1, const float* gamma1, const void* x2,
+                                           const float* fwd_scale2, const float* fwd_shift2, const float* mean2,
+                                           const float* invstd2, const float* gamma2, void* dx1, void* dx2, float* dgamma1,
+                                           float* dbeta1, float* dgamma2, float* dbeta2, long M, int C, int train, void* ws,
+                                           size_t ws_bytes, hupr_stream_t stream) {
+    const float* fwd[4] = {fwd_scale1, fwd_shift1, fwd_scale2, fwd_shift2};
+    return bn_bwd2("hupr_bn_bwd2_remask_bf16act", static_cast<const __bf16*>(dy), (const __bf16*)nullptr, fwd,
                    static_cast<const __bf16*>(x1), mean1, invstd1, gamma1, static_cast<const __bf16*>(x2), mean2, invstd2, gamma2,
                    static_cast<__bf16*>(dx1), static_cast<__bf16*>(dx2), dgamma1, dbeta1, dgamma2, dbeta2, M, C, train, ws,
                    ws_bytes, stream);
@@ -671,7 +749,7 @@ static int colsum(const char* who, const T* x, long M, int C, float* out, void* 
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
-                       (const T*)nullptr, nullptr, nullptr, M, C, partial);
+                       (const T*)nullptr, nullptr, nullptr, M, C, partial, (const float*)nullptr, (const float*)nullptr);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
     hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, out);
     HUPR_LAUNCH_OK("hupr_k_colsum_final");

@@ -457,8 +457,12 @@ def _bn_params(x, bn, training):
     return scale, shift, mean, invstd
 
 
-def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training, beta=None):
-    """-> (dx, dgamma, dbeta) as backward() return values (None for parameters written through the gradient sink)."""
+BN_REMASK = os.environ.get("HUPR_NO_BN_REMASK", "0") != "1"      # recompute ReLU masks in the BatchNorm backward passes
+
+
+def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training, beta=None, fwd=None):
+    """-> (dx, dgamma, dbeta) as backward() return values (None for parameters written through the gradient sink).
+    fwd = (scale, shift) of the forward pass: the ReLU mask is recomputed from x instead of read from y_mask."""
     L = rt.lib()
     C = x.shape[-1]
     M = x.numel() // C
@@ -467,9 +471,14 @@ def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training, beta=None):
     db, db_direct = _pgrad(beta) if beta is not None else (torch.empty_like(gamma), False)
     ws = workspace(L.hupr_bn_ws_bytes(C), x.device)
     assert dy.dtype == x.dtype and (y_mask is None or y_mask.dtype == x.dtype)
-    rt.check(_act("bn_bwd", x)(rt.ptr(dy), rt.ptr(y_mask) if y_mask is not None else None, rt.ptr(x), rt.ptr(mean),
-                               rt.ptr(invstd), rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C,
-                               1 if training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
+    if fwd is not None:
+        rt.check(_act("bn_bwd_remask", x)(rt.ptr(dy), rt.ptr(fwd[0]), rt.ptr(fwd[1]), rt.ptr(x), rt.ptr(mean), rt.ptr(invstd),
+                                          rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C, 1 if training else 0,
+                                          rt.ptr(ws), ws.numel(), rt.stream()))
+    else:
+        rt.check(_act("bn_bwd", x)(rt.ptr(dy), rt.ptr(y_mask) if y_mask is not None else None, rt.ptr(x), rt.ptr(mean),
+                                   rt.ptr(invstd), rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C,
+                                   1 if training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
     return dx, _pret(gamma, dg, dg_direct), _pret(beta, db, db_direct)
 
 
@@ -484,15 +493,18 @@ class BNActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         rt.check(_act("scale_shift_act", x)(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
                                             rt.ptr(y), x.numel() // C, C, 1 if relu else 0, rt.stream()))
-        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        remask = relu and BN_REMASK
+        ctx.save_for_backward(x, y if relu and not remask else None, mean, invstd, gamma, scale if remask else None,
+                              shift if remask else None)
         ctx.beta_ref = beta
         ctx.training = training
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, invstd, gamma = ctx.saved_tensors
-        dx, dg, db = _bn_bwd(_c(dy), y, x, mean, invstd, gamma, ctx.training, ctx.beta_ref)
+        x, y, mean, invstd, gamma, scale, shift = ctx.saved_tensors
+        dx, dg, db = _bn_bwd(_c(dy), y, x, mean, invstd, gamma, ctx.training, ctx.beta_ref,
+                             fwd=(scale, shift) if scale is not None else None)
         return dx, dg, db, None, None, None
 
 
@@ -509,20 +521,23 @@ class BNAddBNReLUFn(torch.autograd.Function):
         assert x1.dtype == x2.dtype
         rt.check(_act("scale_shift_act", x1)(rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(x2), rt.ptr(s2),
                                              rt.ptr(t2), rt.ptr(y), x1.numel() // C, C, 1, rt.stream()))
-        ctx.save_for_backward(x1, x2, y, m1, i1, g1, m2, i2, g2)
+        if BN_REMASK:
+            ctx.save_for_backward(x1, x2, None, m1, i1, g1, m2, i2, g2, s1, t1, s2, t2)
+        else:
+            ctx.save_for_backward(x1, x2, y, m1, i1, g1, m2, i2, g2, None, None, None, None)
         ctx.beta_refs = (b1, b2)
         ctx.training = training
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, x2, y, m1, i1, g1, m2, i2, g2 = ctx.saved_tensors
+        x1, x2, y, m1, i1, g1, m2, i2, g2, s1, t1, s2, t2 = ctx.saved_tensors
         dy = _c(dy)
         # both branches share dy and the ReLU mask: one statistics pass + one apply pass for the pair
         L = rt.lib()
         C = x1.shape[-1]
         M = x1.numel() // C
-        assert dy.dtype == x1.dtype == x2.dtype == y.dtype
+        assert dy.dtype == x1.dtype == x2.dtype and (y is None or y.dtype == dy.dtype)
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         b1, b2 = ctx.beta_refs
         dg1, dg1_d = _pgrad(g1)
@@ -530,9 +545,16 @@ class BNAddBNReLUFn(torch.autograd.Function):
         dg2, dg2_d = _pgrad(g2)
         db2, db2_d = _pgrad(b2)
         ws = workspace(L.hupr_bn_ws_bytes(C), x1.device)
-        rt.check(_act("bn_bwd2", x1)(rt.ptr(dy), rt.ptr(y), rt.ptr(x1), rt.ptr(m1), rt.ptr(i1), rt.ptr(g1), rt.ptr(x2), rt.ptr(m2),
-                                     rt.ptr(i2), rt.ptr(g2), rt.ptr(dx1), rt.ptr(dx2), rt.ptr(dg1), rt.ptr(db1), rt.ptr(dg2),
-                                     rt.ptr(db2), M, C, 1 if ctx.training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
+        if y is None:       # ReLU mask recomputed from x1, x2 and the forward coefficients
+            rt.check(_act("bn_bwd2_remask", x1)(rt.ptr(dy), rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(m1), rt.ptr(i1), rt.ptr(g1),
+                                                rt.ptr(x2), rt.ptr(s2), rt.ptr(t2), rt.ptr(m2), rt.ptr(i2), rt.ptr(g2), rt.ptr(dx1),
+                                                rt.ptr(dx2), rt.ptr(dg1), rt.ptr(db1), rt.ptr(dg2), rt.ptr(db2), M, C,
+                                                1 if ctx.training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
+        else:
+            rt.check(_act("bn_bwd2", x1)(rt.ptr(dy), rt.ptr(y), rt.ptr(x1), rt.ptr(m1), rt.ptr(i1), rt.ptr(g1), rt.ptr(x2),
+                                         rt.ptr(m2), rt.ptr(i2), rt.ptr(g2), rt.ptr(dx1), rt.ptr(dx2), rt.ptr(dg1), rt.ptr(db1),
+                                         rt.ptr(dg2), rt.ptr(db2), M, C, 1 if ctx.training else 0, rt.ptr(ws), ws.numel(),
+                                         rt.stream()))
         return (dx1, _pret(g1, dg1, dg1_d), _pret(b1, db1, db1_d), None, dx2, _pret(g2, dg2, dg2_d), _pret(b2, db2, db2_d),
                 None, None)
 

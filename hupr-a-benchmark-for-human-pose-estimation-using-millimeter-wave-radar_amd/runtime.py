@@ -56,6 +56,10 @@ SIGNATURES = {
     "hupr_scale_shift_act_f32": (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_void_p]),
     "hupr_bn_bwd_f32": (c_int, [c_void_p] * 9 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_bn_bwd2_f32": (c_int, [c_void_p] * 16 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_bn_bwd_remask_f32": (c_int, [c_void_p] * 10 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_bn_bwd_remask_bf16act": (c_int, [c_void_p] * 10 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_bn_bwd2_remask_f32": (c_int, [c_void_p] * 19 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "hupr_bn_bwd2_remask_bf16act": (c_int, [c_void_p] * 19 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_bn_bwd2_bf16act": (c_int, [c_void_p] * 16 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_colsum_f32": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_prelu_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),

@@ -178,6 +178,17 @@ int hupr_bn_bwd2_f32(const float* dy, const float* y_mask, const float* x1, cons
                      const float* gamma1, const float* x2, const float* mean2, const float* invstd2, const float* gamma2,
                      float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, long M, int C,
                      int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
+/* The same two backward passes with the ReLU mask RECOMPUTED from x (x1, x2) and the forward pass's scale / shift
+ * (the outputs of hupr_bn_train_stats_* / hupr_bn_eval_params_f32, i.e. exactly the expression
+ * hupr_scale_shift_act_* evaluated) instead of read back from the activation: one tensor read less per pass. */
+int hupr_bn_bwd_remask_f32(const float* dy, const float* fwd_scale, const float* fwd_shift, const float* x,
+                           const float* save_mean, const float* save_invstd, const float* gamma, float* dx, float* dgamma,
+                           float* dbeta, long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_bn_bwd2_remask_f32(const float* dy, const float* x1, const float* fwd_scale1, const float* fwd_shift1,
+                            const float* mean1, const float* invstd1, const float* gamma1, const float* x2,
+                            const float* fwd_scale2, const float* fwd_shift2, const float* mean2, const float* invstd2,
+                            const float* gamma2, float* dx1, float* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                            float* dbeta2, long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_colsum_f32(const float* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
 
 /* (a6) nn.PReLU() with one shared slope (models/layers.py:26,32) */
@@ -291,6 +302,15 @@ int hupr_bn_bwd2_bf16act(const void* dy, const void* y_mask, const void* x1, con
                          const float* gamma1, const void* x2, const float* mean2, const float* invstd2, const float* gamma2,
                          void* dx1, void* dx2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, long M, int C,
                          int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_bn_bwd_remask_bf16act(const void* dy, const float* fwd_scale, const float* fwd_shift, const void* x,
+                               const float* save_mean, const float* save_invstd, const float* gamma, void* dx,
+                               float* dgamma, float* dbeta, long M, int C, int train, void* ws, size_t ws_bytes,
+                               hupr_stream_t stream);
+int hupr_bn_bwd2_remask_bf16act(const void* dy, const void* x1, const float* fwd_scale1, const float* fwd_shift1,
+                                const float* mean1, const float* invstd1, const float* gamma1, const void* x2,
+                                const float* fwd_scale2, const float* fwd_shift2, const float* mean2, const float* invstd2,
+                                const float* gamma2, void* dx1, void* dx2, float* dgamma1, float* dbeta1, float* dgamma2,
+                                float* dbeta2, long M, int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_colsum_bf16act(const void* x, long M, int C, float* out, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_prelu_fwd_bf16act(const void* x, const float* alpha, void* y, long n, hupr_stream_t stream);
 int hupr_prelu_bwd_bf16act(const void* dy, const void* x, const float* alpha, void* dx, float* dalpha, long n, void* ws,
