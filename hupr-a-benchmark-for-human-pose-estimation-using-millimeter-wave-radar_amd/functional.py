@@ -1,10 +1,14 @@
-"""autograd.Function wrappers: one forward/backward pair of C-ABI calls per operator.
+"""autograd.Function wrappers: one forward/backward pair of C-ABI calls per operator, plus a few fused nodes where a
+chain of reference operators is cheaper as one (MSCSALevelFn, TemporalMergeFn, DualConvFn, the two-branch BatchNorm tail).
 
-Activations are channels-last 5-D tensors ``(B, D, H, W, C)`` (2-D maps use D == 1), fp32,
-contiguous.  Parameters keep the reference's shapes; weight re-packing for the implicit-GEMM
-kernels happens on device each call (35.5 M floats, negligible next to the convolutions).
+Activations are channels-last 5-D tensors ``(B, D, H, W, C)`` (2-D maps use D == 1), contiguous, fp32 — or, with
+bf16 math and ``ACT_BF16``, bf16-stored inside the encoders / decoder stacks (arithmetic and parameters stay fp32).
+Parameters keep the reference's shapes; the packed layouts the convolution kernels read are cached per parameter and
+refreshed by ONE table-driven launch per optimiser step (``_packed`` / ``invalidate_packed``).  Parameter gradients
+are written straight into the flat all-reduce buckets when a gradient sink is installed (``GRAD_SINK``).
 
-Nothing here computes with torch ops except allocation, views and gradient bookkeeping.
+Nothing here computes with torch ops except allocation, views, concatenation of small weight matrices and gradient
+bookkeeping; every kernel is reached through ``runtime.lib()`` and fails loudly without the HIP library.
 """
 import os
 
