@@ -5,6 +5,7 @@ with (B,G,F,2,R,A,E) fp32 inputs, same outputs ``(heatmap (B,K,1,H,W), gcn_heatm
 and the same 255 ``state_dict`` entries; all arithmetic runs in hand-written gfx950 kernels
 through the C ABI (include/hupr.h).  CUDA/ROCm tensors only — there is no CPU fallback.
 """
+import torch
 import torch.nn as nn
 
 from .. import functional as F_
@@ -33,9 +34,23 @@ class HuPRNet(nn.Module):
         return self.RAchirpNet(VRDAEmaps_hori), self.REchirpNet(VRDAEmaps_vert)
 
     def forward(self, VRDAEmaps_hori, VRDAEmaps_vert):
-        RAmaps, REmaps = self.forward_chirp(VRDAEmaps_hori, VRDAEmaps_vert)
-        RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(RAmaps)
-        REl1feat, REl2feat, REfeat = self.REradarEncoder(REmaps)
+        if F_.two_streams_ok(VRDAEmaps_hori):
+            # vertical branch on the side stream, horizontal branch on the current one (see functional.TWO_STREAMS)
+            dev = VRDAEmaps_hori.device
+            F_.refresh_packed(dev)
+            main, side = torch.cuda.current_stream(dev), F_.side_stream(dev)
+            side.wait_stream(main)
+            VRDAEmaps_vert.record_stream(side)
+            with torch.cuda.stream(side):
+                REl1feat, REl2feat, REfeat = self.REradarEncoder(self.REchirpNet(VRDAEmaps_vert))
+            RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(self.RAchirpNet(VRDAEmaps_hori))
+            main.wait_stream(side)
+            for t in (REl1feat, REl2feat, REfeat):
+                t.record_stream(main)                 # allocated on the side stream, consumed by the decoder
+        else:
+            RAmaps, REmaps = self.forward_chirp(VRDAEmaps_hori, VRDAEmaps_vert)
+            RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(RAmaps)
+            REl1feat, REl2feat, REfeat = self.REradarEncoder(REmaps)
         maps16, gcn_heatmap = self.radarDecoder(RAl1feat, RAl2feat, RAfeat, REl1feat, REl2feat, REfeat)
         B, _, H, W, ld = maps16.shape
         heatmap = F_.SigmoidHeadFn.apply(maps16.reshape(B, H * W, ld), self.numKeypoints)

@@ -138,10 +138,13 @@ class GradientBuckets:
         if self.world_size == 1 and not self.force_collective:
             return
         if self.use_streams:
+            from .. import functional as F_
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                for s in F_.side_streams_in_use(self.device):      # gradients of the side-stream branch (host-ordered earlier)
+                    self.comm_stream.wait_stream(s)
                 b.work = dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             b.work = dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

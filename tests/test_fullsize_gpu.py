@@ -165,6 +165,39 @@ def test_graph_replay_matches_eager_steps():
         F_.set_math("f32")
 
 
+def test_two_stream_branches_match_one_stream():
+    """The vertical branch on a side stream (forward and backward) must not change a single bit: three optimisation steps
+    with functional.TWO_STREAMS on and off land on identical parameters, BatchNorm statistics and losses."""
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    saved = F_.TWO_STREAMS
+    try:
+        F_.set_math("bf16")
+        cfg = load_config()
+        dev = torch.device("cuda", 0)
+        B, G = 4, cfg.DATASET.numGroupFrames
+        adc_h = torch.from_numpy(synth.adc_cube_int16(41, sensor=0, nframes=B * G)).to(dev)
+        adc_v = torch.from_numpy(synth.adc_cube_int16(41, sensor=1, nframes=B * G)).to(dev)
+        joints = torch.from_numpy(synth.keypoints(B, 42)).to(dev)
+        states, losses = [], []
+        for two in (True, False, True):
+            F_.TWO_STREAMS = two
+            eng = TrainEngine(cfg, device=dev, seed=0)
+            for _ in range(3):
+                loss, _ = eng.train_step_from_adc(adc_h, adc_v, joints)
+            torch.cuda.synchronize()
+            states.append({k: v.detach().clone() for k, v in eng.model.state_dict().items()})
+            losses.append(float(loss.detach()))
+        for other in (1, 2):
+            assert losses[0] == losses[other], losses
+            for k in states[0]:
+                assert torch.equal(states[0][k], states[other][k]), k
+    finally:
+        F_.TWO_STREAMS = saved
+        F_.set_math("f32")
+
+
 def test_bf16_path_argmax_agreement_b32():
     """SURVEY 8(d) bf16 gate at scale (2 heads x 448 joints, eval, B = 32): the bf16 path (bf16 matrix pipe + bf16-stored
     activations) against the fp32 parity path on the same weights/inputs.  The random-weight fixture has flat heat-maps
