@@ -115,6 +115,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="single-GPU runs: vertical branch on a side HIP stream (functional.TWO_STREAMS, the library default; "
+                         "+2-3 %% frames/s).  Off here by default: with both branches in flight the layer-1 convolutions of "
+                         "the two encoders overlap, and the per-launch duration behind the roofline entry (and the matching "
+                         "rocprofv3 summary) would no longer be that of one kernel owning the GPU")
     ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): training step at 32 samples/GPU from ADC cubes; "
                          "c2: eval-mode forward latency at --batch samples (default 1) from normalised inputs")
@@ -141,6 +146,7 @@ def main():
 
     cfg = load_config()
     F_.set_math(args.dtype)
+    F_.TWO_STREAMS = bool(args.two_streams) and os.environ.get("HUPR_ONE_STREAM", "0") != "1"
     if os.environ.get("HUPR_GEMM_SMALL_TILES_OFF", "0") == "1":      # A/B aid
         F_.rt.lib().hupr_debug_gemm_small_tiles(1)
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
@@ -215,7 +221,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "C3: mscsa_prgcn training fwd+bwd+Adam with on-GPU FFT preprocess fused into the loader "
                                    "(16 un-cached sensor-frames per sample)", "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "dp%d" % world, "model_gflop_per_frame": STEP_GFLOP},
+                       "parallelism": "dp%d" % world, "model_gflop_per_frame": STEP_GFLOP,
+                       "compute_streams": 2 if (F_.TWO_STREAMS and world == 1) else 1},
             "model_tflops": round(value * STEP_GFLOP / 1e3, 2),
             "model_frac_of_mfma_peak": round(value * STEP_GFLOP / 1e3 / world / peak, 4),
             "loss": round(float(loss.item()), 5),
