@@ -78,3 +78,20 @@ def test_single_process_buckets_are_flat_views():
     # parameters alias the flat buffer: an in-place flat update is visible through the module
     b.flat_param.zero_()
     assert all(p.abs().sum() == 0 for p in net.parameters())
+
+
+def test_tail_bucket_is_small_and_covers_every_parameter_once():
+    """The trailing parameters (the last gradients of backward) get a bucket of their own of at most tail_bytes: its
+    all-reduce is the only one that cannot overlap with backward.  Every parameter sits in exactly one bucket, in
+    reverse registration order."""
+    from hupr_amd.tools.distributed import GradientBuckets
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(12)])          # 12 x (16 KiB + 256 B)
+    gb = GradientBuckets(net, bucket_bytes=60 << 10, tail_bytes=20 << 10)
+    sizes = [b.numel * 4 for b in gb.buckets]
+    assert sizes[-1] <= 20 << 10 and len(gb.buckets) >= 3, sizes
+    order = [id(p) for b in gb.buckets for p in b.params]
+    assert order == [id(p) for p in reversed(list(net.parameters()))]
+    # tail_bytes = 0 switches the split off
+    gb0 = GradientBuckets(torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(12)]), bucket_bytes=60 << 10, tail_bytes=0)
+    assert len(gb0.buckets) == len(gb.buckets) - 1
