@@ -84,7 +84,7 @@ def side_streams_in_use(device):
 
 
 def two_streams_ok(t):
-    return TWO_STREAMS and t.is_cuda and not torch.cuda.is_current_stream_capturing()
+    return TWO_STREAMS and t.is_cuda
 
 
 def refresh_packed(device):

@@ -37,16 +37,20 @@ class HuPRNet(nn.Module):
         if F_.two_streams_ok(VRDAEmaps_hori):
             # vertical branch on the side stream, horizontal branch on the current one (see functional.TWO_STREAMS)
             dev = VRDAEmaps_hori.device
-            F_.refresh_packed(dev)
+            capturing = torch.cuda.is_current_stream_capturing()     # graph capture: fork / join become graph edges; the
+            if not capturing:                                       # private pool is not recycled, no record_stream needed
+                F_.refresh_packed(dev)                              # (and the packed-weight cache is bypassed anyway)
             main, side = torch.cuda.current_stream(dev), F_.side_stream(dev)
             side.wait_stream(main)
-            VRDAEmaps_vert.record_stream(side)
+            if not capturing:
+                VRDAEmaps_vert.record_stream(side)
             with torch.cuda.stream(side):
                 REl1feat, REl2feat, REfeat = self.REradarEncoder(self.REchirpNet(VRDAEmaps_vert))
             RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(self.RAchirpNet(VRDAEmaps_hori))
             main.wait_stream(side)
-            for t in (REl1feat, REl2feat, REfeat):
-                t.record_stream(main)                 # allocated on the side stream, consumed by the decoder
+            if not capturing:
+                for t in (REl1feat, REl2feat, REfeat):
+                    t.record_stream(main)             # allocated on the side stream, consumed by the decoder
         else:
             RAmaps, REmaps = self.forward_chirp(VRDAEmaps_hori, VRDAEmaps_vert)
             RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(RAmaps)
