@@ -40,17 +40,14 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     const int bkey = ((wn * 32 + lr) >> 1) & 7;
     const int n_tiles = p.Bn * p.nd * p.nh * p.nw * p.n_co_tiles;
 
-    // weight-stage loads of this thread: item f = tid + 512 j over [ky t][row n][chunk c8]
-    int wt[NB], wdst[NB];
-    long wsrc[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int f = tid + 512 * j;
-        const int t = f / (BN * C8), r = f % (BN * C8), n = r / C8, c8 = r % C8;
-        wt[j] = t;
-        wsrc[j] = (long)n * T * p.Ci + c8 * 8 + (long)t * 3 * p.Ci;     // tap = (kz*3 + ky)*3 + kx
-        wdst[j] = n * LDK + (((c8 ^ (n >> 1)) & 7) << 3);
-    }
+    // weight-stage loads of this thread: item f = tid + 512 j over [ky t][row n][chunk c8].  BN * C8 == 512 == the
+    // workgroup size, so t == j and (n, c8) do not depend on j: one source offset (+ j * 3 Ci: tap = (kz*3 + ky)*3 + kx)
+    // and one LDS offset per thread instead of three of each
+    static_assert(BN * C8 == 512, "weight-stage item map assumes one ky slice per 512 threads");
+    const int wn_ = tid / C8, wc8_ = tid % C8;
+    const int wsrc0 = wn_ * T * p.Ci + wc8_ * 8;                  // < 2^31: Co * 27 * Ci elements
+    const int wstep = 3 * p.Ci;
+    const int wdst0 = wn_ * LDK + (((wc8_ ^ (wn_ >> 1)) & 7) << 3);
 
     f32x16 acc[2];
     u32x4 rb[NB];
@@ -143,10 +140,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #define HUPR_W_ISSUE(COT_, CH_, S_)                                                                                 \
     {                                                                                                               \
         const __bf16* wsrc_ = p.wp + (long)(COT_) * BN * T * p.Ci + (long)(((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + (CH_) * KC; \
-        _Pragma("unroll") for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const u32x4*>(wsrc_ + wsrc[j]);     \
+        _Pragma("unroll") for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const u32x4*>(wsrc_ + wsrc0 + j * wstep); \
     }
 #define HUPR_W_COMMIT(PAR_)                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(&Bs[PAR_][wt[j]][wdst[j]]) = rb[j];
+    _Pragma("unroll") for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(&Bs[PAR_][j][wdst0]) = rb[j];
 
     // prologue: first item's halo, weight stage 0 -> Bs[0], weight stage 1 in flight
     HUPR_HALO_ISSUE(0, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
