@@ -24,10 +24,14 @@ struct HaloArgs {
     int n_co_tiles;
     int ablate;              // profiling only: bit0 skip halo fill, bit1 skip MFMA stages, bit2 skip epilogue stores
     unsigned long long* trace;  // profiling only: s_memtime stamps of workgroup 0 / wave 0 (scripts/halo_trace.py) or null
+    double* stats;           // 256-voxel kernel, bf16 output, no bias / residual: per-workgroup column sums [grid][2][Co] of the
+                             // stored (rounded) output and its square — the BatchNorm statistics pass fused into the epilogue
 };
 
 // 256-voxel persistent variant; returns false when the geometry is not supported
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
+bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf);
+constexpr int kHalo256Grid = 256;      // persistent workgroups (= partial rows of HaloArgs::stats)
 
 // Epilogue of both kernels.  The MFMAs are issued as D' = W * X^T, so a lane holds ONE voxel (column lane & 31 of the
 // 32-voxel group) and 16 channels n = 8 g + 4 (lane >> 5) + j  (g = r >> 2, j = r & 3): four 4-channel runs that go

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     constexpr int NB = TS * BN * C8 / 512;                     // 3 weight loads per thread per stage
     __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];     // double-buffered weight stages
+    __shared__ float Ss[4][2][256];                              // fused BatchNorm statistics: [depth slice wave][sum | sum of squares][channel]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // static issue priority for the second-dispatched half of the workgroup (it loses every arbitration against its older
@@ -124,6 +125,12 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     const int n_chunks = p.Ci / KC;
     const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
     const int t_begin = blockIdx.x * per_wg, t_end = min(n_tiles, t_begin + per_wg);
+    if (p.stats) {
+        for (int i = tid; i < 4 * 2 * 256; i += 512) (&Ss[0][0][0])[i] = 0.f;      // published by the prologue barrier
+        if (t_begin >= t_end) {
+            for (int c = tid; c < 2 * p.Co; c += 512) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
+        }
+    }
     if (t_begin >= t_end) return;
     Pos cur;
     {
@@ -240,6 +247,39 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                 halo_store_voxel<ABF>(p, acc[i], m, n0 + wn * 32 + 4 * lh);
             }
         }
+        if constexpr (ABF) {
+            if (p.stats && last_chunk) {
+                // column sums of what was just stored (the bf16-rounded values): this lane's 16 channels x its two voxels,
+                // summed over the 32 voxel lanes, then lanes 31 / 63 add into the slot only they ever touch
+                float cs[16], cq[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = (float)(__bf16)acc[0][r], c = (float)(__bf16)acc[1][r];
+                    cs[r] = a + c;
+                    cq[r] = fmaf(a, a, c * c);
+                }
+                // 32-lane sums with DPP adds only (row_shr 1/2/4/8 inside each 16-lane row, row_bcast:15 across the two rows
+                // of a half-wave): the totals land in lanes 31 and 63.  (__shfl_xor compiled to 160 ds_bpermute per tile.)
+#define HUPR_DPP_ADD(V_, CTRL_, RMASK_)                                                                             \
+    V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), CTRL_, RMASK_, 0xf, true));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    HUPR_DPP_ADD(cs[r], 0x111, 0xf) HUPR_DPP_ADD(cs[r], 0x112, 0xf) HUPR_DPP_ADD(cs[r], 0x114, 0xf)
+                    HUPR_DPP_ADD(cs[r], 0x118, 0xf) HUPR_DPP_ADD(cs[r], 0x142, 0xa)
+                    HUPR_DPP_ADD(cq[r], 0x111, 0xf) HUPR_DPP_ADD(cq[r], 0x112, 0xf) HUPR_DPP_ADD(cq[r], 0x114, 0xf)
+                    HUPR_DPP_ADD(cq[r], 0x118, 0xf) HUPR_DPP_ADD(cq[r], 0x142, 0xa)
+                }
+#undef HUPR_DPP_ADD
+                if (lr == 31) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = n0 + wn * 32 + 4 * lh + 8 * (r >> 2) + (r & 3);
+                        Ss[wm][0][ch] += cs[r];
+                        Ss[wm][1][ch] += cq[r];
+                    }
+                }
+            }
+        }
         HUPR_STAMP()                                              // 4: tile stored
         if (has_next) {
             HUPR_HALO_COMMIT(0)
@@ -252,11 +292,26 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         HUPR_STAMP()                                              // 5: next halo in LDS
         cur = nxt;
     }
+    if (p.stats) {                                                // the four depth-slice waves' sums, fixed order, as doubles
+        __syncthreads();
+        for (int c = tid; c < 2 * p.Co; c += 512) {
+            const int k = c / p.Co, ch = c - k * p.Co;
+            p.stats[(long)blockIdx.x * 2 * p.Co + c] = ((double)Ss[0][k][ch] + (double)Ss[1][k][ch]) + ((double)Ss[2][k][ch] + (double)Ss[3][k][ch]);
+        }
+    }
 #undef HUPR_W_ISSUE
 #undef HUPR_W_COMMIT
 #undef HUPR_STAMP
 #undef HUPR_HALO_ISSUE
 #undef HUPR_HALO_COMMIT
+}
+
+bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
+    if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
+    const long tiles = (long)Bn * (a.D / 4) * (a.H / 8) * (a.W / 8) * (a.Co / 64);
+    if (tiles >= (1L << 31) || tiles < 256) return false;
+    if (abf && (long)Bn * a.D * a.H * a.W * a.in_ld * 2 >= 0x7ffffff0L) return false;
+    return true;
 }
 
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
@@ -272,8 +327,8 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     if (tiles >= (1L << 31) || tiles < 256) return false;          // small problems: the 128-voxel kernel fills the chip better
     if (abf && (long)Bn * a.D * a.H * a.W * a.in_ld * 2 >= 0x7ffffff0L) return false;   // 32-bit buffer offsets
     // one persistent workgroup per CU
-    if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(256), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<false>, dim3(256), dim3(512), 0, s, a);
+    if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<false>, dim3(kHalo256Grid), dim3(512), 0, s, a);
     return true;
 }
 

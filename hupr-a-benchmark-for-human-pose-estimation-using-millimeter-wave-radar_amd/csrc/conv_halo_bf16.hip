@@ -342,7 +342,7 @@ extern "C" int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, 
 
 static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y, int Bn, int D,
                         int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd, bool abf,
-                        hupr_stream_t stream, const char* who) {
+                        hupr_stream_t stream, const char* who, double* stats = nullptr) {
     HUPR_REQUIRE(x && wp_bf16 && y, "%s: null pointer", who);
     HUPR_REQUIRE(hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1), "%s: unsupported geometry", who);
     const int al = abf ? 8 : 4;                      // 16-byte halo loads, 4-channel output vectors
@@ -354,6 +354,14 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     a.kd = kd;
     a.ablate = g_halo_ablate;
     a.trace = g_halo_trace;
+    a.stats = stats;
+    if (stats) {
+        HUPR_REQUIRE(abf && !bias && !res && Co <= 256 && conv_halo256_supported(a, Bn, abf),
+                     "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);
+        HUPR_REQUIRE(launch_conv_halo256(a, Bn, abf, as_stream(stream)), "%s: 256-voxel kernel refused the launch", who);
+        HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16<stats>");
+        return HUPR_OK;
+    }
     if (g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {
         HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16");
         return HUPR_OK;
@@ -401,4 +409,21 @@ extern "C" int hupr_conv3x3_halo_bf16act(const void* x, const void* wp_bf16, con
                                          int kd, hupr_stream_t stream) {
     return conv3x3_halo(x, wp_bf16, bias, res, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld, kd, true, stream,
                         "hupr_conv3x3_halo_bf16act");
+}
+
+// BatchNorm statistics fused into the convolution (bf16 activations, 256-voxel kernel, no bias / residual): besides y the
+// kernel leaves hupr_conv3x3_halo_stats_rows() rows of per-workgroup column sums [rows][2][Co] (doubles: sum, sum of
+// squares of the STORED, i.e. bf16-rounded, outputs) in `stats`, which hupr_bn_train_finalize_f32 turns into the
+// BatchNorm coefficients — the separate statistics pass over y (hupr_bn_train_stats_*) is not needed then.
+extern "C" int hupr_conv3x3_halo_stats_supported(int Bn, int D, int H, int W, int Ci, int Co, int kd) {
+    HaloArgs a{};
+    a.kd = kd; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.in_ld = Ci;
+    return (Bn > 0 && Co <= 256 && conv_halo256_supported(a, Bn, true)) ? 1 : 0;
+}
+extern "C" int hupr_conv3x3_halo_stats_rows(void) { return kHalo256Grid; }
+extern "C" int hupr_conv3x3_halo_bf16act_stats(const void* x, const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci,
+                                               int in_ld, int Co, int out_ld, int kd, void* stats, hupr_stream_t stream) {
+    HUPR_REQUIRE(stats, "hupr_conv3x3_halo_bf16act_stats: null pointer");
+    return conv3x3_halo(x, wp_bf16, nullptr, nullptr, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, 0, kd, true, stream,
+                        "hupr_conv3x3_halo_bf16act_stats", static_cast<double*>(stats));
 }

@@ -515,6 +515,22 @@ static int bn_train_stats(const char* who, const T* x, long M, int C, const floa
     return HUPR_OK;
 }
 
+// Finalize only: `partial` = nblk rows of [2][C] doubles (column sums and sums of squares) produced elsewhere — by the
+// convolution epilogue (hupr_conv3x3_halo_bf16act_stats).  Same outputs and running-statistics update as
+// hupr_bn_train_stats_*.
+extern "C" int hupr_bn_train_finalize_f32(const void* partial, int nblk, long M, int C, const float* gamma, const float* beta,
+                                          float* running_mean, float* running_var, float momentum, float eps,
+                                          float* save_mean, float* save_invstd, float* scale, float* shift,
+                                          hupr_stream_t stream) {
+    HUPR_REQUIRE(partial && nblk > 0 && M > 0 && C > 0 && gamma && beta && save_mean && save_invstd && scale && shift,
+                 "hupr_bn_train_finalize_f32: bad argument");
+    hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, as_stream(stream),
+                       static_cast<const double*>(partial), nblk, M, C, gamma, beta, running_mean, running_var, momentum, eps,
+                       save_mean, save_invstd, scale, shift);
+    HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd");
+    return HUPR_OK;
+}
+
 extern "C" int hupr_bn_train_stats_f32(const float* x, long M, int C, const float* gamma, const float* beta,
                                        float* running_mean, float* running_var, float momentum, float eps,
                                        float* save_mean, float* save_invstd, float* scale, float* shift,

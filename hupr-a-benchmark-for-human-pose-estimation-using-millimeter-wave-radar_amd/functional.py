@@ -249,7 +249,13 @@ def _halo_ok(x, k, pad, co=4):
     return bool(rt.lib().hupr_conv3x3_halo_supported(Di, Hi, Wi, Ci, k[0], k[1], k[2], pad[0], pad[1], pad[2]))
 
 
-def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None):
+# BatchNorm statistics fused into the producing convolution (hupr_conv3x3_halo_bf16act_stats): the column sums wait here,
+# keyed by the output's address, for the BatchNorm that consumes that tensor next (_bn_params pops them)
+CONV_STATS = os.environ.get("HUPR_NO_CONV_STATS", "0") != "1"
+_conv_stats = {}
+
+
+def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stats=False):
     """weight: parameter-layout tensor (Co', Ci', taps...) packed here (mode 0 forward / 1 input gradient).
     out: write here instead of a fresh tensor (may be ``res`` itself: the epilogue reads a residual element right
     before the same lane overwrites it)."""
@@ -263,6 +269,16 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None):
         wp = _packed(weight, mode, 1)
         if ev is not None:
             ev[0].record()
+        if (stats and CONV_STATS and abf and bias is None and res is None and out is None
+                and rt.lib().hupr_conv3x3_halo_stats_supported(B, Di, Hi, Wi, Ci, co, k[0])):
+            rows = rt.lib().hupr_conv3x3_halo_stats_rows()
+            st = torch.empty((rows, 2, co), dtype=torch.float64, device=x.device)
+            rt.check(rt.lib().hupr_conv3x3_halo_bf16act_stats(rt.ptr(x), rt.ptr(wp), rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co,
+                                                               k[0], rt.ptr(st), rt.stream()))
+            _conv_stats[y.data_ptr()] = (st, rows, B * Do * Ho * Wo, co)
+            if ev is not None:
+                ev[1].record()
+            return y
         fn = rt.lib().hupr_conv3x3_halo_bf16act if abf else rt.lib().hupr_conv3x3_halo_bf16
         rt.check(fn(rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
                     rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
@@ -294,13 +310,14 @@ class ConvFn(torch.autograd.Function):
     residual add.  ``pad`` is (pd, ph, pw)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, pad):
+    def forward(ctx, x, weight, bias, res, pad, want_stats=False):
         x = _c(x)
         k = _ksize(weight)
         B, Di, Hi, Wi, Ci = _vox(x)
         assert weight.shape[1] == Ci, (weight.shape, x.shape)
         out_extent = (Di + 2 * pad[0] - k[0] + 1, Hi + 2 * pad[1] - k[1] + 1, Wi + 2 * pad[2] - k[2] + 1)
-        y = _conv_raw(x, weight, 0, bias, _c(res) if res is not None else None, weight.shape[0], k, pad, out_extent)
+        y = _conv_raw(x, weight, 0, bias, _c(res) if res is not None else None, weight.shape[0], k, pad, out_extent,
+                      stats=want_stats)
         ctx.save_for_backward(x, weight)
         ctx.bias_ref = bias                       # only its identity/shape is needed (gradient destination)
         ctx.pad, ctx.k, ctx.has_bias, ctx.has_res = pad, k, bias is not None, res is not None
@@ -349,7 +366,7 @@ class ConvFn(torch.autograd.Function):
             rt.check(_act("colsum", dy)(rt.ptr(dy), B * Do * Ho * Wo, Co, rt.ptr(db), rt.ptr(ws), ws.numel(),
                                         rt.stream()))
         dres = dy if ctx.has_res else None
-        return dx, _pret(weight, dw, dw_direct), _pret(ctx.bias_ref, db, db_direct), dres, None
+        return dx, _pret(weight, dw, dw_direct), _pret(ctx.bias_ref, db, db_direct), dres, None, None
 
 
 class DualConvFn(torch.autograd.Function):
@@ -358,14 +375,14 @@ class DualConvFn(torch.autograd.Function):
     in the second kernel's residual epilogue instead of by a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w_a, w_b, pad):
+    def forward(ctx, x, w_a, w_b, pad, want_stats=False):
         x = _c(x)
         k = _ksize(w_a)
         B, D, H, W, Ci = _vox(x)
         co = w_a.shape[0]
         assert w_b.shape == w_a.shape and _halo_ok(x, k, pad, co)
-        y_a = _conv_raw(x, w_a, 0, None, None, co, k, pad, (D, H, W))
-        y_b = _conv_raw(x, w_b, 0, None, None, co, k, pad, (D, H, W))
+        y_a = _conv_raw(x, w_a, 0, None, None, co, k, pad, (D, H, W), stats=want_stats)
+        y_b = _conv_raw(x, w_b, 0, None, None, co, k, pad, (D, H, W), stats=want_stats)
         ctx.save_for_backward(x, w_a, w_b)
         ctx.k, ctx.pad = k, pad
         return y_a, y_b
@@ -394,20 +411,21 @@ class DualConvFn(torch.autograd.Function):
             rt.check(fn(rt.ptr(x), rt.ptr(dy[i]), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, k[0], rt.ptr(ws), ws.numel(),
                         rt.stream()))
             grads.append(_pret(w, dw, direct))
-        return dx, grads[0], grads[1], None
+        return dx, grads[0], grads[1], None, None
 
 
-def dual_conv(x, w_a, w_b, pad):
+def dual_conv(x, w_a, w_b, pad, stats=False):
     """(conv(x, w_a), conv(x, w_b)); fused input-gradient accumulation where the halo kernels apply."""
     k = _ksize(w_a)
     if w_a.shape == w_b.shape and _halo_ok(x, k, pad, w_a.shape[0]) and x.shape[-1] % 32 == 0 and w_a.shape[0] % 8 == 0 \
             and os.environ.get("HUPR_NO_DUAL_CONV", "0") != "1":
-        return DualConvFn.apply(x, w_a, w_b, tuple(pad))
-    return ConvFn.apply(x, w_a, None, None, tuple(pad)), ConvFn.apply(x, w_b, None, None, tuple(pad))
+        return DualConvFn.apply(x, w_a, w_b, tuple(pad), bool(stats))
+    return ConvFn.apply(x, w_a, None, None, tuple(pad), bool(stats)), ConvFn.apply(x, w_b, None, None, tuple(pad), bool(stats))
 
 
-def conv(x, weight, bias=None, res=None, pad=(0, 0, 0)):
-    return ConvFn.apply(x, weight, bias, res, tuple(pad))
+def conv(x, weight, bias=None, res=None, pad=(0, 0, 0), stats=False):
+    """stats: a BatchNorm in training mode consumes the output next — let the convolution leave its column sums."""
+    return ConvFn.apply(x, weight, bias, res, tuple(pad), bool(stats))
 
 
 class TemporalMergeFn(torch.autograd.Function):
@@ -476,14 +494,23 @@ def _bn_params(x, bn, training):
     shift = torch.empty_like(scale)
     mean = torch.empty_like(scale)
     invstd = torch.empty_like(scale)
+    fused = _conv_stats.pop(x.data_ptr(), None)
+    if fused is not None and not (training and fused[2] == M and fused[3] == C):
+        fused = None
     if training:
-        ws = workspace(L.hupr_bn_ws_bytes(C), dev)
         track = bn.running_mean is not None
-        rt.check(_act("bn_train_stats", x)(
-            rt.ptr(x), M, C, rt.ptr(bn.weight), rt.ptr(bn.bias),
-            rt.ptr(bn.running_mean) if track else None, rt.ptr(bn.running_var) if track else None,
-            float(bn.momentum), float(bn.eps), rt.ptr(mean), rt.ptr(invstd), rt.ptr(scale), rt.ptr(shift),
-            rt.ptr(ws), ws.numel(), rt.stream()))
+        if fused is not None:           # the producing convolution left the column sums: finalize only
+            rt.check(L.hupr_bn_train_finalize_f32(
+                rt.ptr(fused[0]), fused[1], M, C, rt.ptr(bn.weight), rt.ptr(bn.bias),
+                rt.ptr(bn.running_mean) if track else None, rt.ptr(bn.running_var) if track else None,
+                float(bn.momentum), float(bn.eps), rt.ptr(mean), rt.ptr(invstd), rt.ptr(scale), rt.ptr(shift), rt.stream()))
+        else:
+            ws = workspace(L.hupr_bn_ws_bytes(C), dev)
+            rt.check(_act("bn_train_stats", x)(
+                rt.ptr(x), M, C, rt.ptr(bn.weight), rt.ptr(bn.bias),
+                rt.ptr(bn.running_mean) if track else None, rt.ptr(bn.running_var) if track else None,
+                float(bn.momentum), float(bn.eps), rt.ptr(mean), rt.ptr(invstd), rt.ptr(scale), rt.ptr(shift),
+                rt.ptr(ws), ws.numel(), rt.stream()))
         if track and bn.num_batches_tracked is not None:
             if BN_COUNTER_SINK is not None:
                 BN_COUNTER_SINK.append(bn)          # the engine bumps all counters of a step with one launch

@@ -67,10 +67,12 @@ class BasicBlock3D(nn.Module):
 
     def forward(self, x):
         # the two convolutions of x as one node: their input gradients are summed in the second kernel's epilogue
-        out, res = F_.dual_conv(x, self.main[0].weight, self.downsample[0].weight, tuple(self.main[0].padding))
+        # every convolution of the block feeds a BatchNorm: in training mode they leave its column sums (stats=True)
+        out, res = F_.dual_conv(x, self.main[0].weight, self.downsample[0].weight, tuple(self.main[0].padding),
+                                stats=self.training)
         bn1 = self.main[1]
         out = F_.BNActFn.apply(out, bn1.weight, bn1.bias, bn1, self.training, True)
-        out = _conv(out, self.main[3])
+        out = F_.conv(out, self.main[3].weight, None, None, tuple(self.main[3].padding), stats=self.training)
         bn2, bnd = self.main[4], self.downsample[1]
         return F_.BNAddBNReLUFn.apply(out, bn2.weight, bn2.bias, bn2, res, bnd.weight, bnd.bias, bnd, self.training)
 

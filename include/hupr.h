@@ -133,6 +133,15 @@ int hupr_tmerge_dgrad_bf16(const float* dy, const float* wp1, void* dx, int dx_b
 /* LDS halo-tiled 3x3x3 / 1x3x3 "same" convolution on the bf16 matrix pipe (forward, and input gradient
  * with mode-1 packed weights): the input halo of a 128-voxel tile is staged once as bf16 and all taps
  * run from LDS.  wp_bf16 from hupr_pack_conv_weights_bf16 ([Co][kd*9][Ci] bf16). */
+/* BatchNorm statistics fused into the convolution epilogue (BasicBlock3D: every 3x3x3 convolution is followed by a
+ * BatchNorm3d, reference models/layers.py:55-65): bf16 activations, the 256-voxel persistent kernel, no bias / residual.
+ * `stats`: hupr_conv3x3_halo_stats_rows() x [2][Co] doubles — per-workgroup column sums and sums of squares of the stored
+ * (bf16-rounded) outputs; hupr_bn_train_finalize_f32 (below, with the BatchNorm entry points) turns them into the
+ * BatchNorm coefficients, so the separate statistics pass over y is skipped. */
+int hupr_conv3x3_halo_stats_supported(int Bn, int D, int H, int W, int Ci, int Co, int kd);
+int hupr_conv3x3_halo_stats_rows(void);
+int hupr_conv3x3_halo_bf16act_stats(const void* x, const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci,
+                                    int in_ld, int Co, int out_ld, int kd, void* stats, hupr_stream_t stream);
 int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
                                 hupr_stream_t stream);
 /* Repack many weights (both layouts each) in ONE launch.  descs_dev: device array of 48-byte records
@@ -168,6 +177,10 @@ int hupr_bn_eval_params_f32(const float* gamma, const float* beta, const float* 
 int hupr_scale_shift_act_f32(const float* x1, const float* scale1, const float* shift1, const float* x2,
                              const float* scale2, const float* shift2, float* y, long M, int C, int act,
                              hupr_stream_t stream);
+/* finalize only, from nblk rows of [2][C] double column sums produced elsewhere (hupr_conv3x3_halo_bf16act_stats) */
+int hupr_bn_train_finalize_f32(const void* partial, int nblk, long M, int C, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                               float* save_invstd, float* scale, float* shift, hupr_stream_t stream);
 int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float* x, const float* save_mean,
                     const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta, long M,
                     int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);

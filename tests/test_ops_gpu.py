@@ -612,6 +612,37 @@ def test_mscsa_level_bf16_concatenated_output(C, H, bf16_math):
         assert torch.equal(x, y), "gradient %d differs" % i
 
 
+@pytest.mark.parametrize("Ci,Co,shape", [(64, 64, (8, 8, 32, 32)), (64, 128, (16, 4, 32, 32))])
+def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
+    """The 256-voxel convolution kernel leaves the column sums of its (bf16-rounded) output for the BatchNorm that follows
+    (functional.conv(..., stats=True) -> BNActFn): mean / variance / running statistics and the normalised output must
+    match the separate statistics pass over the same tensor."""
+    import torch.nn as nn
+    from hupr_amd import functional as F_
+    B, D, H, W = shape
+    x = cl(rnd(B, Ci, D, H, W, seed=160)).cuda().bfloat16()
+    w = (rnd(Co, Ci, 3, 3, 3, seed=161, scale=(Ci * 27) ** -0.5)).cuda()
+    assert F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, Co, 3)
+    res = []
+    for fused in (True, False):
+        bn = nn.BatchNorm3d(Co).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(rnd(Co, seed=162).cuda() * 0.2 + 1.0)
+            bn.bias.copy_(rnd(Co, seed=163).cuda() * 0.1)
+        F_._conv_stats.clear()
+        y = F_.conv(x, w, None, None, (1, 1, 1), stats=fused)
+        assert (y.data_ptr() in F_._conv_stats) == fused
+        out = F_.BNActFn.apply(y, bn.weight, bn.bias, bn, True, True)
+        assert not F_._conv_stats
+        res.append((y, out, bn.running_mean.clone(), bn.running_var.clone()))
+    (y1, o1, m1, v1), (y0, o0, m0, v0) = res
+    assert torch.equal(y1, y0)
+    close(m1, m0, 2e-6, "running mean")
+    close(v1, v0, 2e-5, "running var")
+    close(o1.float(), o0.float(), 8e-3, "normalised output (bf16 storage)")
+    assert (o1 != o0).float().mean().item() < 2e-3           # only last-bit scale / shift differences
+
+
 @pytest.mark.parametrize("act", ["bf16", "f32"])
 def test_dual_conv_matches_two_convs(act, bf16_math):
     """DualConvFn (input gradients of the two convolutions summed in the second kernel's residual epilogue, in place)
