@@ -250,8 +250,11 @@ def _halo_ok(x, k, pad, co=4):
 
 
 # BatchNorm statistics fused into the producing convolution (hupr_conv3x3_halo_bf16act_stats): the column sums wait here,
-# keyed by the output's address, for the BatchNorm that consumes that tensor next (_bn_params pops them)
-CONV_STATS = os.environ.get("HUPR_NO_CONV_STATS", "0") != "1"
+# keyed by the output's address, for the BatchNorm that consumes that tensor next (_bn_params pops them).
+# OFF by default (HUPR_CONV_STATS=1 switches it on): measured per training step, the separate statistics passes shrink by
+# 0.37 ms and the convolution epilogues grow by 0.27 ms (160 DPP adds + 32 LDS updates per tile per wave, all eight waves
+# at once) — +0.4 % frames/s at the price of ~14 us on every forward launch of the dominant kernel.
+CONV_STATS = os.environ.get("HUPR_CONV_STATS", "0") == "1"
 _conv_stats = {}
 
 

@@ -624,6 +624,8 @@ def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
     w = (rnd(Co, Ci, 3, 3, 3, seed=161, scale=(Ci * 27) ** -0.5)).cuda()
     assert F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, Co, 3)
     res = []
+    saved = F_.CONV_STATS
+    F_.CONV_STATS = True                     # off by default (see functional.CONV_STATS)
     for fused in (True, False):
         bn = nn.BatchNorm3d(Co).cuda()
         with torch.no_grad():
@@ -635,6 +637,7 @@ def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
         out = F_.BNActFn.apply(y, bn.weight, bn.bias, bn, True, True)
         assert not F_._conv_stats
         res.append((y, out, bn.running_mean.clone(), bn.running_var.clone()))
+    F_.CONV_STATS = saved
     (y1, o1, m1, v1), (y0, o0, m0, v0) = res
     assert torch.equal(y1, y0)
     close(m1, m0, 2e-6, "running mean")
