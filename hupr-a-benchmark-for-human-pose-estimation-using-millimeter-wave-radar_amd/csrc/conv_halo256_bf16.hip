@@ -262,20 +262,21 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                 // of a half-wave): the totals land in lanes 31 and 63.  (__shfl_xor compiled to 160 ds_bpermute per tile.)
 #define HUPR_DPP_ADD(V_, CTRL_, RMASK_)                                                                             \
     V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), CTRL_, RMASK_, 0xf, true));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    HUPR_DPP_ADD(cs[r], 0x111, 0xf) HUPR_DPP_ADD(cs[r], 0x112, 0xf) HUPR_DPP_ADD(cs[r], 0x114, 0xf)
-                    HUPR_DPP_ADD(cs[r], 0x118, 0xf) HUPR_DPP_ADD(cs[r], 0x142, 0xa)
-                    HUPR_DPP_ADD(cq[r], 0x111, 0xf) HUPR_DPP_ADD(cq[r], 0x112, 0xf) HUPR_DPP_ADD(cq[r], 0x114, 0xf)
-                    HUPR_DPP_ADD(cq[r], 0x118, 0xf) HUPR_DPP_ADD(cq[r], 0x142, 0xa)
-                }
+                // step-major order: the 32 chains are independent, a chain's own steps are not (DPP source hazards)
+#define HUPR_DPP_STEP(CTRL_, RMASK_)                                                                                \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) { HUPR_DPP_ADD(cs[r], CTRL_, RMASK_) HUPR_DPP_ADD(cq[r], CTRL_, RMASK_) } \
+    __builtin_amdgcn_sched_barrier(0);
+                HUPR_DPP_STEP(0x111, 0xf) HUPR_DPP_STEP(0x112, 0xf) HUPR_DPP_STEP(0x114, 0xf) HUPR_DPP_STEP(0x118, 0xf)
+                HUPR_DPP_STEP(0x142, 0xa)
+#undef HUPR_DPP_STEP
 #undef HUPR_DPP_ADD
                 if (lr == 31) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ch = n0 + wn * 32 + 4 * lh + 8 * (r >> 2) + (r & 3);
-                        Ss[wm][0][ch] += cs[r];
-                        Ss[wm][1][ch] += cq[r];
+                        // return-less LDS adds (only this lane ever touches the address: order = program order, deterministic)
+                        __hip_atomic_fetch_add(&Ss[wm][0][ch], cs[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&Ss[wm][1][ch], cq[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
