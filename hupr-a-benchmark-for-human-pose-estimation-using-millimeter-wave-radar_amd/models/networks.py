@@ -34,6 +34,7 @@ class HuPRNet(nn.Module):
         return self.RAchirpNet(VRDAEmaps_hori), self.REchirpNet(VRDAEmaps_vert)
 
     def forward(self, VRDAEmaps_hori, VRDAEmaps_vert):
+        F_._conv_stats.clear()                  # no fused-statistics hand-over survives a forward pass
         if F_.two_streams_ok(VRDAEmaps_hori):
             # vertical branch on the side stream, horizontal branch on the current one (see functional.TWO_STREAMS)
             dev = VRDAEmaps_hori.device
