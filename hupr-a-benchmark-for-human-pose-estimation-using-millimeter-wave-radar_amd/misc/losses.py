@@ -39,6 +39,10 @@ class LossComputer():
             loss = loss1 + loss2
         if not decode:
             return loss, loss2, None, None
+        if decode == "device":
+            # the reference decodes both arg-max sets every iteration (misc/losses.py:43-44); here the two decodes are
+            # kernels on the step's stream and the (B,K) index / maximum tensors stay on the device (no sync, no D2H)
+            return loss, loss2, F_.argmax_rows(preds2.detach().reshape(-1, H * W)), F_.argmax_rows(heatmaps.reshape(-1, H * W))
         pred2d, _ = get_max_preds(preds2.detach().reshape(-1, K, H, W))
         gt2d, _ = get_max_preds(heatmaps)
         return loss, loss2, pred2d, gt2d

@@ -112,6 +112,13 @@ SIGNATURES = {
     "hupr_interp_linear_bwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    # (e) RCCL exchange step
+    "hupr_comm_load": (c_int, [c_char_p]),
+    "hupr_comm_unique_id": (c_int, [c_void_p]),
+    "hupr_comm_init_rank": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "hupr_comm_destroy": (c_int, [c_void_p]),
+    "hupr_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "hupr_broadcast_bucket": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -107,10 +107,7 @@ class BaseRunner():
         self.model.load_state_dict(ck["model_state_dict"])
         if not self.args.eval and not getattr(self.args, "pretrained", False):
             print("==========>Load the previous optimizer")
-            try:
-                self.optimizer.load_state_dict(ck["optimizer_state_dict"])
-            except Exception as e:      # optimiser layouts differ (flat buckets vs per-tensor)
-                print("==========>Optimizer state not restored (%s)" % e)
+            self.optimizer.load_state_dict(ck["optimizer_state_dict"])      # torch.optim.Adam layout either way
             self.start_epoch = ck["epoch"]
             self.logger.updateBestAcc(ck["accuracy"])
         print("==========>Load the model weight from %s, saved at epoch %d" % (self.dir, ck["epoch"]))

@@ -15,11 +15,97 @@ the new part BASELINE.json asks for.  Design:
     fused Adam launch per bucket with grad_scale = 1/world_size (sum -> mean);
   * BatchNorm statistics stay per rank (the reference is single-device, no SyncBN).
 
-Works with the ``gloo`` backend on CPU tensors too (no streams), which is how the ``not gpu``
-tests exercise world_size 2.
+Transport.  On GPUs the exchange goes through the C ABI (``hupr_allreduce_bucket`` /
+``hupr_broadcast_bucket`` in include/hupr.h: ncclAllReduce on the library's own RCCL communicator, one per
+process): the host enqueues it on the communication stream like any other kernel, and — unlike a
+``torch.distributed`` work object — it can be captured into the hipGraph of the whole training step.
+``torch.distributed`` stays the control plane (rendezvous, exchange of the communicator id, barriers) and
+is the transport for CPU tensors (``gloo``: how the ``not gpu`` tests exercise world_size 2).  If the native
+communicator cannot be created the launcher says so on stderr and falls back to ``dist.all_reduce`` on the
+``nccl`` (= RCCL) process group; ``HUPR_COLLECTIVE=torch`` selects that transport explicitly.
+
+Gradient accumulation (``stash()``): with a fixed global batch a rank may run several micro-batches per
+optimiser step (``bench.py --strong``); the buckets of the first m-1 micro-batches are summed into an
+accumulator, which is added to the bucket on the communication stream right before the last micro-batch's
+all-reduce — one exchange per optimiser step, still overlapped with the last backward.
 """
+import ctypes
+import os
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+class TorchTransport:
+    """``torch.distributed`` collectives (gloo on CPU tensors; nccl/RCCL process group as the GPU fallback)."""
+    name = "torch.distributed"
+    capturable = False
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_reduce(self, flat, stream=None):
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def broadcast(self, flat, src):
+        dist.broadcast(flat, src=src, group=self.group)
+
+
+class RcclTransport:
+    """The C ABI's own RCCL communicator (``hupr_comm_*`` / ``hupr_allreduce_bucket``), bound to the current device.
+    The 128-byte communicator id is created on rank 0 and handed to the other ranks through the existing
+    ``torch.distributed`` group (any backend); a single-rank communicator needs no process group at all."""
+    name = "rccl (hupr_allreduce_bucket)"
+    capturable = True
+
+    def __init__(self, device, group=None):
+        from .. import runtime as rt
+        self.rt, self.L = rt, rt.lib()
+        self.device = device
+        multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rank = dist.get_rank(group) if multi else 0
+        self.world = dist.get_world_size(group) if multi else 1
+        rt.check(self.L.hupr_comm_load(None))
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            rt.check(self.L.hupr_comm_unique_id(uid))
+        if multi:
+            box = [uid.raw if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rt.check(self.L.hupr_comm_init_rank(ctypes.byref(comm), uid, self.world, self.rank))
+        self.comm = comm
+
+    def all_reduce(self, flat, stream=None):
+        """Enqueue on ``stream`` (a torch stream; default: the current one).  Returns None: ordering is the stream's."""
+        s = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        self.rt.check(self.L.hupr_allreduce_bucket(self.comm, self.rt.ptr(flat), flat.numel(), 0, s))
+        return None
+
+    def broadcast(self, flat, src):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.rt.check(self.L.hupr_broadcast_bucket(self.comm, self.rt.ptr(flat), flat.numel(), 0, src, s))
+
+    def close(self):
+        if self.comm is not None and self.comm.value:
+            self.L.hupr_comm_destroy(self.comm)
+            self.comm = None
+
+
+def make_transport(device, group=None):
+    """RCCL through the C ABI for GPU buckets (fallback: torch.distributed on the nccl group), gloo for CPU tensors."""
+    if device.type != "cuda" or os.environ.get("HUPR_COLLECTIVE", "rccl") == "torch":
+        return TorchTransport(group)
+    try:
+        return RcclTransport(device, group)
+    except Exception as exc:      # noqa: BLE001 — an exchange step on the slower transport beats no exchange step
+        sys.stderr.write("hupr: native RCCL communicator unavailable (%s); gradients go through torch.distributed\n" % exc)
+        if not dist.is_initialized():
+            raise
+        return TorchTransport(group)
 
 
 class _Bucket:
@@ -47,13 +133,17 @@ class GradientBuckets:
     def __init__(self, module, bucket_bytes=48 << 20, process_group=None, tail_bytes=8 << 20):
         self.group = process_group
         # HUPR_FORCE_ALLREDUCE=1: run the collectives even with one rank (exercises RCCL + the side stream on a 1-GPU box)
-        import os
-        self.force_collective = os.environ.get("HUPR_FORCE_ALLREDUCE", "0") == "1" and dist.is_initialized()
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
             raise ValueError("module has no trainable parameters")
         self.device = params[0].device
+        self.force_collective = os.environ.get("HUPR_FORCE_ALLREDUCE", "0") == "1" and \
+            (dist.is_initialized() or self.device.type == "cuda")
+        self.active = self.world_size > 1 or self.force_collective      # is there an exchange step at all?
+        self.transport = make_transport(self.device, process_group) if self.active else None
+        self.reduce_this_pass = True      # False while accumulating the leading micro-batches of an optimiser step
+        self._accum_live = False
         self.use_streams = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_streams else None
         # reverse registration order, split by size.  The all-reduce of the LAST bucket cannot overlap with anything
@@ -110,14 +200,17 @@ class GradientBuckets:
             self._launch(b)
 
     # -- per-iteration protocol ---------------------------------------------------------------
-    def prepare(self):
-        """Zero the flat gradients and (re)install the views; call before every backward."""
+    def prepare(self, reduce=True):
+        """Zero the flat gradients and (re)install the views; call before every backward.  ``reduce=False``: this
+        backward is a leading micro-batch of an accumulated step — no exchange, ``stash()`` follows."""
         from .. import functional as F_
+        self.reduce_this_pass = reduce
         for b in self.buckets:
             b.flat_grad.zero_()
             b.pending = len(b.params)
             b.written = [False] * len(b.params)
             b.work = None
+            b.launched = False
             for p, v in zip(b.params, b.views):
                 p.grad = v
         self._armed = self.direct
@@ -135,7 +228,7 @@ class GradientBuckets:
             self._launch(b)
 
     def _launch(self, b):
-        if self.world_size == 1 and not self.force_collective:
+        if not self.active or not self.reduce_this_pass:
             return
         if self.use_streams:
             from .. import functional as F_
@@ -145,9 +238,26 @@ class GradientBuckets:
                 self.comm_stream.wait_event(ev)
                 for s in F_.side_streams_in_use(self.device):      # gradients of the side-stream branch (host-ordered earlier)
                     self.comm_stream.wait_stream(s)
-                b.work = dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self._accum_live:                               # earlier micro-batches of this optimiser step
+                    b.flat_grad.add_(b.accum)
+                b.work = self.transport.all_reduce(b.flat_grad, self.comm_stream)
         else:
-            b.work = dist.all_reduce(b.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self._accum_live:
+                b.flat_grad.add_(b.accum)
+            b.work = self.transport.all_reduce(b.flat_grad)
+        b.launched = True
+
+    def stash(self):
+        """After the backward of a leading micro-batch (``prepare(reduce=False)``): add its gradients to the accumulator."""
+        self._armed = False
+        for b in self.buckets:
+            if getattr(b, "accum", None) is None:
+                b.accum = torch.zeros_like(b.flat_grad)
+            if self._accum_live:
+                b.accum.add_(b.flat_grad)
+            else:
+                b.accum.copy_(b.flat_grad)
+        self._accum_live = True
 
     def finish(self):
         """Block the compute stream on outstanding collectives (call after backward)."""
@@ -156,22 +266,37 @@ class GradientBuckets:
         if F_.GRAD_SINK is self:
             F_.GRAD_SINK = None
         for b in self.buckets:
-            if b.pending != 0 and (self.world_size > 1 or self.force_collective):
+            if self.active and self.reduce_this_pass and not b.launched:
                 # a parameter received no gradient this iteration: reduce what we have
                 b.pending = 0
                 self._launch(b)
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-        if self.use_streams and (self.world_size > 1 or self.force_collective):
+            if self._accum_live and self.reduce_this_pass and not self.active:
+                b.flat_grad.add_(b.accum)                       # single rank: no exchange, just the micro-batch sum
+        if self.use_streams and self.active and self.reduce_this_pass:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if self.reduce_this_pass:
+            self._accum_live = False
 
     def flat_pairs(self):
         return [(b.flat_param, b.flat_grad) for b in self.buckets]
+
+    def layout(self):
+        """Per bucket: [(parameter, offset, numel)] in bucket order (FusedAdam's checkpoint scatter/gather map)."""
+        out = []
+        for b in self.buckets:
+            off, ent = 0, []
+            for p in b.params:
+                ent.append((p, off, p.numel()))
+                off += p.numel()
+            out.append(ent)
+        return out
 
     def broadcast_parameters(self, src=0):
         """Make every rank start from rank ``src``'s weights (and buffers are left per rank)."""
         if self.world_size == 1:
             return
         for b in self.buckets:
-            dist.broadcast(b.flat_param, src=src, group=self.group)
+            self.transport.broadcast(b.flat_param, src)

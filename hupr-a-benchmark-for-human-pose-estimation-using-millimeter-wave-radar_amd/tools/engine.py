@@ -21,14 +21,14 @@ class TrainEngine:
         self.buckets = GradientBuckets(self.model, bucket_bytes=bucket_bytes)
         self.buckets.broadcast_parameters(0)
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
-        if self.world_size > 1 or self.buckets.force_collective:
+        if self.buckets.active:
             # measured with the RCCL path active (single rank, forced collectives): the side-stream branch costs 1 %
             # instead of gaining 2 % — the all-reduce kernels already fill the gaps it would use.  One compute stream then.
             from .. import functional as F_
             F_.TWO_STREAMS = False
         self.optimizer = FusedAdam(self.model.parameters(), lr=lr if lr is not None else cfg.TRAINING.lr,
                                    betas=(0.9, 0.999), weight_decay=1e-4)
-        self.optimizer.attach_flat_buckets(self.buckets.flat_pairs())
+        self.optimizer.attach_flat_buckets(self.buckets.flat_pairs(), self.buckets.layout())
         self.optimizer.grad_scale = 1.0 / self.world_size
         self.G = cfg.DATASET.numGroupFrames
         self._fft_ws = None
@@ -52,10 +52,13 @@ class TrainEngine:
         return h, v
 
     # -- steps ------------------------------------------------------------------------------------
-    def train_step(self, hori, vert, joints):
+    def train_step(self, hori, vert, joints, decode=False, _last=True, _micro=1):
+        """One forward + loss + backward (+ exchange + Adam when ``_last``).  ``decode="device"`` also runs the two
+        arg-max decodes of the reference's per-iteration ``computeLoss`` (misc/losses.py:43-44) as kernels on the
+        step's stream; their results stay on the device (``self.last_decode``)."""
         from .. import functional as F_
         self.model.train()
-        self.buckets.prepare()
+        self.buckets.prepare(reduce=_last)
         F_.BN_COUNTER_SINK = due = []
         try:
             preds = self.model(hori, vert)
@@ -66,44 +69,72 @@ class TrainEngine:
         else:
             for m in due:
                 m.num_batches_tracked.add_(1)
-        loss, loss2, _, _ = self.lossComputer.computeLoss(preds, joints, decode=False)
+        loss, loss2, p2d, g2d = self.lossComputer.computeLoss(preds, joints, decode=decode)
+        self.last_decode = (p2d, g2d)
         loss.backward()
         if self.device.type == "cuda":
             for s in F_.side_streams_in_use(self.device):           # the side-stream branch's backward joins here
                 torch.cuda.current_stream(self.device).wait_stream(s)
+        if not _last:
+            self.buckets.stash()
+            return loss, loss2
         self.buckets.finish()
+        self.optimizer.grad_scale = 1.0 / (self.world_size * _micro)
         self.optimizer.step()
         return loss, loss2
 
-    def train_step_from_adc(self, adc_hori, adc_vert, joints):
+    def train_step_accumulated(self, micro_batches, from_adc=True, decode=False):
+        """One optimiser step over several micro-batches (fixed GLOBAL batch, ``bench.py --strong``): gradients of the
+        leading micro-batches are summed locally, the exchange happens once, overlapped with the last backward.
+        ``micro_batches``: list of (hori, vert, joints) — ADC cubes when ``from_adc`` — each a per-rank micro-batch whose
+        loss is its own mean, so the step's gradient is the mean over all ``world * len(micro_batches)`` of them.
+        BatchNorm statistics are per micro-batch (as they are per rank in data parallel)."""
+        m = len(micro_batches)
+        out = None
+        for i, (a, b, joints) in enumerate(micro_batches):
+            h, v = self.preprocess(a, b) if from_adc else (a, b)
+            out = self.train_step(h, v, joints, decode=decode, _last=i == m - 1, _micro=m)
+        return out
+
+    def train_step_from_adc(self, adc_hori, adc_vert, joints, decode=False):
         if self._graph is not None:
             return self._replay(adc_hori, adc_vert, joints)
         h, v = self.preprocess(adc_hori, adc_vert)
-        return self.train_step(h, v, joints)
+        return self.train_step(h, v, joints, decode=decode)
 
     # -- hipGraph capture of the whole step (single-GPU) --------------------------------------------------------
-    def capture(self, adc_hori, adc_vert, joints, warmup=2):
-        """Capture preprocess + forward + loss + backward + Adam as ONE hipGraph and replay it from then on
-        (``train_step_from_adc``).  ~1000 kernel launches per step otherwise cost ~24 ms of host time, which bounds the
-        step once the kernels are faster than that.  Requirements: fixed shapes (the static input buffers are refilled
-        by copy), world size 1 (the RCCL all-reduce stays on the eager path), ``sync_lr()`` after LR changes.  The
-        ``warmup`` eager steps are real optimisation steps."""
-        if self.world_size != 1:
-            raise RuntimeError("graph capture is only wired for single-GPU runs")
+    def capture(self, adc_hori, adc_vert, joints, warmup=2, decode=False):
+        """Capture preprocess + forward + loss + backward (+ the bucket all-reduces on the communication stream) + Adam
+        as ONE hipGraph and replay it from then on (``train_step_from_adc``).  ~700 kernel launches per step otherwise
+        cost 9-18 ms of host time, which bounds the step once the kernels are faster than that.  Data parallel: the
+        exchange is ``hupr_allreduce_bucket`` (ncclAllReduce enqueued on a stream), which is capturable — the fork to the
+        communication stream and the join before Adam become edges of the graph; every rank must capture and replay
+        in lock step.  Requirements: fixed shapes (the static input buffers are refilled by copy), joints already on
+        the device (a pageable host-to-device copy is illegal inside a capture), ``TRAINING.lossDecay == -1`` (the
+        alpha/beta loss weights would be frozen at their capture-time values), ``sync_lr()`` after LR changes.
+        The ``warmup`` eager steps are real optimisation steps."""
+        tr = self.buckets.transport
+        if self.buckets.active and not getattr(tr, "capturable", False):
+            raise RuntimeError("graph capture needs the native RCCL transport (got %s)" % getattr(tr, "name", tr))
+        if self.cfg.TRAINING.lossDecay != -1:
+            raise RuntimeError("graph capture would freeze the loss weights alpha/beta (TRAINING.lossDecay != -1)")
+        if not (adc_hori.is_cuda and adc_vert.is_cuda and joints.is_cuda):
+            raise RuntimeError("graph capture needs ADC cubes and joints resident on the GPU")
         self.optimizer.use_device_state()
+        self._g_decode = decode
         self._g_in = (adc_hori.clone(), adc_vert.clone(), joints.clone())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 h, v = self.preprocess(self._g_in[0], self._g_in[1])
-                self.train_step(h, v, self._g_in[2])
+                self.train_step(h, v, self._g_in[2], decode=decode)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             h, v = self.preprocess(self._g_in[0], self._g_in[1])
-            self._g_out = self.train_step(h, v, self._g_in[2])
+            self._g_out = self.train_step(h, v, self._g_in[2], decode=decode)
         self._graph = g
 
     def sync_lr(self):

@@ -28,6 +28,7 @@ extern "C" {
 #define HUPR_ERR_ARG (-1)       /* bad argument (null pointer, unsupported shape)   */
 #define HUPR_ERR_WORKSPACE (-2) /* workspace too small                               */
 #define HUPR_ERR_LAUNCH (-3)    /* hipLaunch / runtime error                         */
+#define HUPR_ERR_COMM (-4)      /* librccl missing / RCCL returned an error          */
 
 typedef void* hupr_stream_t; /* hipStream_t */
 
@@ -340,6 +341,33 @@ int hupr_interp_linear_bwd_bf16act(const void* dy, void* dx, int Bn, int Di, int
 /* boundary casts of the bf16-activation region (n % 4 == 0) */
 int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream);
 int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (e) Data-parallel exchange over RCCL / xGMI.  Nothing in the reference to mirror: it trains on one
+ *     device (tools/base.py:14 `self.device = 'cuda'`, tools/run.py:76-79 forward / backward / step with no
+ *     collective); BASELINE.json's configs 4-5 add 8-GPU data parallelism, whose only exchange is the sum
+ *     all-reduce of the flat gradient buckets between `loss.backward()` (run.py:78) and `optimizer.step()`
+ *     (run.py:79), plus one parameter broadcast at start-up.
+ *
+ *     librccl.so.1 is bound at run time (hupr_comm_load: the copy already mapped into the process wins, so
+ *     the library never brings a second RCCL next to PyTorch's); one communicator per process = per GPU.
+ *     hupr_comm_unique_id() is called on rank 0 and the HUPR_COMM_ID_BYTES blob is handed to every rank
+ *     out of band (the Python host uses the torch.distributed store); hupr_comm_init_rank() is collective
+ *     and binds the communicator to the CURRENT HIP device.  The two data entry points are in place,
+ *     stream-ordered and capturable in a hipGraph; they never synchronise the host.
+ * ---------------------------------------------------------------------------------------- */
+#define HUPR_COMM_ID_BYTES 128
+#define HUPR_COMM_F32 0
+#define HUPR_COMM_BF16 1
+typedef void* hupr_comm_t; /* ncclComm_t */
+int hupr_comm_load(const char* librccl_path_or_null);
+int hupr_comm_unique_id(void* id_out /* HUPR_COMM_ID_BYTES */);
+int hupr_comm_init_rank(hupr_comm_t* comm_out, const void* id, int n_ranks, int rank);
+int hupr_comm_destroy(hupr_comm_t comm);
+/* bucket[i] <- sum over ranks of bucket[i]  (count elements of dtype HUPR_COMM_F32 / HUPR_COMM_BF16) */
+int hupr_allreduce_bucket(hupr_comm_t comm, void* bucket, size_t count, int dtype, hupr_stream_t stream);
+/* bucket <- rank `root`'s bucket (initial parameter synchronisation) */
+int hupr_broadcast_bucket(hupr_comm_t comm, void* bucket, size_t count, int dtype, int root, hupr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -95,3 +95,98 @@ def test_tail_bucket_is_small_and_covers_every_parameter_once():
     # tail_bytes = 0 switches the split off
     gb0 = GradientBuckets(torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(12)]), bucket_bytes=60 << 10, tail_bytes=0)
     assert len(gb0.buckets) == len(gb.buckets) - 1
+
+
+def _accum_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hupr_amd.tools.distributed import GradientBuckets
+    torch.manual_seed(99)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 1))
+    gb = GradientBuckets(net, bucket_bytes=1024)
+    g = torch.Generator().manual_seed(3)
+    X, Y = torch.randn(24, 16, generator=g), torch.randn(24, 1, generator=g)
+    for _ in range(2):                                  # two optimiser steps: the accumulator must be re-armed
+        for m in range(3):                              # 3 micro-batches of 4 samples per rank per optimiser step
+            lo = (rank * 3 + m) * 4
+            gb.prepare(reduce=m == 2)
+            ((net(X[lo:lo + 4]) - Y[lo:lo + 4]) ** 2).sum().backward()
+            if m < 2:
+                gb.stash()
+        gb.finish()
+    out[rank] = torch.cat([b.flat_grad for b in gb.buckets]).clone()
+    if rank == 0:
+        ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 1))
+        ref.load_state_dict(net.state_dict())
+        ((ref(X) - Y) ** 2).sum().backward()
+        out["ref"] = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_accumulated_micro_batches_world2_one_exchange_per_step():
+    """bench.py --strong: m micro-batches per rank, gradients summed locally, ONE all-reduce per optimiser step."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_accum_worker, args=(world, port, out), nprocs=world, join=True)
+    assert torch.allclose(out[0], out[1]) and torch.allclose(out[0], out["ref"], atol=1e-5)
+
+
+def test_single_rank_accumulation_sums_micro_batches():
+    from hupr_amd.tools.distributed import GradientBuckets
+    torch.manual_seed(5)
+    net = torch.nn.Linear(6, 3)
+    gb = GradientBuckets(net)
+    X = torch.randn(8, 6)
+    for m in range(2):
+        gb.prepare(reduce=m == 1)
+        net(X[m * 4:m * 4 + 4]).sum().backward()
+        if m == 0:
+            gb.stash()
+    gb.finish()
+    ref = torch.nn.Linear(6, 3)
+    ref.load_state_dict(net.state_dict())
+    ref(X).sum().backward()
+    want = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+    assert torch.allclose(gb.buckets[0].flat_grad, want, atol=1e-6)
+
+
+def test_fused_adam_checkpoint_interchanges_with_torch_adam():
+    """the flat-bucket moments must round-trip through torch.optim.Adam's per-parameter state_dict layout
+    (reference tools/base.py:76-81 saves optimizer.state_dict(), :113 restores it)."""
+    from hupr_amd.tools.distributed import GradientBuckets
+    from hupr_amd.tools.optim import FusedAdam
+    torch.manual_seed(11)
+
+    def make():
+        return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    net = make()
+    gb = GradientBuckets(net, bucket_bytes=256, tail_bytes=0)
+    assert len(gb.buckets) >= 2
+    opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt.attach_flat_buckets(gb.flat_pairs(), gb.layout())
+    assert opt.state_dict()["state"] == {}                      # nothing before the first step, like torch
+    for st in opt._flat_state:                                  # as if 7 steps had run
+        st["step"] = 7
+        st["exp_avg"].normal_()
+        st["exp_avg_sq"].uniform_(0.1, 1.0)
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == list(range(6)) and sd["param_groups"][0]["params"] == list(range(6))
+    # (a) a torch.optim.Adam over the same parameters accepts it and sees the right slices
+    tad = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-4)
+    tad.load_state_dict(sd)
+    for i, entries in enumerate(gb.layout()):
+        for p, off, n in entries:
+            assert float(tad.state[p]["step"]) == 7
+            assert torch.equal(tad.state[p]["exp_avg"].reshape(-1), opt._flat_state[i]["exp_avg"][off:off + n])
+            assert torch.equal(tad.state[p]["exp_avg_sq"].reshape(-1), opt._flat_state[i]["exp_avg_sq"][off:off + n])
+    # (b) a fresh FusedAdam restores the flat buffers from torch's state_dict
+    net2 = make()
+    gb2 = GradientBuckets(net2, bucket_bytes=256, tail_bytes=0)
+    opt2 = FusedAdam(net2.parameters(), lr=5e-4, weight_decay=1e-4)
+    opt2.attach_flat_buckets(gb2.flat_pairs(), gb2.layout())
+    opt2.load_state_dict(tad.state_dict())
+    assert opt2.param_groups[0]["lr"] == 1e-3 and len(opt2.state) == 0
+    for a, b in zip(opt._flat_state, opt2._flat_state):
+        assert b["step"] == 7 and torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])

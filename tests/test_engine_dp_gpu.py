@@ -1,0 +1,206 @@
+"""GPU (-m gpu): the data-parallel exchange step and the engine features around it, on ONE MI355X.
+
+RCCL refuses two ranks on one device, so the exchange runs as a single-rank communicator (``HUPR_FORCE_ALLREDUCE=1``):
+every byte still goes through ``hupr_allreduce_bucket`` (ncclAllReduce on the C ABI's own communicator, enqueued on the
+communication stream and joined before Adam), and the sum over one rank must leave every bit unchanged.  The world-size-2
+logic (bucket order, broadcast, accumulation) is covered on CPU over gloo in tests/test_distributed_cpu.py.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from hupr_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(B=4, seed=51):
+    from hupr_amd.config_tree import load_config
+    cfg = load_config()
+    dev = torch.device("cuda", 0)
+    G = cfg.DATASET.numGroupFrames
+    adc_h = torch.from_numpy(synth.adc_cube_int16(seed, sensor=0, nframes=B * G)).to(dev)
+    adc_v = torch.from_numpy(synth.adc_cube_int16(seed, sensor=1, nframes=B * G)).to(dev)
+    joints = torch.from_numpy(synth.keypoints(B, seed + 1)).to(dev)
+    return cfg, dev, adc_h, adc_v, joints
+
+
+def _flat(eng):
+    return torch.cat([p.detach().flatten() for p in eng.model.parameters()])
+
+
+def test_rccl_exchange_single_rank_is_bit_transparent(monkeypatch):
+    """3 optimisation steps with every gradient bucket pushed through hupr_allreduce_bucket on the communication stream
+    == 3 steps without any collective, bit for bit (parameters, BatchNorm statistics, loss)."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    saved = F_.TWO_STREAMS
+    try:
+        F_.set_math("bf16")
+        F_.TWO_STREAMS = False
+        cfg, dev, adc_h, adc_v, joints = _setup()
+        monkeypatch.delenv("HUPR_FORCE_ALLREDUCE", raising=False)
+        e0 = TrainEngine(cfg, device=dev, seed=0)
+        assert not e0.buckets.active and e0.buckets.transport is None
+        monkeypatch.setenv("HUPR_FORCE_ALLREDUCE", "1")
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        assert e1.buckets.active and e1.buckets.transport.name.startswith("rccl"), e1.buckets.transport.name
+        for _ in range(3):
+            l0, _ = e0.train_step_from_adc(adc_h, adc_v, joints)
+            l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)
+        torch.cuda.synchronize()
+        assert all(b.launched for b in e1.buckets.buckets)
+        assert float(l0) == float(l1)
+        assert torch.equal(_flat(e0), _flat(e1))
+        s0, s1 = e0.model.state_dict(), e1.model.state_dict()
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+        e1.buckets.transport.close()
+    finally:
+        F_.TWO_STREAMS = saved
+        F_.set_math("f32")
+
+
+def test_graph_captures_the_exchange_step(monkeypatch):
+    """The data-parallel step as ONE hipGraph: the fork to the communication stream, ncclAllReduce and the join before Adam
+    are captured; 2 eager + 1 warm-up + 2 replays == 5 eager steps."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    saved = F_.TWO_STREAMS
+    try:
+        F_.set_math("bf16")
+        F_.TWO_STREAMS = False
+        monkeypatch.setenv("HUPR_FORCE_ALLREDUCE", "1")
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=61)
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        for _ in range(5):
+            l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)
+        e2 = TrainEngine(cfg, device=dev, seed=0)
+        for _ in range(2):
+            e2.train_step_from_adc(adc_h, adc_v, joints)
+        e2.capture(adc_h, adc_v, joints, warmup=1, decode="device")
+        for _ in range(2):
+            l2, _ = e2.train_step_from_adc(adc_h, adc_v, joints)
+        torch.cuda.synchronize()
+        p1, p2 = _flat(e1), _flat(e2)
+        assert torch.isfinite(p2).all()
+        rel = ((p1 - p2).norm() / p1.norm()).item()
+        assert rel <= 1e-5, rel
+        assert abs(float(l1) - float(l2)) <= 1e-4 * abs(float(l1))
+        # guards: host joints / a loss-weight schedule cannot be captured
+        e3 = TrainEngine(cfg, device=dev, seed=0)
+        with pytest.raises(RuntimeError, match="resident on the GPU"):
+            e3.capture(adc_h, adc_v, joints.cpu())
+    finally:
+        F_.TWO_STREAMS = saved
+        F_.set_math("f32")
+
+
+def test_accumulated_micro_batches_equal_one_step():
+    """bench.py --strong: two identical micro-batches accumulated into one optimiser step give exactly the parameters of
+    one step on that micro-batch ((g + g) / 2 == g in binary floating point); BatchNorm statistics saw two batches."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    try:
+        F_.set_math("bf16")
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=71)
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        e1.train_step_from_adc(adc_h, adc_v, joints)
+        e2 = TrainEngine(cfg, device=dev, seed=0)
+        e2.train_step_accumulated([(adc_h, adc_v, joints)] * 2)
+        torch.cuda.synchronize()
+        assert torch.equal(_flat(e1), _flat(e2))
+        nbt = [int(v) for k, v in e2.model.state_dict().items() if k.endswith("num_batches_tracked")]
+        assert set(nbt) == {2}
+        # and a second accumulated step starts from a clean accumulator
+        e1.train_step_from_adc(adc_h, adc_v, joints)
+        e2.train_step_accumulated([(adc_h, adc_v, joints)] * 2)
+        rel = ((_flat(e1) - _flat(e2)).norm() / _flat(e1).norm()).item()
+        assert rel < 1e-4, rel            # BatchNorm running stats differ (2 vs 1 updates) but train-mode outputs do not
+    finally:
+        F_.set_math("f32")
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """optimizer_state_dict must carry the Adam moments.  train 2 steps -> save -> (fresh engine) load ->
+    step 3 lands on the same bits as the uninterrupted run; the saved state has torch.optim.Adam's layout."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    try:
+        F_.set_math("bf16")
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=81)
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        for _ in range(2):
+            e1.train_step_from_adc(adc_h, adc_v, joints)
+        ck = {"model_state_dict": e1.model.state_dict(), "optimizer_state_dict": e1.optimizer.state_dict()}
+        torch.save(ck, tmp_path / "checkpoint.pth")
+        e1.train_step_from_adc(adc_h, adc_v, joints)
+        n_params = sum(1 for _ in e1.model.parameters())
+        ck = torch.load(tmp_path / "checkpoint.pth", map_location="cuda")
+        st = ck["optimizer_state_dict"]["state"]
+        assert len(st) == n_params and all(float(s["step"]) == 2 and s["exp_avg_sq"].abs().sum() > 0 for s in st.values())
+        e2 = TrainEngine(cfg, device=dev, seed=123)              # different init on purpose
+        e2.model.load_state_dict(ck["model_state_dict"])
+        e2.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        F_.invalidate_packed()
+        e2.train_step_from_adc(adc_h, adc_v, joints)
+        torch.cuda.synchronize()
+        assert torch.equal(_flat(e1), _flat(e2))
+        # the same state drives torch.optim.Adam (the reference's optimiser, tools/base.py:47)
+        tad = torch.optim.Adam(e2.model.parameters(), lr=cfg.TRAINING.lr, weight_decay=1e-4)
+        tad.load_state_dict(ck["optimizer_state_dict"])
+        assert len(tad.state) == n_params
+    finally:
+        F_.set_math("f32")
+
+
+def _bench(args, env_extra=None, launcher=False):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29671"]
+    cmd += [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu_carries_every_object():
+    out = _bench(["--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["dtype"] == "bf16"
+    assert out["config"]["parallelism"] == "dp1" and out["config"]["launch"] == "eager"
+    assert out["roofline"]["launches"] == 3 * 12 and 0 < out["roofline"]["frac"] < 1
+    assert out["fft_roofline"]["bound"] == "hbm" and 0 < out["fft_roofline"]["frac"] < 1
+    assert out["parity_path"]["dtype"] == "f32" and out["parity_path"]["roofline"]["peak"] == 157.3
+    assert "arg-max" in out["config"]["workload"]
+
+
+def test_bench_under_launcher_uses_rccl_and_graph():
+    """One rank started the way the driver starts N: gloo control plane + the C ABI's RCCL communicator for the buckets;
+    --graph replays the captured data-parallel step."""
+    out = _bench(["--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "4", "--no-cpu-baseline", "--no-parity-path", "--graph"],
+                 env_extra={"HUPR_FORCE_ALLREDUCE": "1"}, launcher=True)
+    assert out["n_gpus"] == 1 and out["config"]["collective"].startswith("rccl")
+    assert out["config"]["launch"] == "hipGraph replay" and out["roofline"]["launches"] == 3 * 12
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_strong_scaling_accumulates_micro_batches():
+    out = _bench(["--steps", "2", "--warmup", "1", "--batch", "32", "--strong", "--no-cpu-baseline"])
+    assert out["scaling"] == "strong" and out["config"]["global_batch"] == 256 and out["config"]["micro_batches_per_step"] == 8
+    assert abs(out["value"] - 256 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-2 * out["value"]
