@@ -15,7 +15,9 @@
 
 namespace hupr {
 
-template <bool ABF>
+// ABL: compile-time phase ablation for scripts/halo_ablation.py (wrong results, timing only): 1 = no weight staging
+// (stages read whatever Bs holds), 2 = no per-stage barrier, 4 = fragments of K-step 0 only (no re-reads inside a stage)
+template <bool ABF, int ABL = 0>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
     constexpr int TD = 4, TH = 8, TW = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2;
@@ -23,8 +25,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     constexpr int T = 27, NSTAGE = 9;                          // stage = (kz, kx), its three taps = ky 0..2
     constexpr int NI = (NVOX * C8 + 511) / 512;                // 10 halo items (8 channels of a voxel) per thread ...
     constexpr int NH = ABF ? NI : NI / 2;                      // ... fp32 sources: two half batches (register budget)
-    constexpr int NB = TS * BN * C8 / 512;                     // 3 weight loads per thread per stage
-    __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
+        __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];     // double-buffered weight stages
     __shared__ float Ss[4][2][256];                              // fused BatchNorm statistics: [depth slice wave][sum | sum of squares][channel]
 
@@ -41,17 +42,21 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     const int bkey = ((wn * 32 + lr) >> 1) & 7;
     const int n_tiles = p.Bn * p.nd * p.nh * p.nw * p.n_co_tiles;
 
-    // weight-stage loads of this thread: item f = tid + 512 j over [ky t][row n][chunk c8].  BN * C8 == 512 == the
-    // workgroup size, so t == j and (n, c8) do not depend on j: one source offset (+ j * 3 Ci: tap = (kz*3 + ky)*3 + kx)
-    // and one LDS offset per thread instead of three of each
-    static_assert(BN * C8 == 512, "weight-stage item map assumes one ky slice per 512 threads");
-    const int wn_ = tid / C8, wc8_ = tid % C8;
-    const int wsrc0 = wn_ * T * p.Ci + wc8_ * 8;                  // < 2^31: Co * 27 * Ci elements
-    const int wstep = 3 * p.Ci;
-    const int wdst0 = wn_ * LDK + (((wc8_ ^ (wn_ >> 1)) & 7) << 3);
+    // Weight stages travel global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write burst behind
+    // every barrier; measured -19 us of the 191 us tap loop on the layer-1 shape).  A stage (3 taps x 64 rows x 128 B) is
+    // 24 pieces of 1 KiB = 8 rows; wave w moves rows 8 w .. 8 w + 7 of each tap: lane l deposits 16 bytes at piece base +
+    // 16 l = row 8 w + (l >> 3), chunk position l & 7.  The row swizzle (chunk c8 of row n lives at position c8 ^ (n >> 1))
+    // is applied on the SOURCE side: position c' is filled with source chunk c' ^ ((n >> 1) & 7).
+    // The DMA is issued from inline asm (M0 = LDS address, saved / restored around it): hipcc then neither counts it nor
+    // guards later LDS reads with vmcnt(0); the stage protocol below does its own counted waits.
+    const int wrow_ = 8 * wave + (lane >> 3);
+    const int wsrc_lane = (wrow_ * T * p.Ci + (((lane & 7) ^ (wrow_ >> 1)) & 7) * 8) * 2;      // bytes; < 2^31
+    const u32x4 wrs = {(unsigned)(unsigned long)p.wp, (unsigned)((unsigned long)p.wp >> 32) & 0xffffu,
+                       (unsigned)((long)p.Co * T * p.Ci * 2), 0x00020000u};
+    const unsigned bs_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
+    const unsigned wdst_wave = __builtin_amdgcn_readfirstlane(bs_lds + wave * 1024);
 
     f32x16 acc[2];
-    u32x4 rb[NB];
     f32x4n va[ABF ? 1 : NH], vc[ABF ? 1 : NH];
     u32x4 vb[ABF ? NH : 1];
 
@@ -124,7 +129,11 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     struct Pos { int cot, twi, thi, tdi, b, ch; };
     const int n_chunks = p.Ci / KC;
     const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const int t_begin = blockIdx.x * per_wg, t_end = min(n_tiles, t_begin + per_wg);
+    // XCD-aware range assignment: workgroup id -> XCD is id % 8 and every XCD has its own L2, so the eight XCDs each walk
+    // ONE contiguous eighth of the tile sequence (neighbouring tile rows / depth slabs, whose halos overlap, then hit in
+    // the same L2 instead of being fetched from HBM once per XCD)
+    const int wg_rank = (p.ablate & 8) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    const int t_begin = wg_rank * per_wg, t_end = min(n_tiles, t_begin + per_wg);
     if (p.stats) {
         for (int i = tid; i < 4 * 2 * 256; i += 512) (&Ss[0][0][0])[i] = 0.f;      // published by the prologue barrier
         if (t_begin >= t_end) {
@@ -143,25 +152,31 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         cur.ch = 0;
     }
     const int n_items = (t_end - t_begin) * n_chunks;
-    // weights of stage S_ (0..8) of the item at co tile COT_ / chunk CH_:  tap (kz, ky = 0, kx) + this thread's ky rows
-#define HUPR_W_ISSUE(COT_, CH_, S_)                                                                                 \
+    // weights of stage S_ (0..8) of the item at co tile COT_ / chunk CH_ -> Bs[PAR_]: taps (kz, ky = 0..2, kx)
+#define HUPR_W_DMA(COT_, CH_, S_, PAR_)                                                                             \
     {                                                                                                               \
-        const __bf16* wsrc_ = p.wp + (long)(COT_) * BN * T * p.Ci + (long)(((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + (CH_) * KC; \
-        _Pragma("unroll") for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const u32x4*>(wsrc_ + wsrc0 + j * wstep); \
+        const int wbase_ = (((COT_) * BN * T + ((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + (CH_) * KC) * 2 + wsrc_lane;   \
+        _Pragma("unroll") for (int j = 0; j < TS; ++j) {                                                            \
+            unsigned keep_;                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
+                         "s_mov_b32 m0, %0"                                                                         \
+                         : "=&s"(keep_)                                                                             \
+                         : "s"(wdst_wave + ((PAR_) * TS + j) * (BN * LDK * 2)), "v"(wbase_ + j * (3 * p.Ci * 2)), "s"(wrs) \
+                         : "memory");                                                                               \
+        }                                                                                                           \
     }
-#define HUPR_W_COMMIT(PAR_)                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(&Bs[PAR_][j][wdst0]) = rb[j];
+    // all but the youngest N_ vector-memory operations of this wave have completed (vmcnt is 6 bits: [3:0] and [15:14])
+#define HUPR_VMCNT(N_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N_) & 15) | (((N_) >> 4) << 14))
 
     // prologue: first item's halo, weight stage 0 -> Bs[0], weight stage 1 in flight
+    HUPR_W_DMA(cur.cot, cur.ch, 0, 0)
     HUPR_HALO_ISSUE(0, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
-    HUPR_W_ISSUE(cur.cot, cur.ch, 0)
-    HUPR_W_COMMIT(0)
-    HUPR_W_ISSUE(cur.cot, cur.ch, 1)
     HUPR_HALO_COMMIT(0)
     if constexpr (!ABF) {
         HUPR_HALO_ISSUE(NH, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
         HUPR_HALO_COMMIT(NH)
     }
+    HUPR_VMCNT(0);
     __syncthreads();
 
     int g = 0;                                                    // global stage counter: stage g reads Bs[g & 1]
@@ -193,10 +208,11 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #pragma unroll
         for (int st_ = 0; st_ < NSTAGE; ++st_) {
             const int par = (g + st_) & 1;
-            // weights of the next stage -> the idle half of Bs; weights two stages ahead -> registers
-            if (st_ + 1 < NSTAGE || has_next) { HUPR_W_COMMIT(par ^ 1) }
-            if (st_ + 2 < NSTAGE) { HUPR_W_ISSUE(cur.cot, cur.ch, st_ + 2) }
-            else if (has_next) { HUPR_W_ISSUE(nxt.cot, nxt.ch, st_ + 2 - NSTAGE) }
+            // weights of the next stage -> the idle half of Bs (everyone left it at the previous barrier)
+            if constexpr (!(ABL & 1)) {
+                if (st_ + 1 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 1, par ^ 1) }
+                else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, 0, par ^ 1) }
+            }
             if (st_ == 0 && has_next) {                           // next item's halo rides under the remaining stages
                 HUPR_HALO_ISSUE(0, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
             }
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                 HUPR_FRAGS(0, 0)
 #pragma unroll
                 for (int ks = 0; ks < KC / 16; ++ks) {
-                    if (ks + 1 < KC / 16) {
+                    if (ks + 1 < KC / 16 && !(ABL & 4)) {
                         if (ks & 1) { HUPR_FRAGS(0, ks + 1) } else { HUPR_FRAGS(1, ks + 1) }
                     }
                     // keep the machine scheduler from sinking the prefetch reads back next to their uses (it would
@@ -228,14 +244,19 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < TS; ++t) {                // ky;  D'[channel][voxel]
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t + 1], acc[1], 0, 0, 0);
+                        constexpr int fs = (ABL & 4) ? 0 : -1;
+                        const int set = fs == 0 ? 0 : (ks & 1);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[set][t], af[set][t], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[set][t], af[set][t + 1], acc[1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef HUPR_FRAGS
             }
-            __syncthreads();                                      // Bs[par ^ 1] complete; all waves done with Bs[par] (and, after stage 8, Hs)
+            // this wave's pieces of the next stage have landed (in stage 0 the next halo's NH younger register loads stay in
+            // flight); after the barrier Bs[par ^ 1] is complete and all waves are done with Bs[par] (and, after stage 8, Hs)
+            if (ABF && st_ == 0 && has_next) { HUPR_VMCNT(NH); } else { HUPR_VMCNT(0); }      // (guarded fp32 loads: no fixed count)
+            if constexpr (!(ABL & 2)) __syncthreads();
             if (st_ == 0) { HUPR_STAMP() }                        // 2: first stage computed
         }
         g += NSTAGE;
@@ -300,8 +321,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             p.stats[(long)blockIdx.x * 2 * p.Co + c] = ((double)Ss[0][k][ch] + (double)Ss[1][k][ch]) + ((double)Ss[2][k][ch] + (double)Ss[3][k][ch]);
         }
     }
-#undef HUPR_W_ISSUE
-#undef HUPR_W_COMMIT
+#undef HUPR_W_DMA
+#undef HUPR_VMCNT
 #undef HUPR_STAMP
 #undef HUPR_HALO_ISSUE
 #undef HUPR_HALO_COMMIT
@@ -328,6 +349,17 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     if (tiles >= (1L << 31) || tiles < 256) return false;          // small problems: the 128-voxel kernel fills the chip better
     if (abf && (long)Bn * a.D * a.H * a.W * a.in_ld * 2 >= 0x7ffffff0L) return false;   // 32-bit buffer offsets
     // one persistent workgroup per CU
+    if (abf && (a.ablate >> 4)) {      // compile-time ablations (profiling only)
+        switch (a.ablate >> 4) {
+            case 1: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 1>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 2>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 3: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 4>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 5: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 5>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            default: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 7>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+        }
+        return true;
+    }
     if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(kHalo256Grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<false>, dim3(kHalo256Grid), dim3(512), 0, s, a);
     return true;

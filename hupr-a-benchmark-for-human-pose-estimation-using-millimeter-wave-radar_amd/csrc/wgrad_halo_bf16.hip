@@ -30,6 +30,7 @@ struct WgradHaloArgs {
     int Bn, D, H, W, Ci, in_ld, Co, dy_ld;
     int kd, TD, log2TW, nd, nh, nw;
     int n_ci_tiles, n_co_tiles, groups, n_spatial;
+    int xcd_map;           // LDS-DMA kernel: 1-D XCD-aware grid (see hupr_k_wgrad_halo_glds)
 };
 
 constexpr int kRowB = 128;                   // bytes per LDS row: 64 bf16 channels
@@ -240,9 +241,26 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     const int wm = (wave >> 1) & 1, wn = wave & 1;    // 32-row (co) / 32-col (ci) quadrant of the 64x64 tile
     const int pd = p.kd >> 1;
     const int T = p.kd * 9;
-    const int group = blockIdx.x;
-    const int td = blockIdx.y;
-    const int cot = blockIdx.z / p.n_ci_tiles, cit = blockIdx.z % p.n_ci_tiles;
+    // XCD-aware 1-D grid (p.xcd_map): the kd depth-tap planes and the (co, ci) tile pairs of one spatial group re-read the
+    // same x / dy tiles, so all of them are given workgroup ids that are congruent mod 8 (= one XCD, one L2): measured on
+    // the layer-1 shape the HBM fetch drops from 3.1x to 1.1x of the algorithmic bytes.  id = c + 8 n, c = group % 8,
+    // n = (group / 8) * members + member.  The launcher only chooses it when members * groups / 8 <= 32 workgroups per XCD
+    // still fill >= 90 % of the CUs; otherwise the grid is (groups, kd, tile pairs) as before.
+    int group, td, pair_;
+    if (p.xcd_map) {
+        const int members = p.kd * p.n_ci_tiles * p.n_co_tiles;
+        const int slot = (int)blockIdx.x >> 3;
+        group = (slot / members) * 8 + ((int)blockIdx.x & 7);
+        const int member = slot % members;
+        td = member % p.kd;
+        pair_ = member / p.kd;
+    } else {
+        group = blockIdx.x;
+        td = blockIdx.y;
+        pair_ = blockIdx.z;
+    }
+    const int cot = pair_ / p.n_ci_tiles, cit = pair_ % p.n_ci_tiles;
+    if (group >= p.groups) return;
     const int co0 = cot * 64, ci0 = cit * 64;
 
     const int g = lane >> 4, s = lane & 15;
@@ -441,6 +459,9 @@ extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
     return groups * one;
 }
 
+static int g_wgrad_groups = 0;      // A/B aid (hupr_debug_wgrad_groups): > 0 forces the workgroup count per (kz, tile pair)
+extern "C" void hupr_debug_wgrad_groups(int g) { g_wgrad_groups = g; }      // 0 auto, > 0 forced, < 0 auto without XCD affinity
+
 static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci, int in_ld, int Co,
                       int dy_ld, int kd, void* ws, size_t ws_bytes, bool abf, hupr_stream_t stream, const char* who) {
     HUPR_REQUIRE(x && dy && dw && ws, "%s: null pointer", who);
@@ -451,6 +472,7 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
                  "%s: unsupported geometry", who);
     HUPR_REQUIRE((long)Bn * D * H * W * (in_ld > dy_ld ? in_ld : dy_ld) < (1L << 31), "%s: tensor too large for 32-bit offsets", who);
     WgradHaloArgs a;
+    a.xcd_map = 0;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(ws);
     a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.dy_ld = dy_ld;
     a.kd = kd;
@@ -471,12 +493,19 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     if (abf && max_bytes < 0x7ffffff0L) {
         // LDS-DMA kernel: one 512-thread workgroup per CU (two K halves, merged in LDS), one partial tensor per workgroup
         int gw = max(1, min(128, 256 / pairs));
+        // XCD affinity: 8 * floor(32 / members) groups put every member of a group on one XCD with <= 32 workgroups per XCD
+        const int g8 = pairs <= 32 ? 8 * (32 / pairs) : 0;
+        a.xcd_map = g8 > 0 && 10 * g8 >= 9 * gw && g8 <= a.n_spatial;
+        if (a.xcd_map) gw = min(g8, 128);
+        if (g_wgrad_groups > 0) { gw = g_wgrad_groups; a.xcd_map = gw % 8 == 0; }
+        if (g_wgrad_groups < 0) a.xcd_map = 0;                       // A/B aid: the pre-affinity grid
         gw = min(gw, a.n_spatial);
-        while (gw > 1 && (size_t)gw * one > ws_bytes) gw >>= 1;
+        while (gw > 1 && (size_t)gw * one > ws_bytes) { gw >>= 1; a.xcd_map = 0; }
         if ((size_t)gw * one <= ws_bytes) {
             a.groups = gw;
-            if (kd == 3) hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<true>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<false>, dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles), dim3(512), 0, s, a);
+            const dim3 grid = a.xcd_map ? dim3(gw * pairs) : dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles);
+            if (kd == 3) hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<true>, grid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<false>, grid, dim3(512), 0, s, a);
             HUPR_LAUNCH_OK("hupr_k_wgrad_halo_glds");
             launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw, n, kd * 9, Ci, s);
             HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
