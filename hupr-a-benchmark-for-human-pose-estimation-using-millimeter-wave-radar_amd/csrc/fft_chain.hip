@@ -75,6 +75,13 @@ __device__ __forceinline__ void fft16(float2 (&x)[16]) {
 // K1: range FFT + crop + clutter removal + Doppler FFT + crop
 // grid = n_sf * 12, block = 256
 // ------------------------------------------------------------------------------------------
+// WIN (opt-in, OFF for every parity path — the reference applies no window, process_iwr1843.py:130-134): bit 0 = Hann over
+// the 256 range samples, bit 1 = Hann over the 64 chirp loops (after the clutter-removal mean), both in np.hanning's
+// symmetric form 0.5 - 0.5 cos(2 pi n / (N - 1)).  The range window commutes with the chirp mean, so it is applied to the
+// samples as they are converted; the Doppler window multiplies the mean-free range profile right before its FFT.
+__device__ __forceinline__ float hann(int n, int N) { return 0.5f - 0.5f * cospif(2.0f * (float)n / (float)(N - 1)); }
+
+template <int WIN>
 __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __restrict__ iq,
                                                             float2* __restrict__ rd) {
     __shared__ float2 tw[256];                       // W_256^t
@@ -111,6 +118,11 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
     float2 twl[16];
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) twl[k1] = tw[(l16 * k1) & 255];
+    float wr[(WIN & 1) ? 16 : 1];
+    if constexpr (WIN & 1) {
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) wr[n1] = hann(16 * n1 + l16, kSamples);
+    }
     float2* xch = rbuf_x + (wave * 4 + cs) * 273;   // 16 x 17 transpose tile of this lane's chirp slot (+1: bank offset between slots)
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -119,6 +131,10 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1)
             x[n1] = make_float2((float)(int16_t)(raw[ps][n1] & 0xffff), (float)(raw[ps][n1] >> 16));
+        if constexpr (WIN & 1) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) { x[n1].x *= wr[n1]; x[n1].y *= wr[n1]; }
+        }
         fft16(x);                                        // Y[k1 = g + 4 q] at x[4 g + q]
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -163,6 +179,10 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
         sy *= (1.0f / 64.0f);
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) { x[n1].x -= sx; x[n1].y -= sy; }
+        if constexpr (WIN & 2) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) { const float w = hann(4 * n1 + n2, 64); x[n1].x *= w; x[n1].y *= w; }
+        }
         fft16(x);                                        // Y[k1 = g + 4 q] at x[4 g + q]
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -222,8 +242,10 @@ __device__ __forceinline__ AngleOut angle_cell(const float2* __restrict__ cell, 
     return r;
 }
 
-template <bool LOADER>
+// MODE 0: complex64 cube (the reference's output); 1: loader epilogue (Normalize fused); 2 (opt-in): magnitude |X| as fp32
+template <int MODE>
 __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ rd, void* __restrict__ out_) {
+    constexpr bool LOADER = MODE == 1;
     __shared__ float2 cells[kRange * kVant];   // RD for this (sf, i): 64 range bins x 12 antennas
     __shared__ float2 tw64[64];
     __shared__ float red[4][32];
@@ -301,6 +323,18 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
             pr[1] = (f32x4){re[4], re[5], re[6], re[7]};
             pi[0] = (f32x4){im[0], im[1], im[2], im[3]};
             pi[1] = (f32x4){im[4], im[5], im[6], im[7]};
+        }
+    } else if (MODE == 2) {
+        float* out = reinterpret_cast<float*>(out_) + ((size_t)(sf * kDop + i) * kRange) * kAz * kEl;
+        for (int j = 0; j < 16; ++j) {
+            const int r = wave * 16 + j;
+            AngleOut v = angle_cell(cells + r * kVant, twl);
+            float m[kEl];
+#pragma unroll
+            for (int e = 0; e < kEl; ++e) m[e] = sqrtf(fmaf(v.o[e].x, v.o[e].x, v.o[e].y * v.o[e].y));
+            f32x4* p = reinterpret_cast<f32x4*>(out + ((size_t)r * kAz + a_out) * kEl);
+            p[0] = (f32x4){m[0], m[1], m[2], m[3]};
+            p[1] = (f32x4){m[4], m[5], m[6], m[7]};
         }
     } else {
         float2* out = reinterpret_cast<float2*>(out_) + ((size_t)(sf * kDop + i) * kRange) * kAz * kEl;
@@ -394,7 +428,9 @@ extern "C" size_t hupr_fft_chain_ws_bytes(int n_sf) {
 }
 
 static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws, size_t ws_bytes,
-                            hupr_stream_t stream, bool loader) {
+                            hupr_stream_t stream, bool loader, int flags = 0) {
+    HUPR_REQUIRE((flags & ~(HUPR_FFT_HANN_RANGE | HUPR_FFT_HANN_DOPPLER | HUPR_FFT_MAGNITUDE)) == 0, "hupr_fft_chain: flags=0x%x", flags);
+    HUPR_REQUIRE(!(loader && (flags & HUPR_FFT_MAGNITUDE)), "hupr_fft_chain: the loader epilogue splits re/im, it has no magnitude form");
     HUPR_REQUIRE(n_sf >= 0, "hupr_fft_chain: n_sf=%d", n_sf);
     if (n_sf == 0) return HUPR_OK;                      // empty batch is a no-op
     HUPR_REQUIRE(adc_iq && out && ws, "hupr_fft_chain: null pointer");
@@ -406,12 +442,19 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
                     hupr_fft_chain_ws_bytes(n_sf));
     hipStream_t s = as_stream(stream);
     float2* rd = reinterpret_cast<float2*>(ws);
-    hipLaunchKernelGGL(hupr_k_range_doppler, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd);
+    switch (flags & 3) {
+        case 0: hipLaunchKernelGGL(hupr_k_range_doppler<0>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+        case 1: hipLaunchKernelGGL(hupr_k_range_doppler<1>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+        case 2: hipLaunchKernelGGL(hupr_k_range_doppler<2>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+        default: hipLaunchKernelGGL(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+    }
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
     if (loader)
-        hipLaunchKernelGGL(hupr_k_angle<true>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
+        hipLaunchKernelGGL(hupr_k_angle<1>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
+    else if (flags & HUPR_FFT_MAGNITUDE)
+        hipLaunchKernelGGL(hupr_k_angle<2>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
     else
-        hipLaunchKernelGGL(hupr_k_angle<false>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
+        hipLaunchKernelGGL(hupr_k_angle<0>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
     HUPR_LAUNCH_OK("hupr_k_angle");
     return HUPR_OK;
 }
@@ -424,6 +467,11 @@ extern "C" int hupr_fft_chain_c64(const int16_t* adc_iq, int n_sf, void* out_c64
 extern "C" int hupr_fft_chain_loader_f32(const int16_t* adc_iq, int n_sf, float* out, void* ws,
                                          size_t ws_bytes, hupr_stream_t stream) {
     return fft_chain_common(adc_iq, n_sf, out, ws, ws_bytes, stream, true);
+}
+
+extern "C" int hupr_fft_chain_opts(const int16_t* adc_iq, int n_sf, void* out, int flags, int loader, void* ws, size_t ws_bytes,
+                                   hupr_stream_t stream) {
+    return fft_chain_common(adc_iq, n_sf, out, ws, ws_bytes, stream, loader != 0, flags);
 }
 
 extern "C" int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* out, hupr_stream_t stream) {

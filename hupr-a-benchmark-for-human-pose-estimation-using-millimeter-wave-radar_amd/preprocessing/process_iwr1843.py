@@ -27,22 +27,39 @@ def _check_adc(adc_iq):
         raise ValueError("adc_iq must be int16 (n,4,192,256,2), got %s %r" % (adc_iq.dtype, tuple(adc_iq.shape)))
 
 
-def fft_chain(adc_iq, ws=None):
-    """adc_iq: int16 GPU tensor (n,4,192,256,2) -> complex64 GPU tensor (n,16,64,64,8)."""
+HANN_RANGE, HANN_DOPPLER, MAGNITUDE = 1, 2, 4      # include/hupr.h HUPR_FFT_*
+
+
+def _flags(window, magnitude):
+    """window: None / False (the reference: rectangular), "hann" / True (range + Doppler), "range", "doppler"."""
+    table = {None: 0, False: 0, "none": 0, True: 3, "hann": 3, "range": 1, "doppler": 2}
+    if window not in table:
+        raise ValueError("window must be one of None, 'hann', 'range', 'doppler'; got %r" % (window,))
+    return table[window] | (MAGNITUDE if magnitude else 0)
+
+
+def fft_chain(adc_iq, ws=None, window=None, magnitude=False):
+    """adc_iq: int16 GPU tensor (n,4,192,256,2) -> complex64 GPU tensor (n,16,64,64,8).
+    Opt-in (defaults = the reference: no window, complex output): ``window="hann"`` applies np.hanning windows over the
+    range samples and the chirp loops, ``magnitude=True`` returns |X| as fp32."""
     _check_adc(adc_iq)
     n = adc_iq.shape[0]
-    out = torch.empty((n, 16, 64, 64, 8), dtype=torch.complex64, device=adc_iq.device)
+    flags = _flags(window, magnitude)
+    out = torch.empty((n, 16, 64, 64, 8), dtype=torch.float32 if magnitude else torch.complex64, device=adc_iq.device)
     if ws is None:
         ws, nbytes = _workspace(n, adc_iq.device)
     else:
         nbytes = ws.numel() * ws.element_size()
-    rt.check(rt.lib().hupr_fft_chain_c64(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
+    if flags == 0:
+        rt.check(rt.lib().hupr_fft_chain_c64(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
+    else:
+        rt.check(rt.lib().hupr_fft_chain_opts(rt.ptr(adc_iq), n, rt.ptr(out), flags, 0, rt.ptr(ws), nbytes, rt.stream()))
     return out
 
 
-def fft_chain_loader(adc_iq, ws=None, out=None):
+def fft_chain_loader(adc_iq, ws=None, out=None, window=None):
     """adc_iq: int16 GPU tensor (n,4,192,256,2) -> fp32 GPU tensor (n, 8, 2, 64, 64, 8):
-    Doppler bins 4..11, re/im split, per-elevation Normalize (datasets glue fused in)."""
+    Doppler bins 4..11, re/im split, per-elevation Normalize (datasets glue fused in).  ``window``: see fft_chain."""
     _check_adc(adc_iq)
     n = adc_iq.shape[0]
     if out is None:
@@ -51,8 +68,11 @@ def fft_chain_loader(adc_iq, ws=None, out=None):
         ws, nbytes = _workspace(n, adc_iq.device)
     else:
         nbytes = ws.numel() * ws.element_size()
-    rt.check(rt.lib().hupr_fft_chain_loader_f32(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes,
-                                               rt.stream()))
+    flags = _flags(window, False)
+    if flags == 0:
+        rt.check(rt.lib().hupr_fft_chain_loader_f32(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
+    else:
+        rt.check(rt.lib().hupr_fft_chain_opts(rt.ptr(adc_iq), n, rt.ptr(out), flags, 1, rt.ptr(ws), nbytes, rt.stream()))
     return out
 
 
@@ -106,8 +126,9 @@ class RadarObject:
         z = fr[..., 0].astype(np.float64) + 1j * fr[..., 1].astype(np.float64)
         return np.ascontiguousarray(z.transpose(1, 0, 2, 3).reshape(self.numRX, -1, self.numADCSamples))
 
-    def generateHeatmap(self, frame):
-        """frame: complex ndarray (4,192,256) -> complex128 ndarray (16,64,64,8)."""
+    def generateHeatmap(self, frame, window=None, magnitude=False):
+        """frame: complex ndarray (4,192,256) -> complex128 ndarray (16,64,64,8) (float64 with ``magnitude``).
+        ``window`` / ``magnitude`` are opt-in extras (see ``fft_chain``); the defaults are the reference's arithmetic."""
         frame = np.asarray(frame)
         if frame.shape != (self.numRX, self.numChirp, self.numADCSamples):
             raise ValueError("frame must be (4,192,256), got %r" % (frame.shape,))
@@ -115,5 +136,5 @@ class RadarObject:
         if not np.all(np.abs(iq) <= 32767) or not np.array_equal(iq, np.rint(iq)):
             raise ValueError("generateHeatmap expects integer-valued 16-bit ADC samples")
         dev = torch.from_numpy(iq.astype(np.int16)[None]).to(self.device)
-        out = fft_chain(dev)
-        return out[0].cpu().numpy().astype(np.complex128)
+        out = fft_chain(dev, window=window, magnitude=magnitude)
+        return out[0].cpu().numpy().astype(np.float64 if magnitude else np.complex128)

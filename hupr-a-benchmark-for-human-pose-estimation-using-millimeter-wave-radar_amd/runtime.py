@@ -23,6 +23,7 @@ SIGNATURES = {
     "hupr_fft_chain_ws_bytes": (c_size_t, [c_int]),
     "hupr_fft_chain_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_fft_chain_loader_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_fft_chain_opts": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_loader_normalize_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "hupr_dca1000_deinterleave": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hupr_gemm_f32": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long,

@@ -56,6 +56,20 @@ int hupr_fft_chain_c64(const int16_t* adc_iq, int n_sf, void* out_c64, void* ws,
 int hupr_fft_chain_loader_f32(const int16_t* adc_iq, int n_sf, float* out, void* ws, size_t ws_bytes,
                               hupr_stream_t stream);
 
+/* (a1, opt-in variants) north_star asks for "Hanning windowing and magnitude"; the reference has neither
+ *      (process_iwr1843.py:130-151 is bare np.fft.fft2 / np.fft.fft, np.abs only in the plotting helper :207-208), so
+ *      both are flags that are OFF on every parity path:
+ *        HUPR_FFT_HANN_RANGE    x[c,s] *= hann256[s]            before the range FFT   (np.hanning(256), symmetric)
+ *        HUPR_FFT_HANN_DOPPLER  (x - mean_c x)[c] *= hann64[c]  before the Doppler FFT (after clutter removal :122-128)
+ *        HUPR_FFT_MAGNITUDE     out = |X| as float [n_sf][16][64][64][8] (2 097 152 B) instead of complex64
+ *      loader != 0 selects the fused loader epilogue of hupr_fft_chain_loader_f32 (window flags only).
+ *      flags == 0 is exactly hupr_fft_chain_c64 / hupr_fft_chain_loader_f32. */
+#define HUPR_FFT_HANN_RANGE 1
+#define HUPR_FFT_HANN_DOPPLER 2
+#define HUPR_FFT_MAGNITUDE 4
+int hupr_fft_chain_opts(const int16_t* adc_iq, int n_sf, void* out, int flags, int loader, void* ws, size_t ws_bytes,
+                        hupr_stream_t stream);
+
 /* (a2) loader glue alone on a precomputed cube (the .npy hand-off of the reference):
  * cube_c64 : float2 [n_sf][16][64][64][8]  ->  out float [n_sf][8][2][64][64][8]            */
 int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* out, hupr_stream_t stream);

@@ -42,10 +42,19 @@ def demux(frame):
     return az, el
 
 
-def range_doppler(az, el):
-    """Clutter removal (mean over the 64 chirp loops) + unnormalised fft2 over (chirp, sample)."""
+def range_doppler(az, el, window=0):
+    """Clutter removal (mean over the 64 chirp loops) + unnormalised fft2 over (chirp, sample).
+
+    window (opt-in, 0 = the reference, which applies none — :130-134 are bare fft2 calls): bit 0 multiplies the 256 range
+    samples by np.hanning(256), bit 1 multiplies the mean-free chirp loops by np.hanning(64) — the build's definition of
+    north_star's "Hanning windowing", pinned only against this restatement.
+    """
     az = az - az.mean(axis=1, keepdims=True)
     el = el - el.mean(axis=1, keepdims=True)
+    if window & 1:
+        az, el = az * np.hanning(NUM_SAMPLE)[None, None, :], el * np.hanning(NUM_SAMPLE)[None, None, :]
+    if window & 2:
+        az, el = az * np.hanning(NUM_LOOPS)[None, :, None], el * np.hanning(NUM_LOOPS)[None, :, None]
     az = np.fft.fft2(az, axes=(1, 2))
     el = np.fft.fft2(el, axes=(1, 2))
     return az, el
@@ -61,13 +70,14 @@ def angle_cube(az, el):
     return M
 
 
-def generate_heatmap(frame):
+def generate_heatmap(frame, window=0, magnitude=False):
     """Closed form of ``RadarObject.generateHeatmap`` (reference :106-173).
 
     frame: complex (4, 192, 256)  ->  complex128 (16 doppler, 64 range, 64 az, 8 el).
+    window / magnitude: opt-in extras (see range_doppler; magnitude = np.abs of the result); defaults = the reference.
     """
     az, el = demux(frame)
-    az, el = range_doppler(az, el)
+    az, el = range_doppler(az, el, window)
     M5 = angle_cube(az, el)
     # out[i, r, a, e] = M5[(3-e)%8, (31-a)%64, (56+i)%64, 94-r]   (SURVEY.md App. A)
     e_idx = (3 - np.arange(NUM_EL)) % NUM_EL
@@ -76,7 +86,8 @@ def generate_heatmap(frame):
     r_idx = RANGE_HI - np.arange(64)
     out = M5[e_idx[None, None, None, :], a_idx[None, None, :, None],
              d_idx[:, None, None, None], r_idx[None, :, None, None]]
-    return np.ascontiguousarray(out)
+    out = np.ascontiguousarray(out)
+    return np.abs(out) if magnitude else out
 
 
 def generate_heatmap_percell(frame):

@@ -9,6 +9,9 @@ Fixtures are data (inputs are regenerable from seeds; expected outputs are store
   loader_seed0.npz                     Normalize + Doppler select         (datasets/base.py:13-24, dataset.py:144-150)
   model_eval.npz, model_train.npz      HuPRNet fwd (+ autograd bwd)        (models/*.py)
   loss_seed0.npz                       LossComputer/generateTarget/argmax (misc/losses.py, utils.py, metrics.py)
+  model_trained.npz                    TRAIN_STEPS reference Adam steps (tools/run.py:71-79, tools/base.py:47) on a fixed
+                                       batch from the seed weights -> peaky heat-maps: loss trajectory, eval outputs on
+                                       the training batch and on EXTRA unseen samples, arg-max (`python make_golden.py trained`)
   oks_eval.json                        COCOeval('keypoints') stats on a synthetic set (misc/coco.py, misc/cocoeval.py)
   contract.json                        state_dict keys/shapes, YAML dump, Runner helper outputs (tools/base.py)
 """
@@ -147,6 +150,69 @@ def make_model():
     return net, cfg
 
 
+TRAIN_STEPS, TRAIN_LR, TRAIN_WD, EXTRA, EXTRA_SEED = 120, 1e-4, 1e-4, 8, 9
+
+
+def make_trained():
+    """The random-weight fixture has flat heat-maps (max/mean 1.06: every arg-max is a near-tie, useless for gating a
+    reduced-precision path).  Train the reference on CPU the way tools/run.py does (Adam lr 1e-4 / wd 1e-4 = the YAML's
+    values, BCE on both heads) for TRAIN_STEPS steps on the fixed B=2 synthetic batch: the eval-mode maps become peaky
+    (max/mean 50-100).  Weights are NOT stored (142 MB): the GPU tests regenerate them by running the same steps on the
+    fp32 parity path, whose per-step agreement with the reference is what the loss trajectory pins."""
+    import time
+    cfg = ref_import.load_cfg()
+    models = ref_import.model_module()
+    LossComputer, _, _, _ = ref_import.misc_parts()
+    torch.manual_seed(0)
+    net = models.HuPRNet(cfg)
+    st = synth.hupr_state(MODEL_SEED, gain=GAIN)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+    hn, vn = synth.model_inputs(2, INPUT_SEED)
+    h, v = torch.from_numpy(hn), torch.from_numpy(vn)
+    gt = torch.from_numpy(synth.keypoints(2, KP_SEED))
+    lc = LossComputer(cfg, "cpu")
+    opt = torch.optim.Adam(net.parameters(), lr=TRAIN_LR, betas=(0.9, 0.999), weight_decay=TRAIN_WD)
+    losses = []
+    t0 = time.time()
+    net.train()
+    for it in range(TRAIN_STEPS):
+        opt.zero_grad()
+        p1, p2 = net(h, v)
+        loss, loss2, _, _ = lc.computeLoss((p1, p2), gt)
+        loss.backward()
+        opt.step()
+        losses.append((loss.item(), loss2.item()))
+        if it % 10 == 0:
+            print("  step %d loss %.5f %.5f  (%.0fs)" % (it, loss.item(), loss2.item(), time.time() - t0), flush=True)
+    net.eval()
+    xh, xv = synth.model_inputs(EXTRA, EXTRA_SEED)
+    with torch.no_grad():
+        p1, p2 = net(h, v)
+        q1, q2 = net(torch.from_numpy(xh), torch.from_numpy(xv))
+
+    def peak(t):
+        f = t.reshape(-1, 64 * 64)
+        return (f.max(1)[0] / f.mean(1)).numpy()
+    names, pnorm = [], []
+    for n, p in net.named_parameters():
+        names.append(n)
+        pnorm.append(p.detach().double().norm().item())
+    np.savez_compressed(
+        os.path.join(HERE, "model_trained.npz"),
+        model_seed=MODEL_SEED, input_seed=INPUT_SEED, kp_seed=KP_SEED, gain=GAIN, steps=TRAIN_STEPS, lr=TRAIN_LR, wd=TRAIN_WD,
+        extra=EXTRA, extra_seed=EXTRA_SEED, losses=np.array(losses),
+        heatmap=p1.numpy().astype(np.float16), gcn_heatmap=p2.numpy().astype(np.float16),
+        argmax1=p1.reshape(2, 14, -1).argmax(-1).numpy(), argmax2=p2.reshape(2, 14, -1).argmax(-1).numpy(),
+        max1=p1.reshape(2, 14, -1).max(-1)[0].numpy(), max2=p2.reshape(2, 14, -1).max(-1)[0].numpy(),
+        x_argmax1=q1.reshape(EXTRA, 14, -1).argmax(-1).numpy(), x_argmax2=q2.reshape(EXTRA, 14, -1).argmax(-1).numpy(),
+        x_max1=q1.reshape(EXTRA, 14, -1).max(-1)[0].numpy(), x_max2=q2.reshape(EXTRA, 14, -1).max(-1)[0].numpy(),
+        x_top2=q2.reshape(EXTRA, 14, -1).topk(2, dim=-1)[0].numpy(),
+        peak1=peak(p1), peak2=peak(p2), x_peak1=peak(q1), x_peak2=peak(q2),
+        param_names=np.array(names), param_l2=np.array(pnorm))
+    print("trained fixture: final loss %.5f; median max/mean train-batch %.1f / %.1f, unseen %.1f / %.1f" %
+          (losses[-1][0], np.median(peak(p1)), np.median(peak(p2)), np.median(peak(q1)), np.median(peak(q2))))
+
+
 def make_contract(net, cfg):
     import yaml
     sd = net.state_dict()
@@ -246,8 +312,12 @@ if __name__ == "__main__":
         make_oks()
         sys.exit(0)
     assert ref_import.available(), "reference tree not found"
+    if len(sys.argv) > 1 and sys.argv[1] == "trained":
+        make_trained()
+        sys.exit(0)
     ro = make_fft()
     make_loader(ro)
     net, cfg = make_model()
     make_contract(net, cfg)
     make_oks()
+    make_trained()

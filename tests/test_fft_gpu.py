@@ -164,3 +164,53 @@ def test_sequence_fft_cache_matches_uncached_loader():
         h, v = cache.window(index)
         assert torch.equal(h, ref_h) and torch.equal(v, ref_v)
         assert torch.equal(hb[k], ref_h) and torch.equal(vb[k], ref_v)
+
+
+@pytest.mark.parametrize("window,flags", [("hann", 3), ("range", 1), ("doppler", 2)])
+def test_optin_hanning_window_and_magnitude_vs_oracle(window, flags):
+    """north_star's "Hanning windowing and magnitude" exist as opt-in flags (the reference has neither,
+    process_iwr1843.py:130-151); default OFF = the parity path.  Gate as for the plain chain: rel-L2 <= 1e-5."""
+    from hupr_amd import preprocessing
+    from oracle import fft_chain as offt
+    iq = synth.adc_cube_int16(1)
+    dev = torch.from_numpy(iq).cuda()
+    ref = offt.generate_heatmap(synth.adc_cube_complex(iq)[0], window=flags)
+    got = preprocessing.fft_chain(dev, window=window)[0].cpu().numpy()
+    keep = np.arange(16) != 8 if not flags & 2 else np.ones(16, bool)      # a Doppler window un-nulls bin 0 (leakage)
+    rel = np.linalg.norm(got[keep] - ref[keep]) / np.linalg.norm(ref[keep])
+    assert rel <= 1e-5, rel
+    mag = preprocessing.fft_chain(dev, window=window, magnitude=True)[0].cpu().numpy()
+    assert mag.dtype == np.float32 and mag.shape == (16, 64, 64, 8)
+    rm = offt.generate_heatmap(synth.adc_cube_complex(iq)[0], window=flags, magnitude=True)
+    assert np.abs(mag[keep] - rm[keep]).max() <= 2e-5 * rm.max()
+    np.testing.assert_allclose(mag, np.abs(got), rtol=2e-6, atol=1e-6 * rm.max())
+    # the windowed loader variant == loader glue applied to the windowed cube
+    ld = preprocessing.fft_chain_loader(dev, window=window)[0].cpu().numpy()
+    ld_ref = preprocessing.loader_normalize(preprocessing.fft_chain(dev, window=window))[0].cpu().numpy()
+    f_ok = np.arange(8) != 4 if not flags & 2 else np.ones(8, bool)
+    assert np.abs(ld[f_ok] - ld_ref[f_ok]).max() <= 2e-3
+
+
+def test_window_flags_default_off_is_bit_identical_and_hann_suppresses_sidelobes():
+    from hupr_amd import preprocessing, runtime as rt
+    iq = synth.adc_cube_int16(2)
+    dev = torch.from_numpy(iq).cuda()
+    a = preprocessing.fft_chain(dev)
+    b = preprocessing.fft_chain(dev, window=None, magnitude=False)
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+    with pytest.raises(ValueError):
+        preprocessing.fft_chain(dev, window="blackman")
+    # a point target between range bins: Hann trades main-lobe width for > 20 dB lower far sidelobes along range
+    tg = [dict(range_bin=60.5, doppler_bin=3, az_bin=10, el_bin=2, amp=800.0)]
+    cube = torch.from_numpy(synth.point_target_cube(tg)).cuda()
+    plain = preprocessing.fft_chain(cube, magnitude=True)[0].sum(dim=(2, 3))[11].cpu().numpy()       # (range,) at the target's Doppler bin
+    hann = preprocessing.fft_chain(cube, window="range", magnitude=True)[0].sum(dim=(2, 3))[11].cpu().numpy()
+    pk = int(plain.argmax())
+    far = np.r_[0:max(pk - 8, 0), min(pk + 9, 64):64]
+    assert (hann[far].max() / hann.max()) < 0.1 * (plain[far].max() / plain.max())
+    # flags the C ABI must refuse
+    L = rt.lib()
+    out = torch.empty((1, 8, 2, 64, 64, 8), device="cuda")
+    ws = torch.empty(L.hupr_fft_chain_ws_bytes(1), dtype=torch.uint8, device="cuda")
+    assert L.hupr_fft_chain_opts(rt.ptr(dev), 1, rt.ptr(out), 4, 1, rt.ptr(ws), ws.numel(), None) == -1      # loader + magnitude
+    assert L.hupr_fft_chain_opts(rt.ptr(dev), 1, rt.ptr(out), 64, 0, rt.ptr(ws), ws.numel(), None) == -1     # unknown flag

@@ -160,3 +160,31 @@ def test_dca1000_oracle_matches_golden_and_reference(tmp_path):
         with contextlib.redirect_stdout(io.StringIO()):
             ref = ref_import.radar_object().getadcDataFromDCA1000(str(tmp_path))
         assert np.array_equal(ref, z)
+
+
+def test_oracle_optin_window_and_magnitude_are_consistent():
+    """The opt-in Hanning / magnitude variants (north_star; absent from the reference) are defined by the oracle.  Pin the
+    definition to things that do not depend on it: the range window commutes with the chirp-mean removal, so windowing ==
+    the plain chain on a pre-multiplied frame; the Doppler window == the plain Doppler FFT of the windowed mean-free loops;
+    magnitude == |complex output|; default flags == the reference's arithmetic (golden SHA checked above)."""
+    import numpy as np
+    from hupr_amd import synth
+    from oracle import fft_chain as offt
+    frame = synth.adc_cube_complex(synth.adc_cube_int16(3))[0]
+    plain = offt.generate_heatmap(frame)
+    assert np.array_equal(plain, offt.generate_heatmap(frame, window=0, magnitude=False))
+    w = np.hanning(256)
+    a = offt.generate_heatmap(frame, window=1)
+    b = offt.generate_heatmap(frame * w[None, None, :])
+    keep = np.arange(16) != 8
+    assert np.abs(a[keep] - b[keep]).max() <= 1e-9 * np.abs(b).max()
+    assert np.array_equal(offt.generate_heatmap(frame, window=3, magnitude=True), np.abs(offt.generate_heatmap(frame, window=3)))
+    # Doppler window by hand on one virtual antenna / range bin
+    az, el = offt.demux(frame)
+    x = az[2] - az[2].mean(axis=0, keepdims=True)
+    want = np.fft.fft(np.fft.fft(x, axis=1) * np.hanning(64)[:, None], axis=0)
+    got_az, _ = offt.range_doppler(az, el, window=2)
+    assert np.abs(got_az[2] - want).max() <= 1e-9 * np.abs(want).max()
+    # a Hann window has coherent gain 0.5 -> total energy drops to ~3/8 per windowed axis
+    e0, e3 = (np.abs(plain[keep]) ** 2).sum(), (np.abs(offt.generate_heatmap(frame, window=1)[keep]) ** 2).sum()
+    assert 0.3 < e3 / e0 < 0.45
