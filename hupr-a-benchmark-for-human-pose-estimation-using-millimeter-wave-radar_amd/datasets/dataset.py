@@ -7,17 +7,26 @@
   (datasets/dataset.py:120-139) as a pure function, used by ``HuPR3D_horivert``.
 * ``HuPR3D_horivert`` — reader for the reference's on-disk layout (``single_<n>/{hori,vert}/%09d.npy``
   complex cubes + ``hrnet_annot_<phase>.json``); cubes go to the GPU as complex64 and through
-  ``loader_normalize`` (the fused equivalent of the 256 per-slice transform calls of :144-150).
+  ``loader_normalize`` (the fused equivalent of the 256 per-slice transform calls of :144-150).  Same item
+  dictionary, index arithmetic (``sampling_ratio``, random multiplier) and ``<phase>_gt.json`` /
+  ``evaluate`` / ``evaluateEach`` protocol as the reference class.
+* ``HuPRRawADC`` — the same items straight from the DCA1000 captures (``single_<n>/{hori,vert}/adc_data.bin``,
+  what the reference's offline driver process_iwr1843.py:184-196 consumes): a sequence is de-interleaved and
+  transformed ONCE on the GPU (``SequenceFFTCache``) and windows are gathers — no 8.39 MB/frame ``.npy`` hand-off.
 """
 import json
 import os
+import random as _random
+from collections import OrderedDict
 
 import numpy as np
 import torch
 import torch.utils.data as data
 
 from .. import synth
-from ..preprocessing.process_iwr1843 import loader_normalize
+from ..misc.oks_eval import evaluate_keypoints
+from ..preprocessing.process_iwr1843 import dca1000_frames, loader_normalize
+from .base import generateGTAnnot
 
 
 def window_indices(index, duration, num_group_frames):
@@ -94,54 +103,147 @@ class SyntheticHuPR(data.Dataset):
         x1, y1 = joints.max(0)
         return {"adc_hori": torch.from_numpy(hori), "adc_vert": torch.from_numpy(vert),
                 "imageId": index, "jointsGroup": torch.from_numpy(joints),
+                "jointsFloat": torch.from_numpy(joints.astype(np.float64)),
                 "bbox": torch.tensor([x0, y0, x1 - x0, y1 - y0], dtype=torch.float32)}
 
 
-class HuPR3D_horivert(data.Dataset):
-    """Real-data reader (reference layout).  Returns network-ready tensors on ``device``."""
+class _AnnotatedHuPR(data.Dataset):
+    """Shared host logic of the two real-data datasets: the annotation list in ``<phase>_gt.json`` order, the reference's
+    index arithmetic, and its evaluation protocol (datasets/dataset.py:17-46,48-88,120-124,161-162)."""
 
-    def __init__(self, phase, cfg, args, device="cuda"):
+    def __init__(self, phase, cfg, args, random=True):
         if phase not in ("train", "val", "test"):
             raise ValueError("Invalid phase: {}".format(phase))
-        self.phase, self.cfg, self.device = phase, cfg, device
+        self.phase, self.cfg = phase, cfg
         self.duration = cfg.DATASET.duration
-        self.G = cfg.DATASET.numGroupFrames
+        self.G = self.numGroupFrames = cfg.DATASET.numGroupFrames
+        self.numKeypoints = cfg.DATASET.numKeypoints
         self.sampling_ratio = getattr(args, "sampling_ratio", 1)
         self.dirRoot = cfg.DATASET.dataDir
-        groups = getattr(cfg.DATASET, phase + "Name")
-        with open(os.path.join(self.dirRoot, "hrnet_annot_%s.json" % phase)) as fp:
-            annot = json.load(fp)
+        self.idxToJoints = cfg.DATASET.idxToJoints
+        self.random = random
+        gt = generateGTAnnot(cfg, phase)                      # writes <dataDir>/<phase>_gt.json like the reference (:35)
+        self.gtFile = os.path.join(self.dirRoot, "%s_gt.json" % phase)
+        self.gt_annotations = gt["annotations"]
+        self.imageIds = [im["id"] for im in gt["images"]]
         self.items = []
-        for gi, blocks in enumerate(annot):
-            for blk in blocks:
-                frame = int(blk["image"][:-4])
-                bbox = blk["bbox"]
-                self.items.append({"seq": groups[gi], "frame": frame, "imageId": frame + groups[gi] * 100000,
-                                   "joints": np.asarray(blk["joints"], dtype=np.float64),
-                                   "bbox": [bbox[0], bbox[1], bbox[2] - bbox[0], bbox[3] - bbox[1]]})
+        for ann in self.gt_annotations:
+            name = "%09d" % ann["image_id"]                   # sequence / frame decoded like :41-44
+            kp = np.asarray(ann["keypoints"], dtype=np.float64).reshape(-1, 3)[:, :2]
+            self.items.append({"seq": int(name[:4]), "frame": int(name[-4:]), "imageId": ann["image_id"], "joints": kp,
+                               "bbox": ann["bbox"]})
 
     def __len__(self):
         return len(self.items) // self.sampling_ratio
 
-    def _cube(self, item_idx, sensor):
-        it = self.items[item_idx]
-        path = os.path.join(self.dirRoot, "single_%d/%s/%09d.npy" % (it["seq"], sensor, it["frame"]))
-        return torch.from_numpy(np.load(path).astype(np.complex64))
+    def _index(self, index):
+        """:121-124 — with ``random`` (the reference default, also for val/test) the sample index is multiplied by a random
+        factor in [1, sampling_ratio]; at ``-sr 1`` both forms are the identity."""
+        return index * (_random.randint(1, self.sampling_ratio) if self.random else self.sampling_ratio)
+
+    def _labels(self, index):
+        it = self.items[index]
+        return {"imageId": it["imageId"], "jointsGroup": torch.LongTensor(it["joints"]),        # truncates like :152
+                "jointsFloat": torch.from_numpy(it["joints"].copy()),                          # what <phase>_gt.json holds
+                "bbox": torch.FloatTensor(it["bbox"])}
+
+    # ---- evaluation protocol (COCO OKS against <phase>_gt.json) -------------------------------------------------
+    def _stats(self, loadDir, idx_keypoint=-1):
+        with open(os.path.join(loadDir, "%s_results.json" % self.phase)) as fp:
+            dts = json.load(fp)
+        return evaluate_keypoints(self.gt_annotations, dts, idx_keypoint)
+
+    def evaluate(self, loadDir):
+        """AP of ``<loadDir>/<phase>_results.json`` (datasets/dataset.py:68-88): prints the ten numbers, returns AP."""
+        stats = self._stats(loadDir)
+        names = ["AP", "Ap .5", "AP .75", "AP (M)", "AP (L)", "AR", "AR .5", "AR .75", "AR (M)", "AR (L)"]
+        for i, (n, v) in enumerate(zip(names, stats)):
+            print("%s:\t%.3f\t" % (n, v), end="\n" if (i + 1) % 5 == 0 else "")
+        return stats[0]
+
+    def evaluateEach(self, loadDir):
+        """Per-joint AP (``--keypoints``; datasets/dataset.py:48-66): prints one line per joint, returns the last AP."""
+        aps = [self._stats(loadDir, i)[0] for i in range(self.numKeypoints)]
+        for i, ap in enumerate(aps):
+            print("%s: %.3f" % (self.idxToJoints[i], ap))
+        return aps[-1]
+
+
+class HuPR3D_horivert(_AnnotatedHuPR):
+    """Real-data reader (reference layout).  Returns network-ready tensors on ``device``."""
+
+    def __init__(self, phase, cfg, args, random=True, device="cuda"):
+        super().__init__(phase, cfg, args, random)
+        self.device = device
+        self.VRDAEPaths_hori = [os.path.join(self.dirRoot, "single_%d/hori/%09d.npy" % (it["seq"], it["frame"])) for it in self.items]
+        self.VRDAEPaths_vert = [os.path.join(self.dirRoot, "single_%d/vert/%09d.npy" % (it["seq"], it["frame"])) for it in self.items]
 
     def __getitem__(self, index):
-        index = index * self.sampling_ratio
+        index = self._index(index)
         idxs = window_indices(index, self.duration, self.G)
         out = {}
-        for sensor in ("hori", "vert"):
-            cubes = torch.stack([self._cube(i, sensor) for i in idxs]).to(self.device)
+        for sensor, paths in (("hori", self.VRDAEPaths_hori), ("vert", self.VRDAEPaths_vert)):
+            cubes = torch.stack([torch.from_numpy(np.load(paths[i]).astype(np.complex64)) for i in idxs]).to(self.device)
             out["VRDAEmap_" + sensor] = loader_normalize(cubes)          # (G, F, 2, R, A, E)
+        out.update(self._labels(index))
+        return out
+
+
+class HuPRRawADC(_AnnotatedHuPR):
+    """Items straight from the raw captures: ``<rawDir>/single_<n>/{hori,vert}/adc_data.bin`` (the files the reference's
+    offline driver reads, process_iwr1843.py:184-196) + the same ``hrnet_annot_<phase>.json``.  A sequence's two streams
+    go to the GPU once (int16), are de-interleaved there (``hupr_dca1000_deinterleave``) and transformed by the fused FFT
+    loader for all frames at once; items are window gathers out of an LRU of ``cache_sequences`` sequences (a 600-frame
+    sequence costs 2 x 1.26 GB of loader-ready cubes and ~1 ms of FFT time)."""
+
+    def __init__(self, phase, cfg, args, random=True, device="cuda", cache_sequences=4):
+        super().__init__(phase, cfg, args, random)
+        self.device = device
+        self.rawRoot = getattr(cfg.DATASET, "rawDir", None) or self.dirRoot
+        self.cache_sequences = cache_sequences
+        self._cache = OrderedDict()
+        self._seq_start = {}
+        for i, it in enumerate(self.items):                   # first item of every sequence (frames are contiguous per sequence)
+            self._seq_start.setdefault(it["seq"], i)
+
+    def _sequence(self, seq):
+        c = self._cache.get(seq)
+        if c is None:
+            streams = []
+            for sensor in ("hori", "vert"):
+                path = os.path.join(self.rawRoot, "single_%d" % seq, sensor, "adc_data.bin")
+                raw = torch.from_numpy(np.fromfile(path, dtype=np.int16)).to(self.device)
+                streams.append(dca1000_frames(raw))            # (frames, 4, 192, 256, 2) int16
+            c = SequenceFFTCache(streams[0], streams[1], self.G)
+            self._cache[seq] = c
+            while len(self._cache) > self.cache_sequences:
+                self._cache.popitem(last=False)
+        else:
+            self._cache.move_to_end(seq)
+        return c
+
+    def __getitem__(self, index):
+        index = self._index(index)
         it = self.items[index]
-        out.update({"imageId": it["imageId"], "jointsGroup": torch.LongTensor(it["joints"]),   # truncates like the reference
-                    "bbox": torch.FloatTensor(it["bbox"])})
+        cache = self._sequence(it["seq"])
+        pos = index - self._seq_start[it["seq"]]
+        if cache.duration != self.duration:
+            raise ValueError("single_%d holds %d frames, cfg.DATASET.duration is %d" % (it["seq"], cache.duration, self.duration))
+        h, v = cache.window(pos)
+        out = {"VRDAEmap_hori": h, "VRDAEmap_vert": v}
+        out.update(self._labels(index))
         return out
 
 
 def getDataset(phase, cfg, args, random=True):
-    if str(cfg.DATASET.dataDir).startswith("synthetic") or not os.path.isdir(str(cfg.DATASET.dataDir)):
+    """Reference signature (datasets/dataset.py:14).  ``dataDir: synthetic`` selects the build-owned generator,
+    ``DATASET.rawDir`` (opt-in key) the raw-capture reader, anything else the reference's ``.npy`` layout — a missing
+    directory is an error, never a silent switch to synthetic data."""
+    root = str(cfg.DATASET.dataDir)
+    if root.startswith("synthetic"):
         return SyntheticHuPR(phase, cfg, args, length=getattr(args, "synthetic_length", 64))
-    return HuPR3D_horivert(phase, cfg, args)
+    if not os.path.isdir(root):
+        raise FileNotFoundError("cfg.DATASET.dataDir %r does not exist (use dataDir: synthetic for the built-in generator)" % root)
+    if getattr(cfg.DATASET, "rawDir", None):
+        return HuPRRawADC(phase, cfg, args, random)
+    return HuPR3D_horivert(phase, cfg, args, random)

@@ -46,7 +46,9 @@ def main(argv=None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # control plane (rendezvous, communicator id, gathers of evaluation records) on gloo; the gradient exchange is the
+        # C ABI's own RCCL communicator (tools/distributed.py); the nccl half is only used if that has to fall back
+        dist.init_process_group("cpu:gloo,cuda:nccl")
     cfg_dir = "./config" if os.path.isdir("./config") else None
     cfg = load_config(args.config, cfg_dir)
     trigger = Runner(args, cfg)

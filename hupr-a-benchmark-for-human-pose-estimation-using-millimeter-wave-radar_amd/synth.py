@@ -124,6 +124,65 @@ def point_target_cube(targets, noise=0.0, seed=0):
     return iq[None]
 
 
+def dca1000_encode(frames):
+    """int16 (n_frames, 4, 192, 256, 2) cube -> the flat int16 stream a DCA1000 capture of those frames would hold
+    (inverse of the layout getadcDataFromDCA1000 parses, process_iwr1843.py:54-83): per chirp the complex samples run
+    [rx0 x 256][rx1 x 256][rx2 x 256][rx3 x 256], and every two of them are stored as [I0, I1, Q0, Q1]."""
+    fr = np.asarray(frames, dtype=np.int16)
+    n = fr.shape[0]
+    z = fr.transpose(0, 2, 1, 3, 4).reshape(n * NUM_CHIRP * NUM_RX * NUM_SAMPLE, 2)      # stream order: frame, chirp, rx, sample
+    pairs = z.reshape(-1, 2, 2)                                                           # (pair, sample-in-pair, I/Q)
+    return np.ascontiguousarray(pairs.transpose(0, 2, 1)).reshape(-1)                     # I0 I1 Q0 Q1
+
+
+TINY = {"duration": 6, "trainName": [3, 12], "valName": [7], "testName": [7]}
+
+
+def tiny_cube(seq, frame, sensor):
+    """Deterministic complex64 (16, 64, 64, 8) stand-in for one pre-processed ``.npy`` cube of the reference layout."""
+    k = (seq * 1000 + frame) * 2 + sensor
+    return (100.0 * (normal((16, 64, 64, 8), "tiny_re", k) + 1j * normal((16, 64, 64, 8), "tiny_im", k))).astype(np.complex64)
+
+
+def tiny_annotations(seqs, duration):
+    """hrnet_annot_<phase>.json content: per sequence a list of {image, joints (14 x [x, y] floats), bbox [x0, y0, x1, y1]}."""
+    out = []
+    for seq in seqs:
+        blocks = []
+        for fr in range(duration):
+            j = uniform((14, 2), 40.0, 216.0, "tiny_joints", seq, fr, dtype=np.float64)
+            x0, y0 = j.min(0) - 6.5
+            x1, y1 = j.max(0) + 7.25
+            blocks.append({"image": "%09d.jpg" % fr, "joints": j.tolist(), "bbox": [float(x0), float(y0), float(x1), float(y1)]})
+        out.append(blocks)
+    return out
+
+
+def write_tiny_dataset(root, cubes=True, raw=False, phases=("train", "val")):
+    """A miniature HuPR tree under ``root`` (2 + 1 sequences of TINY["duration"] frames): ``hrnet_annot_<phase>.json`` and,
+    per frame and sensor, either the reference's pre-processed ``single_<n>/<sensor>/%09d.npy`` cube (``cubes``) or per
+    sequence the raw ``single_<n>/<sensor>/adc_data.bin`` capture (``raw``).  Used by tests/golden/make_golden.py (the
+    reference reads it) and by the dataset tests (the product reads the identical files)."""
+    import json
+    import os
+    os.makedirs(root, exist_ok=True)
+    for phase in phases:
+        seqs = TINY[phase + "Name"]
+        with open(os.path.join(root, "hrnet_annot_%s.json" % phase), "w") as fp:
+            json.dump(tiny_annotations(seqs, TINY["duration"]), fp)
+        for seq in seqs:
+            for si, sensor in enumerate(("hori", "vert")):
+                d = os.path.join(root, "single_%d" % seq, sensor)
+                os.makedirs(d, exist_ok=True)
+                if cubes:
+                    for fr in range(TINY["duration"]):
+                        np.save(os.path.join(d, "%09d.npy" % fr), tiny_cube(seq, fr, si))
+                if raw:
+                    frames = np.concatenate([adc_cube_int16(77, seq=seq, frame=fr, sensor=si) for fr in range(TINY["duration"])])
+                    dca1000_encode(frames).tofile(os.path.join(d, "adc_data.bin"))
+    return root
+
+
 def model_inputs(batch, seed, G=8, F=8, R=64, A=64, E=8):
     """Two (B,G,F,2,R,A,E) fp32 standard-normal cubes (what Normalize emits statistically)."""
     shape = (batch, G, F, 2, R, A, E)

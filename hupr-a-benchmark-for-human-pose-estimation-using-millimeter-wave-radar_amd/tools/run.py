@@ -42,7 +42,9 @@ class Runner(BaseRunner):
         else:
             self.trainLoader = [0]
         self.testSet = getDataset("test" if args.eval else "val", cfg, args)
-        self.testLoader = data.DataLoader(self.testSet, cfg.TEST.batchSize, shuffle=False, num_workers=0, collate_fn=_collate)
+        # evaluation is sharded over the ranks (rank r takes samples r, r + world, ...) and gathered on rank 0
+        shard = data.Subset(self.testSet, range(self.rank, len(self.testSet), self.world)) if self.world > 1 else self.testSet
+        self.testLoader = data.DataLoader(shard, cfg.TEST.batchSize, shuffle=False, num_workers=0, collate_fn=_collate)
         warm = cfg.TRAINING.warmupEpoch
         self.stepSize = len(self.trainLoader) * warm
         LR = cfg.TRAINING.lr if warm == -1 else cfg.TRAINING.lr / (cfg.TRAINING.warmupGrowth ** self.stepSize)
@@ -64,6 +66,10 @@ class Runner(BaseRunner):
         return batch["VRDAEmap_hori"].float().to(dev), batch["VRDAEmap_vert"].float().to(dev)
 
     def eval(self, visualization=True, epoch=-1):
+        """-> AP (reference tools/run.py:35-63).  Predictions are decoded from the GCN head, scaled to image pixels,
+        written to ``<phase>_results.json`` by rank 0 and scored with the OKS evaluator against the ground truth the
+        reference uses: the float joints of ``<phase>_gt.json`` (not the integer-truncated ``jointsGroup`` the loss sees).
+        ``--keypoints`` prints the per-joint APs (``evaluateEach``) instead of the summary line."""
         self.logger.clear(len(self.testLoader.dataset))
         savePreds, gts = [], []
         for batch in self.testLoader:
@@ -74,14 +80,33 @@ class Runner(BaseRunner):
                 loss, loss2, pred2d, _ = self.lossComputer.computeLoss(preds, keypoints)
             self.logger.display(loss, loss2, keypoints.size(0), epoch)
             self.saveKeypoints(savePreds, pred2d * self.imgHeatmapRatio, batch["bbox"], batch["imageId"])
+            gt_joints = batch["jointsFloat"] if "jointsFloat" in batch else keypoints
             for j in range(keypoints.size(0)):
-                gts.append({"image_id": int(batch["imageId"][j]), "keypoints": keypoints[j].numpy().astype(np.float64),
+                gts.append({"image_id": int(batch["imageId"][j]), "keypoints": gt_joints[j].numpy().astype(np.float64),
                             "bbox": batch["bbox"][j].numpy().astype(np.float64)})
-        self.writeKeypoints(savePreds)
-        stats = evaluate_keypoints(gts, savePreds)
-        names = ["AP", "Ap .5", "AP .75", "AP (M)", "AP (L)", "AR", "AR .5", "AR .75", "AR (M)", "AR (L)"]
-        print("  ".join("%s: %.3f" % (n, s) for n, s in zip(names, stats)))
-        return float(stats[0])
+        if self.world > 1:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, (savePreds, gts))
+            savePreds = [r for p in parts for r in p[0]]
+            gts = [g for p in parts for g in p[1]]
+        ap = 0.0
+        if self.rank == 0:
+            self.writeKeypoints(savePreds)
+            names = ["AP", "Ap .5", "AP .75", "AP (M)", "AP (L)", "AR", "AR .5", "AR .75", "AR (M)", "AR (L)"]
+            if getattr(self.args, "keypoints", False):
+                idx2j = self.cfg.DATASET.idxToJoints
+                for k in range(self.numKeypoints):
+                    ap = float(evaluate_keypoints(gts, savePreds, idx_keypoint=k)[0])
+                    print("%s: %.3f" % (idx2j[k], ap))
+            else:
+                stats = evaluate_keypoints(gts, savePreds)
+                print("  ".join("%s: %.3f" % (n, s) for n, s in zip(names, stats)))
+                ap = float(stats[0])
+        if self.world > 1:
+            box = [ap]
+            dist.broadcast_object_list(box, src=0)
+            ap = box[0]
+        return ap
 
     def train(self):
         for epoch in range(self.start_epoch, self.cfg.TRAINING.epochs):

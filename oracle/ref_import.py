@@ -142,6 +142,40 @@ def misc_parts():
     return _with_ref_path(go)
 
 
+def refcoco():
+    """The reference's pycocotools fork (misc/coco.py + misc/cocoeval.py) as a synthetic package with an empty ``mask``
+    submodule (they do ``from . import mask``, coco.py:55, cocoeval.py:7); np.float shim for cocoeval.py:381-382."""
+    import importlib.util
+    import numpy as np
+    np.float = float
+    _install_stubs()
+    if "_refcoco.coco" in sys.modules:
+        return sys.modules["_refcoco.coco"], sys.modules["_refcoco.cocoeval"]
+    pkg = types.ModuleType("_refcoco")
+    pkg.__path__ = [os.path.join(REF, "misc")]
+    sys.modules["_refcoco"] = pkg
+    sys.modules["_refcoco.mask"] = types.ModuleType("_refcoco.mask")
+    mods = {}
+    for name in ("coco", "cocoeval"):
+        spec = importlib.util.spec_from_file_location("_refcoco." + name, os.path.join(REF, "misc", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules["_refcoco." + name] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods["coco"], mods["cocoeval"]
+
+
+def dataset_module():
+    """The reference's ``datasets.dataset`` (HuPR3D_horivert, getDataset) with ``pycocotools`` served by its own fork."""
+    coco, cocoeval = refcoco()
+    sys.modules["pycocotools.coco"].COCO = coco.COCO
+    sys.modules["pycocotools.cocoeval"].COCOeval = cocoeval.COCOeval
+
+    def go():
+        return importlib.import_module("datasets.dataset")
+    return _with_ref_path(go)
+
+
 def load_cfg():
     """Reference config/mscsa_prgcn.yaml -> attribute tree, built as main.py:7-13 does."""
     import yaml

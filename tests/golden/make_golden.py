@@ -12,6 +12,8 @@ Fixtures are data (inputs are regenerable from seeds; expected outputs are store
   model_trained.npz                    TRAIN_STEPS reference Adam steps (tools/run.py:71-79, tools/base.py:47) on a fixed
                                        batch from the seed weights -> peaky heat-maps: loss trajectory, eval outputs on
                                        the training batch and on EXTRA unseen samples, arg-max (`python make_golden.py trained`)
+  dataset_tiny.npz                     HuPR3D_horivert items / <phase>_gt.json / evaluate on a miniature on-disk tree
+                                       (datasets/dataset.py:17-165, datasets/base.py:26-92; `python make_golden.py dataset`)
   oks_eval.json                        COCOeval('keypoints') stats on a synthetic set (misc/coco.py, misc/cocoeval.py)
   contract.json                        state_dict keys/shapes, YAML dump, Runner helper outputs (tools/base.py)
 """
@@ -32,6 +34,7 @@ from hupr_amd import synth            # noqa: E402
 from oracle import ref_import         # noqa: E402
 
 STRIDE = 61
+DS_STRIDE = 997
 MODEL_SEED, INPUT_SEED, KP_SEED, GAIN = 1, 5, 7, 1.4
 
 
@@ -213,6 +216,69 @@ def make_trained():
           (losses[-1][0], np.median(peak(p1)), np.median(peak(p2)), np.median(peak(q1)), np.median(peak(q2))))
 
 
+def make_dataset():
+    """The reference's HuPR3D_horivert (datasets/dataset.py:17-165) reading the miniature on-disk tree of
+    synth.write_tiny_dataset: item dictionaries (network inputs as strided samples + moments, labels), the
+    ``train_gt.json`` it generates, and COCOeval on a result file built from perturbed ground truth."""
+    import copy
+    import tempfile
+    cfg = copy.deepcopy(ref_import.load_cfg())
+    ds_mod = ref_import.dataset_module()
+
+    class Args:
+        sampling_ratio = 1
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        synth.write_tiny_dataset(root)
+        cfg.DATASET.dataDir = root
+        cfg.DATASET.duration = synth.TINY["duration"]
+        cfg.DATASET.trainName, cfg.DATASET.valName, cfg.DATASET.testName = (synth.TINY[k] for k in ("trainName", "valName", "testName"))
+        ds = ds_mod.getDataset("train", cfg, Args(), random=False)
+        assert len(ds) == 12
+        out["train_gt_json"] = open(os.path.join(root, "train_gt.json")).read()
+        for idx in (0, 1, 4, 5, 6, 11):
+            it = ds[idx]
+            for sensor in ("hori", "vert"):
+                m = it["VRDAEmap_" + sensor].numpy()
+                out["i%d_%s_sample" % (idx, sensor)] = m.reshape(-1)[::DS_STRIDE].copy()
+                out["i%d_%s_moments" % (idx, sensor)] = np.array([m.astype(np.float64).sum(), (m.astype(np.float64) ** 2).sum()])
+                # which source frame fed each window slot: slot means identify the frame (window clamping, :125-139)
+                out["i%d_%s_slot_l1" % (idx, sensor)] = np.abs(m.astype(np.float64)).reshape(8, -1).sum(1)
+            out["i%d_joints" % idx] = it["jointsGroup"].numpy()
+            out["i%d_bbox" % idx] = it["bbox"].numpy()
+            out["i%d_imageId" % idx] = np.array(it["imageId"])
+        # sampling_ratio arithmetic (:121-124,161-162) with random=False
+        Args.sampling_ratio = 3
+        ds3 = ds_mod.getDataset("train", cfg, Args(), random=False)
+        out["sr3_len"] = np.array(len(ds3))
+        out["sr3_imageIds"] = np.array([ds3[i]["imageId"] for i in range(len(ds3))])
+        # evaluation protocol: results = ground truth shifted by a deterministic offset -> COCOeval stats (+ per-joint APs)
+        Args.sampling_ratio = 1
+        dsv = ds_mod.getDataset("val", cfg, Args(), random=False)
+        recs = []
+        for i in range(len(dsv)):
+            ann = dsv.annots[i]
+            j = ann["joints"] + synth.uniform((14, 2), -9.0, 9.0, "tiny_shift", i, dtype=np.float64)
+            kp = np.concatenate([j, np.ones((14, 1))], axis=1).reshape(-1).tolist()
+            recs.append({"category_id": 1, "image_id": int(ann["imageId"]), "score": 1.0, "keypoints": kp})
+        logd = os.path.join(root, "logs")
+        os.makedirs(logd)
+        json.dump(recs, open(os.path.join(logd, "val_results.json"), "w"))
+        out["val_results_json"] = json.dumps(recs)
+        out["val_ap"] = np.array(dsv.evaluate(logd))
+        aps = []
+        coco_eval = ds_mod.COCOeval(dsv.coco, dsv.coco.loadRes(os.path.join(logd, "val_results.json")), "keypoints")
+        coco_eval.params.useSegm = None
+        for k in range(14):
+            coco_eval.evaluate(k)
+            coco_eval.accumulate()
+            coco_eval.summarize()
+            aps.append(float(coco_eval.stats[0]))
+        out["val_ap_each"] = np.array(aps)
+    np.savez_compressed(os.path.join(HERE, "dataset_tiny.npz"), stride=DS_STRIDE, **out)
+    print("dataset fixture ok: val AP %.4f, per-joint %s" % (float(out["val_ap"]), np.round(out["val_ap_each"], 3).tolist()))
+
+
 def make_contract(net, cfg):
     import yaml
     sd = net.state_dict()
@@ -315,9 +381,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trained":
         make_trained()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        make_dataset()
+        sys.exit(0)
     ro = make_fft()
     make_loader(ro)
     net, cfg = make_model()
     make_contract(net, cfg)
     make_oks()
+    make_dataset()
     make_trained()

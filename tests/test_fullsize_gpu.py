@@ -225,3 +225,51 @@ def test_bf16_path_argmax_agreement_b32():
             assert gap.numel() == 0 or gap.max().item() <= 2e-3, gap.max().item()
     finally:
         F_.set_math("f32")
+
+
+def test_benched_step_bf16_batch32_from_adc_properties():
+    """The exact step bench.py times (bf16 pipe + bf16 activations, B = 32, int16 ADC cubes -> FFT loader -> forward -> BCE x2
+    + device arg-max decode -> backward -> Adam): loss within 1 % of the fp32 parity path on the same data and weights, finite
+    gradients for every parameter, BatchNorm running statistics moved, every parameter updated, decode tensors well-formed."""
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    cfg = load_config()
+    dev = torch.device("cuda", 0)
+    B, G = 32, cfg.DATASET.numGroupFrames
+    base_h = torch.from_numpy(synth.adc_cube_int16(10, sensor=0, nframes=16)).to(dev)
+    base_v = torch.from_numpy(synth.adc_cube_int16(10, sensor=1, nframes=16)).to(dev)
+    adc_h = base_h.repeat(B * G // 16, 1, 1, 1, 1).contiguous()
+    adc_v = base_v.repeat(B * G // 16, 1, 1, 1, 1).contiguous()
+    joints = torch.from_numpy(synth.keypoints(B, 20)).to(dev)
+    out = {}
+    try:
+        for math in ("f32", "bf16"):
+            F_.set_math(math)
+            eng = TrainEngine(cfg, device=dev, seed=0)
+            p0 = torch.cat([p.detach().flatten() for p in eng.model.parameters()]).clone()
+            rm0 = eng.model.RAradarEncoder.layer1[1].main[1].running_mean.clone()
+            loss, loss2 = eng.train_step_from_adc(adc_h, adc_v, joints, decode="device")
+            torch.cuda.synchronize()
+            grads = torch.cat([b.flat_grad for b in eng.buckets.buckets])
+            p1 = torch.cat([p.detach().flatten() for p in eng.model.parameters()])
+            (pi, pm), (gi, gm) = eng.last_decode
+            out[math] = dict(loss=float(loss.detach()), loss2=float(loss2.detach()), grads=grads.clone(), moved=(p1 != p0).float().mean().item(),
+                             rm=(eng.model.RAradarEncoder.layer1[1].main[1].running_mean - rm0).abs().max().item(), pi=pi.clone(), gi=gi.clone(), gm=gm.clone())
+            assert torch.isfinite(grads).all() and torch.isfinite(p1).all() and torch.isfinite(loss)
+            assert grads.abs().max() > 0 and out[math]["moved"] > 0.99 and out[math]["rm"] > 0
+            assert pi.shape == (B * 14,) and pi.dtype == torch.int32 and int(pi.min()) >= 0 and int(pi.max()) < 4096
+            del eng
+    finally:
+        F_.set_math("f32")
+    f, b = out["f32"], out["bf16"]
+    rel = abs(b["loss"] - f["loss"]) / f["loss"]
+    gcos = torch.nn.functional.cosine_similarity(f["grads"], b["grads"], dim=0).item()
+    print("B=32 step from ADC cubes: loss f32 %.5f bf16 %.5f (rel %.2e), gradient cosine %.5f, |g| ratio %.4f" %
+          (f["loss"], b["loss"], rel, gcos, (b["grads"].norm() / f["grads"].norm()).item()))
+    assert rel <= 1e-2 and abs(b["loss2"] - f["loss2"]) / f["loss2"] <= 1e-2
+    assert gcos >= 0.98 and 0.9 <= (b["grads"].norm() / f["grads"].norm()).item() <= 1.1
+    # the ground-truth decode does not depend on the pipe: target maxima sit at int(x / 4 + 0.5) (misc/utils.py:37-38)
+    assert torch.equal(f["gi"], b["gi"]) and bool((f["gm"] == 1.0).all())
+    mu = (joints.float() / 4 + 0.5).long()
+    assert torch.equal(f["gi"].long(), (mu[..., 1] * 64 + mu[..., 0]).reshape(-1))

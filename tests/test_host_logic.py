@@ -135,3 +135,81 @@ def test_adjacency_equals_live_reference():
     from oracle.model import adjacency
     net = HuPRNet(_cfg())
     assert torch.equal(net.radarDecoder.gcn.A, adjacency())
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- real-data dataset host logic against the reference's HuPR3D_horivert on a miniature tree (tests/golden/dataset_tiny.npz) ----
+def _tiny_cfg(root):
+    import copy
+    from hupr_amd import synth
+    from hupr_amd.config_tree import load_config
+    cfg = copy.deepcopy(load_config())
+    cfg.DATASET.dataDir = str(root)
+    cfg.DATASET.duration = synth.TINY["duration"]
+    cfg.DATASET.trainName, cfg.DATASET.valName, cfg.DATASET.testName = (synth.TINY[k] for k in ("trainName", "valName", "testName"))
+    return cfg
+
+
+class _Args:
+    def __init__(self, sr=1):
+        self.sampling_ratio = sr
+
+
+def test_gt_annot_file_and_index_arithmetic_match_reference(tmp_path):
+    """generateGTAnnot writes the same <phase>_gt.json as the reference (datasets/base.py:26-92); items, sampling_ratio
+    arithmetic (dataset.py:121-124,161-162) and labels follow the reference's HuPR3D_horivert."""
+    import json
+    import numpy as np
+    from hupr_amd import synth
+    from hupr_amd.datasets import HuPR3D_horivert, generateGTAnnot, getDataset
+    g = np.load(os.path.join(GOLDEN, "dataset_tiny.npz"))
+    root = synth.write_tiny_dataset(str(tmp_path / "tiny"), cubes=False)
+    cfg = _tiny_cfg(root)
+    annot = generateGTAnnot(cfg, "train")
+    want = json.loads(str(g["train_gt_json"]))
+    assert annot == want and json.load(open(os.path.join(root, "train_gt.json"))) == want
+    ds = getDataset("train", cfg, _Args(), random=False)
+    assert isinstance(ds, HuPR3D_horivert) and len(ds) == 12
+    for idx in (0, 1, 4, 5, 6, 11):
+        lab = ds._labels(ds._index(idx))
+        assert np.array_equal(lab["jointsGroup"].numpy(), g["i%d_joints" % idx])          # LongTensor truncation like :152
+        assert np.allclose(lab["bbox"].numpy(), g["i%d_bbox" % idx]) and lab["imageId"] == int(g["i%d_imageId" % idx])
+        assert np.allclose(np.floor(lab["jointsFloat"].numpy()), lab["jointsGroup"].numpy())
+    ds3 = getDataset("train", cfg, _Args(3), random=False)
+    assert len(ds3) == int(g["sr3_len"])
+    assert [ds3.items[ds3._index(i)]["imageId"] for i in range(len(ds3))] == g["sr3_imageIds"].tolist()
+    # random=True (the reference default): index * randint(1, sr), within range, identity at sr == 1
+    dsr = getDataset("train", cfg, _Args(3), random=True)
+    assert all(dsr._index(2) in (2, 4, 6) for _ in range(20)) and getDataset("train", cfg, _Args(1))._index(5) == 5
+    # a missing data directory is an error, not a silent switch to synthetic data (ADVICE r1)
+    cfg.DATASET.dataDir = str(tmp_path / "nope")
+    with pytest.raises(FileNotFoundError):
+        getDataset("train", cfg, _Args())
+
+
+def test_dataset_evaluate_and_per_joint_ap_match_reference(tmp_path, capsys):
+    """evaluate / evaluateEach (dataset.py:48-88) on the reference-scored result file: AP and the 14 per-joint APs."""
+    import numpy as np
+    from hupr_amd import synth
+    from hupr_amd.datasets import getDataset
+    g = np.load(os.path.join(GOLDEN, "dataset_tiny.npz"))
+    root = synth.write_tiny_dataset(str(tmp_path / "tiny"), cubes=False)
+    ds = getDataset("val", _tiny_cfg(root), _Args(), random=False)
+    logd = tmp_path / "logs"
+    logd.mkdir()
+    (logd / "val_results.json").write_text(str(g["val_results_json"]))
+    assert abs(ds.evaluate(str(logd)) - float(g["val_ap"])) < 1e-12
+    each = [ds._stats(str(logd), k)[0] for k in range(14)]
+    assert np.allclose(each, g["val_ap_each"], atol=1e-12)
+    assert abs(ds.evaluateEach(str(logd)) - float(g["val_ap_each"][-1])) < 1e-12
+    assert "R_Wrist: %.3f" % g["val_ap_each"][-1] in capsys.readouterr().out
+
+
+def test_dca1000_encode_is_the_inverse_of_the_parser():
+    import numpy as np
+    from hupr_amd import synth
+    from oracle import dca1000
+    frames = np.concatenate([synth.adc_cube_int16(5, frame=f) for f in range(3)])
+    assert np.array_equal(dca1000.frames_int16(synth.dca1000_encode(frames)), frames)
