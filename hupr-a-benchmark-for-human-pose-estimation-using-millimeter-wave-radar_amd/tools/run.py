@@ -14,6 +14,7 @@ import torch.utils.data as data
 
 from ..datasets import getDataset
 from ..misc.oks_eval import evaluate_keypoints
+from ..misc.plot import plotHumanPose
 from .base import BaseRunner
 from .engine import TrainEngine
 
@@ -79,6 +80,8 @@ class Runner(BaseRunner):
             with torch.no_grad():
                 loss, loss2, pred2d, _ = self.lossComputer.computeLoss(preds, keypoints)
             self.logger.display(loss, loss2, keypoints.size(0), epoch)
+            if visualization:                       # --visDir given: one skeleton overlay per sample (run.py:50-52)
+                plotHumanPose(pred2d * self.imgHeatmapRatio, self.cfg, self.visDir, batch["imageId"], None)
             self.saveKeypoints(savePreds, pred2d * self.imgHeatmapRatio, batch["bbox"], batch["imageId"])
             gt_joints = batch["jointsFloat"] if "jointsFloat" in batch else keypoints
             for j in range(keypoints.size(0)):

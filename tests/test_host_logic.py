@@ -213,3 +213,25 @@ def test_dca1000_encode_is_the_inverse_of_the_parser():
     from oracle import dca1000
     frames = np.concatenate([synth.adc_cube_int16(5, frame=f) for f in range(3)])
     assert np.array_equal(dca1000.frames_int16(synth.dca1000_encode(frames)), frames)
+
+
+def test_plot_human_pose_writes_skeleton_overlays(tmp_path):
+    """misc/plot.py:14-80 without cv2: file naming single_<seq>/<frame>.png from the image id, 2-pixel make_grid border,
+    red joints / edges at the padded coordinates, green box, black canvas when the camera frame is absent."""
+    import numpy as np
+    from PIL import Image
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.misc.plot import EDGES, plotHumanPose
+    cfg = load_config()
+    joints = np.stack([np.stack([np.linspace(30, 220, 14), np.linspace(40, 200, 14)[::-1]], 1),
+                       np.full((14, 2), 100.0)])
+    files = plotHumanPose(joints, cfg, str(tmp_path), torch.tensor([1200034, 7]), bbox=torch.tensor([[20., 30., 200., 180.], [5., 5., 50., 60.]]))
+    assert [os.path.relpath(f, tmp_path) for f in files] == ["single_12/000000034.png", "single_0/000000007.png"]
+    img = np.asarray(Image.open(files[0]))
+    assert img.shape == (260, 260, 3)                       # 256 + 2 x 2 padding
+    x, y = int(2 + joints[0, 3, 0]), int(2 + joints[0, 3, 1])
+    assert tuple(img[y, x + 3]) == (255, 0, 0)              # the joint ring, offset by the padding
+    assert tuple(img[30, 120]) == (0, 255, 0)               # top edge of the box
+    assert len(EDGES) == 14 and sorted(set(i for e in EDGES for i in e)) == list(range(14))
+    red = (img[..., 0] == 255) & (img[..., 1] == 0)
+    assert red.sum() > 14 * 20                               # joints + connecting lines drawn
