@@ -767,6 +767,8 @@ class AttentionFn(torch.autograd.Function):
         B, N, C = v.shape
         L = rt.lib()
         ctx.flash = MATH == "bf16" and USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
+        if attn_fp8_ok(v):                # config 5 (opt-in, no_grad only): nothing is saved for a backward pass
+            return attention_fp8(k, q, v, residual)[0]
         if ctx.flash:
             out = torch.empty_like(v)
             lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
@@ -813,6 +815,28 @@ class AttentionFn(torch.autograd.Function):
         return dk, dq, dv, None
 
 
+# BASELINE.json config 5: fp8 (e4m3) MFMA operands in the MSCSA attention — opt-in, forward only, the C = 64 level.  Measured
+# against the bf16 flash kernel (scripts/attn_fp8_ab.py -> profiles/r02_attn_fp8_ab.txt) it is not the default: see DESIGN.md.
+ATTN_FP8 = os.environ.get("HUPR_ATTN_FP8", "0") == "1"
+
+
+def attention_fp8(k, q, v, residual):
+    """MSCSA attention forward on the fp8 kernels; k, q, v: fp32 (B, N, 64) token-major -> (out fp32 (B, N, 64), lse (B, N))."""
+    k, q, v = _c(k), _c(q), _c(v)
+    B, N, C = v.shape
+    L = rt.lib()
+    out = torch.empty_like(v)
+    lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
+    ws = workspace(L.hupr_attn_fp8_ws_bytes(B, N, C), v.device)
+    rt.check(L.hupr_attn_fwd_fp8(rt.ptr(k), rt.ptr(q), rt.ptr(v), 1 if residual else 0, rt.ptr(out), rt.ptr(lse), B, N, C,
+                                 rt.ptr(ws), ws.numel(), rt.stream()))
+    return out, lse
+
+
+def attn_fp8_ok(v):
+    return ATTN_FP8 and MATH == "bf16" and not torch.is_grad_enabled() and v.shape[-1] == 64 and v.shape[1] % 128 == 0
+
+
 LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
 FLASH256 = os.environ.get("HUPR_NO_FLASH256", "0") != "1"      # A/B aid: level-0 (C = 256) attention on the fused kernels
 CAT_FUSION = os.environ.get("HUPR_NO_CAT_FUSION", "0") != "1"      # fused levels return their maps concatenated as bf16
@@ -822,6 +846,8 @@ def mscsa_level_fused_ok(ra):
     """One MSCSA level can run as MSCSALevelFn (bf16 math; any (N, C) — shapes without a fused attention kernel keep the
     GEMM / row-softmax attention core inside the node)."""
     B, _, H, W, C = ra.shape
+    if ATTN_FP8 and C == 64 and not torch.is_grad_enabled():
+        return False                      # config 5: this level runs as separate projections + fp8 attentions
     return LEVEL_FUSION and MATH == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
 
 

@@ -114,6 +114,10 @@ SIGNATURES = {
     "hupr_interp_linear_bwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "hupr_attn_fp8_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "hupr_attn_quant_fp8": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_attn_fwd_fp8_quantized": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_size_t, c_void_p]),
+    "hupr_attn_fwd_fp8": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
     # (e) RCCL exchange step
     "hupr_comm_load": (c_int, [c_char_p]),
     "hupr_comm_unique_id": (c_int, [c_void_p]),

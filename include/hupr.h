@@ -357,6 +357,20 @@ int hupr_interp_linear_bwd_bf16act(const void* dy, void* dx, int Bn, int Di, int
 int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream);
 int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream);
 
+/* (a5, BASELINE.json config 5) MSCSA attention forward (models/layers.py:126-133) with fp8 (OCP e4m3) MFMA operands, for the
+ *      level that carries 88 % of the attention flops (C = 64, N % 128 == 0).  K, Q, V, out: fp32 (Bn, N, C) token-major;
+ *      per-tensor scales 448 / amax; probabilities rounded to e4m3; fp32 accumulate / softmax statistics; residual != 0 adds V
+ *      (cross attention :146,148).  hupr_attn_fwd_fp8 = hupr_attn_quant_fp8 (amax + convert, V transposed) followed by
+ *      hupr_attn_fwd_fp8_quantized; ws holds the three e4m3 copies.  Opt-in (functional.ATTN_FP8 / HUPR_ATTN_FP8=1, forward
+ *      under no_grad only): measured against the bf16 kernel in profiles/r02_attn_fp8_ab.txt. */
+size_t hupr_attn_fp8_ws_bytes(int Bn, int N, int C);
+int hupr_attn_quant_fp8(const float* K, const float* Q, const float* V, int Bn, int N, int C, void* ws, size_t ws_bytes,
+                        hupr_stream_t stream);
+int hupr_attn_fwd_fp8_quantized(const void* ws, const float* Vres, float* out, float* lse, int Bn, int N, int C, size_t ws_bytes,
+                                hupr_stream_t stream);
+int hupr_attn_fwd_fp8(const float* K, const float* Q, const float* V, int residual, float* out, float* lse, int Bn, int N, int C,
+                      void* ws, size_t ws_bytes, hupr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * (e) Data-parallel exchange over RCCL / xGMI.  Nothing in the reference to mirror: it trains on one
  *     device (tools/base.py:14 `self.device = 'cuda'`, tools/run.py:76-79 forward / backward / step with no

@@ -771,3 +771,54 @@ def test_interp_mnet_cast_bf16_activations():
         m[dt] = (o.detach().float(), wi.grad, bi.grad)
     assert torch.equal(m[torch.bfloat16][0], _q(m[torch.float32][0]))
     assert torch.equal(m[torch.bfloat16][1], m[torch.float32][1]) and torch.equal(m[torch.bfloat16][2], m[torch.float32][2])
+
+
+@pytest.mark.parametrize("residual", [True, False])
+def test_attention_fp8_forward_vs_fp64(residual):
+    """BASELINE.json config 5: e4m3 MFMA operands for QK^T and PV (per-tensor scales, probabilities rounded to e4m3) against
+    the fp64 statement of models/layers.py:126-133.  fp8 has 3 mantissa bits: the gate is on the attention term relative to its
+    own norm (measured 8e-2 at logit std 3 — e4m3 K and Q perturb every un-normalised logit by a few percent of its size; the
+    bf16 kernel sits at 5e-3, profiles/r02_attn_fp8_ab.txt), and on the log-sum-exp."""
+    from hupr_amd import functional as F_
+    torch.manual_seed(3)
+    B, N, C = 2, 1024, 64
+    k = torch.randn(B, N, C, device="cuda") * 0.6
+    q = torch.randn(B, N, C, device="cuda") * 0.6
+    v = torch.randn(B, N, C, device="cuda")
+    out, lse = F_.attention_fp8(k, q, v, residual)
+    S = torch.einsum("bjc,bqc->bjq", k.double(), q.double())
+    att = torch.einsum("bjq,bjc->bqc", torch.softmax(S, dim=1), v.double())
+    ref = att + (v.double() if residual else 0)
+    rel = ((out.double() - ref).norm() / att.norm()).item()
+    print("fp8 attention (residual=%s): rel-L2 of the attention term %.3e, lse max-abs %.3e" %
+          (residual, rel, (lse.double() - torch.logsumexp(S, dim=1)).abs().max().item()))
+    assert rel <= 1.5e-1
+    assert (lse.double() - torch.logsumexp(S, dim=1)).abs().max().item() <= 1.5
+    # shapes outside the kernel's envelope are refused by the C ABI
+    L = F_.rt.lib()
+    assert L.hupr_attn_fwd_fp8(F_.rt.ptr(k), F_.rt.ptr(q), F_.rt.ptr(v), 0, F_.rt.ptr(out), F_.rt.ptr(lse), B, 1000, C, F_.rt.ptr(k), 1 << 30, None) == -1
+
+
+def test_model_eval_with_fp8_attention_stays_inside_the_bf16_envelope():
+    """HuPRNet eval forward with config 5 switched on (level-1 attentions on the fp8 kernels): finite, close to the bf16 run."""
+    import numpy as np
+    from hupr_amd import functional as F_, synth
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.models import HuPRNet
+    saved = F_.ATTN_FP8
+    try:
+        F_.set_math("bf16")
+        net = HuPRNet(load_config()).cuda().eval()
+        net.load_state_dict({k_: torch.from_numpy(np.array(v_)) for k_, v_ in synth.hupr_state(1, gain=1.4).items()})
+        h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(2, 5))
+        with torch.no_grad():
+            F_.ATTN_FP8 = False
+            a1, a2 = net(h, v)
+            F_.ATTN_FP8 = True
+            b1, b2 = net(h, v)
+        d1, d2 = (a1 - b1).abs().max().item(), (a2 - b2).abs().max().item()
+        print("fp8 vs bf16 attention inside the model: heat-map max-abs %.3e / %.3e" % (d1, d2))
+        assert torch.isfinite(b1).all() and torch.isfinite(b2).all() and 0 < d1 <= 2e-2 and d2 <= 2e-2
+    finally:
+        F_.ATTN_FP8 = saved
+        F_.set_math("f32")
