@@ -91,4 +91,26 @@ __device__ __forceinline__ void halo_store_voxel(const HaloArgs& p, const f32x16
     }
 }
 
+// Deferred bf16 epilogue of the 256-voxel kernel (no bias / residual): a finished accumulator tile is parked as 8 packed
+// bf16 pairs (halo_pack_tile: pk[2 g] / pk[2 g + 1] = channels 0-1 / 2-3 of group g) and stored in two pieces — channel groups
+// gp, gp + 1 (gp = 0 or 2): two permlane32_swap + one 16-byte store — between the MFMA groups of the NEXT tile's first stage,
+// where they cost no matrix-pipe time.
+__device__ __forceinline__ void halo_pack_tile(const f32x16& acc, unsigned* pk) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const bf16x2 lo = {(__bf16)acc[4 * g], (__bf16)acc[4 * g + 1]};
+        const bf16x2 hi = {(__bf16)acc[4 * g + 2], (__bf16)acc[4 * g + 3]};
+        pk[2 * g] = __builtin_bit_cast(unsigned, lo);
+        pk[2 * g + 1] = __builtin_bit_cast(unsigned, hi);
+    }
+}
+__device__ __forceinline__ void halo_store_packed_part(const HaloArgs& p, const unsigned* pk, long m, int chb, int gp) {
+    const int lh = (chb >> 2) & 1, cb = chb - 4 * lh;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp], pk[2 * gp + 2], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp + 1], pk[2 * gp + 3], false, false);
+    const int ch = cb + 8 * (gp + lh);
+    *reinterpret_cast<u32x4*>(static_cast<__bf16*>(p.y) + m * p.out_ld + ch) = (u32x4){r0[0], r1[0], r0[1], r1[1]};
+}
+
 }  // namespace hupr

@@ -57,6 +57,13 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     const unsigned wdst_wave = __builtin_amdgcn_readfirstlane(bs_lds + wave * 1024);
 
     f32x16 acc[2];
+    // deferred epilogue (bf16 output, no bias / residual / fused statistics, Co % 8 == 0): a finished tile's accumulators are
+    // parked in accP and stored in four pieces between the MFMA groups of the next item's first stage
+    unsigned accP[2][8];                                          // parked tile, already rounded to bf16 pairs
+    long mP = 0;
+    int chP = 0;
+    bool pend = false;
+    const bool defer = ABF && !p.bias && !p.res && !p.stats && (p.Co & 7) == 0 && (p.out_ld & 7) == 0 && !(p.ablate & (4 | 2));      // ablate bit 1: A/B switch (immediate epilogue)
     f32x4n va[ABF ? 1 : NH], vc[ABF ? 1 : NH];
     u32x4 vb[ABF ? NH : 1];
 
@@ -208,7 +215,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #pragma unroll
         for (int st_ = 0; st_ < NSTAGE; ++st_) {
             const int par = (g + st_) & 1;
-            // weights of the next stage -> the idle half of Bs (everyone left it at the previous barrier)
+            // weights of the next stage -> the idle half of Bs (everyone left it at the previous barrier).  (A ring of three
+            // with the DMA two stages ahead measured no faster: the wait below is not where the staging cost sits.)
             if constexpr (!(ABL & 1)) {
                 if (st_ + 1 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 1, par ^ 1) }
                 else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, 0, par ^ 1) }
@@ -249,23 +257,35 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[set][t], af[set][t], acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[set][t], af[set][t + 1], acc[1], 0, 0, 0);
                     }
+                    if constexpr (ABF) {
+                        if (st_ == 0 && pend) {                   // piece ks of the previous tile's epilogue rides under these MFMAs
+                            halo_store_packed_part(p, accP[ks >> 1], mP + (ks >> 1) * p.W, chP, (ks & 1) * 2);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef HUPR_FRAGS
             }
             // this wave's pieces of the next stage have landed (in stage 0 the next halo's NH younger register loads stay in
             // flight); after the barrier Bs[par ^ 1] is complete and all waves are done with Bs[par] (and, after stage 8, Hs)
-            if (ABF && st_ == 0 && has_next) { HUPR_VMCNT(NH); } else { HUPR_VMCNT(0); }      // (guarded fp32 loads: no fixed count)
+            // (the parked tile's four stores of stage 0 are younger still; guarded fp32 loads have no fixed count)
+            if (ABF && st_ == 0 && has_next) { if (pend) { HUPR_VMCNT(NH + 4); } else { HUPR_VMCNT(NH); } } else { HUPR_VMCNT(0); }
             if constexpr (!(ABL & 2)) __syncthreads();
-            if (st_ == 0) { HUPR_STAMP() }                        // 2: first stage computed
+            if (st_ == 0) { pend = false; HUPR_STAMP() }          // 2: first stage computed (and the parked tile stored)
         }
         g += NSTAGE;
         HUPR_STAMP()                                              // 3: all stages done
         if (last_chunk && !(p.ablate & 4)) {
+            const long m0 = (((long)b * p.D + d0 + wm) * p.H + h0 + hy0) * p.W + w0 + wx;
+            if (defer && has_next) {                              // park: stored during the next item's stage 0
+                halo_pack_tile(acc[0], accP[0]);
+                halo_pack_tile(acc[1], accP[1]);
+                mP = m0;
+                chP = n0 + wn * 32 + 4 * lh;
+                pend = true;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const long m = (((long)b * p.D + d0 + wm) * p.H + h0 + hy0 + i) * p.W + w0 + wx;
-                halo_store_voxel<ABF>(p, acc[i], m, n0 + wn * 32 + 4 * lh);
+                for (int i = 0; i < 2; ++i) halo_store_voxel<ABF>(p, acc[i], m0 + i * p.W, n0 + wn * 32 + 4 * lh);
             }
         }
         if constexpr (ABF) {
