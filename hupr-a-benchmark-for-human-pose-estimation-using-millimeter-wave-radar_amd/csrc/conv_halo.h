@@ -31,6 +31,8 @@ struct HaloArgs {
 // 256-voxel persistent variant; returns false when the geometry is not supported
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf);
+bool launch_conv_halo512(HaloArgs a, int Bn, bool abf, hipStream_t s);      // 512-voxel register-blocked variant (conv_halo512_bf16.hip)
+bool conv_halo512_supported(const HaloArgs& a, int Bn, bool abf);
 constexpr int kHalo256Grid = 256;      // persistent workgroups (= partial rows of HaloArgs::stats)
 
 // Epilogue of both kernels.  The MFMAs are issued as D' = W * X^T, so a lane holds ONE voxel (column lane & 31 of the

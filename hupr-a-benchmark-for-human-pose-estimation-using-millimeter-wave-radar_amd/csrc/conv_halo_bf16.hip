@@ -325,7 +325,7 @@ extern "C" int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co
 }
 
 static int g_halo_ablate = 0;
-static int g_halo_variant = 0;      // 0 auto, 1 force the 128-voxel kernel (A/B comparisons)
+static int g_halo_variant = 0;      // 0 auto, 1 force the 128-voxel kernel, 2 skip the 512-voxel kernel (A/B comparisons)
 static unsigned long long* g_halo_trace = nullptr;
 extern "C" void hupr_debug_halo_trace(void* buf) { g_halo_trace = reinterpret_cast<unsigned long long*>(buf); }
 extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
@@ -360,6 +360,12 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
                      "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);
         HUPR_REQUIRE(launch_conv_halo256(a, Bn, abf, as_stream(stream)), "%s: 256-voxel kernel refused the launch", who);
         HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16<stats>");
+        return HUPR_OK;
+    }
+    // variants: 0 auto (512-voxel register-blocked kernel where its envelope holds, then 256-, then 128-voxel), 1 force the
+    // 128-voxel kernel, 2 skip the 512-voxel kernel (A/B comparisons)
+    if (g_halo_variant == 0 && launch_conv_halo512(a, Bn, abf, as_stream(stream))) {
+        HUPR_LAUNCH_OK("hupr_k_conv_halo512_bf16");
         return HUPR_OK;
     }
     if (g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {

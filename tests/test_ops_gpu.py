@@ -822,3 +822,28 @@ def test_model_eval_with_fp8_attention_stays_inside_the_bf16_envelope():
     finally:
         F_.ATTN_FP8 = saved
         F_.set_math("f32")
+
+
+def test_conv_halo512_first_layer_shape_matches_the_128_voxel_kernel(bf16_math):
+    """The 512-voxel register-blocked kernel (Ci = 32: the encoder's first layer at the bench batch) against the 128-voxel
+    kernel on the same bf16 operands — same products, another fp32 summation order (K chunks of 32, kz-major taps): equal up to
+    one rounding of the bf16 store — and against fp64 on one sample."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    B, Ci, Co, D, H, W = 32, 32, 64, 8, 64, 64
+    x = _q(rnd(B, D, H, W, Ci, seed=90)).cuda().bfloat16()
+    w = rnd(Co, Ci, 3, 3, 3, seed=91, scale=(Ci * 27) ** -0.5).cuda()
+    bias = rnd(Co, seed=92).cuda()
+    try:
+        L.hupr_debug_halo_variant(0)
+        y512 = F_._conv_raw(x, w, 0, bias, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        L.hupr_debug_halo_variant(1)
+        y128 = F_._conv_raw(x, w, 0, bias, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+    finally:
+        L.hupr_debug_halo_variant(0)
+    d = (y512.float() - y128.float()).abs()
+    ulp = y128.float().abs().clamp_min(2.0 ** -6) * 2.0 ** -7           # one bf16 step of the stored value
+    assert bool((d <= ulp).all()), (d / ulp).max().item()
+    assert (d > 0).float().mean().item() < 0.05                           # and almost all of them identical
+    ref = F.conv3d(_bf16_round(ncdhw(x.float().cpu()))[:1], _bf16_round(w.cpu()), bias.cpu().double(), 1, 1)
+    close(ncdhw(y512.float().cpu())[:1], ref, 6e-3, "halo512 vs fp64 (one bf16 store rounding)")
