@@ -71,13 +71,32 @@ class RcclTransport:
         if self.rank == 0:
             rt.check(self.L.hupr_comm_unique_id(uid))
         if multi:
-            box = [uid.raw if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            uid = ctypes.create_string_buffer(box[0], 128)
+            uid = ctypes.create_string_buffer(self._exchange_id(uid.raw if self.rank == 0 else None, group), 128)
         comm = ctypes.c_void_p()
         with torch.cuda.device(device):
             rt.check(self.L.hupr_comm_init_rank(ctypes.byref(comm), uid, self.world, self.rank))
         self.comm = comm
+
+    _n_comms = 0
+
+    @classmethod
+    def _exchange_id(cls, uid_bytes, group):
+        """Rank 0's 128-byte communicator id to every rank.  Default group: through the rendezvous key-value store (no
+        collective, no device traffic: works whatever backends the group was initialised with); sub-groups: object broadcast."""
+        if group is None:
+            try:
+                store = dist.distributed_c10d._get_default_store()
+                key = "hupr_rccl_uid_%d" % cls._n_comms
+                cls._n_comms += 1
+                if uid_bytes is not None:
+                    store.set(key, uid_bytes)
+                    return uid_bytes
+                return bytes(store.get(key))                  # blocks until rank 0 has published it
+            except Exception as exc:      # noqa: BLE001 — private accessor: fall back to the collective
+                sys.stderr.write("hupr: store exchange of the RCCL id failed (%s); using broadcast_object_list\n" % exc)
+        box = [uid_bytes]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return box[0]
 
     def all_reduce(self, flat, stream=None):
         """Enqueue on ``stream`` (a torch stream; default: the current one).  Returns None: ordering is the stream's."""

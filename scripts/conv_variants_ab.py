@@ -1,6 +1,9 @@
+"""128- / 256- / 512-voxel halo convolution kernels on the 3-D encoder shapes (B = 32, bf16 activations), interleaved rounds.
+HUPR_HALO512_ALL=1 lets the 512-voxel kernel run on every shape of its envelope (the dispatcher uses it for Ci = 32 only)."""
 import os, sys
+os.environ["HUPR_HALO512_ALL"] = "1"
 import torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hupr_amd import functional as F_
 F_.set_math("bf16")
 L = F_.rt.lib()

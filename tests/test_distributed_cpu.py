@@ -190,3 +190,25 @@ def test_fused_adam_checkpoint_interchanges_with_torch_adam():
     assert opt2.param_groups[0]["lr"] == 1e-3 and len(opt2.state) == 0
     for a, b in zip(opt._flat_state, opt2._flat_state):
         assert b["step"] == 7 and torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
+
+
+def _uid_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hupr_amd.tools.distributed import RcclTransport
+    # two communicators in a row: the second exchange must not read the first one's key
+    a = RcclTransport._exchange_id(bytes([rank + 1] * 128) if rank == 0 else None, None)
+    b = RcclTransport._exchange_id(bytes([7] * 128) if rank == 0 else None, None)
+    out[rank] = (a, b)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_id_exchange_through_the_store_world2():
+    """The only multi-rank-specific step of the native RCCL transport that cannot run on a 1-GPU box: every rank must end up
+    with rank 0's 128-byte communicator id (hupr_comm_unique_id), via the rendezvous store, once per communicator."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_uid_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1] == (bytes([1] * 128), bytes([7] * 128))
