@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         }
     }
     if (t_begin >= t_end) return;
+    if (p.trace != nullptr && tid == 0) p.trace[4096 + 2 * blockIdx.x] = wall_clock64();      // profiling: per-workgroup start / end
     Pos cur;
     {
         cur.cot = t_begin % p.n_co_tiles;
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         HUPR_STAMP()                                              // 5: next halo in LDS
         cur = nxt;
     }
+    if (p.trace != nullptr && tid == 0) p.trace[4096 + 2 * blockIdx.x + 1] = wall_clock64();
     if (p.stats) {                                                // the four depth-slice waves' sums, fixed order, as doubles
         __syncthreads();
         for (int c = tid; c < 2 * p.Co; c += 512) {

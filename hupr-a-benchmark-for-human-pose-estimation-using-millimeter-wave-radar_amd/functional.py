@@ -87,6 +87,31 @@ def two_streams_ok(t):
     return TWO_STREAMS and t.is_cuda
 
 
+# With two compute streams the two encoders' large persistent convolutions (one workgroup per CU, all of the LDS) are
+# dispatched at the same time; they cannot co-reside, the second one's workgroups start as the first one's finish, and every
+# per-launch duration — bench.py's roofline probe, a rocprofv3 trace — measures queueing (357 instead of 212 us).  HEAVY_SERIAL
+# (opt-in, HUPR_HEAVY_SERIAL=1) orders those launches across the streams with events so that the probe stays a kernel
+# measurement; it costs 3.3 % of the two-stream throughput (1 456 -> 1 408 frames/s: the free-running version also overlaps the
+# convolutions' tails), which is why bench.py measures one stream by default instead.
+HEAVY_SERIAL = os.environ.get("HUPR_HEAVY_SERIAL", "0") == "1"
+_heavy_last = {}
+
+
+def _heavy_begin(device):
+    if not (HEAVY_SERIAL and TWO_STREAMS) or torch.cuda.is_current_stream_capturing():
+        return False
+    ev = _heavy_last.get(device.index)
+    if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
+    return True
+
+
+def _heavy_end(device):
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _heavy_last[device.index] = ev
+
+
 def refresh_packed(device):
     """Run the packed-weight table refresh now (on the current stream) if any cached entry is stale — called before
     the branches fork so that the refresh is ordered in front of both."""
@@ -270,6 +295,7 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stat
     if _halo_ok(x, k, pad, co):
         assert res is None or res.dtype == x.dtype
         wp = _packed(weight, mode, 1)
+        heavy = k[0] == 3 and B * Do * Ho * Wo * co >= (1 << 24) and _heavy_begin(x.device)
         if ev is not None:
             ev[0].record()
         if (stats and CONV_STATS and abf and bias is None and res is None and out is None
@@ -281,12 +307,16 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stat
             _conv_stats[y.data_ptr()] = (st, rows, B * Do * Ho * Wo, co)
             if ev is not None:
                 ev[1].record()
+            if heavy:
+                _heavy_end(x.device)
             return y
         fn = rt.lib().hupr_conv3x3_halo_bf16act if abf else rt.lib().hupr_conv3x3_halo_bf16
         rt.check(fn(rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
                     rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
         if ev is not None:
             ev[1].record()
+        if heavy:
+            _heavy_end(x.device)
         return y
     if abf:
         raise rt.HuprError("bf16-stored activations are only supported by the halo-tiled 3x3 convolutions "

@@ -1,6 +1,8 @@
 """Training/inference engine shared by the Runner and bench.py: HuPRNet + LossComputer +
 flat gradient buckets (+ RCCL all-reduce when world_size > 1) + fused Adam, optionally fed by the
 on-GPU FFT loader (int16 ADC cubes -> normalised network input, config "C3" of BASELINE.json)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -21,9 +23,10 @@ class TrainEngine:
         self.buckets = GradientBuckets(self.model, bucket_bytes=bucket_bytes)
         self.buckets.broadcast_parameters(0)
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
-        if self.buckets.active:
-            # measured with the RCCL path active (single rank, forced collectives): the side-stream branch costs 1 %
-            # instead of gaining 2 % — the all-reduce kernels already fill the gaps it would use.  One compute stream then.
+        if self.buckets.active and os.environ.get("HUPR_DP_ONE_STREAM", "0") == "1":
+            # A/B aid.  (Round 1, torch.distributed work objects: the side-stream branch cost 1 % with collectives in flight;
+            # with the stream-ordered hupr_allreduce_bucket it gains 3 % — 1 368 -> 1 412 frames/s with forced single-rank
+            # collectives — so data-parallel runs keep the library default of two compute streams.)
             from .. import functional as F_
             F_.TWO_STREAMS = False
         self.optimizer = FusedAdam(self.model.parameters(), lr=lr if lr is not None else cfg.TRAINING.lr,
