@@ -212,6 +212,12 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
 // K2: pruned angle DFT + index map (+ optional loader epilogue)
 // grid = n_sf * (LOADER ? 8 : 16), block = 256 (4 waves x 16 range cells each)
 // ------------------------------------------------------------------------------------------
+// From here on floating-point contraction is OFF: the angle kernel exists in four instantiations (complex cube, loader,
+// magnitude, loader + elevation mean) that must produce the SAME bits for the same cell — left to its own devices hipcc fuses
+// different multiply-add pairs in different instantiations (measured: 30 % of the loader values differed by 1-2 ulp between
+// MODE 1 and MODE 3).  The DFT itself is written with explicit fmaf (cfma), so nothing is lost.
+#pragma clang fp contract(off)
+
 struct AngleOut {
     float2 o[kEl];   // indexed by OUTPUT elevation bin e
 };
@@ -235,17 +241,23 @@ __device__ __forceinline__ AngleOut angle_cell(const float2* __restrict__ cell, 
 #pragma unroll
     for (int e = 0; e < kEl; ++e) {
         const int ep = (3 - e) & 7;                // source elevation-FFT bin for output bin e
-        float2 v = cadd(P, cmul(w8[ep], Q));
-        if (ep == 0) v = cadd(v, R);
+        // explicit rounding steps (intrinsics are exempt from contraction / re-association): hupr_common.h's cmul was
+        // compiled with contraction on and fused differently per instantiation once inlined here
+        const float2 wq = make_float2(__fmaf_rn(w8[ep].x, Q.x, -__fmul_rn(w8[ep].y, Q.y)),
+                                      __fmaf_rn(w8[ep].x, Q.y, __fmul_rn(w8[ep].y, Q.x)));
+        float2 v = make_float2(__fadd_rn(P.x, wq.x), __fadd_rn(P.y, wq.y));
+        if (ep == 0) v = make_float2(__fadd_rn(v.x, R.x), __fadd_rn(v.y, R.y));
         r.o[e] = v;
     }
     return r;
 }
 
-// MODE 0: complex64 cube (the reference's output); 1: loader epilogue (Normalize fused); 2 (opt-in): magnitude |X| as fp32
+// MODE 0: complex64 cube (the reference's output); 1: loader epilogue (Normalize fused); 2 (opt-in): magnitude |X| as fp32;
+// 3: loader epilogue + HuPRNet's elevation mean (models/networks.py:26-27) — writes the (re/im, Doppler) planes
+// means[sf][2 f + c][range][azimuth] that the MNet front end consumes: 1/8 of the loader's bytes, and MNet no longer re-reads them
 template <int MODE>
 __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ rd, void* __restrict__ out_) {
-    constexpr bool LOADER = MODE == 1;
+    constexpr bool LOADER = MODE == 1 || MODE == 3;
     __shared__ float2 cells[kRange * kVant];   // RD for this (sf, i): 64 range bins x 12 antennas
     __shared__ float2 tw64[64];
     __shared__ float red[4][32];
@@ -305,6 +317,25 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
 #pragma unroll
         for (int k = 0; k < 16; ++k) { mean[k] = s_mean[k]; rstd[k] = s_rstd[k]; }
         float* out = reinterpret_cast<float*>(out_);
+        if constexpr (MODE == 3) {
+            // means[sf][j = 2 pl + c][r][a] = mean over the 8 elevation bins of the normalised plane, summed exactly like
+            // hupr_k_mnet_fwd sums the stored loader tensor (same association -> the two paths agree bit for bit)
+            float* mre = out + ((size_t)(sf * 16 + 2 * pl) * kRange) * kAz;
+            float* mim = mre + (size_t)kRange * kAz;
+            for (int j = 0; j < 16; ++j) {
+                const int r = wave * 16 + j;
+                AngleOut v = angle_cell(cells + r * kVant, twl);
+                float re[8], im[8];
+#pragma unroll
+                for (int e = 0; e < kEl; ++e) {
+                    re[e] = __fmul_rn(v.o[e].x - mean[e], rstd[e]);       // rounded products, as the stored loader tensor holds them
+                    im[e] = __fmul_rn(v.o[e].y - mean[8 + e], rstd[8 + e]);   // (no contraction into the sums below)
+                }
+                mre[r * kAz + a_out] = (((re[0] + re[1]) + (re[2] + re[3])) + ((re[4] + re[5]) + (re[6] + re[7]))) * 0.125f;
+                mim[r * kAz + a_out] = (((im[0] + im[1]) + (im[2] + im[3])) + ((im[4] + im[5]) + (im[6] + im[7]))) * 0.125f;
+            }
+            return;
+        }
         // out[sf][f=pl][c][r][a][e]
         float* base_re = out + ((size_t)((sf * 8 + pl) * 2 + 0) * kRange) * kAz * kEl;
         float* base_im = base_re + (size_t)kRange * kAz * kEl;
@@ -428,7 +459,7 @@ extern "C" size_t hupr_fft_chain_ws_bytes(int n_sf) {
 }
 
 static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws, size_t ws_bytes,
-                            hupr_stream_t stream, bool loader, int flags = 0) {
+                            hupr_stream_t stream, bool loader, int flags = 0, bool means = false) {
     HUPR_REQUIRE((flags & ~(HUPR_FFT_HANN_RANGE | HUPR_FFT_HANN_DOPPLER | HUPR_FFT_MAGNITUDE)) == 0, "hupr_fft_chain: flags=0x%x", flags);
     HUPR_REQUIRE(!(loader && (flags & HUPR_FFT_MAGNITUDE)), "hupr_fft_chain: the loader epilogue splits re/im, it has no magnitude form");
     HUPR_REQUIRE(n_sf >= 0, "hupr_fft_chain: n_sf=%d", n_sf);
@@ -449,7 +480,9 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
         default: hipLaunchKernelGGL(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
     }
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
-    if (loader)
+    if (loader && means)
+        hipLaunchKernelGGL(hupr_k_angle<3>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
+    else if (loader)
         hipLaunchKernelGGL(hupr_k_angle<1>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
     else if (flags & HUPR_FFT_MAGNITUDE)
         hipLaunchKernelGGL(hupr_k_angle<2>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
@@ -467,6 +500,11 @@ extern "C" int hupr_fft_chain_c64(const int16_t* adc_iq, int n_sf, void* out_c64
 extern "C" int hupr_fft_chain_loader_f32(const int16_t* adc_iq, int n_sf, float* out, void* ws,
                                          size_t ws_bytes, hupr_stream_t stream) {
     return fft_chain_common(adc_iq, n_sf, out, ws, ws_bytes, stream, true);
+}
+
+extern "C" int hupr_fft_chain_loader_means_f32(const int16_t* adc_iq, int n_sf, float* means, void* ws, size_t ws_bytes,
+                                               hupr_stream_t stream) {
+    return fft_chain_common(adc_iq, n_sf, means, ws, ws_bytes, stream, true, 0, true);
 }
 
 extern "C" int hupr_fft_chain_opts(const int16_t* adc_iq, int n_sf, void* out, int flags, int loader, void* ws, size_t ws_bytes,

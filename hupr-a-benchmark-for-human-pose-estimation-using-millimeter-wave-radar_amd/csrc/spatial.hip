@@ -69,6 +69,52 @@ __global__ __launch_bounds__(256) void hupr_k_mnet_fwd(const float* __restrict__
     }
 }
 
+// The same front end fed by the fused loader's elevation-mean planes mp[bg][16][pixels] (hupr_fft_chain_loader_means_f32):
+// sixteen coalesced 4-byte reads per pixel instead of 512 bytes; also leaves the pixel-major means the backward pass reads.
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_mnet_fwd_means(const float* __restrict__ mp, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ out,
+                                                             float* __restrict__ means, long n_bg, int pixels) {
+    __shared__ float sw[kNF * 4 + kNF];
+    for (int i = threadIdx.x; i < kNF * 4 + kNF; i += 256) sw[i] = (i < kNF * 4) ? w[i] : bias[i - kNF * 4];
+    __syncthreads();
+    const long total = n_bg * pixels;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long bg = idx / pixels, pix = idx - bg * pixels;
+        const float* xb = mp + bg * 16 * (long)pixels + pix;
+        float m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m[j] = xb[(long)j * pixels];
+        if (means) {
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                *reinterpret_cast<float4*>(means + idx * 16 + j) = make_float4(m[j], m[j + 1], m[j + 2], m[j + 3]);
+        }
+        T* o = out + idx * kNF;
+#pragma unroll
+        for (int c4 = 0; c4 < kNF / 4; ++c4) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = c4 * 4 + k;
+                const float w00 = sw[co * 4 + 0], w01 = sw[co * 4 + 1], w10 = sw[co * 4 + 2], w11 = sw[co * 4 + 3];
+                float best = -INFINITY;
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    float v = sw[kNF * 4 + co];
+                    v = fmaf(w00, m[2 * t2], v);
+                    v = fmaf(w01, m[2 * t2 + 1], v);
+                    v = fmaf(w10, m[8 + 2 * t2], v);
+                    v = fmaf(w11, m[8 + 2 * t2 + 1], v);
+                    best = fmaxf(best, v);
+                }
+                r[k] = best;
+            }
+            st_act4(o + c4 * 4, make_float4(r[0], r[1], r[2], r[3]));
+        }
+    }
+}
+
 // backward: recompute the arg-max chirp step, accumulate dW[co][ch2][kt] and dbias[co]
 // partial[blk][160].  A thread owns one pixel x 8 output channels (four threads per pixel): 40 accumulators instead of
 // 160 keeps the kernel at full occupancy — the one-pixel-x-32-channels version ran at 0.66 TB/s on 134 MB.
@@ -348,6 +394,26 @@ extern "C" int hupr_mnet_fwd_f32(const float* x, const float* w, const float* bi
 extern "C" int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, float* means_or_null,
                                      long n_bg, int pixels, hupr_stream_t stream) {
     return mnet_fwd("hupr_mnet_fwd_bf16act", x, w, bias, static_cast<__bf16*>(out), means_or_null, n_bg, pixels, stream);
+}
+
+template <typename T>
+static int mnet_fwd_means(const char* who, const float* mp, const float* w, const float* bias, T* out, float* means, long n_bg,
+                          int pixels, hupr_stream_t stream) {
+    HUPR_REQUIRE(mp && w && bias && out && n_bg > 0 && pixels > 0, "%s: bad argument", who);
+    const long total = n_bg * pixels;
+    const int grid = (int)min((long)8192, (total + 255) / 256);
+    hipLaunchKernelGGL(hupr_k_mnet_fwd_means<T>, dim3(grid), dim3(256), 0, as_stream(stream), mp, w, bias, out, means, n_bg, pixels);
+    HUPR_LAUNCH_OK("hupr_k_mnet_fwd_means");
+    return HUPR_OK;
+}
+extern "C" int hupr_mnet_fwd_means_f32(const float* mean_planes, const float* w, const float* bias, float* out,
+                                       float* means_or_null, long n_bg, int pixels, hupr_stream_t stream) {
+    return mnet_fwd_means("hupr_mnet_fwd_means_f32", mean_planes, w, bias, out, means_or_null, n_bg, pixels, stream);
+}
+extern "C" int hupr_mnet_fwd_means_bf16act(const float* mean_planes, const float* w, const float* bias, void* out,
+                                           float* means_or_null, long n_bg, int pixels, hupr_stream_t stream) {
+    return mnet_fwd_means("hupr_mnet_fwd_means_bf16act", mean_planes, w, bias, static_cast<__bf16*>(out), means_or_null, n_bg,
+                          pixels, stream);
 }
 
 extern "C" size_t hupr_mnet_bwd_ws_bytes(void) { return (size_t)1024 * kNF * 5 * sizeof(float); }

@@ -685,20 +685,28 @@ class PReLUFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------------------------
 class MNetFn(torch.autograd.Function):
-    """x (B,G,F,2,R,A,E) -> (B, G, R, A, 32) channels-last with depth axis = group frame."""
+    """x (B,G,F,2,R,A,E) — or its elevation mean as planes (B,G,16,R,A) — -> (B, G, R, A, 32) channels-last, depth = group frame."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, out_dtype=torch.float32):
         x = _c(x)
-        B, G, F, two, R, A, E = x.shape
-        if (F, two, E) != (8, 2, 8) or weight.shape != (32, 2, 2, 1, 1):
+        if weight.shape != (32, 2, 2, 1, 1):
             raise ValueError("MNet kernel is specialised for F=8, 2 (re/im), E=8, 32 filters")
+        from_means = x.dim() == 5            # (B, G, 16, R, A): the fused loader's elevation-mean planes (fft_chain_loader_means)
+        if from_means:
+            B, G, P16, R, A = x.shape
+            if P16 != 16:
+                raise ValueError("elevation-mean input must be (B, G, 16, R, A)")
+        else:
+            B, G, F, two, R, A, E = x.shape
+            if (F, two, E) != (8, 2, 8):
+                raise ValueError("MNet kernel is specialised for F=8, 2 (re/im), E=8, 32 filters")
         out = torch.empty((B, G, R, A, 32), dtype=out_dtype, device=x.device)
         # training: keep the 16 elevation means per pixel (1/8 of x) — the backward pass recomputes everything from them
         need = weight.requires_grad or bias.requires_grad
         means = torch.empty((B * G, R * A, 16), dtype=torch.float32, device=x.device) if need else None
-        rt.check(_act("mnet_fwd", out)(rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(out),
-                                       rt.ptr(means) if need else None, B * G, R * A, rt.stream()))
+        rt.check(_act("mnet_fwd_means" if from_means else "mnet_fwd", out)(
+            rt.ptr(x), rt.ptr(_c(weight)), rt.ptr(bias), rt.ptr(out), rt.ptr(means) if need else None, B * G, R * A, rt.stream()))
         ctx.save_for_backward(means, weight, bias)
         ctx.geom = (B, G, R, A)
         return out

@@ -4,6 +4,9 @@ Same constructor (cfg attribute tree), same ``forward(VRDAEmaps_hori, VRDAEmaps_
 with (B,G,F,2,R,A,E) fp32 inputs, same outputs ``(heatmap (B,K,1,H,W), gcn_heatmap (B,1,K,H,W))``
 and the same 255 ``state_dict`` entries; all arithmetic runs in hand-written gfx950 kernels
 through the C ABI (include/hupr.h).  CUDA/ROCm tensors only — there is no CPU fallback.
+
+Extension used by the fused training loader: ``forward`` also accepts the two inputs already averaged over the elevation
+axis (the first thing the reference's forward_chirp does, networks.py:26-27) as planes (B, G, 16, R, A).
 """
 import torch
 import torch.nn as nn

@@ -1,1 +1,2 @@
-from .process_iwr1843 import RadarObject, dca1000_frames, fft_chain, fft_chain_loader, loader_normalize  # noqa: F401
+from .process_iwr1843 import (RadarObject, dca1000_frames, fft_chain, fft_chain_loader, fft_chain_loader_means,  # noqa: F401
+                              loader_normalize)

@@ -76,6 +76,21 @@ def fft_chain_loader(adc_iq, ws=None, out=None, window=None):
     return out
 
 
+def fft_chain_loader_means(adc_iq, ws=None):
+    """adc_iq: int16 GPU tensor (n,4,192,256,2) -> fp32 GPU tensor (n, 16, 64, 64): the loader tensor of ``fft_chain_loader``
+    averaged over its elevation axis, plane index 2 f + c — what ``HuPRNet.forward`` computes first (models/networks.py:26-27).
+    The fused training loader hands these planes to the model instead of the 8x larger (n,8,2,64,64,8) tensor."""
+    _check_adc(adc_iq)
+    n = adc_iq.shape[0]
+    out = torch.empty((n, 16, 64, 64), dtype=torch.float32, device=adc_iq.device)
+    if ws is None:
+        ws, nbytes = _workspace(n, adc_iq.device)
+    else:
+        nbytes = ws.numel() * ws.element_size()
+    rt.check(rt.lib().hupr_fft_chain_loader_means_f32(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
+    return out
+
+
 def loader_normalize(cube):
     """cube: complex64 GPU tensor (n,16,64,64,8) -> fp32 (n,8,2,64,64,8) (dataset.py:144-150)."""
     if cube.dtype != torch.complex64 or tuple(cube.shape[1:]) != (16, 64, 64, 8):

@@ -23,6 +23,9 @@ SIGNATURES = {
     "hupr_fft_chain_ws_bytes": (c_size_t, [c_int]),
     "hupr_fft_chain_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_fft_chain_loader_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_fft_chain_loader_means_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_mnet_fwd_means_f32": (c_int, [c_void_p] * 5 + [c_long, c_int, c_void_p]),
+    "hupr_mnet_fwd_means_bf16act": (c_int, [c_void_p] * 5 + [c_long, c_int, c_void_p]),
     "hupr_fft_chain_opts": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_loader_normalize_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "hupr_dca1000_deinterleave": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

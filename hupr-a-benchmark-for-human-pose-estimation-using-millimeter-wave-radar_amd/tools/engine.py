@@ -8,7 +8,7 @@ import torch.distributed as dist
 
 from ..misc.losses import LossComputer
 from ..models import HuPRNet
-from ..preprocessing.process_iwr1843 import fft_chain_loader
+from ..preprocessing.process_iwr1843 import fft_chain_loader, fft_chain_loader_means
 from .distributed import GradientBuckets
 from .optim import FusedAdam
 
@@ -34,6 +34,7 @@ class TrainEngine:
         self.optimizer.attach_flat_buckets(self.buckets.flat_pairs(), self.buckets.layout())
         self.optimizer.grad_scale = 1.0 / self.world_size
         self.G = cfg.DATASET.numGroupFrames
+        self.fuse_elevation_mean = os.environ.get("HUPR_NO_FUSED_MEAN", "0") != "1"
         self._fft_ws = None
         self._graph = None
         # the num_batches_tracked counters of all BatchNorms as views of one int64 vector: a training step bumps them
@@ -47,9 +48,15 @@ class TrainEngine:
 
     # -- data -------------------------------------------------------------------------------------
     def preprocess(self, adc_hori, adc_vert):
-        """int16 ADC cubes (B*G, 4, 192, 256, 2) per sensor -> two (B,G,F,2,R,A,E) fp32 network inputs."""
+        """int16 ADC cubes (B*G, 4, 192, 256, 2) per sensor -> the two network inputs.  Default (``fuse_elevation_mean``): the
+        loader tensor already averaged over its elevation axis, (B, G, 16, R, A) planes — 1/8 of the bytes written by the FFT
+        chain and read back by the MNet front end, bit-identical results; ``HUPR_NO_FUSED_MEAN=1`` keeps the reference-shaped
+        (B,G,F,2,R,A,E) hand-over."""
         n = adc_hori.shape[0]
         B = n // self.G
+        if self.fuse_elevation_mean:
+            return (fft_chain_loader_means(adc_hori).view(B, self.G, 16, 64, 64),
+                    fft_chain_loader_means(adc_vert).view(B, self.G, 16, 64, 64))
         h = fft_chain_loader(adc_hori).view(B, self.G, 8, 2, 64, 64, 8)
         v = fft_chain_loader(adc_vert).view(B, self.G, 8, 2, 64, 64, 8)
         return h, v

@@ -56,6 +56,13 @@ int hupr_fft_chain_c64(const int16_t* adc_iq, int n_sf, void* out_c64, void* ws,
 int hupr_fft_chain_loader_f32(const int16_t* adc_iq, int n_sf, float* out, void* ws, size_t ws_bytes,
                               hupr_stream_t stream);
 
+/* (a1+a2+a3 seam) the same, with HuPRNet's elevation mean (models/networks.py:26-27, the first thing forward_chirp does to the
+ *      loader tensor) folded in: means[n_sf][16 = 2 f + c][64 range][64 az] = mean over the 8 elevation bins of the normalised
+ *      plane — 262 144 B / sensor-frame instead of 2 097 152 B (1 048 576 B algorithmic incl. the ADC read).
+ *      Consumed by hupr_mnet_fwd_means_*; bit-identical to hupr_fft_chain_loader_f32 followed by hupr_mnet_fwd_*. */
+int hupr_fft_chain_loader_means_f32(const int16_t* adc_iq, int n_sf, float* means, void* ws, size_t ws_bytes,
+                                    hupr_stream_t stream);
+
 /* (a1, opt-in variants) north_star asks for "Hanning windowing and magnitude"; the reference has neither
  *      (process_iwr1843.py:130-151 is bare np.fft.fft2 / np.fft.fft, np.abs only in the plotting helper :207-208), so
  *      both are flags that are OFF on every parity path:
@@ -346,6 +353,12 @@ int hupr_prelu_bwd_bf16act(const void* dy, const void* x, const float* alpha, vo
                            size_t ws_bytes, hupr_stream_t stream);
 int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, float* means_or_null, long n_bg,
                           int pixels, hupr_stream_t stream);
+/* MNet front end from the fused loader's elevation-mean planes [n_bg][16][pixels] (hupr_fft_chain_loader_means_f32); also
+ * leaves the pixel-major means [n_bg][pixels][16] hupr_mnet_bwd_* reads (means_or_null). */
+int hupr_mnet_fwd_means_f32(const float* mean_planes, const float* w, const float* bias, float* out, float* means_or_null,
+                            long n_bg, int pixels, hupr_stream_t stream);
+int hupr_mnet_fwd_means_bf16act(const float* mean_planes, const float* w, const float* bias, void* out, float* means_or_null,
+                                long n_bg, int pixels, hupr_stream_t stream);
 int hupr_mnet_bwd_bf16act(const float* x_or_null, const float* means_or_null, const float* w, const float* bias,
                           const void* dy, float* dw, float* dbias, long n_bg, int pixels, void* ws, size_t ws_bytes,
                           hupr_stream_t stream);

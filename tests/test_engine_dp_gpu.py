@@ -179,7 +179,7 @@ def test_bench_line_single_gpu_carries_every_object():
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["dtype"] == "bf16"
     assert out["config"]["parallelism"] == "dp1" and out["config"]["launch"] == "eager"
     assert out["roofline"]["launches"] == 3 * 12 and 0 < out["roofline"]["frac"] < 1
-    assert out["fft_roofline"]["bound"] == "hbm" and 0 < out["fft_roofline"]["frac"] < 1
+    assert out["fft_roofline"]["bound"] == "hbm" and 0 < out["fft_roofline"]["frac"] < 1 and "loader_variant" in out["fft_roofline"]
     assert out["parity_path"]["dtype"] == "f32" and out["parity_path"]["roofline"]["peak"] == 157.3
     assert "arg-max" in out["config"]["workload"]
 
@@ -204,3 +204,26 @@ def test_bench_strong_scaling_accumulates_micro_batches():
     out = _bench(["--steps", "2", "--warmup", "1", "--batch", "32", "--strong", "--no-cpu-baseline"])
     assert out["scaling"] == "strong" and out["config"]["global_batch"] == 256 and out["config"]["micro_batches_per_step"] == 8
     assert abs(out["value"] - 256 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-2 * out["value"]
+
+
+def test_fused_elevation_mean_step_equals_reference_shaped_handover(monkeypatch):
+    """TrainEngine.preprocess hands the model the elevation-mean planes by default; three optimisation steps land on exactly the
+    parameters of the (B,G,F,2,R,A,E) hand-over (HUPR_NO_FUSED_MEAN=1)."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    try:
+        F_.set_math("bf16")
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=91)
+        monkeypatch.delenv("HUPR_NO_FUSED_MEAN", raising=False)
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        assert e1.fuse_elevation_mean and e1.preprocess(adc_h, adc_v)[0].shape == (4, 8, 16, 64, 64)
+        monkeypatch.setenv("HUPR_NO_FUSED_MEAN", "1")
+        e2 = TrainEngine(cfg, device=dev, seed=0)
+        assert not e2.fuse_elevation_mean and e2.preprocess(adc_h, adc_v)[0].shape == (4, 8, 8, 2, 64, 64, 8)
+        for _ in range(3):
+            l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)
+            l2, _ = e2.train_step_from_adc(adc_h, adc_v, joints)
+        torch.cuda.synchronize()
+        assert float(l1.detach()) == float(l2.detach()) and torch.equal(_flat(e1), _flat(e2))
+    finally:
+        F_.set_math("f32")

@@ -214,3 +214,29 @@ def test_window_flags_default_off_is_bit_identical_and_hann_suppresses_sidelobes
     ws = torch.empty(L.hupr_fft_chain_ws_bytes(1), dtype=torch.uint8, device="cuda")
     assert L.hupr_fft_chain_opts(rt.ptr(dev), 1, rt.ptr(out), 4, 1, rt.ptr(ws), ws.numel(), None) == -1      # loader + magnitude
     assert L.hupr_fft_chain_opts(rt.ptr(dev), 1, rt.ptr(out), 64, 0, rt.ptr(ws), ws.numel(), None) == -1     # unknown flag
+
+
+def test_fused_elevation_mean_loader_is_bit_identical_to_loader_plus_mnet_mean():
+    """hupr_fft_chain_loader_means_f32 (FFT chain + Normalize + HuPRNet's elevation mean, models/networks.py:26-27) against the
+    two-step path it replaces: same planes as averaging the stored loader tensor with the MNet kernel's association, and the
+    MNet front end fed by them produces the same bits (output and the means it keeps for the backward pass)."""
+    from hupr_amd import functional as F_, preprocessing
+    iq = np.concatenate([synth.adc_cube_int16(4, frame=f) for f in range(16)])
+    dev = torch.from_numpy(iq).cuda()
+    full = preprocessing.fft_chain_loader(dev)                                   # (16, 8, 2, 64, 64, 8)
+    planes = preprocessing.fft_chain_loader_means(dev)                           # (16, 16, 64, 64)
+    assert planes.shape == (16, 16, 64, 64) and planes.dtype == torch.float32
+    x = full.reshape(16, 16, 64, 64, 8)
+    want = (((x[..., 0] + x[..., 1]) + (x[..., 2] + x[..., 3])) + ((x[..., 4] + x[..., 5]) + (x[..., 6] + x[..., 7]))) * 0.125
+    assert torch.equal(planes, want)
+    # through the MNet front end (train mode: weights require grad -> the pixel-major means are kept)
+    torch.manual_seed(0)
+    w = torch.randn(32, 2, 2, 1, 1, device="cuda", requires_grad=True)
+    b = torch.randn(32, device="cuda", requires_grad=True)
+    for dt in (torch.float32, torch.bfloat16):
+        ya = F_.MNetFn.apply(full.view(2, 8, 8, 2, 64, 64, 8), w, b, dt)
+        yb = F_.MNetFn.apply(planes.view(2, 8, 16, 64, 64), w, b, dt)
+        assert torch.equal(ya, yb)
+        ga = torch.autograd.grad(ya.float().square().sum(), (w, b))
+        gb = torch.autograd.grad(yb.float().square().sum(), (w, b))
+        assert torch.equal(ga[0], gb[0]) and torch.equal(ga[1], gb[1])
