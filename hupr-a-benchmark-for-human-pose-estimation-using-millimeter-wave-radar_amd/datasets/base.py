@@ -53,13 +53,21 @@ def generateGTAnnot(cfg, phase="train"):
 
 
 class Normalize(object):
+    """Per-slice form of the reference transform.  The batched kernel normalises the 16 planes of a Doppler slot at once; a
+    single (8,64,64) slice is placed in the real AND imaginary plane of slot f = 0 of a staging cube that is allocated once per
+    device and reused (only that slot is read back)."""
+    _staging = {}
+
     def __call__(self, radarData):
         """radarData: GPU tensor (C=8,H=64,W=64) real -> same shape, per-channel (x-mean)/std."""
         if tuple(radarData.shape) != (8, 64, 64):
             raise ValueError("Normalize expects an (8,64,64) elevation-major slice")
         hwc = radarData.permute(1, 2, 0).to(torch.float32).contiguous()
-        cube = torch.zeros((1, 16, 64, 64, 8), dtype=torch.complex64, device=radarData.device)
-        # put the slice in both the real and imaginary plane of Doppler slot 4 (f = 0)
+        key = (radarData.device.type, radarData.device.index)
+        cube = Normalize._staging.get(key)
+        if cube is None:
+            cube = Normalize._staging[key] = torch.zeros((1, 16, 64, 64, 8), dtype=torch.complex64, device=radarData.device)
+        # Doppler slot 4 is loader slot f = 0
         cube[0, 4] = torch.complex(hwc, hwc)
         out = loader_normalize(cube)[0, 0, 0]
         return out.permute(2, 0, 1).contiguous()
