@@ -321,7 +321,9 @@ __global__ __launch_bounds__(256) void hupr_k_interp_fwd(const T* __restrict__ s
 // that touched it — deterministic, no atomics, no zero-fill pass.  The kernel is VALU-bound on the candidate-weight
 // arithmetic (tens of weights per voxel), so a thread covers as many channels of its voxel as the shape allows and the
 // candidate window per axis is the exact contributor range widened by a rounding margin only.
-template <typename T, int VPT>
+// ACC: dx already holds another consumer's gradient of the same tensor (e.g. the temporal merge's): start from it instead of
+// zero — the separate gradient-accumulation kernel autograd would run (read 2, write 1 tensor) becomes one extra read here.
+template <typename T, int VPT, bool ACC = false>
 __global__ __launch_bounds__(256) void hupr_k_interp_bwd(const T* __restrict__ dy, T* __restrict__ dx, int Bn,
                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                                                          int in_ld, int out_ld) {
@@ -341,8 +343,14 @@ __global__ __launch_bounds__(256) void hupr_k_interp_bwd(const T* __restrict__ d
         lin_range(ih, ah, hlo, hhi);
         lin_range(iw, aw, wlo, whi);
         float acc[CH];
+        const long ivox0 = (((long)b * Di + id) * Hi + ih) * Wi + iw;
+        if constexpr (ACC) {
 #pragma unroll
-        for (int k = 0; k < CH; ++k) acc[k] = 0.f;
+            for (int u = 0; u < VPT; ++u) ActVec<T>::load(dx + ivox0 * in_ld + c0 + u * V, acc + u * V);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc[k] = 0.f;
+        }
         for (int od = dlo; od <= dhi; ++od) {
             const float wd = (Di == 1 && Do == 1) ? 1.f : lin_weight(od, id, ad);
             if (wd == 0.f) continue;
@@ -476,7 +484,7 @@ extern "C" int hupr_interp_linear_fwd_bf16act(const void* x, void* y, int Bn, in
 }
 
 // dx = adjoint of the forward map applied to dy (gather form: deterministic, every dx voxel written once)
-template <typename T>
+template <typename T, bool ACC = false>
 static int interp_bwd(const char* who, const T* dy, T* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                       int in_ld, int out_ld, hupr_stream_t stream) {
     HUPR_REQUIRE(dy && dx, "%s: null pointer", who);
@@ -487,11 +495,11 @@ static int interp_bwd(const char* who, const T* dy, T* dx, int Bn, int Di, int H
     const long voxels = (long)Bn * Di * Hi * Wi;
     if (C % (4 * V) == 0 && voxels * (C / (4 * V)) >= 256 * 256) {       // 4 vectors per thread while the grid stays full
         const long total = voxels * (C / (4 * V));
-        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 4>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
+        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 4, ACC>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
                            as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     } else {
         const long total = voxels * (C / V);
-        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 1>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
+        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 1, ACC>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
                            as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     }
     HUPR_LAUNCH_OK("hupr_k_interp_bwd");
@@ -505,4 +513,15 @@ extern "C" int hupr_interp_linear_bwd_bf16act(const void* dy, void* dx, int Bn, 
                                               int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
     return interp_bwd("hupr_interp_linear_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), Bn, Di,
                       Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld, stream);
+}
+
+// dx += the input gradient (dx holds another consumer's gradient of the same tensor on entry)
+extern "C" int hupr_interp_linear_bwd_acc_f32(const float* dy, float* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                              int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    return interp_bwd<float, true>("hupr_interp_linear_bwd_acc_f32", dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld, stream);
+}
+extern "C" int hupr_interp_linear_bwd_acc_bf16act(const void* dy, void* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho,
+                                                  int Wo, int C, int in_ld, int out_ld, hupr_stream_t stream) {
+    return interp_bwd<__bf16, true>("hupr_interp_linear_bwd_acc_bf16act", static_cast<const __bf16*>(dy), static_cast<__bf16*>(dx), Bn,
+                                    Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld, stream);
 }

@@ -502,6 +502,59 @@ class TemporalMergeFn(torch.autograd.Function):
         return dx, _pret(weight, dw, direct)
 
 
+class MergeDownFn(torch.autograd.Function):
+    """An encoder level map feeds TWO consumers (reference models/layers.py:212-217): its temporal merge and the next level's
+    align_corners down-sampling.  As separate nodes autograd adds their two input gradients with a kernel of its own (three
+    tensor passes over the largest activations of the network); as one node the merge's input gradient is written first and
+    the resampling backward accumulates onto it (hupr_interp_linear_bwd_acc_*).  bf16-stored maps, bf16 math.
+    -> (merged fp32 (B,1,H,W,Co), down-sampled bf16 (B, D', H', W', C))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, size):
+        x = _c(x)
+        B, G, H, W, Ci = _vox(x)
+        Co = weight.shape[0]
+        assert tuple(weight.shape[1:]) == (Ci, G, 1, 1) and x.dtype == torch.bfloat16
+        L = rt.lib()
+        merged = torch.empty((B, 1, H, W, Co), dtype=torch.float32, device=x.device)
+        rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 1, rt.ptr(_packed(weight, 0, 0)), None, rt.ptr(merged), 0,
+                                            B, G, H, W, Ci, Ci, 1, H, W, Co, Co, G, 1, 1, 0, 0, 0, rt.stream()))
+        Do, Ho, Wo = size
+        down = torch.empty((B, Do, Ho, Wo, Ci), dtype=x.dtype, device=x.device)
+        rt.check(L.hupr_interp_linear_fwd_bf16act(rt.ptr(x), rt.ptr(down), B, G, H, W, Do, Ho, Wo, Ci, Ci, Ci, rt.stream()))
+        ctx.save_for_backward(x, weight)
+        ctx.size = size
+        return merged, down
+
+    @staticmethod
+    def backward(ctx, d_merged, d_down):
+        x, weight = ctx.saved_tensors
+        B, G, H, W, Ci = _vox(x)
+        Co = weight.shape[0]
+        Do, Ho, Wo = ctx.size
+        L = rt.lib()
+        d_merged, d_down = _c(d_merged), _c(d_down)
+        dx = torch.empty_like(x)
+        rt.check(L.hupr_tmerge_dgrad_bf16(rt.ptr(d_merged), rt.ptr(_packed(weight, 1, 0)), rt.ptr(dx), 1, B, G, H * W, Ci, Co,
+                                          rt.stream()))
+        rt.check(L.hupr_interp_linear_bwd_acc_bf16act(rt.ptr(d_down), rt.ptr(dx), B, G, H, W, Do, Ho, Wo, Ci, Ci, Ci, rt.stream()))
+        dw = None
+        direct = False
+        if ctx.needs_input_grad[1]:
+            dw, direct = _pgrad(weight)
+            ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, Ci, Co, G, 1, 1), x.device)
+            rt.check(L.hupr_conv_wgrad_bf16_mixed(rt.ptr(x), 1, rt.ptr(d_merged), rt.ptr(dw), B, G, H, W, Ci, Ci, 1, H, W,
+                                                  Co, Co, G, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
+        return dx, _pret(weight, dw, direct), None
+
+
+MERGE_DOWN = os.environ.get("HUPR_NO_MERGE_DOWN", "0") != "1"
+
+
+def merge_down_ok(x):
+    return MERGE_DOWN and MATH == "bf16" and x.dtype == torch.bfloat16 and x.is_cuda
+
+
 def temporal_merge(x, weight):
     """(B,G,H,W,C) -> (B,1,H,W,Co) fp32.  bf16-stored maps go through the mixed-storage kernels (bf16 math only);
     fp32 maps through the generic convolution."""

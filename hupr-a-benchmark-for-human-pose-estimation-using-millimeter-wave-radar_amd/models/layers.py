@@ -85,11 +85,13 @@ class _Resample(nn.Module):
         super().__init__()
         self.scale_factor, self.dims = scale_factor, dims
 
-    def forward(self, x):
+    def size_of(self, x):
         B, D, H, W, C = x.shape
         s = self.scale_factor
-        size = (int(D * s) if self.dims == 3 else D, int(H * s), int(W * s))
-        return F_.interp(x, size)
+        return (int(D * s) if self.dims == 3 else D, int(H * s), int(W * s))
+
+    def forward(self, x):
+        return F_.interp(x, self.size_of(x))
 
 
 class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
@@ -200,6 +202,14 @@ class Encoder3D(nn.Module):
         BatchNorms and resamplings that dominate the step — reads and writes bf16 tensors; the merges read those
         bf16 maps directly and emit fp32 (F_.temporal_merge)."""
         l1maps = self.layer1[1](_conv(maps, self.layer1[0]))
+        if F_.merge_down_ok(l1maps):
+            # a level map feeds its temporal merge AND the next level's down-sampling: one autograd node for the pair, so the two
+            # input gradients are summed inside the resampling backward instead of by a separate pass (F_.MergeDownFn)
+            l1m, d1 = F_.MergeDownFn.apply(l1maps, self.l1temporalMerge.weight, self.layer2[0].size_of(l1maps))
+            l2maps = self.layer2[2](self.layer2[1](d1))
+            l2m, d2 = F_.MergeDownFn.apply(l2maps, self.l2temporalMerge.weight, self.layer3[0].size_of(l2maps))
+            l3maps = self.layer3[2](self.layer3[1](d2))
+            return l1m, l2m, F_.temporal_merge(l3maps, self.temporalMerge.weight)
         l2maps = self.layer2(l1maps)
         l3maps = self.layer3(l2maps)
         return (F_.temporal_merge(l1maps, self.l1temporalMerge.weight),

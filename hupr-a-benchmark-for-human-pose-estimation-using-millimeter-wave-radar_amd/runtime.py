@@ -115,6 +115,8 @@ SIGNATURES = {
     "hupr_mnet_bwd_bf16act": (c_int, [c_void_p] * 7 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_interp_linear_fwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_interp_linear_bwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "hupr_interp_linear_bwd_acc_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "hupr_interp_linear_bwd_acc_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_attn_fp8_ws_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -366,6 +366,12 @@ int hupr_interp_linear_fwd_bf16act(const void* x, void* y, int Bn, int Di, int H
                                    int C, int in_ld, int out_ld, hupr_stream_t stream);
 int hupr_interp_linear_bwd_bf16act(const void* dy, void* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                                    int C, int in_ld, int out_ld, hupr_stream_t stream);
+/* the same with dx += ...: dx already holds another consumer's gradient of the tensor (Encoder3D's level maps feed both a temporal
+ * merge and the next level's down-sampling, models/layers.py:212-217) — replaces autograd's separate accumulation kernel */
+int hupr_interp_linear_bwd_acc_f32(const float* dy, float* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
+                                   int in_ld, int out_ld, hupr_stream_t stream);
+int hupr_interp_linear_bwd_acc_bf16act(const void* dy, void* dx, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                                       int C, int in_ld, int out_ld, hupr_stream_t stream);
 /* boundary casts of the bf16-activation region (n % 4 == 0) */
 int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream);
 int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream);

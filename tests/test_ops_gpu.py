@@ -847,3 +847,30 @@ def test_conv_halo512_first_layer_shape_matches_the_128_voxel_kernel(bf16_math):
     assert (d > 0).float().mean().item() < 0.05                           # and almost all of them identical
     ref = F.conv3d(_bf16_round(ncdhw(x.float().cpu()))[:1], _bf16_round(w.cpu()), bias.cpu().double(), 1, 1)
     close(ncdhw(y512.float().cpu())[:1], ref, 6e-3, "halo512 vs fp64 (one bf16 store rounding)")
+
+
+def test_merge_down_node_matches_separate_nodes(bf16_math):
+    """F_.MergeDownFn (temporal merge + next level's down-sampling of one encoder map as ONE autograd node) against the two
+    separate nodes: forward bit-identical; the input gradient differs only by where the bf16 rounding of the sum happens
+    (accumulated in fp32 inside the resampling backward instead of bf16 + bf16 by autograd), weight gradient identical."""
+    from hupr_amd import functional as F_
+    B, G, H, W, C = 2, 8, 32, 32, 64
+    x0 = _q(rnd(B, G, H, W, C, seed=95)).cuda().bfloat16()
+    w0 = rnd(C, C, G, 1, 1, seed=96, scale=(C * G) ** -0.5).cuda()
+    gm = rnd(B, 1, H, W, C, seed=97).cuda()
+    gd = _q(rnd(B, G // 2, H // 2, W // 2, C, seed=98)).cuda().bfloat16()
+    outs = []
+    for fused in (True, False):
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        if fused:
+            m, d = F_.MergeDownFn.apply(x, w, (G // 2, H // 2, W // 2))
+        else:
+            m, d = F_.temporal_merge(x, w), F_.interp(x, (G // 2, H // 2, W // 2))
+        torch.autograd.backward((m, d), (gm, gd))
+        outs.append((m.detach(), d.detach(), x.grad.float(), w.grad))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    # two bf16 roundings (each addend) + one of the sum on the separate path, two on the fused one: a couple of bf16 steps of
+    # the larger addend, which can exceed the (possibly cancelled) sum's own step
+    d = (a[2] - b[2]).abs()
+    assert d.max().item() <= 2.0 ** -6 * b[2].abs().max().item() and d.mean().item() <= 2.0 ** -9 * b[2].abs().mean().item() * 4
