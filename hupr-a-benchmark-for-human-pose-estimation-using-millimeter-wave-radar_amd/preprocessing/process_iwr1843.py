@@ -9,6 +9,8 @@ The batched device entry points (`fft_chain`, `fft_chain_loader`) are what the t
 loader uses: int16 I/Q cubes resident in HBM in, complex64 cubes or normalised fp32 network
 input out.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -114,9 +116,15 @@ def dca1000_frames(raw):
 
 
 class RadarObject:
-    """Same constants and operator surface as the reference class (process_iwr1843.py:8-34)."""
+    """Same constants and operator surface as the reference class (process_iwr1843.py:8-34).  ``numGroup`` / ``root`` /
+    ``saveRoot`` / ``rawRoot`` parametrise the directory lists the reference hard-codes in ``initialize`` (:36-46); the
+    defaults reproduce its paths."""
 
-    def __init__(self, device="cuda"):
+    def __init__(self, device="cuda", numGroup=276, root="HuPR", saveRoot="HuPR", rawRoot="raw_data/iwr1843", dataRoot="../data"):
+        self.root, self.saveRoot, self.sensorType = root, saveRoot, "iwr1843"
+        self.radarDataFileNameGroup = [[os.path.join(rawRoot, root, "single_%d" % i, "hori"), os.path.join(rawRoot, root, "single_%d" % i, "vert")]
+                                       for i in range(1, numGroup + 1)]
+        self.saveDirNameGroup = [os.path.join(dataRoot, saveRoot, "single_%d" % i) for i in range(1, numGroup + 1)]
         self.numADCSamples = 256
         self.adcRatio = 4
         self.numAngleBins = self.numADCSamples // self.adcRatio
@@ -135,11 +143,33 @@ class RadarObject:
     def getadcDataFromDCA1000(self, fileName):
         """<fileName>/adc_data.bin -> complex128 ndarray (4, n_chirps, 256), like the reference; the de-interleave
         runs on the GPU.  Use ``dca1000_frames`` directly to keep the cube on the device for ``fft_chain``."""
-        import os
         raw = np.fromfile(os.path.join(fileName, "adc_data.bin"), dtype=np.int16)
         fr = dca1000_frames(torch.from_numpy(raw).to(self.device)).cpu().numpy()      # (F,4,192,256,2)
         z = fr[..., 0].astype(np.float64) + 1j * fr[..., 1].astype(np.float64)
         return np.ascontiguousarray(z.transpose(1, 0, 2, 3).reshape(self.numRX, -1, self.numADCSamples))
+
+    def saveRadarData(self, matrix, dirName, idxFrame):
+        """``<dirName>/<idxFrame:09d>.npy`` (reference :180-182)."""
+        np.save(os.path.join(dirName, "%09d.npy" % idxFrame), matrix)
+
+    def processRadarDataHoriVert(self, frames_per_call=64):
+        """The reference's offline driver (:184-196): every sequence's two captures -> one complex128 ``(16,64,64,8)`` cube per
+        frame and sensor under ``<saveDir>/{hori,vert}/%09d.npy``.  Here a capture goes to the GPU once, is de-interleaved there
+        and transformed ``frames_per_call`` frames at a time (the reference parses 115 200 chirps and runs ~200 000 tiny FFT calls
+        per frame in Python).  Training does not need these files: ``datasets.HuPRRawADC`` feeds the network straight from
+        the captures."""
+        for names, save_dir in zip(self.radarDataFileNameGroup, self.saveDirNameGroup):
+            for sensor, name in zip(("hori", "vert"), names):
+                out_dir = os.path.join(save_dir, sensor)
+                os.makedirs(out_dir, exist_ok=True)
+                raw = np.fromfile(os.path.join(name, "adc_data.bin"), dtype=np.int16)
+                frames = dca1000_frames(torch.from_numpy(raw).to(self.device))
+                n = min(frames.shape[0], self.numFrame)
+                for f0 in range(0, n, frames_per_call):
+                    cubes = fft_chain(frames[f0:min(n, f0 + frames_per_call)]).cpu().numpy().astype(np.complex128)
+                    for k, cube in enumerate(cubes):
+                        self.saveRadarData(cube, out_dir, f0 + k)
+                print("%s, finished %d frames" % (name, n))
 
     def generateHeatmap(self, frame, window=None, magnitude=False):
         """frame: complex ndarray (4,192,256) -> complex128 ndarray (16,64,64,8) (float64 with ``magnitude``).
