@@ -318,31 +318,66 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_bf16(GemmArgs p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    // D' = B A^T: the accumulator tile comes out transposed — a lane owns ONE output row (i, lr) and four runs of
+                    // four consecutive columns, so the epilogue stores 16-byte (fp32) / 8-byte (bf16) vectors instead of 16
+                    // scalars per tile (the skinny, HBM-bound GEMMs of this path spent most of their time issuing 2-byte stores)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
     const float* __restrict__ resg = p.res ? p.res + z0 * p.res_bs0 + z1 * p.res_bs1 : nullptr;
+    typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int row = m0 + wm * WTM + i * 32 + lr;             // this lane's output row
+        if (row >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WTN + j * 32 + lr;
-            if (col >= p.N) continue;
-            const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < p.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (resg) v += resg[(long)row * p.res_ld + col];
-                    if (p.flags & GEMM_C_BF16) {            // bf16-stored output (batch strides in elements)
-                        reinterpret_cast<__bf16*>(p.C)[z0 * p.c_bs0 + z1 * p.c_bs1 + (long)row * p.ldc + col] = (__bf16)v;
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wn * WTN + j * 32 + 8 * g + 4 * lh;      // first of four consecutive columns
+                if (col >= p.N) continue;
+                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                const bool full = col + 3 < p.N;
+                if (p.bias) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (full || col + k < p.N) v[k] += p.bias[col + k];
+                }
+                if (resg) {
+                    const float* rp = resg + (long)row * p.res_ld + col;
+                    if (full && (reinterpret_cast<uintptr_t>(rp) & 15) == 0) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     } else {
-                        float* dst = Cg + (long)row * p.ldc + col;
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (full || col + k < p.N) v[k] += rp[k];
+                    }
+                }
+                if (p.flags & GEMM_C_BF16) {            // bf16-stored output (batch strides in elements)
+                    __bf16* dst = reinterpret_cast<__bf16*>(p.C) + z0 * p.c_bs0 + z1 * p.c_bs1 + (long)row * p.ldc + col;
+                    if (full && (reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
+                        *reinterpret_cast<bf16x4e*>(dst) = (bf16x4e){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (full || col + k < p.N) dst[k] = (__bf16)v[k];
+                    }
+                } else {
+                    float* dst = Cg + (long)row * p.ldc + col;
+                    if (full && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                        if (p.accumulate) {
+                            const float4 o = *reinterpret_cast<const float4*>(dst);
+                            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                        }
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (full || col + k < p.N) {
+                                if (p.accumulate) v[k] += dst[k];
+                                dst[k] = v[k];
+                            }
+                        }
                     }
                 }
             }
