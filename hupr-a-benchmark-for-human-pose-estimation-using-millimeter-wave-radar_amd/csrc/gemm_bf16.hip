@@ -518,7 +518,8 @@ static int conv_wgrad_h(const void* x, int x_bf16, const float* dy, float* dw, i
     const long tiles = (long)((Co + bm - 1) / bm) * ((a.N + 127) / 128);
     const int ktiles = (int)((Mv + BKH - 1) / BKH);
     a.split_stride = (long)a.M * a.N;
-    int splits = wgrad_splits(tiles, ktiles, (size_t)a.split_stride * sizeof(float));
+    const size_t in_bytes = (size_t)Mv * ((size_t)Co * sizeof(float) + (size_t)taps * Ci * (x_bf16 ? 2 : 4));
+    int splits = wgrad_splits(tiles, ktiles, (size_t)a.split_stride * sizeof(float), in_bytes);
     while (splits > 1 && (size_t)splits * a.split_stride * sizeof(float) > ws_bytes) splits >>= 1;
     a.ksplit = splits;
     if (ws_bytes < (size_t)splits * a.split_stride * sizeof(float))

@@ -64,8 +64,16 @@ inline int check_geom(const char* who, int Bn, const ConvGeom& g, int Co, int ci
 // split-K partial reduction + optional [Co][taps][Ci] -> (Co,Ci,taps) relayout (gemm_f32.hip)
 // Voxel-axis slices of the GEMM-form weight gradient: enough workgroups for ~4 per CU, at most 256 slices and at most
 // 256 MiB of partials (a 64x64 1x1 weight over 131k voxels used to run on 64 workgroups: a quarter of the chip).
-inline int wgrad_splits(long tiles, long ktiles, size_t one_bytes) {
+// in_bytes (optional): bytes of the two operands.  Every slice writes one partial tensor that the reduction reads back, so the
+// slices are also capped where that round trip would exceed the operands themselves (a 1024 x 256 gradient over 8 192 voxels
+// ran 64 slices: 134 MB of partial traffic against 42 MB of input) — but never below one workgroup per CU.
+inline int wgrad_splits(long tiles, long ktiles, size_t one_bytes, size_t in_bytes = 0) {
     long s = (1024 + tiles - 1) / tiles;
+    if (in_bytes) {
+        const long cap = (long)(in_bytes / (2 * one_bytes));
+        const long floor_ = (256 + tiles - 1) / tiles;
+        if (s > cap) s = cap > floor_ ? cap : floor_;
+    }
     if (s > 256) s = 256;
     if (s > ktiles) s = ktiles;
     while (s > 1 && (size_t)s * one_bytes > ((size_t)256 << 20)) s >>= 1;
