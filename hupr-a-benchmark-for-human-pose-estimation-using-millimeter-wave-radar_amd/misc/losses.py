@@ -1,5 +1,4 @@
 """LossComputer (reference misc/losses.py:8-48) with device-side targets, BCE and decode."""
-import torch
 
 from .. import functional as F_
 from .metrics import get_max_preds

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "/root/repo")
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from hupr_amd import preprocessing, synth
 iq = np.concatenate([synth.adc_cube_int16(4, frame=f) for f in range(16)])
