@@ -273,3 +273,34 @@ def test_benched_step_bf16_batch32_from_adc_properties():
     assert torch.equal(f["gi"], b["gi"]) and bool((f["gm"] == 1.0).all())
     mu = (joints.float() / 4 + 0.5).long()
     assert torch.equal(f["gi"].long(), (mu[..., 1] * 64 + mu[..., 0]).reshape(-1))
+
+
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_ragged_batches_train_and_eval(B):
+    """SURVEY App. D.16: the reference's DataLoader has no drop_last, so the last step of an epoch is ragged (115 800 mod 256 = 88;
+    odd sizes on small sets).  Any batch size must run through both pipes: finite loss / gradients in train mode, and eval
+    outputs that do not depend on which other samples share the batch."""
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    cfg = load_config()
+    dev = torch.device("cuda", 0)
+    G = cfg.DATASET.numGroupFrames
+    adc_h = torch.from_numpy(synth.adc_cube_int16(55, sensor=0, nframes=B * G)).to(dev)
+    adc_v = torch.from_numpy(synth.adc_cube_int16(55, sensor=1, nframes=B * G)).to(dev)
+    joints = torch.from_numpy(synth.keypoints(B, 56)).to(dev)
+    try:
+        for math in ("f32", "bf16"):
+            F_.set_math(math)
+            eng = TrainEngine(cfg, device=dev, seed=0)
+            loss, _ = eng.train_step_from_adc(adc_h, adc_v, joints, decode="device")
+            torch.cuda.synchronize()
+            assert torch.isfinite(loss) and all(torch.isfinite(b.flat_grad).all() for b in eng.buckets.buckets)
+            h, v = eng.preprocess(adc_h, adc_v)
+            p1, p2 = eng.infer(h, v)
+            q1, q2 = eng.infer(h[:1].contiguous(), v[:1].contiguous())
+            assert p1.shape == (B, 14, 1, 64, 64) and p2.shape == (B, 1, 14, 64, 64)
+            tol = 2e-5 if math == "f32" else 5e-3
+            assert (p1[:1] - q1).abs().max().item() <= tol and (p2[:1] - q2).abs().max().item() <= tol
+    finally:
+        F_.set_math("f32")
