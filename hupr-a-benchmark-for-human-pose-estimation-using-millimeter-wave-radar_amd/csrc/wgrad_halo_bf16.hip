@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256, 2) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p
 //   * 512 threads: waves 0-3 multiply K-steps 0..3 of the tile, waves 4-7 K-steps 4..7, each half keeping its own
 //     9 x (32x32) accumulators and writing its own partial tensor (partial index 2 * group + half).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool IS3D>
+//   * CI32 (Ci <= 32, one ci quadrant): the wn = 1 waves would multiply zero columns; instead the wave's wn bit splits K
+//     once more (K quarter = 2 kq + wn: two K-steps of the tile each) and the four partial accumulator sets are merged in
+//     LDS at the end — half the MFMAs per tile for the 32-channel input of Encoder3D.layer1's first convolution.
+template <bool IS3D, bool CI32>
 __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, LOG2TW = IS3D ? 3 : 4;
     constexpr int HH = 10, HW = TW + 2;
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kq = wave >> 2;                         // K half of this wave
-    const int wm = (wave >> 1) & 1, wn = wave & 1;    // 32-row (co) / 32-col (ci) quadrant of the 64x64 tile
+    const int wm = (wave >> 1) & 1, wbit = wave & 1;  // 32-row (co) quadrant; wbit: 32-col (ci) quadrant, or K quarter (CI32)
+    const int wn = CI32 ? 0 : wbit;
     const int pd = p.kd >> 1;
     const int T = p.kd * 9;
     // XCD-aware 1-D grid (p.xcd_map): the kd depth-tap planes and the (co, ci) tile pairs of one spatial group re-read the
@@ -359,20 +363,23 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
             xq[SET_][kx] = tr_pair((IMG_) + rows_ * kRowB, xb[kx][par_][0], xb[kx][par_][1]);                       \
         if (ky_ == 0) a[ks_ & 1] = tr_pair((IMG_) + ks_ * 16 * kRowB, dyb[0], dyb[1]);                              \
     }
-#define HUPR_WG2_STEP(IMG_, KS0_, J_)                                                                               \
+#define HUPR_WG2_STEP(IMG_, KS0_, J_, NJ_)                                                                          \
     {                                                                                                               \
-        if ((J_) + 1 < 12) { HUPR_WG2_LOAD(IMG_, ((J_) + 1) & 1, KS0_, ((J_) + 1 < 12 ? (J_) + 1 : 0)) }            \
+        if ((J_) + 1 < (NJ_)) { HUPR_WG2_LOAD(IMG_, ((J_) + 1) & 1, KS0_, ((J_) + 1 < (NJ_) ? (J_) + 1 : 0)) }      \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
             acc[((J_) % 3) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((KS0_) + (J_) / 3) & 1], xq[(J_) & 1][kx], \
                                                                                acc[((J_) % 3) * 3 + kx], 0, 0, 0);  \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
-#define HUPR_WG2_TILE(IMG_, KS0_)                                                                                   \
+#define HUPR_WG2_HALF(IMG_, KS0_, NJ_)                                                                              \
     HUPR_WG2_LOAD(IMG_, 0, KS0_, 0)                                                                                 \
-    HUPR_WG2_STEP(IMG_, KS0_, 0) HUPR_WG2_STEP(IMG_, KS0_, 1) HUPR_WG2_STEP(IMG_, KS0_, 2) HUPR_WG2_STEP(IMG_, KS0_, 3)  \
-    HUPR_WG2_STEP(IMG_, KS0_, 4) HUPR_WG2_STEP(IMG_, KS0_, 5) HUPR_WG2_STEP(IMG_, KS0_, 6) HUPR_WG2_STEP(IMG_, KS0_, 7)  \
-    HUPR_WG2_STEP(IMG_, KS0_, 8) HUPR_WG2_STEP(IMG_, KS0_, 9) HUPR_WG2_STEP(IMG_, KS0_, 10) HUPR_WG2_STEP(IMG_, KS0_, 11)
+    HUPR_WG2_STEP(IMG_, KS0_, 0, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 1, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 2, NJ_)           \
+    HUPR_WG2_STEP(IMG_, KS0_, 3, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 4, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 5, NJ_)
+#define HUPR_WG2_TILE(IMG_, KS0_)                                                                                   \
+    HUPR_WG2_HALF(IMG_, KS0_, 12)                                                                                   \
+    HUPR_WG2_STEP(IMG_, KS0_, 6, 12) HUPR_WG2_STEP(IMG_, KS0_, 7, 12) HUPR_WG2_STEP(IMG_, KS0_, 8, 12)              \
+    HUPR_WG2_STEP(IMG_, KS0_, 9, 12) HUPR_WG2_STEP(IMG_, KS0_, 10, 12) HUPR_WG2_STEP(IMG_, KS0_, 11, 12)
 
     // The DMA runs two tiles ahead.  Per tile: wait until this wave's pieces of tile st have landed while leaving its
     // pieces of tile st + 1 in flight (counted vmcnt — the builtin, so that hipcc's own bookkeeping sees it), barrier,
@@ -388,7 +395,12 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
         asm volatile("" ::: "memory");                                                                              \
         HUPR_WG_FILL(st + 2 * p.groups, FILL_)                                                                      \
         if (st >= 0) {                                                                                              \
-            if (kq == 0) { HUPR_WG2_TILE(CUR_, 0) } else { HUPR_WG2_TILE(CUR_, 4) }                                 \
+            if (CI32) {                                                                                             \
+                if (kq == 0) { if (wbit == 0) { HUPR_WG2_HALF(CUR_, 0, 6) } else { HUPR_WG2_HALF(CUR_, 2, 6) } }    \
+                else { if (wbit == 0) { HUPR_WG2_HALF(CUR_, 4, 6) } else { HUPR_WG2_HALF(CUR_, 6, 6) } }            \
+            } else {                                                                                                \
+                if (kq == 0) { HUPR_WG2_TILE(CUR_, 0) } else { HUPR_WG2_TILE(CUR_, 4) }                             \
+            }                                                                                                       \
         }                                                                                                           \
         st += p.groups;                                                                                             \
     }
@@ -405,6 +417,7 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
 #undef HUPR_WG2_LOAD
 #undef HUPR_WG2_STEP
 #undef HUPR_WG2_TILE
+#undef HUPR_WG2_HALF
 
     // Merge the two K halves through the (now dead) images: the kq = 1 waves park their accumulators, six taps and then
     // three, the kq = 0 waves add them — one partial tensor per workgroup instead of two halves what the workgroups
@@ -413,6 +426,27 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
         const int t256 = tid & 255;
         float* const red[3] = {reinterpret_cast<float*>(bufA), reinterpret_cast<float*>(bufB), reinterpret_cast<float*>(bufC)};
         __syncthreads();
+        if (CI32) {                                  // K quarters first: the wbit = 1 waves park, their wbit = 0 partners add
+            const int q256 = (wave >> 1) * 64 + lane;
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                if (round) __syncthreads();
+                if (wbit == 1) {
+#pragma unroll
+                    for (int tap = round * 6; tap < (round ? 9 : 6); ++tap)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[((tap - round * 6) >> 1)][(((tap & 1) * 16 + r) << 8) + q256] = acc[tap][r];
+                }
+                __syncthreads();
+                if (wbit == 0) {
+#pragma unroll
+                    for (int tap = round * 6; tap < (round ? 9 : 6); ++tap)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[tap][r] += red[((tap - round * 6) >> 1)][(((tap & 1) * 16 + r) << 8) + q256];
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
             if (round) __syncthreads();
@@ -431,7 +465,7 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
             }
         }
     }
-    if (kq != 0) return;
+    if (kq != 0 || (CI32 && wbit != 0)) return;
     const int lr = lane & 31, lh = lane >> 5;
     const int ci = ci0 + wn * 32 + lr;
     float* part = p.part + (long)group * p.Co * T * p.Ci;
@@ -461,6 +495,8 @@ extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
 
 static int g_wgrad_groups = 0;      // A/B aid (hupr_debug_wgrad_groups): > 0 forces the workgroup count per (kz, tile pair)
 extern "C" void hupr_debug_wgrad_groups(int g) { g_wgrad_groups = g; }      // 0 auto, > 0 forced, < 0 auto without XCD affinity
+static int g_wgrad_ci32 = 1;        // A/B aid (hupr_debug_wgrad_ci32): 0 = Ci <= 32 through the two-quadrant kernel as before, 2 = K quarters always
+extern "C" void hupr_debug_wgrad_ci32(int on) { g_wgrad_ci32 = on; }
 
 static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci, int in_ld, int Co,
                       int dy_ld, int kd, void* ws, size_t ws_bytes, bool abf, hupr_stream_t stream, const char* who) {
@@ -504,8 +540,16 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
         if ((size_t)gw * one <= ws_bytes) {
             a.groups = gw;
             const dim3 grid = a.xcd_map ? dim3(gw * pairs) : dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles);
-            if (kd == 3) hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<true>, grid, dim3(512), 0, s, a);
-            else hipLaunchKernelGGL(hupr_k_wgrad_halo_glds<false>, grid, dim3(512), 0, s, a);
+            // K quarters pay once a workgroup multiplies enough tiles to amortise the extra LDS merge (measured: 222 -> 160 us on
+            // the 32 -> 64 layer-1 shape at 102 tiles per workgroup; +2-3 us on shapes with one or two tiles per workgroup)
+            const bool ci32 = Ci <= 32 && (g_wgrad_ci32 == 2 || (g_wgrad_ci32 == 1 && a.n_spatial >= 16 * gw));
+            if (kd == 3) {
+                if (ci32) hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<true, true>), grid, dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<true, false>), grid, dim3(512), 0, s, a);
+            } else {
+                if (ci32) hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<false, true>), grid, dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<false, false>), grid, dim3(512), 0, s, a);
+            }
             HUPR_LAUNCH_OK("hupr_k_wgrad_halo_glds");
             launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw, n, kd * 9, Ci, s);
             HUPR_LAUNCH_OK("hupr_k_splitk_reduce");

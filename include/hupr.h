@@ -174,6 +174,7 @@ int hupr_pack_conv_weights_table(const void* descs_dev, const void* blocks_dev, 
 void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel, 2 skip the 512-voxel kernel */
 void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */
 void hupr_debug_gemm_small_tiles(int off); /* A/B aid: 1 = small bf16 GEMMs keep the 64x128 tile instead of 64x64 */
+void hupr_debug_wgrad_ci32(int on);       /* A/B aid: 0 sends Ci <= 32 weight gradients through the two-quadrant kernel (K halves only), 2 forces the K-quarter mode at any size, 1 = default */
 void hupr_debug_wgrad_groups(int groups); /* A/B aid: > 0 forces the LDS-DMA weight-gradient kernel's workgroups per (kz plane, tile pair) */
 void hupr_debug_halo_trace(void* device_u64_4096); /* profiling aid: per-tile s_memtime stamps of workgroup 0 (null = off) */
 int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw);

@@ -504,6 +504,32 @@ def test_conv_halo_bf16_activations(case, bf16_math):
         close(dw16, dw32, 2e-6, "bf16act wgrad vs fp32-stored wgrad")
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 64, 2, 16, 16, 3), (2, 24, 40, 1, 16, 32, 1), (2, 32, 72, 4, 8, 24, 3)])
+def test_wgrad_k_quarter_mode_for_narrow_inputs(shape, bf16_math):
+    """Ci <= 32: the LDS-DMA weight-gradient kernel splits K four ways instead of leaving the second ci quadrant's waves idle.
+    Both modes against fp64 autograd on the same bf16 operands, and against each other (summation order only)."""
+    from hupr_amd import functional as F_
+    B, Ci, Co, D, H, W, kd = shape
+    L = F_.rt.lib()
+    x = _q(rnd(B, D, H, W, Ci, seed=70)).cuda().bfloat16()
+    dy = _q(rnd(B, D, H, W, Co, seed=71)).cuda().bfloat16()
+    w = torch.zeros(Co, Ci, kd, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(x.double().permute(0, 4, 1, 2, 3), w, padding=(kd // 2, 1, 1)).backward(dy.double().permute(0, 4, 1, 2, 3))
+    ws = F_.workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd), x.device)
+    got = {}
+    try:
+        for mode in (0, 2):
+            L.hupr_debug_wgrad_ci32(mode)
+            dw = torch.full((Co, Ci, kd, 3, 3), float("nan"), device="cuda")
+            F_.rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(F_.rt.ptr(x), F_.rt.ptr(dy), F_.rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, kd,
+                                                          F_.rt.ptr(ws), ws.numel(), F_.rt.stream()))
+            got[mode] = dw
+            close(dw, w.grad.float(), 2e-6, "wgrad mode %d vs fp64" % mode)
+    finally:
+        L.hupr_debug_wgrad_ci32(1)
+    close(got[2], got[0], 2e-6, "K quarters vs K halves")
+
+
 def test_conv_autograd_bf16_activations(bf16_math):
     """ConvFn on bf16 tensors (fwd, dgrad, wgrad, bias grad) against fp64 on the same rounded operands."""
     from hupr_amd import functional as F_
