@@ -1075,6 +1075,7 @@ class MSCSALevelFn(torch.autograd.Function):
                                           0, rt.ptr(dV[i]), C, 0, 0, rt.stream()))
                 grads[i] = dx
         wgrads = [None] * 8
+        dsts, srcs, landed = [], [], []
         for i in range(2):
             if not any(ctx.needs_input_grad[3 + 4 * i + j] for j in range(4)):
                 continue
@@ -1086,8 +1087,13 @@ class MSCSALevelFn(torch.autograd.Function):
                 w = weights[4 * i + j]
                 if ctx.needs_input_grad[3 + 4 * i + j]:
                     g, direct = _pgrad(w)
-                    g.copy_(dWc[j * C:(j + 1) * C].view_as(w))
-                    wgrads[4 * i + j] = _pret(w, g, direct)
+                    dsts.append(g)
+                    srcs.append(dWc[j * C:(j + 1) * C].view_as(w))
+                    landed.append((4 * i + j, w, g, direct))
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)        # the eight row blocks of the two fused gradients in one launch
+        for slot, w, g, direct in landed:
+            wgrads[slot] = _pret(w, g, direct)
         return (grads[0], grads[1], None) + tuple(wgrads)
 
 
