@@ -253,11 +253,15 @@ __device__ __forceinline__ void store_ct_add16(float* dst_row, const f32x16* acc
 // TI = float (operands rounded to bf16 while staged) or __bf16 (pre-rounded copies: every workgroup re-reads all of K
 // and V, so halving those bytes and dropping the per-tile conversions is worth one cast pass); Vres = fp32 V for the
 // residual epilogue (exact), or null.
-template <int D, typename TI>
+// SPLIT (few workgroups: small batches, e.g. the B = 1 inference of BASELINE config C2): blockIdx.z walks only its share of the
+// keys and leaves the un-normalised O^T tile, the running maximum and the running sum in part_o / part_ml
+// ([split][B N][D] / [split][B N][2]); hupr_k_attn_combine merges the shares (flash-decoding).
+template <int D, typename TI, bool SPLIT = false>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
                                                        float* __restrict__ out, float* __restrict__ lse, int N, int ldk,
-                                                       int ldq, __bf16* __restrict__ out16, int ld16) {
+                                                       int ldq, __bf16* __restrict__ out16, int ld16,
+                                                       float* __restrict__ part_o = nullptr, float* __restrict__ part_ml = nullptr) {
     // ldk / ldq: row strides (elements) of K and Q — the projections of one map may sit side by side in one tensor;
     // out16 (optional): a bf16 copy of the output with row stride ld16 (a column block of the decoder's input)
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
@@ -276,11 +280,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
     float m_run = -INFINITY, l_run = 0.f;
     constexpr bool PF = (D <= 128);                           // D = 256 has no registers to spare for the prefetch
     StageRegs<PF ? D : 64, 64, TI> kr, vr;
+    const int jb = SPLIT ? (int)blockIdx.z * (N / (int)gridDim.z) : 0;      // this workgroup's key range [jb, je)
+    const int je = SPLIT ? jb + N / (int)gridDim.z : N;
     if (PF) {
-        kr.load(K, ldk, tid);
-        vr.load(V + base, D, tid);
+        kr.load(K + (long)jb * ldk, ldk, tid);
+        vr.load(V + base + (long)jb * D, D, tid);
     }
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = jb; j0 < je; j0 += 64) {
         __syncthreads();
         if (PF) {
             kr.store(Ks, tid);
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
             stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
         }
         __syncthreads();
-        if (PF && j0 + 64 < N) {                              // next tile's rows travel while this one is multiplied
+        if (PF && j0 + 64 < je) {                             // next tile's rows travel while this one is multiplied
             kr.load(K + (long)(j0 + 64) * ldk, ldk, tid);
             vr.load(V + base + (long)(j0 + 64) * D, D, tid);
         }
@@ -325,10 +331,55 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
         mma_tr_x_tile<D>(o, Vs, st, lane);                    // O^T += V^T P^T
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (SPLIT) {
+        const long row = ((long)blockIdx.z * gridDim.y + blockIdx.y) * N + q;
+        store_ct<D>(part_o + row * D, o, 1.f, nullptr, lh);
+        if (lh == 0) {
+            part_ml[2 * row] = m_run;
+            part_ml[2 * row + 1] = l_tot;
+        }
+        return;
+    }
     store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     if (out16)
         store_ct16<D>(out16 + ((long)blockIdx.y * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     if (lh == 0) lse[(long)blockIdx.y * N + q] = m_run + __logf(l_tot);
+}
+
+// merge the key shares of the SPLIT forward: out = sum_s w_s O_s / sum_s w_s l_s with w_s = exp(m_s - max_s m_s) (+ V), the bf16
+// copy and the log-sum-exp; one thread per (row, four channels)
+template <int D>
+__global__ __launch_bounds__(256) void hupr_k_attn_combine(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                          int S, long rows, const float* __restrict__ Vres,
+                                                          float* __restrict__ out, float* __restrict__ lse,
+                                                          __bf16* __restrict__ out16, int ld16) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t / (D / 4);
+    const int c = (int)(t % (D / 4)) * 4;
+    if (row >= rows) return;
+    float m = -INFINITY;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, part_ml[2 * (s * rows + row)]);
+    float L = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const float w = __builtin_amdgcn_exp2f((part_ml[2 * (s * rows + row)] - m) * kLog2e);
+        L = fmaf(w, part_ml[2 * (s * rows + row) + 1], L);
+        const float4 o = *reinterpret_cast<const float4*>(part_o + (s * rows + row) * D + c);
+        acc.x = fmaf(w, o.x, acc.x); acc.y = fmaf(w, o.y, acc.y); acc.z = fmaf(w, o.z, acc.z); acc.w = fmaf(w, o.w, acc.w);
+    }
+    const float inv = 1.f / L;
+    float4 v = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    if (Vres) {
+        const float4 a = *reinterpret_cast<const float4*>(Vres + row * D + c);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    *reinterpret_cast<float4*>(out + row * D + c) = v;
+    if (out16) {
+        const bf16x4 o4 = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4*>(out16 + row * ld16 + c) = o4;
+    }
+    if (c == 0) lse[row] = m + __logf(L);
 }
 
 // D[q] = sum_c dO[q,c] * (out[q,c] - (residual ? V[q,c] : 0))
@@ -491,18 +542,52 @@ using namespace hupr;
 
 extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C == 128 || C == 256) && N % 128 == 0 && N >= 128) ? 1 : 0; }
 
+// key shares of the split forward: only when the plain grid (N / 128 x Bn workgroups) leaves more than half of the 256 CUs idle;
+// then enough shares for ~512 workgroups, a power of two, at least one 64-key tile each
+static int attn_splits(int Bn, int N) {
+    const long wgs = (long)Bn * (N / 128);
+    if (wgs >= 128) return 1;
+    int S = 1;
+    while (S * 2 * wgs <= 512 && (N / 64) % (S * 2) == 0) S *= 2;
+    return S;
+}
+extern "C" size_t hupr_attn_fwd_split_ws_bytes(int Bn, int N, int C) {
+    const int S = attn_splits(Bn, N);
+    return S > 1 ? (size_t)S * Bn * N * (C + 2) * sizeof(float) : 0;
+}
+
 template <typename TI>
 static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const float* Vres, float* out,
-                    float* lse, void* out16, int ld16, int Bn, int N, int C, hupr_stream_t stream) {
+                    float* lse, void* out16, int ld16, int Bn, int N, int C, hupr_stream_t stream, void* ws = nullptr,
+                    size_t ws_bytes = 0) {
     HUPR_REQUIRE(K && Q && V && out && lse && Bn > 0, "%s: bad argument", who);
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
     HUPR_REQUIRE(ldk >= C && ldq >= C && ldk % 8 == 0 && ldq % 8 == 0, "%s: bad row strides %d %d", who, ldk, ldq);
     HUPR_REQUIRE(!out16 || (ld16 >= C && ld16 % 4 == 0), "%s: bad bf16 output stride %d", who, ld16);
     dim3 grid(N / 128, Bn);
     __bf16* o16 = static_cast<__bf16*>(out16);
-    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
-    else if (C == 128) hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
-    else hipLaunchKernelGGL((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16);
+    float* const np = nullptr;
+    const int S = ws ? attn_splits(Bn, N) : 1;
+    if (S > 1) {
+        HUPR_REQUIRE(ws_bytes >= hupr_attn_fwd_split_ws_bytes(Bn, N, C), "%s: workspace too small", who);
+        const long rows = (long)Bn * N;
+        float* part_o = static_cast<float*>(ws);
+        float* part_ml = part_o + (long)S * rows * C;
+        grid.z = S;
+        const dim3 cgrid((unsigned)((rows * (C / 4) + 255) / 256));
+        hipStream_t s = as_stream(stream);
+#define HUPR_ATTN_SPLIT(D_)                                                                                                \
+        hipLaunchKernelGGL((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, \
+                           part_o, part_ml);                                                                               \
+        hipLaunchKernelGGL((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, Vres, out, lse, o16, ld16);
+        if (C == 64) { HUPR_ATTN_SPLIT(64) } else if (C == 128) { HUPR_ATTN_SPLIT(128) } else { HUPR_ATTN_SPLIT(256) }
+#undef HUPR_ATTN_SPLIT
+        HUPR_LAUNCH_OK("hupr_k_attn_fwd (split)");
+        return HUPR_OK;
+    }
+    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np);
+    else if (C == 128) hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np);
+    else hipLaunchKernelGGL((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np);
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
@@ -526,6 +611,14 @@ extern "C" int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, in
                                        hupr_stream_t stream) {
     return attn_fwd("hupr_attn_fwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
                     static_cast<const __bf16*>(V), Vres, out, lse, out16, ld16, Bn, N, C, stream);
+}
+// the same with a workspace of hupr_attn_fwd_split_ws_bytes(Bn, N, C) bytes (0: the plain kernel already fills the GPU and ws may
+// be null): small batches split the keys over blockIdx.z and merge the shares in a second launch (flash-decoding)
+extern "C" int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres,
+                                          float* out, float* lse, void* out16, int ld16, int Bn, int N, int C, void* ws,
+                                          size_t ws_bytes, hupr_stream_t stream) {
+    return attn_fwd("hupr_attn_fwd_bf16in_ld_ws", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
+                    static_cast<const __bf16*>(V), Vres, out, lse, out16, ld16, Bn, N, C, stream, ws, ws_bytes);
 }
 
 // dK, dQ, dV (B,N,C) from dout; Dq: scratch (B,N) floats.  V32 / out / dout32: fp32 tensors of the exact row-sum

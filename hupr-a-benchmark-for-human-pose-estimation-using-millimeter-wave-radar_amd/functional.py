@@ -606,8 +606,9 @@ def _bn_params(x, bn, training):
         rt.check(L.hupr_bn_eval_params_f32(rt.ptr(bn.weight), rt.ptr(bn.bias), rt.ptr(bn.running_mean),
                                            rt.ptr(bn.running_var), float(bn.eps), C, rt.ptr(scale),
                                            rt.ptr(shift), rt.stream()))
-        mean.copy_(bn.running_mean)
-        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        if torch.is_grad_enabled():          # only a backward pass through eval-mode statistics reads these two
+            mean.copy_(bn.running_mean)
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
     return scale, shift, mean, invstd
 
 
@@ -848,6 +849,12 @@ def gemm(ta, tb, A, B, M, N, K, lda, ldb, batch, a_bs, b_bs, out=None, res=None,
     return out
 
 
+def _attn_ws(B, N, C, device):
+    """Workspace of the split-key forward (small batches: the plain grid would leave most CUs idle), or None."""
+    nbytes = rt.lib().hupr_attn_fwd_split_ws_bytes(B, N, C)
+    return workspace(nbytes, device) if nbytes else None
+
+
 class AttentionFn(torch.autograd.Function):
     """MSCSA attention (models/layers.py:126-133) on token-major tensors (B, N, C):
     S[j,k] = sum_c K[j,c] Q[k,c];  P = softmax over keys j;  out[k,c] = sum_j P[j,k] V[j,c] (+ V[k,c])."""
@@ -866,8 +873,10 @@ class AttentionFn(torch.autograd.Function):
             # bf16 copies of the MFMA operands: each is re-read by every workgroup (N / 128 times), and the kernels
             # would round them to bf16 per tile anyway — same bits, half the traffic, also half the saved activations
             kb, qb, vb = _cast(k, torch.bfloat16), _cast(q, torch.bfloat16), _cast(v, torch.bfloat16)
-            rt.check(L.hupr_attn_fwd_bf16in(rt.ptr(kb), rt.ptr(qb), rt.ptr(vb), rt.ptr(v) if residual else None,
-                                            rt.ptr(out), rt.ptr(lse), B, N, C, rt.stream()))
+            ws = _attn_ws(B, N, C, v.device)
+            rt.check(L.hupr_attn_fwd_bf16in_ld_ws(rt.ptr(kb), C, rt.ptr(qb), C, rt.ptr(vb), rt.ptr(v) if residual else None,
+                                                  rt.ptr(out), rt.ptr(lse), None, 0, B, N, C, rt.ptr(ws) if ws is not None else None,
+                                                  ws.numel() if ws is not None else 0, rt.stream()))
             ctx.save_for_backward(kb, qb, vb, v, out, lse)
             ctx.residual = residual
             return out
@@ -995,9 +1004,11 @@ class MSCSALevelFn(torch.autograd.Function):
         for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
             if flash:
-                rt.check(L.hupr_attn_fwd_bf16in_ld(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
-                                                   rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
-                                                   4 * C, B, N, C, rt.stream()))
+                ws = _attn_ws(B, N, C, dev)
+                rt.check(L.hupr_attn_fwd_bf16in_ld_ws(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
+                                                      rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
+                                                      4 * C, B, N, C, rt.ptr(ws) if ws is not None else None,
+                                                      ws.numel() if ws is not None else 0, rt.stream()))
             else:
                 # P[q][j] = Q[q] . K[j], softmax over the keys j (row softmax), out = P V (+ V)
                 rt.check(L.hupr_gemm_bf16(0, 1, qp, kp, rt.ptr(a), N, N, C, 4 * C, 4 * C, N, B, N * 4 * C, N * 4 * C, N * N,

@@ -281,6 +281,13 @@ int hupr_attn_bwd_bf16in(const void* K, const void* Q, const void* V, const void
  * dO: bf16, row stride lddo; dout32 null: the gradient arrived bf16-stored and dO is used for the exact terms too. */
 int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres, float* out,
                             float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, hupr_stream_t stream);
+/* Small batches (BASELINE config C2, B = 1 inference: N / 128 x Bn workgroups leave most of the 256 CUs idle): the same forward
+ * with the keys split over a third grid dimension and a merge launch (flash-decoding).  hupr_attn_fwd_split_ws_bytes returns
+ * the workspace that needs, or 0 when the plain kernel already fills the GPU (ws may then be null). */
+size_t hupr_attn_fwd_split_ws_bytes(int Bn, int N, int C);
+int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres, float* out,
+                               float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, void* ws, size_t ws_bytes,
+                               hupr_stream_t stream);
 int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, const void* V, const void* dO, int lddo,
                             const float* V32, const float* out, const float* dout32_or_null, const float* lse, float* dK,
                             int lddk, float* dQ, int lddq, float* dV, float* Dq_scratch, int Bn, int N, int C,

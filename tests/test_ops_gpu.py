@@ -427,6 +427,35 @@ def test_flash_attention_bf16(N, C, residual, bf16_math):
     close(vg.grad, v2.grad, 1e-2, "flash vs materialised dV")
 
 
+@pytest.mark.parametrize("B,N,C", [(1, 4096, 64), (3, 1024, 128), (1, 256, 256), (2, 128, 64)])
+def test_attention_split_keys_matches_plain_forward(B, N, C, bf16_math):
+    """Small batches walk the keys in shares (blockIdx.z) and merge them in a second launch; against the plain kernel on the same
+    bf16 operands (output, bf16 copy, log-sum-exp) — the shares round P relative to their own running maxima, hence a tolerance —
+    and against fp64."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    k, q, v = (rnd(B, N, C, seed=80 + i, scale=(C ** -0.25 if i < 2 else 1.0)).cuda() for i in range(3))
+    kb, qb, vb = (t.bfloat16() for t in (k, q, v))
+    nbytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C)
+    assert nbytes > 0 and L.hupr_attn_fwd_split_ws_bytes(32, 4096, 64) == 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    res = {}
+    for name, w in (("plain", None), ("split", ws)):
+        out, lse = torch.full((B, N, C), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+        o16 = torch.zeros((B, N, 2 * C), dtype=torch.bfloat16, device="cuda")
+        F_.rt.check(L.hupr_attn_fwd_bf16in_ld_ws(F_.rt.ptr(kb), C, F_.rt.ptr(qb), C, F_.rt.ptr(vb), F_.rt.ptr(v), F_.rt.ptr(out),
+                                                 F_.rt.ptr(lse), o16.data_ptr() + C * 2, 2 * C, B, N, C,
+                                                 F_.rt.ptr(w) if w is not None else None, nbytes if w is not None else 0, F_.rt.stream()))
+        res[name] = (out, lse, o16)
+    sref = torch.einsum("bjc,bkc->bjk", kb.double(), qb.double())
+    ref = torch.einsum("bjc,bjk->bkc", vb.double(), F.softmax(sref, 1)) + v.double()
+    for name in res:
+        close(res[name][0], ref, 1e-2, name + " vs fp64")
+        close(res[name][1], torch.logsumexp(sref, 1), 1e-5, name + " lse")
+        assert torch.equal(res[name][2][..., C:], res[name][0].bfloat16()) and not res[name][2][..., :C].any()
+    close(res["split"][0], res["plain"][0], 4e-3, "split vs plain")
+
+
 def test_flash_attention_large_logits(bf16_math):
     from hupr_amd import functional as F_
     k, q, v = rnd(1, 256, 64, seed=46) * 5, rnd(1, 256, 64, seed=47) * 5, rnd(1, 256, 64, seed=48)
