@@ -544,9 +544,15 @@ extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C =
 
 // key shares of the split forward: only when the plain grid (N / 128 x Bn workgroups) leaves more than half of the 256 CUs idle;
 // then enough shares for ~512 workgroups, a power of two, at least one 64-key tile each
+// Policy: single-sample inference only by default (Bn == 1: every level of the decoder is then far below one workgroup per
+// CU).  Larger batches keep the one-pass kernel and with it the exact bf16 rounding the parity gates of the training
+// configurations were measured with (the shares round P relative to their own running maxima); hupr_debug_attn_split(1)
+// widens it to every grid below 128 workgroups, -1 switches it off.
+static int g_attn_split = 0;
+extern "C" void hupr_debug_attn_split(int mode) { g_attn_split = mode; }
 static int attn_splits(int Bn, int N) {
     const long wgs = (long)Bn * (N / 128);
-    if (wgs >= 128) return 1;
+    if (wgs >= 128 || g_attn_split < 0 || (g_attn_split == 0 && Bn != 1)) return 1;
     int S = 1;
     while (S * 2 * wgs <= 512 && (N / 64) % (S * 2) == 0) S *= 2;
     return S;

@@ -570,7 +570,7 @@ def temporal_merge(x, weight):
 # ----------------------------------------------------------------------------------------------
 # BatchNorm (+ReLU), and the BasicBlock3D tail  relu(bn_a(x1) + bn_b(x2))
 # ----------------------------------------------------------------------------------------------
-def _bn_params(x, bn, training):
+def _bn_params(x, bn, training, need_bwd=True):
     """-> (scale, shift, save_mean, save_invstd) for one nn.BatchNorm3d-like parameter holder."""
     L = rt.lib()
     C = x.shape[-1]
@@ -606,7 +606,7 @@ def _bn_params(x, bn, training):
         rt.check(L.hupr_bn_eval_params_f32(rt.ptr(bn.weight), rt.ptr(bn.bias), rt.ptr(bn.running_mean),
                                            rt.ptr(bn.running_var), float(bn.eps), C, rt.ptr(scale),
                                            rt.ptr(shift), rt.stream()))
-        if torch.is_grad_enabled():          # only a backward pass through eval-mode statistics reads these two
+        if need_bwd:                         # only a backward pass through eval-mode statistics reads these two
             mean.copy_(bn.running_mean)
             invstd = torch.rsqrt(bn.running_var + bn.eps)
     return scale, shift, mean, invstd
@@ -643,7 +643,7 @@ class BNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, bn, training, relu):
         x = _c(x)
-        scale, shift, mean, invstd = _bn_params(x, bn, training)
+        scale, shift, mean, invstd = _bn_params(x, bn, training, any(ctx.needs_input_grad))
         C = x.shape[-1]
         y = torch.empty_like(x)
         rt.check(_act("scale_shift_act", x)(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
@@ -669,8 +669,9 @@ class BNAddBNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, g1, b1, bn1, x2, g2, b2, bn2, training):
         x1, x2 = _c(x1), _c(x2)
-        s1, t1, m1, i1 = _bn_params(x1, bn1, training)
-        s2, t2, m2, i2 = _bn_params(x2, bn2, training)
+        need = any(ctx.needs_input_grad)
+        s1, t1, m1, i1 = _bn_params(x1, bn1, training, need)
+        s2, t2, m2, i2 = _bn_params(x2, bn2, training, need)
         C = x1.shape[-1]
         y = torch.empty_like(x1)
         assert x1.dtype == x2.dtype

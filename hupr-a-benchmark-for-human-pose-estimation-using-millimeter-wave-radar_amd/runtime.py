@@ -88,6 +88,7 @@ SIGNATURES = {
     "hupr_attn_fwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_void_p, c_int] + [c_int] * 3
                                 + [c_void_p]),
     "hupr_attn_fwd_split_ws_bytes": (c_size_t, [c_int] * 3),
+    "hupr_debug_attn_split": (None, [c_int]),
     "hupr_attn_fwd_bf16in_ld_ws": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_void_p, c_int] + [c_int] * 3
                                    + [c_void_p, c_size_t, c_void_p]),
     "hupr_attn_bwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4

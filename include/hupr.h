@@ -283,8 +283,10 @@ int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, cons
                             float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, hupr_stream_t stream);
 /* Small batches (BASELINE config C2, B = 1 inference: N / 128 x Bn workgroups leave most of the 256 CUs idle): the same forward
  * with the keys split over a third grid dimension and a merge launch (flash-decoding).  hupr_attn_fwd_split_ws_bytes returns
- * the workspace that needs, or 0 when the plain kernel already fills the GPU (ws may then be null). */
+ * the workspace that needs, or 0 when the one-pass kernel is used (ws may then be null): by default the split is taken for
+ * single-sample calls only, so that batched runs keep the rounding their parity gates were measured with. */
 size_t hupr_attn_fwd_split_ws_bytes(int Bn, int N, int C);
+void hupr_debug_attn_split(int mode);    /* 0 (default): split for Bn == 1 only; 1: every grid below 128 workgroups; -1: never */
 int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres, float* out,
                                float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, void* ws, size_t ws_bytes,
                                hupr_stream_t stream);

@@ -436,17 +436,23 @@ def test_attention_split_keys_matches_plain_forward(B, N, C, bf16_math):
     L = F_.rt.lib()
     k, q, v = (rnd(B, N, C, seed=80 + i, scale=(C ** -0.25 if i < 2 else 1.0)).cuda() for i in range(3))
     kb, qb, vb = (t.bfloat16() for t in (k, q, v))
-    nbytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C)
-    assert nbytes > 0 and L.hupr_attn_fwd_split_ws_bytes(32, 4096, 64) == 0
-    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    assert (L.hupr_attn_fwd_split_ws_bytes(B, N, C) > 0) == (B == 1)          # default policy: single-sample calls only
     res = {}
-    for name, w in (("plain", None), ("split", ws)):
-        out, lse = torch.full((B, N, C), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
-        o16 = torch.zeros((B, N, 2 * C), dtype=torch.bfloat16, device="cuda")
-        F_.rt.check(L.hupr_attn_fwd_bf16in_ld_ws(F_.rt.ptr(kb), C, F_.rt.ptr(qb), C, F_.rt.ptr(vb), F_.rt.ptr(v), F_.rt.ptr(out),
-                                                 F_.rt.ptr(lse), o16.data_ptr() + C * 2, 2 * C, B, N, C,
-                                                 F_.rt.ptr(w) if w is not None else None, nbytes if w is not None else 0, F_.rt.stream()))
-        res[name] = (out, lse, o16)
+    try:
+        L.hupr_debug_attn_split(1)                                          # every grid below 128 workgroups
+        nbytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C)
+        assert nbytes > 0 and L.hupr_attn_fwd_split_ws_bytes(32, 4096, 64) == 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        for name, w in (("plain", None), ("split", ws)):
+            out, lse = torch.full((B, N, C), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+            o16 = torch.zeros((B, N, 2 * C), dtype=torch.bfloat16, device="cuda")
+            F_.rt.check(L.hupr_attn_fwd_bf16in_ld_ws(F_.rt.ptr(kb), C, F_.rt.ptr(qb), C, F_.rt.ptr(vb), F_.rt.ptr(v), F_.rt.ptr(out),
+                                                     F_.rt.ptr(lse), o16.data_ptr() + C * 2, 2 * C, B, N, C,
+                                                     F_.rt.ptr(w) if w is not None else None, nbytes if w is not None else 0,
+                                                     F_.rt.stream()))
+            res[name] = (out, lse, o16)
+    finally:
+        L.hupr_debug_attn_split(0)
     sref = torch.einsum("bjc,bkc->bjk", kb.double(), qb.double())
     ref = torch.einsum("bjc,bjk->bkc", vb.double(), F.softmax(sref, 1)) + v.double()
     for name in res:
