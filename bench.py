@@ -251,6 +251,8 @@ def main():
     F_.TWO_STREAMS = (bool(args.two_streams) or args.workload == "c2") and os.environ.get("HUPR_ONE_STREAM", "0") != "1"
     if os.environ.get("HUPR_HALO_ABLATE"):                           # A/B aid: conv_halo256 variants inside the real step
         F_.rt.lib().hupr_debug_halo_ablate(int(os.environ["HUPR_HALO_ABLATE"]))
+    if os.environ.get("HUPR_HALO_SMALL_TILES_OFF", "0") == "1":      # A/B aid
+        F_.rt.lib().hupr_debug_halo_small_tiles(0)
     if os.environ.get("HUPR_GEMM_SMALL_TILES_OFF", "0") == "1":      # A/B aid
         F_.rt.lib().hupr_debug_gemm_small_tiles(1)
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS

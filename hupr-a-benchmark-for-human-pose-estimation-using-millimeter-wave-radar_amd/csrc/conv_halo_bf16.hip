@@ -330,6 +330,8 @@ static unsigned long long* g_halo_trace = nullptr;
 extern "C" void hupr_debug_halo_trace(void* buf) { g_halo_trace = reinterpret_cast<unsigned long long*>(buf); }
 extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
 extern "C" void hupr_debug_halo_variant(int v) { g_halo_variant = v; }
+static int g_halo_small_tiles = 1;  // A/B aid: 0 keeps 64-wide channel tiles on small grids
+extern "C" void hupr_debug_halo_small_tiles(int on) { g_halo_small_tiles = on; }
 
 // 1 if hupr_conv3x3_halo_bf16 supports this geometry (else use hupr_conv_fwd_bf16)
 extern "C" int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw) {
@@ -374,7 +376,10 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     }
     if (kd == 3) { a.TD = 2; a.log2TW = 3; } else { a.TD = 1; a.log2TW = 4; }
     a.nd = D / a.TD; a.nh = H / 8; a.nw = W >> a.log2TW;
-    const bool n32 = (Co <= 32);
+    // 32-wide channel tiles for Co <= 32 — and for grids that would leave CUs idle or single-tiled with 64-wide ones (small
+    // batches, e.g. the B = 1 inference): twice the workgroups, two of them per CU (LDS), each with half the weight traffic
+    const long blocks64 = (long)Bn * a.nd * a.nh * a.nw * ((Co + 63) / 64);
+    const bool n32 = (Co <= 32) || (g_halo_small_tiles && blocks64 <= 256 && Co % 32 == 0);
     const int bn = n32 ? 32 : 64;
     a.n_co_tiles = (Co + bn - 1) / bn;
     const long blocks = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;

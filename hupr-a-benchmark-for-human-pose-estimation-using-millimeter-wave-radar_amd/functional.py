@@ -641,9 +641,11 @@ class BNActFn(torch.autograd.Function):
     """y = [relu](batch_norm(x)).  ``bn`` is the parameter holder (running stats updated in place)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, training, relu):
+    def forward(ctx, x, gamma, beta, bn, training, relu, no_bwd=False):
+        # no_bwd: the caller runs under torch.no_grad() (grad mode is always off in here, and needs_input_grad reflects the
+        # tensors' flags whatever the mode) — eval-mode statistics then skip what only a backward pass reads
         x = _c(x)
-        scale, shift, mean, invstd = _bn_params(x, bn, training, any(ctx.needs_input_grad))
+        scale, shift, mean, invstd = _bn_params(x, bn, training, not no_bwd)
         C = x.shape[-1]
         y = torch.empty_like(x)
         rt.check(_act("scale_shift_act", x)(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
@@ -660,18 +662,17 @@ class BNActFn(torch.autograd.Function):
         x, y, mean, invstd, gamma, scale, shift = ctx.saved_tensors
         dx, dg, db = _bn_bwd(_c(dy), y, x, mean, invstd, gamma, ctx.training, ctx.beta_ref,
                              fwd=(scale, shift) if scale is not None else None)
-        return dx, dg, db, None, None, None
+        return dx, dg, db, None, None, None, None
 
 
 class BNAddBNReLUFn(torch.autograd.Function):
     """y = relu(bn_a(x1) + bn_b(x2)) — the tail of BasicBlock3D.forward (models/layers.py:66-70)."""
 
     @staticmethod
-    def forward(ctx, x1, g1, b1, bn1, x2, g2, b2, bn2, training):
+    def forward(ctx, x1, g1, b1, bn1, x2, g2, b2, bn2, training, no_bwd=False):
         x1, x2 = _c(x1), _c(x2)
-        need = any(ctx.needs_input_grad)
-        s1, t1, m1, i1 = _bn_params(x1, bn1, training, need)
-        s2, t2, m2, i2 = _bn_params(x2, bn2, training, need)
+        s1, t1, m1, i1 = _bn_params(x1, bn1, training, not no_bwd)
+        s2, t2, m2, i2 = _bn_params(x2, bn2, training, not no_bwd)
         C = x1.shape[-1]
         y = torch.empty_like(x1)
         assert x1.dtype == x2.dtype
@@ -712,7 +713,7 @@ class BNAddBNReLUFn(torch.autograd.Function):
                                          rt.ptr(dg2), rt.ptr(db2), M, C, 1 if ctx.training else 0, rt.ptr(ws), ws.numel(),
                                          rt.stream()))
         return (dx1, _pret(g1, dg1, dg1_d), _pret(b1, db1, db1_d), None, dx2, _pret(g2, dg2, dg2_d), _pret(b2, db2, db2_d),
-                None, None)
+                None, None, None)
 
 
 class PReLUFn(torch.autograd.Function):

@@ -71,10 +71,11 @@ class BasicBlock3D(nn.Module):
         out, res = F_.dual_conv(x, self.main[0].weight, self.downsample[0].weight, tuple(self.main[0].padding),
                                 stats=self.training)
         bn1 = self.main[1]
-        out = F_.BNActFn.apply(out, bn1.weight, bn1.bias, bn1, self.training, True)
+        no_bwd = not torch.is_grad_enabled()
+        out = F_.BNActFn.apply(out, bn1.weight, bn1.bias, bn1, self.training, True, no_bwd)
         out = F_.conv(out, self.main[3].weight, None, None, tuple(self.main[3].padding), stats=self.training)
         bn2, bnd = self.main[4], self.downsample[1]
-        return F_.BNAddBNReLUFn.apply(out, bn2.weight, bn2.bias, bn2, res, bnd.weight, bnd.bias, bnd, self.training)
+        return F_.BNAddBNReLUFn.apply(out, bn2.weight, bn2.bias, bn2, res, bnd.weight, bnd.bias, bnd, self.training, no_bwd)
 
 
 class _Resample(nn.Module):

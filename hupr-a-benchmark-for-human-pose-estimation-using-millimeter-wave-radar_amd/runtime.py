@@ -50,6 +50,7 @@ SIGNATURES = {
     "hupr_pack_conv_weights_table": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hupr_debug_halo_ablate": (None, [c_int]),
     "hupr_debug_halo_variant": (None, [c_int]),
+    "hupr_debug_halo_small_tiles": (None, [c_int]),
     "hupr_debug_halo_trace": (None, [c_void_p]),
     "hupr_debug_wgrad_groups": (None, [c_int]),
     "hupr_debug_wgrad_ci32": (None, [c_int]),
