@@ -208,6 +208,53 @@ __global__ __launch_bounds__(256) void hupr_k_scale_shift_act(const T* __restric
     }
 }
 
+// Eval-mode BatchNorm (+ second branch) (+ ReLU) in ONE launch: the per-channel coefficients — the very expressions of
+// hupr_k_bn_eval_params — are evaluated by each thread for its own channels instead of by a launch of their own in front
+// (single-sample inference is launch-bound: 30 BatchNorms per forward pass).
+template <int V>
+__device__ __forceinline__ void eval_coef(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ rm,
+                                          const float* __restrict__ rv, float eps, int c, float* sc, float* sh) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const float invstd = 1.0f / sqrtf(rv[c + k] + eps);
+        const float s = g[c + k] * invstd;
+        sc[k] = s;
+        sh[k] = b[c + k] - rm[c + k] * s;
+    }
+}
+struct BnEvalSide { const float *gamma, *beta, *rm, *rv; float eps; };
+template <typename T>
+__global__ __launch_bounds__(256) void hupr_k_bn_eval_act(const T* __restrict__ x1, BnEvalSide p1, const T* __restrict__ x2,
+                                                          BnEvalSide p2, T* __restrict__ y, long nv, int C, int act) {
+    constexpr int V = ActVec<T>::V;
+    const long stride = (long)gridDim.x * 256;
+    const bool fixed = (stride * V) % C == 0;
+    float a[V], b[V], a2[V], b2[V];
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int c = (int)((i * V) % C);
+    if (fixed) {
+        eval_coef<V>(p1.gamma, p1.beta, p1.rm, p1.rv, p1.eps, c, a, b);
+        if (x2) eval_coef<V>(p2.gamma, p2.beta, p2.rm, p2.rv, p2.eps, c, a2, b2);
+    }
+    for (; i < nv; i += stride) {
+        if (!fixed) {
+            c = (int)((i * V) % C);
+            eval_coef<V>(p1.gamma, p1.beta, p1.rm, p1.rv, p1.eps, c, a, b);
+            if (x2) eval_coef<V>(p2.gamma, p2.beta, p2.rm, p2.rv, p2.eps, c, a2, b2);
+        }
+        float v[V], u[V];
+        ActVec<T>::load(x1 + i * V, v);
+        if (x2) ActVec<T>::load(x2 + i * V, u);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            v[k] = fmaf(v[k], a[k], b[k]);
+            if (x2) v[k] += fmaf(u[k], a2[k], b2[k]);
+            if (act == 1) v[k] = fmaxf(v[k], 0.f);
+        }
+        ActVec<T>::store(y + i * V, v);
+    }
+}
+
 // backward finalize: dgamma = S2, dbeta = S1 and the per-channel coefficients of the apply pass
 //   train: dx = w*(g' - S1/M - xhat*S2/M) = cA*g' + cB*(x - mean) + cD,  cA = w, cB = -w*invstd*S2/M, cD = -w*S1/M
 //   eval : dx = w*g'                                                      cB = cD = 0          (w = gamma*invstd)
@@ -580,6 +627,36 @@ extern "C" int hupr_scale_shift_act_bf16act(const void* x1, const float* scale1,
                                             hupr_stream_t stream) {
     return scale_shift_act("hupr_scale_shift_act_bf16act", static_cast<const __bf16*>(x1), scale1, shift1,
                            static_cast<const __bf16*>(x2), scale2, shift2, static_cast<__bf16*>(y), M, C, act, stream);
+}
+
+template <typename T>
+static int bn_eval_act(const char* who, const T* x1, const float* g1, const float* b1, const float* rm1, const float* rv1, float eps1,
+                       const T* x2, const float* g2, const float* b2, const float* rm2, const float* rv2, float eps2, T* y, long M,
+                       int C, int act, hupr_stream_t stream) {
+    HUPR_REQUIRE(x1 && g1 && b1 && rm1 && rv1 && y, "%s: null pointer", who);
+    HUPR_REQUIRE(!x2 || (g2 && b2 && rm2 && rv2), "%s: second branch needs its BatchNorm tensors", who);
+    int rc = bn_check(who, M, C, act_v<T>());
+    if (rc) return rc;
+    const long nv = M * C / act_v<T>();
+    hipLaunchKernelGGL(hupr_k_bn_eval_act<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x1,
+                       BnEvalSide{g1, b1, rm1, rv1, eps1}, x2, BnEvalSide{g2, b2, rm2, rv2, eps2}, y, nv, C, act);
+    HUPR_LAUNCH_OK("hupr_k_bn_eval_act");
+    return HUPR_OK;
+}
+// y = act(bn1_eval(x1) [+ bn2_eval(x2)]) from the BatchNorm tensors themselves (running statistics): hupr_bn_eval_params_f32 +
+// hupr_scale_shift_act_* in one launch, same arithmetic
+extern "C" int hupr_bn_eval_act_f32(const float* x1, const float* gamma1, const float* beta1, const float* mean1, const float* var1,
+                                    float eps1, const float* x2, const float* gamma2, const float* beta2, const float* mean2,
+                                    const float* var2, float eps2, float* y, long M, int C, int act, hupr_stream_t stream) {
+    return bn_eval_act("hupr_bn_eval_act_f32", x1, gamma1, beta1, mean1, var1, eps1, x2, gamma2, beta2, mean2, var2, eps2, y, M, C,
+                       act, stream);
+}
+extern "C" int hupr_bn_eval_act_bf16act(const void* x1, const float* gamma1, const float* beta1, const float* mean1,
+                                        const float* var1, float eps1, const void* x2, const float* gamma2, const float* beta2,
+                                        const float* mean2, const float* var2, float eps2, void* y, long M, int C, int act,
+                                        hupr_stream_t stream) {
+    return bn_eval_act("hupr_bn_eval_act_bf16act", static_cast<const __bf16*>(x1), gamma1, beta1, mean1, var1, eps1,
+                       static_cast<const __bf16*>(x2), gamma2, beta2, mean2, var2, eps2, static_cast<__bf16*>(y), M, C, act, stream);
 }
 
 // BatchNorm backward through an optional ReLU mask (y > 0).  train=1: batch-stat formula.

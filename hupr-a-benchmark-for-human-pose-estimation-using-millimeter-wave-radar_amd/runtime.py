@@ -65,6 +65,8 @@ SIGNATURES = {
                                         c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_bn_eval_params_f32": (c_int, [c_void_p] * 4 + [c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "hupr_scale_shift_act_f32": (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_void_p]),
+    "hupr_bn_eval_act_f32": (c_int, [c_void_p] * 5 + [c_float] + [c_void_p] * 5 + [c_float, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "hupr_bn_eval_act_bf16act": (c_int, [c_void_p] * 5 + [c_float] + [c_void_p] * 5 + [c_float, c_void_p, c_long, c_int, c_int, c_void_p]),
     "hupr_bn_bwd_f32": (c_int, [c_void_p] * 9 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_bn_bwd2_f32": (c_int, [c_void_p] * 16 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_bn_bwd_remask_f32": (c_int, [c_void_p] * 10 + [c_long, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -202,6 +202,15 @@ int hupr_bn_eval_params_f32(const float* gamma, const float* beta, const float* 
 int hupr_scale_shift_act_f32(const float* x1, const float* scale1, const float* shift1, const float* x2,
                              const float* scale2, const float* shift2, float* y, long M, int C, int act,
                              hupr_stream_t stream);
+/* Eval-mode BatchNorm(s) + optional ReLU from the module's own tensors (models/layers.py:57,60,64 in eval mode): the
+ * coefficient launch (hupr_bn_eval_params_f32) and the apply launch as one — single-sample inference is launch-bound.
+ * x2 (and its BatchNorm) may be null.  The bf16act form takes bf16-stored x1 / x2 / y. */
+int hupr_bn_eval_act_f32(const float* x1, const float* gamma1, const float* beta1, const float* mean1, const float* var1,
+                         float eps1, const float* x2, const float* gamma2, const float* beta2, const float* mean2,
+                         const float* var2, float eps2, float* y, long M, int C, int act, hupr_stream_t stream);
+int hupr_bn_eval_act_bf16act(const void* x1, const float* gamma1, const float* beta1, const float* mean1, const float* var1,
+                             float eps1, const void* x2, const float* gamma2, const float* beta2, const float* mean2,
+                             const float* var2, float eps2, void* y, long M, int C, int act, hupr_stream_t stream);
 /* finalize only, from nblk rows of [2][C] double column sums produced elsewhere (hupr_conv3x3_halo_bf16act_stats) */
 int hupr_bn_train_finalize_f32(const void* partial, int nblk, long M, int C, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* save_mean,

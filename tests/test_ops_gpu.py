@@ -462,6 +462,30 @@ def test_attention_split_keys_matches_plain_forward(B, N, C, bf16_math):
     close(res["split"][0], res["plain"][0], 4e-3, "split vs plain")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_batchnorm_single_launch_matches_two_launches(dtype):
+    """Inference (eval mode under no_grad): coefficients + apply in one launch (hupr_bn_eval_act_*) against the coefficient
+    launch followed by the apply launch — same arithmetic, bit for bit; both block tails of BasicBlock3D."""
+    from hupr_amd import functional as F_
+    C = 64
+    bns = []
+    for i in range(2):
+        bn = torch.nn.BatchNorm3d(C).cuda().eval()
+        with torch.no_grad():
+            bn.weight.copy_(rnd(C, seed=90 + i) + 1.0); bn.bias.copy_(rnd(C, seed=92 + i))
+            bn.running_mean.copy_(rnd(C, seed=94 + i)); bn.running_var.copy_(rnd(C, seed=96 + i).abs() + 0.3)
+        bns.append(bn)
+    x1, x2 = (rnd(3, 2, 8, 8, C, seed=98 + i).cuda().to(dtype) for i in range(2))
+    with torch.no_grad():
+        a = F_.BNActFn.apply(x1, bns[0].weight, bns[0].bias, bns[0], False, True, True)
+        b = F_.BNActFn.apply(x1, bns[0].weight, bns[0].bias, bns[0], False, True, False)
+        c = F_.BNAddBNReLUFn.apply(x1, bns[0].weight, bns[0].bias, bns[0], x2, bns[1].weight, bns[1].bias, bns[1], False, True)
+        d = F_.BNAddBNReLUFn.apply(x1, bns[0].weight, bns[0].bias, bns[0], x2, bns[1].weight, bns[1].bias, bns[1], False, False)
+    assert torch.equal(a, b) and torch.equal(c, d) and a.dtype == dtype
+    ref = torch.relu(bns[0](x1.float().permute(0, 4, 1, 2, 3))).permute(0, 2, 3, 4, 1)
+    close(a.float(), ref, 1e-5 if dtype == torch.float32 else 1e-2, "eval bn + relu vs torch")
+
+
 def test_flash_attention_large_logits(bf16_math):
     from hupr_amd import functional as F_
     k, q, v = rnd(1, 256, 64, seed=46) * 5, rnd(1, 256, 64, seed=47) * 5, rnd(1, 256, 64, seed=48)
