@@ -200,20 +200,27 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo512_bf16(HaloArgs p) {
                 for (int ks = 0; ks < 2; ++ks) {
                     const int s0 = ks & 1;                        // weight-fragment set that holds (K-step ks, kz = 0)
                     // kz = 0: prefetch depth row 2 + weights of kz = 1
+                    // (the prefetch reads of a group are spread in front of the MFMAs of the previous one instead of issued as a
+                    // burst, see conv_halo256_bf16.hip)
+#define HUPR_SPREAD(NR_)                                                                                            \
+                    _Pragma("unroll") for (int i_ = 0; i_ < (NR_); ++i_) {                                          \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+                    }                                                                                               \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12 - (NR_), 0);                                     \
+                    __builtin_amdgcn_sched_barrier(0);
                     HUPR_A_ROW(2, ks) HUPR_B_ROW(s0 ^ 1, 1, ks)
-                    __builtin_amdgcn_sched_barrier(0);
                     HUPR_MMA(0, s0)
-                    __builtin_amdgcn_sched_barrier(0);
+                    HUPR_SPREAD(7)
                     // kz = 1: prefetch depth row 3 + weights of kz = 2
                     HUPR_A_ROW(3, ks) HUPR_B_ROW(s0, 2, ks)
-                    __builtin_amdgcn_sched_barrier(0);
                     HUPR_MMA(1, s0 ^ 1)
-                    __builtin_amdgcn_sched_barrier(0);
+                    HUPR_SPREAD(7)
                     // kz = 2: prefetch the next K-step's depth rows 0, 1 (dead by now) + its weights of kz = 0
                     if (ks == 0) { HUPR_A_ROW(0, 1) HUPR_A_ROW(1, 1) HUPR_B_ROW(s0 ^ 1, 0, 1) }
-                    __builtin_amdgcn_sched_barrier(0);
                     HUPR_MMA(2, s0)
-                    __builtin_amdgcn_sched_barrier(0);
+                    HUPR_SPREAD(11)
+#undef HUPR_SPREAD
                 }
 #undef HUPR_A_ROW
 #undef HUPR_B_ROW

@@ -184,12 +184,19 @@ __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {   
                     if (ks + 1 < KC / 16) {
                         if (ks & 1) { HUPR_FRAGS(0, ks + 1) } else { HUPR_FRAGS(1, ks + 1) }
                     }
-                    __builtin_amdgcn_sched_barrier(0);         // keep the prefetch reads ahead of the MFMAs (see conv_halo256_bf16.hip)
+                    // (conv_halo256_bf16.hip: the reads of K-step ks + 1 are spread in front of the MFMAs of ks instead of
+                    // issued as one burst — NA + TS reads against TS * TM MFMAs)
 #pragma unroll
                     for (int t = 0; t < TS; ++t)               // ky;  D'[channel][voxel]
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t + i], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int i_ = 0; i_ < TS * TM; ++i_) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, TM == 2 ? 1 : 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef HUPR_FRAGS

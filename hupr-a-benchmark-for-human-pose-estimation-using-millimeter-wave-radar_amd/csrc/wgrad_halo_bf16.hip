@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void hupr_k_wgrad_halo_bf16(WgradHaloArgs p
 //     LDS at the end — half the MFMAs per tile for the 32-channel input of Encoder3D.layer1's first convolution.
 template <bool IS3D, bool CI32>
 __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
+    constexpr bool g_sched_burst_ = false;      // true: the round-1 order (all reads of a group, then its MFMAs)
     constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, LOG2TW = IS3D ? 3 : 4;
     constexpr int HH = 10, HW = TW + 2;
     constexpr int NVOX = TD * HH * HW;               // 200 (3-D) / 180 (2-D) halo voxels of one depth-tap plane
@@ -366,10 +367,17 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
 #define HUPR_WG2_STEP(IMG_, KS0_, J_, NJ_)                                                                          \
     {                                                                                                               \
         if ((J_) + 1 < (NJ_)) { HUPR_WG2_LOAD(IMG_, ((J_) + 1) & 1, KS0_, ((J_) + 1 < (NJ_) ? (J_) + 1 : 0)) }      \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (g_sched_burst_) __builtin_amdgcn_sched_barrier(0);                                                      \
         _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
             acc[((J_) % 3) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((KS0_) + (J_) / 3) & 1], xq[(J_) & 1][kx], \
                                                                                acc[((J_) % 3) * 3 + kx], 0, 0, 0);  \
+        if (!g_sched_burst_) {            /* the next group's fragment reads spread between this group's MFMAs */   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                      \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                  \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                  \
+            }                                                                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                      \
+        }                                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
 #define HUPR_WG2_HALF(IMG_, KS0_, NJ_)                                                                              \
