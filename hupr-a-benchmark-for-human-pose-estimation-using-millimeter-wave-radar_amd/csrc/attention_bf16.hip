@@ -130,6 +130,7 @@ __device__ __forceinline__ void load_frags(bf16x8* frag, const TI* __restrict__ 
 }
 
 // acc[t] (t = 0,1: image rows 32t..32t+31) = img(64 rows x D) . frags  ->  tile [image row][lane token]
+constexpr int g_attn_sched = 0;      // 1: the round-1 order (all fragment reads of a chunk, then its MFMAs)
 template <int D>
 __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img, const bf16x8* frag, int lr, int lh) {
     // all A fragments of the 64 x D image rows are read before the first MFMA (hipcc otherwise issues each read right in
@@ -144,17 +145,32 @@ __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img,
 #pragma unroll
     for (int k0 = 0; k0 < KS; k0 += CHK) {
         bf16x8 a[2][CHK];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ks = 0; ks < CHK; ++ks)
-                a[t][ks] = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, (k0 + ks) * 2 + lh)]);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < CHK; ++ks)                   // in the order the MFMAs consume them
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                a[t][ks] = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, (k0 + ks) * 2 + lh)]);
 #pragma unroll
         for (int ks = 0; ks < CHK; ++ks)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][ks], frag[k0 + ks], acc[t], 0, 0, 0);
+        if (g_attn_sched == 0) {
+            // four reads ahead, then one read behind every MFMA (a burst of all 2 CHK reads first delays the first MFMA by the
+            // whole burst; a read right in front of its MFMA exposes the LDS latency every time)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i_ = 0; i_ < 2 * CHK - 4; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * CHK, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * CHK, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
