@@ -1,4 +1,6 @@
-"""Attention forward (C = 64, N = 4096) against the number of workgroups per CU: 66.6 us with one, then ~50 us per additional\nworkgroup per CU — each workgroup takes ~50 us of its CU whatever shares it: the kernel is throughput-bound on the sum of its\nVALU, MFMA and LDS issue, not latency-bound.  usage: python scripts/attn_occupancy.py"""
+"""Attention forward (C = 64, N = 4096) against the number of workgroups per CU: 66.6 us with one, then ~50 us per additional
+workgroup per CU — each workgroup takes ~50 us of its CU whatever shares it: the kernel is throughput-bound on the sum of its
+VALU, MFMA and LDS issue, not latency-bound.  usage: python scripts/attn_occupancy.py"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
