@@ -28,13 +28,14 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, 
                                                        double* __restrict__ partial, const float* __restrict__ fs,
                                                        const float* __restrict__ ft) {
     constexpr int V = ActVec<T>::V, U = 4;
-    extern __shared__ double sh[];   // [2][C]
+    // Every row subgroup leaves its fp32 column sums in its own LDS row [rsub][2][C]; they are then added in fp64 in subgroup
+    // order — no atomics: the same input gives the same statistics bit for bit on every run (LDS double atomics made the order,
+    // hence the last bit of a mean now and then, vary, which 120 chaotic training steps amplify: tests/test_trained_gpu.py).
+    extern __shared__ float shf[];   // [rows_per_pass][2][C]
     const int tid = threadIdx.x;
     const int cvn = C / V;                       // channel groups per row
     const int rows_per_pass = 256 / cvn;         // C / V <= 256
     const int cv = tid % cvn, rsub = tid / cvn;
-    for (int i = tid; i < 2 * C; i += 256) sh[i] = 0.0;
-    __syncthreads();
     const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
@@ -88,12 +89,16 @@ __global__ __launch_bounds__(256) void hupr_k_colstats(const T* __restrict__ x, 
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            atomicAdd(&sh[cv * V + k], (double)s1[k]);
-            atomicAdd(&sh[C + cv * V + k], (double)s2[k]);
+            shf[(rsub * 2 + 0) * C + cv * V + k] = s1[k];
+            shf[(rsub * 2 + 1) * C + cv * V + k] = s2[k];
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * C; i += 256) partial[(long)blockIdx.x * 2 * C + i] = sh[i];
+    for (int i = tid; i < 2 * C; i += 256) {
+        double a = 0.0;
+        for (int r = 0; r < rows_per_pass; ++r) a += (double)shf[r * 2 * C + i];
+        partial[(long)blockIdx.x * 2 * C + i] = a;
+    }
 }
 
 
@@ -327,13 +332,11 @@ __global__ __launch_bounds__(256) void hupr_k_colstats2(const T* __restrict__ x1
                                                         const float* __restrict__ fs2, const float* __restrict__ ft2) {
     // y == null: the ReLU mask is recomputed as [fs1 x1 + ft1 + (fs2 x2 + ft2) > 0], the forward pass's own expression
     constexpr int V = ActVec<T>::V, U = 2;
-    extern __shared__ double sh[];   // [3][C]
+    extern __shared__ float shf[];   // [rows_per_pass][3][C] (see hupr_k_colstats: deterministic, no atomics)
     const int tid = threadIdx.x;
     const int cvn = C / V;
     const int rows_per_pass = 256 / cvn;
     const int cv = tid % cvn, rsub = tid / cvn;
-    for (int i = tid; i < 3 * C; i += 256) sh[i] = 0.0;
-    __syncthreads();
     const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(M, r0 + rows_per_block);
@@ -376,13 +379,17 @@ __global__ __launch_bounds__(256) void hupr_k_colstats2(const T* __restrict__ x1
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            atomicAdd(&sh[cv * V + k], (double)s1[k]);
-            atomicAdd(&sh[C + cv * V + k], (double)sa[k]);
-            atomicAdd(&sh[2 * C + cv * V + k], (double)sb[k]);
+            shf[(rsub * 3 + 0) * C + cv * V + k] = s1[k];
+            shf[(rsub * 3 + 1) * C + cv * V + k] = sa[k];
+            shf[(rsub * 3 + 2) * C + cv * V + k] = sb[k];
         }
     }
     __syncthreads();
-    for (int i = tid; i < 3 * C; i += 256) partial[(long)blockIdx.x * 3 * C + i] = sh[i];
+    for (int i = tid; i < 3 * C; i += 256) {
+        double a = 0.0;
+        for (int r = 0; r < rows_per_pass; ++r) a += (double)shf[r * 3 * C + i];
+        partial[(long)blockIdx.x * 3 * C + i] = a;
+    }
 }
 
 // coef[6][C]: {cA, cB, cD} of branch 1, then of branch 2 (see hupr_k_bn_finalize_bwd)
@@ -528,6 +535,8 @@ __global__ void hupr_k_colsum_final(const double* __restrict__ partial, int nblk
 
 static inline int ew_grid(long n4) { return (int)min((long)4096, (n4 + 255) / 256); }
 template <typename T> static inline int act_v() { return sizeof(T) == 2 ? 8 : 4; }
+// dynamic LDS of the statistics kernels: [row subgroups = 256 / (C / V)][NS sums][C] floats
+template <typename T> static inline size_t stats_lds(int C, int ns) { return (size_t)(256 / (C / act_v<T>())) * ns * C * sizeof(float); }
 
 }  // namespace hupr
 
@@ -553,7 +562,7 @@ static int bn_train_stats(const char* who, const T* x, long M, int C, const floa
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
+    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, (const T*)nullptr,
                        (const T*)nullptr, nullptr, nullptr, M, C, partial, (const float*)nullptr, (const float*)nullptr);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
     hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, M, C, gamma,
@@ -673,7 +682,7 @@ static int bn_bwd(const char* who, const T* dy, const T* y_mask, const float* fs
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 2 * C * sizeof(double));
-    hipLaunchKernelGGL((hupr_k_colstats<1, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, dy, y_mask, save_mean,
+    hipLaunchKernelGGL((hupr_k_colstats<1, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, dy, y_mask, save_mean,
                        save_invstd, M, C, partial, fs, ft);
     HUPR_LAUNCH_OK("hupr_k_colstats<1>");
     hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C,
@@ -736,7 +745,7 @@ static int bn_bwd2(const char* who, const T* dy, const T* y_mask, const float* c
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 3 * C * sizeof(double));
-    hipLaunchKernelGGL(hupr_k_colstats2<T>, dim3(nblk), dim3(256), 3 * C * sizeof(double), s, x1, x2, dy, y_mask, mean1, invstd1,
+    hipLaunchKernelGGL(hupr_k_colstats2<T>, dim3(nblk), dim3(256), stats_lds<T>(C, 3), s, x1, x2, dy, y_mask, mean1, invstd1,
                        mean2, invstd2, M, C, partial, fs1, ft1, fs2, ft2);
     HUPR_LAUNCH_OK("hupr_k_colstats2");
     hipLaunchKernelGGL(hupr_k_bn_finalize_bwd2, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, gamma1,
@@ -841,7 +850,7 @@ static int colsum(const char* who, const T* x, long M, int C, float* out, void* 
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), 2 * C * sizeof(double), s, x, (const T*)nullptr,
+    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, (const T*)nullptr,
                        (const T*)nullptr, nullptr, nullptr, M, C, partial, (const float*)nullptr, (const float*)nullptr);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
     hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, out);
