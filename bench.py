@@ -190,6 +190,8 @@ def conv_roofline(events, B, dtype, peak):
             "algorithmic_bytes": pmc.get("algorithmic_bytes_per_launch") if B == 32 else None,
             "traffic_note": pmc.get("note", "HBM bytes/launch from rocprofv3 --pmc, see profiles/"),
             "limiter": pmc.get("limiter"),
+            "measured_ceiling": pmc.get("measured_ceiling_tflops"),
+            "frac_of_measured_ceiling": round(ach / pmc["measured_ceiling_tflops"], 4) if pmc.get("measured_ceiling_tflops") else None,
             "launches": len(ms), "avg_ms": round(avg * 1e3, 4), "flop_per_launch": kflop}
 
 
