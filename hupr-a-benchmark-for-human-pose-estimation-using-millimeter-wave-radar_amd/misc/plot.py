@@ -11,13 +11,13 @@ Host-side by design: one small image per evaluated sample, never on the training
 import os
 
 import numpy as np
-from PIL import Image, ImageDraw
 
 # joint index pairs of the 14-joint HuPR skeleton, in the reference's drawing order (misc/plot.py:48-62)
 EDGES = [(0, 1), (1, 2), (0, 3), (3, 4), (4, 5), (0, 6), (3, 6), (6, 7), (6, 8), (6, 11), (8, 9), (9, 10), (11, 12), (12, 13)]
 
 
 def _canvas(cfg, seq, frame, size, padding):
+    from PIL import Image  # lazily: Pillow is needed for --visDir only, never by training / inference
     path = os.path.join("../frames", str(cfg.TEST.plotImgDir), "single_%d" % seq, "processed/images", "%09d.jpg" % frame)
     grid = Image.new("RGB", (size[0] + 2 * padding, size[1] + 2 * padding), (0, 0, 0))
     if os.path.exists(path):
@@ -28,6 +28,7 @@ def _canvas(cfg, seq, frame, size, padding):
 def plotHumanPose(batch_joints, cfg, visDir, imageIdx, bbox=None, upsamplingSize=(256, 256), nrow=8, padding=2):
     """batch_joints: (B, 14, 2) image-pixel coordinates (x, y); imageIdx: (B,) ids = frame + 100000 * sequence;
     bbox: optional (B, 4) [x, y, w, h].  Returns the list of files written."""
+    from PIL import ImageDraw
     written = []
     for j in range(len(batch_joints)):
         iid = imageIdx[j]

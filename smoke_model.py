@@ -5,10 +5,10 @@ import torch
 
 
 def run():
-    from . import synth
-    from .config_tree import load_config
-    from .misc import LossComputer
-    from .models import HuPRNet
+    from hupr_amd import synth
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.misc import LossComputer
+    from hupr_amd.models import HuPRNet
     from oracle import loss as oloss, model as omodel
 
     cfg = load_config()
