@@ -27,6 +27,8 @@ struct Api {
     int (*get_unique_id)(rccl_unique_id*) = nullptr;
     int (*comm_init_rank)(rccl_comm_t*, int, rccl_unique_id, int) = nullptr;
     int (*comm_destroy)(rccl_comm_t) = nullptr;
+    int (*comm_count)(const rccl_comm_t, int*) = nullptr;
+    int (*comm_user_rank)(const rccl_comm_t, int*) = nullptr;
     int (*all_reduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     int (*broadcast)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
     const char* (*error_string)(int) = nullptr;
@@ -61,7 +63,8 @@ extern "C" int hupr_comm_load(const char* path_or_null) {
     Api a;
     a.handle = h;
     if (!bind(h, "ncclGetUniqueId", a.get_unique_id) || !bind(h, "ncclCommInitRank", a.comm_init_rank) ||
-        !bind(h, "ncclCommDestroy", a.comm_destroy) || !bind(h, "ncclAllReduce", a.all_reduce) ||
+        !bind(h, "ncclCommDestroy", a.comm_destroy) ||
+        !bind(h, "ncclCommCount", a.comm_count) || !bind(h, "ncclCommUserRank", a.comm_user_rank) || !bind(h, "ncclAllReduce", a.all_reduce) ||
         !bind(h, "ncclBroadcast", a.broadcast) || !bind(h, "ncclGetErrorString", a.error_string))
         return hupr::fail(HUPR_ERR_COMM, "hupr_comm_load: librccl lacks a required symbol: %s", dlerror());
     g_api = a;
@@ -93,6 +96,14 @@ extern "C" int hupr_comm_destroy(hupr_comm_t comm) {
     if (comm == nullptr) return HUPR_OK;
     if (int rc = ensure_loaded()) return rc;
     if (int rc = g_api.comm_destroy(comm)) return rccl_fail("ncclCommDestroy", rc);
+    return HUPR_OK;
+}
+
+extern "C" int hupr_comm_info(hupr_comm_t comm, int* n_ranks_out, int* rank_out) {
+    HUPR_REQUIRE(comm != nullptr && n_ranks_out != nullptr && rank_out != nullptr, "hupr_comm_info: null pointer");
+    if (int rc = ensure_loaded()) return rc;
+    if (int rc = g_api.comm_count(comm, n_ranks_out)) return rccl_fail("ncclCommCount", rc);
+    if (int rc = g_api.comm_user_rank(comm, rank_out)) return rccl_fail("ncclCommUserRank", rc);
     return HUPR_OK;
 }
 

@@ -235,6 +235,53 @@ class HuPRRawADC(_AnnotatedHuPR):
         return out
 
 
+class SequenceGroupedSampler(data.Sampler):
+    """Shuffled training order for ``HuPRRawADC`` that keeps its sequence cache hot.  A uniformly shuffled loader touches a
+    different sequence with nearly every sample, and a miss re-reads ~0.9 GB of ``adc_data.bin`` and transforms 2 x 600
+    sensor-frames.  Here the SEQUENCES are shuffled (same order on every rank, seeded by epoch), every rank takes its own
+    sequences (``rank::world``), and the windows of ``group`` sequences at a time are shuffled together: with
+    ``group <= cache_sequences`` every sequence is read and transformed exactly once per epoch and a batch still mixes
+    windows of ``group`` recordings.  Memory bound of the cache: ``cache_sequences`` x 2 sensors x duration x 2.1 MB
+    (4 x 2.5 GB = 10 GB at the default).  All ranks yield the same number of indices (shortest rank's count).
+    With ``-sr > 1`` and the reference's random index multiplier (datasets/dataset.py:121-124) a sampled index may land
+    in an earlier sequence than the one it is grouped with: still correct, occasionally a miss."""
+
+    def __init__(self, dataset, group=4, seed=0, rank=0, world=1):
+        self.ds, self.group, self.seed, self.rank, self.world = dataset, max(1, int(group)), int(seed), rank, world
+        self.epoch = 0
+        sr = dataset.sampling_ratio
+        self.by_seq = OrderedDict()
+        for i in range(len(dataset)):
+            self.by_seq.setdefault(dataset.items[min(i * sr, len(dataset.items) - 1)]["seq"], []).append(i)
+        if len(self.by_seq) < world:
+            raise ValueError("%d sequences cannot be sharded over %d ranks" % (len(self.by_seq), world))
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _plan(self):
+        rng = np.random.default_rng([self.seed, self.epoch])
+        seqs = list(self.by_seq)
+        rng.shuffle(seqs)
+        per_rank = len(seqs) // self.world
+        shares = [seqs[r::self.world][:per_rank] for r in range(self.world)]
+        return shares, min(sum(len(self.by_seq[s]) for s in sh) for sh in shares)
+
+    def __len__(self):
+        return self._plan()[1]
+
+    def __iter__(self):
+        shares, n = self._plan()
+        mine = shares[self.rank]
+        rng = np.random.default_rng([self.seed, self.epoch, self.rank + 1])
+        out = []
+        for g0 in range(0, len(mine), self.group):
+            pool = np.concatenate([np.asarray(self.by_seq[s]) for s in mine[g0:g0 + self.group]])
+            rng.shuffle(pool)
+            out.extend(int(i) for i in pool)
+        return iter(out[:n])
+
+
 def getDataset(phase, cfg, args, random=True):
     """Reference signature (datasets/dataset.py:14).  ``dataDir: synthetic`` selects the build-owned generator,
     ``DATASET.rawDir`` (opt-in key) the raw-capture reader, anything else the reference's ``.npy`` layout — a missing

@@ -32,6 +32,54 @@ def set_math(mode):
     MATH = mode
 
 
+# Per-region precision inside a bf16 run: PRECISION[region] = "f32" runs that region of HuPRNet.forward on the fp32 matrix
+# pipe with fp32-stored activations (models/layers.py wraps its regions in ``region(name)``); casts happen at the region
+# borders (``to_act``).  Every autograd node remembers the mode of its forward and restores it for its backward, so the
+# switches hold for training too.  Used to localise where the bf16 path loses arg-max agreement (scripts/precision_regions.py)
+# and to keep the cheapest set that clears SURVEY 8(d)'s gate; HUPR_F32_REGIONS="lvl0,head" presets it.
+REGIONS = ("mnet", "enc1", "enc2", "enc3", "merge", "lvl0", "lvl1", "lvl2", "dec3", "dec2", "dec1", "head")
+PRECISION = {r: "f32" for r in os.environ.get("HUPR_F32_REGIONS", "").split(",") if r}
+
+
+class region:
+    """``with region("dec1"):`` — the ops inside follow PRECISION["dec1"] when the run is a bf16 run."""
+
+    def __init__(self, name):
+        assert name in REGIONS, name
+        self.name = name
+
+    def __enter__(self):
+        global MATH
+        self.prev = MATH
+        if MATH == "bf16" and PRECISION.get(self.name) == "f32":
+            MATH = "f32"
+        return self
+
+    def __exit__(self, *exc):
+        global MATH
+        MATH = self.prev
+        return False
+
+
+def _math_scoped(cls):
+    """Class decorator for the autograd nodes: the backward pass runs under the matrix-pipe mode of its forward."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *a):
+        ctx._hupr_math = MATH
+        return fwd(ctx, *a)
+
+    def backward(ctx, *g):
+        global MATH
+        prev, MATH = MATH, ctx._hupr_math
+        try:
+            return bwd(ctx, *g)
+        finally:
+            MATH = prev
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
 def _fn(stem):
     return getattr(rt.lib(), "hupr_%s_%s" % (stem, MATH))
 
@@ -338,6 +386,7 @@ def _ksize(w):
     return (1,) + k if len(k) == 2 else k
 
 
+@_math_scoped
 class ConvFn(torch.autograd.Function):
     """Stride-1 convolution (nn.Conv3d / nn.Conv2d of the reference) with optional bias and fused
     residual add.  ``pad`` is (pd, ph, pw)."""
@@ -402,6 +451,7 @@ class ConvFn(torch.autograd.Function):
         return dx, _pret(weight, dw, dw_direct), _pret(ctx.bias_ref, db, db_direct), dres, None, None
 
 
+@_math_scoped
 class DualConvFn(torch.autograd.Function):
     """Two bias-free "same" 3x3(x3) convolutions of one bf16-stored map (the main[0] / downsample[0] pair of a
     BasicBlock3D, reference models/layers.py:55-65) as one autograd node, so that the two input gradients are summed
@@ -461,6 +511,7 @@ def conv(x, weight, bias=None, res=None, pad=(0, 0, 0), stats=False):
     return ConvFn.apply(x, weight, bias, res, tuple(pad), bool(stats))
 
 
+@_math_scoped
 class TemporalMergeFn(torch.autograd.Function):
     """Frame-axis merge: Conv3d with kernel (G,1,1), no padding and no bias on a (B,G,H,W,C) map (the
     l1temporalMerge / l2temporalMerge / temporalMerge of the reference, models/layers.py:195-197,218-220), taking
@@ -502,6 +553,7 @@ class TemporalMergeFn(torch.autograd.Function):
         return dx, _pret(weight, dw, direct)
 
 
+@_math_scoped
 class MergeDownFn(torch.autograd.Function):
     """An encoder level map feeds TWO consumers (reference models/layers.py:212-217): its temporal merge and the next level's
     align_corners down-sampling.  As separate nodes autograd adds their two input gradients with a kernel of its own (three
@@ -637,6 +689,7 @@ def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training, beta=None, fwd=None):
     return dx, _pret(gamma, dg, dg_direct), _pret(beta, db, db_direct)
 
 
+@_math_scoped
 class BNActFn(torch.autograd.Function):
     """y = [relu](batch_norm(x)).  ``bn`` is the parameter holder (running stats updated in place)."""
 
@@ -671,6 +724,7 @@ class BNActFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None
 
 
+@_math_scoped
 class BNAddBNReLUFn(torch.autograd.Function):
     """y = relu(bn_a(x1) + bn_b(x2)) — the tail of BasicBlock3D.forward (models/layers.py:66-70)."""
 
@@ -731,6 +785,7 @@ class BNAddBNReLUFn(torch.autograd.Function):
                 None, None, None)
 
 
+@_math_scoped
 class PReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, alpha):
@@ -755,6 +810,7 @@ class PReLUFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------
+@_math_scoped
 class MNetFn(torch.autograd.Function):
     """x (B,G,F,2,R,A,E) — or its elevation mean as planes (B,G,16,R,A) — -> (B, G, R, A, 32) channels-last, depth = group frame."""
 
@@ -796,6 +852,7 @@ class MNetFn(torch.autograd.Function):
         return None, _pret(weight, dw, dw_direct), _pret(bias, db, db_direct), None
 
 
+@_math_scoped
 class InterpFn(torch.autograd.Function):
     """align_corners=True linear resampling of a channels-last (B,D,H,W,C) tensor to ``size``."""
 
@@ -836,6 +893,7 @@ def _cast(x, dtype):
     return y
 
 
+@_math_scoped
 class CastFn(torch.autograd.Function):
     """Boundary of the bf16-activation region: y = x in ``dtype``; the gradient comes back in x's dtype."""
 
@@ -851,6 +909,12 @@ class CastFn(torch.autograd.Function):
 
 def cast(x, dtype):
     return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
+def to_act(x, decoder=False):
+    """Region border: ``x`` in the activation storage type of the current mode (bf16 inside bf16-activation regions)."""
+    want = torch.bfloat16 if (act_bf16() and (ACT_BF16_DECODER or not decoder)) else torch.float32
+    return cast(x, want)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -872,6 +936,7 @@ def _attn_ws(B, N, C, device):
     return workspace(nbytes, device) if nbytes else None
 
 
+@_math_scoped
 class AttentionFn(torch.autograd.Function):
     """MSCSA attention (models/layers.py:126-133) on token-major tensors (B, N, C):
     S[j,k] = sum_c K[j,c] Q[k,c];  P = softmax over keys j;  out[k,c] = sum_j P[j,k] V[j,c] (+ V[k,c])."""
@@ -968,6 +1033,7 @@ def mscsa_level_fused_ok(ra):
     return LEVEL_FUSION and MATH == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
 
 
+@_math_scoped
 class MSCSALevelFn(torch.autograd.Function):
     """One level of the multi-scale cross/self attention (models/layers.py:150-163 of the reference): eight 1x1
     projections of the two maps and the four attentions they feed, as one autograd node.
@@ -1132,6 +1198,7 @@ class MSCSALevelFn(torch.autograd.Function):
 GCN_MATH = None if os.environ.get("HUPR_GCN_BF16", "0") == "1" else "f32"
 
 
+@_math_scoped
 class GCNLayerFn(torch.autograd.Function):
     """y = act( (W x) A + bias ) == W (x A) + bias  (models/gcn_networks.py:23-29); x, y: (B, F, ld=16)."""
 
@@ -1174,6 +1241,7 @@ class GCNLayerFn(torch.autograd.Function):
         return dx, dw, dbias, None, None
 
 
+@_math_scoped
 class SigmoidHeadFn(torch.autograd.Function):
     """channels-last logits (B, HW, ld) -> probabilities (B, K, HW) in NCHW order."""
 
@@ -1196,6 +1264,7 @@ class SigmoidHeadFn(torch.autograd.Function):
         return dx, None
 
 
+@_math_scoped
 class BCEFn(torch.autograd.Function):
     """nn.BCELoss(reduction='mean') on probabilities."""
 

@@ -21,5 +21,6 @@ class MNet(nn.Module):
         """VRDAEmaps: (B,G,F,2,R,A,E) fp32 -> channels-last (B, G, R, A, out_channels); stored as bf16 when the
         encoders run on bf16 activations (functional.act_bf16()).  Also accepts the tensor already averaged over its
         elevation axis, as planes (B, G, 16 = 2 f + c, R, A) — what the fused FFT loader emits (fft_chain_loader_means)."""
-        return F_.MNetFn.apply(VRDAEmaps, self.temporalConvWx1x1.weight, self.temporalConvWx1x1.bias,
-                               torch.bfloat16 if F_.act_bf16() else torch.float32)
+        with F_.region("mnet"):
+            return F_.MNetFn.apply(VRDAEmaps, self.temporalConvWx1x1.weight, self.temporalConvWx1x1.bias,
+                                   torch.bfloat16 if F_.act_bf16() else torch.float32)

@@ -156,18 +156,26 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
 
     def forward(self, ral1maps, ral2maps, ramaps, rel1maps, rel2maps, remaps):
         # with bf16 activations (F_.act_bf16()) the BasicBlock2D stacks (3x3 convolutions, PReLU, up-sampling) read and
-        # write bf16 too; the attention outputs are cast once on the way in, the 1x1 head gets fp32 back
-        act = torch.bfloat16 if (F_.act_bf16() and F_.ACT_BF16_DECODER) else torch.float32
-        # bf16 decoder input: a fused level hands back its four maps already concatenated and cast (one tensor)
-        lvl = lambda i, ra, re: [F_.cast(t, act) for t in self._level(i, ra, re, act == torch.bfloat16 and F_.CAT_FUSION)]
-        maps = self.decoderLayer3(torch.cat(lvl(0, ramaps, remaps), 4))
-        maps = self.decoderLayer2(torch.cat([maps] + lvl(1, ral2maps, rel2maps), 4))
-        x = torch.cat([maps] + lvl(2, ral1maps, rel1maps), 4)
-        x = F_.cast(self.decoderLayer1[1](self.decoderLayer1[0](x)), torch.float32)
+        # write bf16 too; the attention outputs are cast once on the way in, the 1x1 head gets fp32 back.  Every stage sits in a
+        # precision region (F_.region): a region switched to fp32 takes / hands over its maps through casts at its borders.
+        maps = None
+        stages = ((0, "dec3", self.decoderLayer3, ramaps, remaps), (1, "dec2", self.decoderLayer2, ral2maps, rel2maps),
+                  (2, "dec1", self.decoderLayer1[:2], ral1maps, rel1maps))
+        for i, dec, stack, ra, re in stages:
+            with F_.region(dec):
+                bf16_in = F_.act_bf16() and F_.ACT_BF16_DECODER
+            with F_.region("lvl%d" % i):
+                # bf16 decoder input: a fused level hands back its four maps already concatenated and cast (one tensor)
+                lv = self._level(i, ra, re, bf16_in and F_.CAT_FUSION)
+            with F_.region(dec):
+                parts = ([] if maps is None else [maps]) + list(lv)
+                maps = stack(torch.cat([F_.to_act(t, decoder=True) for t in parts], 4))
+        x = F_.cast(maps, torch.float32)
         # 1x1 head with the 14 output channels zero-padded to 16 so later kernels stay float4-aligned
-        head = self.decoderLayer1[2]
-        w16 = torch.nn.functional.pad(head.weight, (0, 0, 0, 0, 0, 0, 0, 16 - self.numKeypoints))
-        maps16 = F_.conv(x, w16, None, None, (0, 0, 0))
+        with F_.region("head"):
+            head = self.decoderLayer1[2]
+            w16 = torch.nn.functional.pad(head.weight, (0, 0, 0, 0, 0, 0, 0, 16 - self.numKeypoints))
+            maps16 = F_.conv(x, w16, None, None, (0, 0, 0))
         return maps16, self.gcn(maps16)
 
 
@@ -196,23 +204,33 @@ class Encoder3D(nn.Module):
         self.l2temporalMerge = nn.Conv3d(nf * 4, nf * 4, (G // 2, 1, 1), 1, 0, bias=False)
         self.temporalMerge = nn.Conv3d(nf * 8, nf * 8, (G // 4, 1, 1), 1, 0, bias=False)
 
+    def _merge_and_down(self, x, merge, resample):
+        """A level map feeds its temporal merge AND the next level's down-sampling: one autograd node for the pair where the
+        fused kernels apply (bf16-stored map, bf16 math), so the two input gradients are summed inside the resampling backward
+        instead of by a separate pass (F_.MergeDownFn).  -> (merged fp32, down-sampled in x's storage type)."""
+        if F_.merge_down_ok(x):
+            return F_.MergeDownFn.apply(x, merge.weight, resample.size_of(x))
+        if x.dtype == torch.bfloat16 and F_.MATH != "bf16":          # the "merge" region on the fp32 pipe
+            x = F_.cast(x, torch.float32)
+        return F_.temporal_merge(x, merge.weight), resample(x)
+
     def forward(self, maps):
         """maps: channels-last (B, G, R, A, nf) -> three channels-last (B,1,h,w,c) fp32 feature maps.
 
         With bf16 activations (F_.act_bf16()) everything up to the temporal merges — the 3x3x3 convolutions,
         BatchNorms and resamplings that dominate the step — reads and writes bf16 tensors; the merges read those
-        bf16 maps directly and emit fp32 (F_.temporal_merge)."""
-        l1maps = self.layer1[1](_conv(maps, self.layer1[0]))
-        if F_.merge_down_ok(l1maps):
-            # a level map feeds its temporal merge AND the next level's down-sampling: one autograd node for the pair, so the two
-            # input gradients are summed inside the resampling backward instead of by a separate pass (F_.MergeDownFn)
-            l1m, d1 = F_.MergeDownFn.apply(l1maps, self.l1temporalMerge.weight, self.layer2[0].size_of(l1maps))
-            l2maps = self.layer2[2](self.layer2[1](d1))
-            l2m, d2 = F_.MergeDownFn.apply(l2maps, self.l2temporalMerge.weight, self.layer3[0].size_of(l2maps))
-            l3maps = self.layer3[2](self.layer3[1](d2))
+        bf16 maps directly and emit fp32 (F_.temporal_merge).  The three levels and the merges are precision regions."""
+        with F_.region("enc1"):
+            l1maps = self.layer1[1](_conv(F_.to_act(maps), self.layer1[0]))
+        with F_.region("merge"):
+            l1m, d1 = self._merge_and_down(l1maps, self.l1temporalMerge, self.layer2[0])
+        with F_.region("enc2"):
+            l2maps = self.layer2[2](self.layer2[1](F_.to_act(d1)))
+        with F_.region("merge"):
+            l2m, d2 = self._merge_and_down(l2maps, self.l2temporalMerge, self.layer3[0])
+        with F_.region("enc3"):
+            l3maps = self.layer3[2](self.layer3[1](F_.to_act(d2)))
+        with F_.region("merge"):
+            if l3maps.dtype == torch.bfloat16 and F_.MATH != "bf16":
+                l3maps = F_.cast(l3maps, torch.float32)
             return l1m, l2m, F_.temporal_merge(l3maps, self.temporalMerge.weight)
-        l2maps = self.layer2(l1maps)
-        l3maps = self.layer3(l2maps)
-        return (F_.temporal_merge(l1maps, self.l1temporalMerge.weight),
-                F_.temporal_merge(l2maps, self.l2temporalMerge.weight),
-                F_.temporal_merge(l3maps, self.temporalMerge.weight))

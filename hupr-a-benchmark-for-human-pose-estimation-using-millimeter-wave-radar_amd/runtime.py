@@ -136,6 +136,7 @@ SIGNATURES = {
     "hupr_comm_unique_id": (c_int, [c_void_p]),
     "hupr_comm_init_rank": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_int, c_int]),
     "hupr_comm_destroy": (c_int, [c_void_p]),
+    "hupr_comm_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "hupr_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "hupr_broadcast_bucket": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
 }
@@ -165,6 +166,11 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def last_error():
+    """The calling thread's last error message (hupr_last_error)."""
+    return lib().hupr_last_error().decode()
 
 
 def check(rc):

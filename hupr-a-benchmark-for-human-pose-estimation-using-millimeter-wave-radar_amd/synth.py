@@ -195,6 +195,52 @@ def keypoints(batch, seed, K=14, lo=40, hi=216):
 
 
 # ----------------------------------------------------------------------------
+# pose scenes: a LEARNABLE synthetic task (the uniform-noise inputs above carry no information about the labels, so a
+# network fitted to them memorises its batch and answers unseen samples with multi-modal maps — useless for gating a
+# reduced-precision path on arg-max agreement).  A scene puts one reflector per joint into the (range, azimuth) plane of
+# both sensors, at the cell the joint's target heat-map is centred on; the joint's identity is carried by WHEN and in
+# WHICH Doppler half the reflector shows: joint k lives in frame k % G of the window and in Doppler slots
+# 4 (k // G) .. 4 (k // G) + 3 (the two halves are the two "channels" MNet sees after the reference's .view,
+# models/networks.py:26-27).  On top of unit Gaussian noise, like real Normalize output.
+# ----------------------------------------------------------------------------
+POSE_AMP, POSE_SIGMA = 3.0, 1.25
+
+
+def pose_scene_blobs(joints, G=8, R=64, A=64, img=256):
+    """joints (B,K,2) integer (x, y) image coordinates -> reflector planes (B, G, 2, R, A) fp32 (unit-height Gaussians)."""
+    joints = np.asarray(joints)
+    B, K, _ = joints.shape
+    mu = (joints.astype(np.int64).astype(np.float64) * (R / img) + 0.5).astype(np.int64)      # the target centres (misc/utils.py:37-38)
+    rr = np.arange(R, dtype=np.float64)[:, None]
+    aa = np.arange(A, dtype=np.float64)[None, :]
+    out = np.zeros((B, G, 2, R, A), dtype=np.float64)
+    for b in range(B):
+        for k in range(K):
+            x, y = mu[b, k]
+            out[b, k % G, (k // G) % 2] += np.exp(-((rr - y) ** 2 + (aa - x) ** 2) / (2.0 * POSE_SIGMA ** 2))
+    return out.astype(np.float32)
+
+
+def pose_scene_inputs(blobs, noise_h, noise_v, amp=POSE_AMP):
+    """noise_* (B,G,F,2,R,A,E) unit normal (numpy arrays or torch tensors), blobs (B,G,2,R,A) of the same kind ->
+    the two network inputs: noise + amp * reflectors broadcast over re/im, elevation and the 4 Doppler slots of their half."""
+    B, G, F = noise_h.shape[:3]
+    half = F // 2
+    b = blobs[:, :, :, None, None, :, :, None]                         # (B,G,2,1,1,R,A,1)
+    sh = (B, G, 2, half) + tuple(noise_h.shape[3:])
+    return ((noise_h.reshape(sh) + amp * b).reshape(noise_h.shape),
+            (noise_v.reshape(sh) + amp * b).reshape(noise_v.shape))
+
+
+def pose_scenes(batch, seed):
+    """Deterministic held-out scenes: (hori, vert, joints) numpy, regenerable anywhere from the seed."""
+    joints = keypoints(batch, 7919 + 104729 * int(seed))
+    nh, nv = model_inputs(batch, 7919 + 104729 * int(seed))
+    h, v = pose_scene_inputs(pose_scene_blobs(joints), nh, nv)
+    return h, v, joints
+
+
+# ----------------------------------------------------------------------------
 # HuPRNet parameter inventory (reference state_dict contract, SURVEY.md App. C)
 # ----------------------------------------------------------------------------
 def _bn_specs(pre, c):

@@ -52,10 +52,32 @@ class TorchTransport:
         dist.broadcast(flat, src=src, group=self.group)
 
 
+_ID_ERROR = b"HUPR_RCCL_ID_ERROR"          # sentinel rank 0 publishes instead of the id when it could not create one
+
+
+def _all_ok(ok, group, device):
+    """Group decision: True only if EVERY rank reports success (MIN all-reduce over the control plane; a CPU tensor rides
+    gloo, and a group without a CPU backend gets a device tensor)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    try:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    except (RuntimeError, ValueError):
+        flag = flag.to(device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 class RcclTransport:
     """The C ABI's own RCCL communicator (``hupr_comm_*`` / ``hupr_allreduce_bucket``), bound to the current device.
     The 128-byte communicator id is created on rank 0 and handed to the other ranks through the existing
-    ``torch.distributed`` group (any backend); a single-rank communicator needs no process group at all."""
+    ``torch.distributed`` group (any backend); a single-rank communicator needs no process group at all.
+
+    Construction is a group decision in three agreed phases, so that a failure on SOME ranks can neither leave the others
+    blocked nor split the job over two transports: (1) every rank binds librccl — agreed; (2) rank 0 creates the id and
+    publishes it, or an error sentinel the waiting ranks fail fast on; (3) ncclCommInitRank (collective inside RCCL) —
+    agreed; a rank whose peers failed destroys its communicator again.  Any disagreement raises on every rank."""
     name = "rccl (hupr_allreduce_bucket)"
     capturable = True
 
@@ -63,40 +85,63 @@ class RcclTransport:
         from .. import runtime as rt
         self.rt, self.L = rt, rt.lib()
         self.device = device
+        self.comm = None
         multi = dist.is_initialized() and dist.get_world_size(group) > 1
         self.rank = dist.get_rank(group) if multi else 0
         self.world = dist.get_world_size(group) if multi else 1
-        rt.check(self.L.hupr_comm_load(None))
+        loaded = self.L.hupr_comm_load(None) == 0
+        if not _all_ok(loaded, group, device):
+            raise rt.HuprError("librccl could not be bound on every rank (this rank: %s)" % ("ok" if loaded else rt.last_error()))
         uid = ctypes.create_string_buffer(128)
+        got = None
         if self.rank == 0:
-            rt.check(self.L.hupr_comm_unique_id(uid))
+            got = uid.raw if self.L.hupr_comm_unique_id(uid) == 0 else _ID_ERROR
+            err = rt.last_error() if got == _ID_ERROR else ""
         if multi:
-            uid = ctypes.create_string_buffer(self._exchange_id(uid.raw if self.rank == 0 else None, group), 128)
+            got = self._exchange_id(got, group)
+        if got == _ID_ERROR:
+            raise rt.HuprError("rank 0 could not create an RCCL communicator id" + (": " + err if self.rank == 0 else ""))
+        uid = ctypes.create_string_buffer(got, 128)
         comm = ctypes.c_void_p()
         with torch.cuda.device(device):
-            rt.check(self.L.hupr_comm_init_rank(ctypes.byref(comm), uid, self.world, self.rank))
-        self.comm = comm
+            ok = self.L.hupr_comm_init_rank(ctypes.byref(comm), uid, self.world, self.rank) == 0
+        err = "" if ok else rt.last_error()
+        if ok:
+            self.comm = comm
+        if not _all_ok(ok, group, device):
+            self.close()
+            raise rt.HuprError("ncclCommInitRank did not succeed on every rank (this rank: %s)" % (err or "ok"))
 
     _n_comms = 0
 
     @classmethod
     def _exchange_id(cls, uid_bytes, group):
-        """Rank 0's 128-byte communicator id to every rank.  Default group: through the rendezvous key-value store (no
-        collective, no device traffic: works whatever backends the group was initialised with); sub-groups: object broadcast."""
+        """Rank 0's 128-byte communicator id (or the error sentinel) to every rank.  Default group: through the rendezvous
+        key-value store (no collective, no device traffic: works whatever backends the group was initialised with);
+        sub-groups, or a store that cannot be reached ON ANY RANK (agreed, so nobody waits on a key the others never
+        write): object broadcast."""
         if group is None:
+            store = None
             try:
                 store = dist.distributed_c10d._get_default_store()
+            except Exception as exc:      # noqa: BLE001 — private accessor
+                sys.stderr.write("hupr: no rendezvous store for the RCCL id (%s)\n" % exc)
+            if _all_ok(store is not None, group, torch.device("cpu")):
                 key = "hupr_rccl_uid_%d" % cls._n_comms
                 cls._n_comms += 1
                 if uid_bytes is not None:
                     store.set(key, uid_bytes)
                     return uid_bytes
-                return bytes(store.get(key))                  # blocks until rank 0 has published it
-            except Exception as exc:      # noqa: BLE001 — private accessor: fall back to the collective
-                sys.stderr.write("hupr: store exchange of the RCCL id failed (%s); using broadcast_object_list\n" % exc)
+                return bytes(store.get(key))                  # blocks until rank 0 has published the id or the sentinel
         box = [uid_bytes]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return box[0]
+
+    def ranks(self):
+        """(n_ranks, rank) as the live communicator reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = ctypes.c_int(0), ctypes.c_int(0)
+        self.rt.check(self.L.hupr_comm_info(self.comm, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
 
     def all_reduce(self, flat, stream=None):
         """Enqueue on ``stream`` (a torch stream; default: the current one).  Returns None: ordering is the stream's."""
@@ -111,11 +156,13 @@ class RcclTransport:
     def close(self):
         if self.comm is not None and self.comm.value:
             self.L.hupr_comm_destroy(self.comm)
-            self.comm = None
+        self.comm = None
 
 
 def make_transport(device, group=None):
-    """RCCL through the C ABI for GPU buckets (fallback: torch.distributed on the nccl group), gloo for CPU tensors."""
+    """RCCL through the C ABI for GPU buckets (fallback: torch.distributed on the nccl group), gloo for CPU tensors.  The
+    constructor's failures are agreed over the control plane, so either every rank holds a native communicator or every
+    rank lands in the except branch together — never a mix of transports."""
     if device.type != "cuda" or os.environ.get("HUPR_COLLECTIVE", "rccl") == "torch":
         return TorchTransport(group)
     try:
@@ -298,6 +345,13 @@ class GradientBuckets:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         if self.reduce_this_pass:
             self._accum_live = False
+
+    def close(self):
+        """Release the native communicator (engines that are re-created would otherwise leak one each)."""
+        tr, self.transport = self.transport, None
+        if tr is not None and hasattr(tr, "close"):
+            tr.close()
+        self.active = False
 
     def flat_pairs(self):
         return [(b.flat_param, b.flat_grad) for b in self.buckets]

@@ -46,6 +46,10 @@ class TrainEngine:
             self._bn_counts[i] = m.num_batches_tracked
             m._buffers["num_batches_tracked"] = self._bn_counts[i]
 
+    def close(self):
+        """Release the exchange step's native communicator (call before building another engine in the same process)."""
+        self.buckets.close()
+
     # -- data -------------------------------------------------------------------------------------
     def preprocess(self, adc_hori, adc_vert):
         """int16 ADC cubes (B*G, 4, 192, 256, 2) per sensor -> the two network inputs.  Default (``fuse_elevation_mean``): the

@@ -13,6 +13,7 @@ import torch.distributed as dist
 import torch.utils.data as data
 
 from ..datasets import getDataset
+from ..datasets.dataset import HuPRRawADC, SequenceGroupedSampler
 from ..misc.oks_eval import evaluate_keypoints
 from ..misc.plot import plotHumanPose
 from .base import BaseRunner
@@ -36,7 +37,13 @@ class Runner(BaseRunner):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if not args.eval:
             self.trainSet = getDataset("train", cfg, args)
-            sampler = data.distributed.DistributedSampler(self.trainSet, shuffle=True, drop_last=True) if self.world > 1 else None
+            if isinstance(self.trainSet, HuPRRawADC):
+                # raw captures: a cache miss costs a whole sequence (0.9 GB of adc_data.bin + its FFT), so the loader walks
+                # shuffled GROUPS of sequences and shuffles the windows inside a group (SequenceGroupedSampler)
+                sampler = SequenceGroupedSampler(self.trainSet, group=self.trainSet.cache_sequences, seed=args.seed,
+                                                 rank=self.rank, world=self.world)
+            else:
+                sampler = data.distributed.DistributedSampler(self.trainSet, shuffle=True, drop_last=True) if self.world > 1 else None
             self.trainLoader = data.DataLoader(self.trainSet, cfg.TRAINING.batchSize, shuffle=sampler is None,
                                                sampler=sampler, num_workers=0, collate_fn=_collate,
                                                drop_last=self.world > 1)      # ragged last step only single-GPU
@@ -95,16 +102,20 @@ class Runner(BaseRunner):
         ap = 0.0
         if self.rank == 0:
             self.writeKeypoints(savePreds)
+            # ground truth = the whole <phase>_gt.json where the dataset has one (the reference scores against the full file,
+            # datasets/dataset.py:68-88: with -sr > 1 the frames the loader never visited count as misses); the synthetic
+            # dataset has no file, its ground truth is what the loader visited
+            full_gt = getattr(self.testSet, "gt_annotations", None)
+            if full_gt is not None:
+                gts = full_gt
             names = ["AP", "Ap .5", "AP .75", "AP (M)", "AP (L)", "AR", "AR .5", "AR .75", "AR (M)", "AR (L)"]
-            if getattr(self.args, "keypoints", False):
+            if getattr(self.args, "keypoints", False):            # evaluateEach, THEN the summary (tools/run.py:60-63)
                 idx2j = self.cfg.DATASET.idxToJoints
                 for k in range(self.numKeypoints):
-                    ap = float(evaluate_keypoints(gts, savePreds, idx_keypoint=k)[0])
-                    print("%s: %.3f" % (idx2j[k], ap))
-            else:
-                stats = evaluate_keypoints(gts, savePreds)
-                print("  ".join("%s: %.3f" % (n, s) for n, s in zip(names, stats)))
-                ap = float(stats[0])
+                    print("%s: %.3f" % (idx2j[k], float(evaluate_keypoints(gts, savePreds, idx_keypoint=k)[0])))
+            stats = evaluate_keypoints(gts, savePreds)
+            print("  ".join("%s: %.3f" % (n, s) for n, s in zip(names, stats)))
+            ap = float(stats[0])
         if self.world > 1:
             box = [ap]
             dist.broadcast_object_list(box, src=0)
@@ -115,7 +126,7 @@ class Runner(BaseRunner):
         for epoch in range(self.start_epoch, self.cfg.TRAINING.epochs):
             loss_list = []
             self.logger.clear(len(self.trainLoader.dataset))
-            if self.world > 1:
+            if hasattr(self.trainLoader.sampler, "set_epoch"):
                 self.trainLoader.sampler.set_epoch(epoch)
             for idxBatch, batch in enumerate(self.trainLoader):
                 hori, vert = self._inputs(batch)

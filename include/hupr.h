@@ -432,6 +432,8 @@ int hupr_comm_load(const char* librccl_path_or_null);
 int hupr_comm_unique_id(void* id_out /* HUPR_COMM_ID_BYTES */);
 int hupr_comm_init_rank(hupr_comm_t* comm_out, const void* id, int n_ranks, int rank);
 int hupr_comm_destroy(hupr_comm_t comm);
+/* ncclCommCount / ncclCommUserRank of a live communicator (what the bench line reports as rccl_ranks). */
+int hupr_comm_info(hupr_comm_t comm, int* n_ranks_out, int* rank_out);
 /* bucket[i] <- sum over ranks of bucket[i]  (count elements of dtype HUPR_COMM_F32 / HUPR_COMM_BF16) */
 int hupr_allreduce_bucket(hupr_comm_t comm, void* bucket, size_t count, int dtype, hupr_stream_t stream);
 /* bucket <- rank `root`'s bucket (initial parameter synchronisation) */

@@ -216,6 +216,66 @@ def make_trained():
           (losses[-1][0], np.median(peak(p1)), np.median(peak(p2)), np.median(peak(q1)), np.median(peak(q2))))
 
 
+def make_trained_spread():
+    """how far does the REFERENCE drift from ITSELF over the same TRAIN_STEPS fit when only the rounding
+    changes?  Re-runs make_trained()'s loop on the imported reference (a) with torch.set_num_threads(1) (different reduction
+    order inside ATen's convolutions / BatchNorm), (b) in fp64 (the un-rounded trajectory), (c) with the input batch
+    perturbed by one fp32 ulp-scale relative noise (1e-7).  Stores the per-step losses next to the default run's
+    (model_trained.npz `losses`) in model_trained_spread.npz; tests/test_trained_gpu.py gates the HIP fp32 path's deviation
+    against this spread instead of a flat tolerance.  (`python make_golden.py spread`; ~1 h on 8 cores.)"""
+    import time
+    cfg = ref_import.load_cfg()
+    models = ref_import.model_module()
+    LossComputer, _, _, _ = ref_import.misc_parts()
+    st = synth.hupr_state(MODEL_SEED, gain=GAIN)
+    hn, vn = synth.model_inputs(2, INPUT_SEED)
+    gtn = synth.keypoints(2, KP_SEED)
+    out = {}
+
+    def fit(tag, dtype, threads, eps):
+        if threads:
+            torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        net = models.HuPRNet(cfg)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+        net = net.to(dtype)
+        net.radarDecoder.gcn.A = net.radarDecoder.gcn.A.to(dtype)     # plain attribute, not a buffer (gcn_networks.py:44)
+        h, v = torch.from_numpy(hn).to(dtype), torch.from_numpy(vn).to(dtype)
+        if eps:
+            g = torch.Generator().manual_seed(1234)
+            h = h * (1 + eps * torch.randn(h.shape, generator=g).to(dtype))
+            v = v * (1 + eps * torch.randn(v.shape, generator=g).to(dtype))
+        gt = torch.from_numpy(gtn)
+        lc = LossComputer(cfg, "cpu")
+        if dtype == torch.float64:                      # keep the whole loss in fp64 (the targets are built as fp32)
+            bce = lc.bce
+            lc.bce = lambda p, t: bce(p, t.to(p.dtype))
+        opt = torch.optim.Adam(net.parameters(), lr=TRAIN_LR, betas=(0.9, 0.999), weight_decay=TRAIN_WD)
+        losses, t0 = [], time.time()
+        net.train()
+        for it in range(TRAIN_STEPS):
+            opt.zero_grad()
+            p1, p2 = net(h, v)
+            loss, loss2, _, _ = lc.computeLoss((p1, p2), gt)
+            loss.backward()
+            opt.step()
+            losses.append((loss.item(), loss2.item()))
+            if it % 10 == 0:
+                print("  [%s] step %d loss %.6f %.6f (%.0fs)" % (tag, it, loss.item(), loss2.item(), time.time() - t0), flush=True)
+        out["losses_" + tag] = np.array(losses)
+        np.savez_compressed(os.path.join(HERE, "model_trained_spread.npz"), steps=TRAIN_STEPS, **out)
+
+    nt = torch.get_num_threads()
+    fit("f64", torch.float64, nt, 0.0)
+    fit("eps", torch.float32, nt, 1e-7)
+    fit("t1", torch.float32, 1, 0.0)
+    base = np.load(os.path.join(HERE, "model_trained.npz"))["losses"]
+    for k, v in out.items():
+        rel = np.abs(v - base) / base
+        print("reference vs reference (%s): rel loss deviation at steps 3/10/30/120: %.2e %.2e %.2e %.2e" %
+              (k, rel[:3].max(), rel[:10].max(), rel[:30].max(), rel.max()))
+
+
 def make_dataset():
     """The reference's HuPR3D_horivert (datasets/dataset.py:17-165) reading the miniature on-disk tree of
     synth.write_tiny_dataset: item dictionaries (network inputs as strided samples + moments, labels), the
@@ -380,6 +440,9 @@ if __name__ == "__main__":
     assert ref_import.available(), "reference tree not found"
     if len(sys.argv) > 1 and sys.argv[1] == "trained":
         make_trained()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "spread":
+        make_trained_spread()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         make_dataset()

@@ -1,0 +1,114 @@
+"""Test infrastructure: fit HuPRNet to the LEARNABLE synthetic task (hupr_amd.synth.pose_scene_*) on the GPU, so that the
+parity gates on reduced-precision paths see what SURVEY 8(d) had in mind — a trained network whose eval-mode maps on UNSEEN
+samples are uni-modal Gaussian blobs with a decisive maximum (the reference's trained maps: max/mean ~ 50) — instead of the
+multi-modal maps of a network that memorised two noise samples.
+
+The fit runs on the benched path (bf16 matrix pipe + bf16 activations, TrainEngine, fused Adam) from the seed weights, on a
+fresh batch of scenes every step (noise drawn on the device; joints from a seeded NumPy generator), so it generalises; the
+resulting weights are then handed to the oracle / the fp32 path / the bf16 path on held-out scenes that regenerate anywhere
+from their seed (synth.pose_scenes).  Used by tests/test_trained_gpu.py and scripts/precision_regions.py.
+"""
+import time
+
+import numpy as np
+import torch
+
+from hupr_amd import functional as F_, synth
+from hupr_amd.config_tree import load_config
+
+
+def scene_batch(batch, rng, gen, device):
+    """One training batch of scenes: noise from the device generator, reflectors from NumPy joints."""
+    joints = rng.integers(40, 216, size=(batch, 14, 2)).astype(np.int64)
+    blobs = torch.from_numpy(synth.pose_scene_blobs(joints)).to(device)
+    shape = (batch, 8, 8, 2, 64, 64, 8)
+    nh = torch.randn(shape, device=device, generator=gen)
+    nv = torch.randn(shape, device=device, generator=gen)
+    h, v = synth.pose_scene_inputs(blobs, nh, nv)
+    return h.contiguous(), v.contiguous(), torch.from_numpy(joints)
+
+
+def hit_rate(p, joints):
+    """Fraction of joints whose arg-max is the target centre (misc/utils.py:37-38)."""
+    B = p.shape[0]
+    mu = (joints.to(torch.float32) / 4 + 0.5).long()
+    want = (mu[..., 1] * 64 + mu[..., 0]).to(p.device)
+    return (p.reshape(B, 14, -1).argmax(-1) == want).float().mean().item()
+
+
+def fit(steps=600, batch=32, lr=1e-3, math="bf16", model_seed=1, gain=1.0, log_every=100, verbose=True):
+    """-> (state_dict on the GPU, cfg, log list of (step, loss, loss2))."""
+    from hupr_amd.tools.engine import TrainEngine
+    cfg = load_config()
+    dev = torch.device("cuda")
+    prev = F_.MATH
+    F_.set_math(math)
+    try:
+        eng = TrainEngine(cfg, device="cuda", lr=lr)
+        eng.model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in synth.hupr_state(model_seed, gain=gain).items()})
+        F_.invalidate_packed()
+        rng = np.random.default_rng(20240917)
+        gen = torch.Generator(device=dev).manual_seed(4321)
+        log, t0 = [], time.time()
+        for it in range(steps):
+            h, v, joints = scene_batch(batch, rng, gen, dev)
+            loss, loss2 = eng.train_step(h, v, joints)
+            if it % log_every == 0 or it == steps - 1:
+                log.append((it, loss.item(), loss2.item()))
+                if verbose:
+                    print("  pose fit step %4d  loss %.5f  (gcn %.5f)  %.0fs" % (it, log[-1][1], log[-1][2], time.time() - t0), flush=True)
+        torch.cuda.synchronize()
+        sd = {k: t.detach().clone() for k, t in eng.model.state_dict().items()}
+    finally:
+        F_.set_math(prev)
+    return sd, cfg, log
+
+
+def evaluate(sd, cfg, h, v, math, precision=None):
+    """Eval-mode forward of the weights ``sd`` under ``math`` (+ per-region precision switches) -> (p1, p2) on the device."""
+    from hupr_amd.models import HuPRNet
+    prev, prev_p = F_.MATH, dict(F_.PRECISION)
+    F_.set_math(math)
+    F_.PRECISION.clear()
+    F_.PRECISION.update(precision or {})
+    try:
+        net = HuPRNet(cfg).cuda().eval()
+        net.load_state_dict(sd)
+        F_.invalidate_packed()
+        with torch.no_grad():
+            p1, p2 = net(h, v)
+        torch.cuda.synchronize()
+    finally:
+        F_.set_math(prev)
+        F_.PRECISION.clear()
+        F_.PRECISION.update(prev_p)
+        F_.invalidate_packed()
+    return p1.float(), p2.float()
+
+
+def agreement(b, r):
+    """bf16-side map ``b`` against reference-side map ``r`` (any (B,...,64,64) layout with 14 joints per sample) ->
+    (identical fraction, within-1-pixel fraction, worst reference gap at a flipped index, max-abs difference)."""
+    n = b.shape[0] * 14
+    bb, rr = b.reshape(n, -1).float().cpu(), r.reshape(n, -1).float().cpu()
+    ab, ar = bb.argmax(1), rr.argmax(1)
+    d = torch.maximum((ab % 64 - ar % 64).abs(), (ab // 64 - ar // 64).abs())
+    gap = rr.max(1)[0] - rr.gather(1, ab[:, None])[:, 0]
+    return (d == 0).float().mean().item(), (d <= 1).float().mean().item(), gap.max().item(), (bb - rr).abs().max().item()
+
+
+def decode_ap(p2, joints, first_id=0):
+    """OKS AP of the decoded (PRGCN) head against the scene's joints, the way tools/run.py:57 / tools/base.py:124-152 decode:
+    key-point = arg-max (x, y) * 4, visibility 1, score 1."""
+    from hupr_amd.misc import oks_eval
+    B = p2.shape[0]
+    idx = p2.reshape(B, 14, -1).argmax(-1).cpu().numpy()
+    gts, dts = [], []
+    for b in range(B):
+        kp = np.stack([idx[b] % 64, idx[b] // 64], 1).astype(np.float64) * 4.0
+        j = np.asarray(joints[b], dtype=np.float64)
+        x0, y0 = j.min(0)
+        x1, y1 = j.max(0)
+        gts.append({"image_id": first_id + b, "keypoints": j, "bbox": [x0, y0, x1 - x0, y1 - y0]})
+        dts.append({"image_id": first_id + b, "keypoints": np.concatenate([kp, np.ones((14, 1))], 1).reshape(-1), "score": 1.0})
+    return oks_eval.evaluate_keypoints(gts, dts)[0]

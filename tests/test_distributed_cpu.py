@@ -212,3 +212,27 @@ def test_rccl_id_exchange_through_the_store_world2():
     out = mp.Manager().dict()
     mp.spawn(_uid_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] == out[1] == (bytes([1] * 128), bytes([7] * 128))
+
+
+def _agree_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hupr_amd.tools import distributed as D
+    cpu = torch.device("cpu")
+    res = [D._all_ok(True, None, cpu), D._all_ok(rank == 0, None, cpu), D._all_ok(rank == 1, None, cpu), D._all_ok(False, None, cpu)]
+    # rank 0 could not create an id: it publishes the sentinel, the waiting rank gets it instead of blocking forever
+    got = D.RcclTransport._exchange_id(D._ID_ERROR if rank == 0 else None, None)
+    out[rank] = (res, got == D._ID_ERROR)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_transport_choice_is_a_group_decision_world2():
+    """a native-communicator failure on SOME ranks must not split the job over two transports or leave ranks
+    blocked: every phase of RcclTransport's construction is agreed with a MIN all-reduce (all ranks see the same verdict),
+    and rank 0 publishes an error sentinel under the store key instead of leaving the other ranks waiting for an id."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_agree_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0] == out[1] == ([True, False, False, False], True)

@@ -235,3 +235,44 @@ def test_plot_human_pose_writes_skeleton_overlays(tmp_path):
     assert len(EDGES) == 14 and sorted(set(i for e in EDGES for i in e)) == list(range(14))
     red = (img[..., 0] == 255) & (img[..., 1] == 0)
     assert red.sum() > 14 * 20                               # joints + connecting lines drawn
+
+
+def test_sequence_grouped_sampler_keeps_the_raw_capture_cache_hot():
+    """with HuPRRawADC a uniformly shuffled loader misses its 4-sequence cache on nearly every sample (each miss =
+    a whole sequence read + transformed).  The sampler must (1) visit every index exactly once per epoch, (2) never have more
+    than `group` sequences open, finishing them before moving on (each sequence loaded once), (3) give the ranks disjoint
+    sequences and equal counts, (4) reshuffle per epoch, identically on every rank for the sequence order."""
+    from collections import OrderedDict
+    from hupr_amd.datasets.dataset import SequenceGroupedSampler
+    dur, seqs = 30, [3, 5, 8, 9, 12, 17, 20, 21, 33, 40]
+    items = [{"seq": s, "frame": f} for s in seqs for f in range(dur)]
+    class DS:
+        sampling_ratio = 1
+
+        def __len__(self):
+            return len(self.items)
+    ds = DS()
+    ds.items = items
+    smp = SequenceGroupedSampler(ds, group=4, seed=1)
+    order = list(smp)
+    assert sorted(order) == list(range(len(items))) and len(smp) == len(items)
+    # replay through an LRU of 4 sequences: exactly one load per sequence
+    cache, loads = OrderedDict(), 0
+    for i in order:
+        s = items[i]["seq"]
+        if s not in cache:
+            loads += 1
+            cache[s] = True
+            while len(cache) > 4:
+                cache.popitem(last=False)
+        else:
+            cache.move_to_end(s)
+    assert loads == len(seqs)
+    assert len({items[i]["seq"] for i in order[:32]}) > 1                # a batch still mixes recordings
+    smp.set_epoch(1)
+    assert list(smp) != order
+    # two ranks: disjoint sequences, equal counts, together all of them
+    a, b = (SequenceGroupedSampler(ds, group=4, seed=1, rank=r, world=2) for r in (0, 1))
+    ia, ib = list(a), list(b)
+    sa, sb = {items[i]["seq"] for i in ia}, {items[i]["seq"] for i in ib}
+    assert len(ia) == len(ib) == len(a) == 5 * dur and not (sa & sb) and len(sa | sb) == 10
