@@ -31,8 +31,10 @@ FWD_GFLOP, STEP_GFLOP = 137.09, 411.3          # per sample
 PEAK_F32_MFMA_TFLOPS = 157.3                   # MI355X_MICROARCH.md: dense fp32 MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0                 # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E
-FFT_LOADER_BYTES_PER_SF = 786432 + 2 * 98304 + 2097152      # int16 cube + RD round trip + fp32 loader output
-FFT_MEANS_BYTES_PER_SF = 786432 + 2 * 98304 + 262144        # ... with HuPRNet's elevation mean folded in (what the step runs)
+# ALGORITHMIC bytes per sensor-frame exactly as SURVEY.md 8(d) defines them: int16 cube in + loader tensor out.  The
+# range-Doppler intermediate the two-kernel chain hands over through HBM is implementation traffic, not algorithmic.
+FFT_LOADER_BYTES_PER_SF = 786432 + 2097152      # = 2 883 584: a1 + a2, fp32 (8 Doppler x 2 x 64 x 64 x 8) out
+FFT_MEANS_BYTES_PER_SF = 786432 + 262144        # = 1 048 576: ... with HuPRNet's elevation mean folded in (what the step runs)
 STRONG_GLOBAL_BATCH = 256                      # BASELINE.json configs[3]
 
 
@@ -93,19 +95,21 @@ def cpu_baseline():
                        "frames_per_s_as_written_loops_amortised": round(as_written, 4)}}
 
 
-def bench_inference(args, cfg, dev, rank, world, peak):
+def bench_inference(args, cfg, dev, rank, world, peak, steps=None, batch=None, emit=True):
     """BASELINE.json configs 'C2': eval-mode forward (MNet .. PRGCN heads) from normalised network inputs resident in HBM;
-    replicas only (no collective).  Not the headline metric — printed in the same JSON shape for convenience."""
+    replicas only (no collective).  Not the headline metric — `--workload c2` prints it in the same JSON shape, and the
+    default C3 line carries it as its `c2` object (B = 1 latency, one hipGraph replay per frame)."""
     from hupr_amd import synth
     from hupr_amd.models import HuPRNet
-    B = 1 if args.batch == 32 else args.batch
+    B = batch if batch is not None else (1 if args.batch == 32 else args.batch)
+    steps = steps if steps is not None else args.steps
     net = HuPRNet(cfg).to(dev).eval()
     h, v = (torch.from_numpy(t).to(dev) for t in synth.model_inputs(B, 5 + rank))
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             net(h, v)
         torch.cuda.synchronize()
-        # the B = 1 forward is ~300 launches of a few microseconds each: replay it as one hipGraph (eager as a fallback)
+        # the B = 1 forward is ~160 launches of a few microseconds each: replay it as one hipGraph (eager as a fallback)
         run, mode = (lambda: net(h, v)), "eager"
         try:
             side = torch.cuda.Stream(device=dev)
@@ -122,19 +126,21 @@ def bench_inference(args, cfg, dev, rank, world, peak):
         run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             run()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if rank == 0:
-        value = world * B * args.steps / dt
-        print(json.dumps({"metric": "radar frames/sec (heat-map forward, eval)", "value": round(value, 3), "unit": "frames/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                          "config": {"workload": "C2: mscsa_prgcn eval forward from normalised inputs", "batch_per_gpu": B,
-                                     "parallelism": "replicas%d" % world, "model_gflop_per_frame": FWD_GFLOP, "launch": mode},
-                          "model_tflops": round(value * FWD_GFLOP / 1e3, 2)}), flush=True)
+    value = world * B * steps / dt
+    obj = {"metric": "radar frames/sec (heat-map forward, eval)", "value": round(value, 3), "unit": "frames/s",
+           "n_gpus": world, "steps": steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "C2: mscsa_prgcn eval forward from normalised inputs", "batch_per_gpu": B,
+                      "parallelism": "replicas%d" % world, "model_gflop_per_frame": FWD_GFLOP, "launch": mode},
+           "model_tflops": round(value * FWD_GFLOP / 1e3, 2)}
+    if emit and rank == 0:
+        print(json.dumps(obj), flush=True)
+    return obj
 
 
 def _free_port():
@@ -207,6 +213,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step (incl. the RCCL all-reduce) as one hipGraph; the roofline probe then runs on "
                          "a few eager steps after the timed region")
+    ap.add_argument("--sustain", type=float, default=3.0,
+                    help="seconds of additional steps after the timed region, reported as the `sustained` object (0 = off)")
+    ap.add_argument("--no-c2", action="store_true", help="skip the `c2` object (eval forward B = 1 latency, N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-path", action="store_true", help="skip the short fp32 parity-path measurement (N = 1 only)")
     ap.add_argument("--two-streams", action="store_true",
@@ -262,6 +271,8 @@ def main():
         return bench_inference(args, cfg, dev, rank, world, peak)
     eng = TrainEngine(cfg, device=dev, seed=0)
     transport = getattr(eng.buckets.transport, "name", None)
+    # ranks of the live native communicator (ncclCommCount), not WORLD_SIZE: proves N > 1 ran through hupr_comm_init_rank
+    rccl_ranks = eng.buckets.transport.ranks()[0] if hasattr(eng.buckets.transport, "ranks") else None
     fused_step = eng.fuse_elevation_mean
     B, G = args.batch, cfg.DATASET.numGroupFrames
     micro = 1
@@ -311,6 +322,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     loss_value = float(loss.item())
+    enq_ranks = [t_enq / args.steps * 1e3]
+    if dist.is_initialized():
+        enq_ranks = [None] * world
+        dist.all_gather_object(enq_ranks, t_enq / args.steps * 1e3)
+
+    # Sustained rate: a short --steps (the driver's 20 = 0.4 s) measures a burst at boost clocks.  Continue for >= 3 s more
+    # of the same step (same buffers, nothing re-initialised) and report that window separately; `value` stays the --steps region.
+    sustained = None
+    if args.sustain > 0 and not args.graph:
+        n_more = max(int(np.ceil(args.sustain / (dt / args.steps))), 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_more):
+            one_step()
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+        if dist.is_initialized():
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        d_more = float(ts.item())
+        sustained = {"value": round(world * B * micro * n_more / d_more, 3), "unit": "frames/s", "steps": n_more,
+                     "seconds": round(d_more, 2), "ms_per_step": round(d_more / n_more * 1e3, 3),
+                     "note": "continuation of the timed region on the same state; `value` above is the --steps window only"}
 
     if args.graph:      # roofline probe on a few eager steps (events cannot be read back from inside a graph replay)
         eng._graph = None
@@ -323,8 +356,8 @@ def main():
     fft_roof = parity = None
     if rank == 0:
         # FFT chain on its own (HBM-bound): the step's 2 x B*G sensor-frames, HIP events on the launch stream.  Primary entry =
-        # the variant the timed step ran (a1 + a2 + the elevation mean of a3 fused: 1.25 MB algorithmic per sensor-frame);
-        # `loader_variant` = the reference-shaped hand-over (a1 + a2: 3.08 MB per sensor-frame) for comparison.
+        # the variant the timed step ran (a1 + a2 + the elevation mean of a3 fused: 1 048 576 B algorithmic per sensor-frame);
+        # `loader_variant` = the reference-shaped hand-over (a1 + a2: 2 883 584 B per sensor-frame) for comparison.
         def fft_time(fn):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             fn(adc_h)
@@ -374,6 +407,24 @@ def main():
         del eng32
         F_.set_math(args.dtype)
 
+    c2 = None
+    if rank == 0 and world == 1 and not args.no_c2 and not args.strong:
+        # config C2 beside the headline: eval forward, B = 1, the library default of two branch streams inside one hipGraph
+        try:
+            eng.close()
+            del eng
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        two = F_.TWO_STREAMS
+        F_.TWO_STREAMS = os.environ.get("HUPR_ONE_STREAM", "0") != "1"
+        try:
+            o = bench_inference(args, cfg, dev, rank, 1, peak, steps=250, batch=1, emit=False)
+            c2 = {"workload": o["config"]["workload"], "batch": 1, "frames_per_s": o["value"], "latency_ms": o["ms_per_step"],
+                  "steps": o["steps"], "launch": o["config"]["launch"], "dtype": o["dtype"], "model_tflops": o["model_tflops"]}
+        finally:
+            F_.TWO_STREAMS = two
+
     if rank == 0:
         frames = world * B * micro * args.steps
         value = frames / dt
@@ -394,11 +445,16 @@ def main():
             "model_frac_of_mfma_peak": round(value * STEP_GFLOP / 1e3 / world / peak, 4),
             "loss": round(loss_value, 5),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
+            "host_enqueue_ms_per_step_by_rank": [round(float(x), 2) for x in enq_ranks],
+            "rccl_ranks": rccl_ranks,
+            "sustained": sustained,
             "roofline": conv_roofline(probe_events, B, args.dtype, peak),
             "fft_roofline": fft_roof,
         }
         if parity is not None:
             out["parity_path"] = parity
+        if c2 is not None:
+            out["c2"] = c2
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

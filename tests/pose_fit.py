@@ -36,8 +36,9 @@ def hit_rate(p, joints):
     return (p.reshape(B, 14, -1).argmax(-1) == want).float().mean().item()
 
 
-def fit(steps=600, batch=32, lr=1e-3, math="bf16", model_seed=1, gain=1.0, log_every=100, verbose=True):
-    """-> (state_dict on the GPU, cfg, log list of (step, loss, loss2))."""
+def fit(steps=600, batch=32, lr=3e-4, math="bf16", model_seed=1, gain=1.0, log_every=100, verbose=True, drops=(0.7, 0.9)):
+    """-> (state_dict on the GPU, cfg, log list of (step, loss, loss2)).  Adam at ``lr``, divided by 3 at each fraction of
+    ``drops`` of the run (the reference decays its rate too, tools/base.py:49-58)."""
     from hupr_amd.tools.engine import TrainEngine
     cfg = load_config()
     dev = torch.device("cuda")
@@ -50,7 +51,12 @@ def fit(steps=600, batch=32, lr=1e-3, math="bf16", model_seed=1, gain=1.0, log_e
         rng = np.random.default_rng(20240917)
         gen = torch.Generator(device=dev).manual_seed(4321)
         log, t0 = [], time.time()
+        drop_at = {int(f * steps) for f in drops}
         for it in range(steps):
+            if it in drop_at:
+                for gr in eng.optimizer.param_groups:
+                    gr["lr"] = gr["lr"] / 3.0
+                eng.sync_lr()
             h, v, joints = scene_batch(batch, rng, gen, dev)
             loss, loss2 = eng.train_step(h, v, joints)
             if it % log_every == 0 or it == steps - 1:

@@ -182,6 +182,13 @@ def test_bench_line_single_gpu_carries_every_object():
     assert out["fft_roofline"]["bound"] == "hbm" and 0 < out["fft_roofline"]["frac"] < 1 and "loader_variant" in out["fft_roofline"]
     assert out["parity_path"]["dtype"] == "f32" and out["parity_path"]["roofline"]["peak"] == 157.3
     assert "arg-max" in out["config"]["workload"]
+    # SURVEY 8(d)'s algorithmic bytes, not the implementation's traffic
+    assert out["fft_roofline"]["algorithmic_bytes_per_sensor_frame"] == 1048576
+    assert out["fft_roofline"]["loader_variant"]["algorithmic_bytes_per_sensor_frame"] == 2883584
+    # the line is self-sufficient: a sustained continuation and config C2 beside the burst number
+    assert out["sustained"]["seconds"] >= 3.0 and out["sustained"]["steps"] >= 1 and out["sustained"]["value"] > 0
+    assert out["c2"]["batch"] == 1 and out["c2"]["steps"] == 250 and 0 < out["c2"]["latency_ms"] < 50
+    assert out["rccl_ranks"] is None and len(out["host_enqueue_ms_per_step_by_rank"]) == 1
 
 
 def test_bench_under_launcher_uses_rccl_and_graph():
@@ -191,6 +198,7 @@ def test_bench_under_launcher_uses_rccl_and_graph():
                  env_extra={"HUPR_FORCE_ALLREDUCE": "1"}, launcher=True)
     assert out["n_gpus"] == 1 and out["config"]["collective"].startswith("rccl")
     assert out["config"]["launch"] == "hipGraph replay" and out["roofline"]["launches"] == 3 * 12
+    assert out["rccl_ranks"] == 1                                  # as the live communicator reports it (ncclCommCount)
 
 
 def test_bench_refuses_more_gpus_than_visible():
@@ -227,3 +235,74 @@ def test_fused_elevation_mean_step_equals_reference_shaped_handover(monkeypatch)
         assert float(l1.detach()) == float(l2.detach()) and torch.equal(_flat(e1), _flat(e2))
     finally:
         F_.set_math("f32")
+
+
+# ---- two real ranks: run only where >= 2 GPUs are visible (the first multi-GPU box validates hupr_comm_init_rank(n > 1)) ----
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
+
+
+@needs_two_gpus
+def test_bench_two_ranks_over_rccl():
+    """`bench.py --gpus 2` spawns two ranks; the native communicator must report 2 ranks, every rank its enqueue time."""
+    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--no-cpu-baseline", "--sustain", "0"])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 8
+    assert out["config"]["collective"].startswith("rccl") and out["rccl_ranks"] == 2
+    assert len(out["host_enqueue_ms_per_step_by_rank"]) == 2 and out["value"] > 0
+
+
+def _dp2_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    torch.cuda.set_device(rank)
+    dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+    F_.set_math("bf16")
+    F_.TWO_STREAMS = False
+    cfg = load_config()
+    dev = torch.device("cuda", rank)
+    eng = TrainEngine(cfg, device=dev, seed=rank)                  # different init per rank: the broadcast must fix it
+    assert eng.buckets.transport.name.startswith("rccl") and eng.buckets.transport.ranks() == (world, rank)
+    h, v = (torch.from_numpy(t).to(dev) for t in synth.model_inputs(2, 300 + rank))
+    joints = torch.from_numpy(synth.keypoints(2, 310 + rank))
+    for _ in range(2):
+        eng.train_step(h, v, joints)
+    torch.cuda.synchronize()
+    torch.save(_flat(eng).cpu(), os.path.join(out_dir, "p%d.pt" % rank))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@needs_two_gpus
+def test_two_rank_step_equals_the_single_process_accumulated_step(tmp_path):
+    """Two ranks x one micro-batch each, gradients summed by ncclAllReduce on the communication stream, == one process
+    accumulating the same two micro-batches (BatchNorm statistics are per micro-batch in both): identical parameters on both
+    ranks, and equal to the single-process result (a + b is the same fp32 number whichever device adds it)."""
+    import torch.multiprocessing as mp
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    mp.spawn(_dp2_worker, args=(2, 29683, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert torch.equal(p0, p1), "ranks diverged"
+    saved = F_.TWO_STREAMS
+    try:
+        F_.set_math("bf16")
+        F_.TWO_STREAMS = False
+        dev = torch.device("cuda", 0)
+        eng = TrainEngine(load_config(), device=dev, seed=0)      # seed 0 == rank 0's init, which the broadcast distributed
+        mb = []
+        for r in range(2):
+            h, v = (torch.from_numpy(t).to(dev) for t in synth.model_inputs(2, 300 + r))
+            mb.append((h, v, torch.from_numpy(synth.keypoints(2, 310 + r))))
+        for _ in range(2):
+            eng.train_step_accumulated(mb, from_adc=False)
+        torch.cuda.synchronize()
+        ref = _flat(eng).cpu()
+    finally:
+        F_.TWO_STREAMS = saved
+        F_.set_math("f32")
+    rel = ((p0 - ref).norm() / ref.norm()).item()
+    assert rel < 1e-6, rel
