@@ -209,59 +209,258 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// Packed complex arithmetic: one complex number = one 64-bit VGPR pair, every complex add / rotate-and-add is ONE
+// v_pk_add_f32 and every complex multiply TWO packed instructions (op_sel picks the re/im halves, neg_lo/neg_hi the signs).
+// hipcc's SLP vectoriser pairs components of DIFFERENT complex numbers and then shuffles them back with v_mov (a quarter of
+// the range-first kernel's instruction stream); written out with the modifiers there is nothing to shuffle.
+// ------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_add_mi(v2f a, v2f b) {          // a - i b = (a.x + b.y, a.y - b.x)
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_add_pi(v2f a, v2f b) {          // a + i b = (a.x - b.y, a.y + b.x)
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a * w:  t = (a.x w.x, a.x w.y);  d = (t.x - a.y w.y, t.y + a.y w.x).   _s: w uniform (SGPR pair), _v: w per lane.
+__device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f w) {
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f pk_cmul_v(v2f a, v2f w) {
+    v2f t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
+}
+__device__ __forceinline__ v2f pk_cfma_s(v2f acc, v2f a, v2f w) {  // acc + a * w
+    v2f t, d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "s"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    return d;
+}
+
+__device__ __forceinline__ void r4p(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {      // radix-4 DIF butterfly, forward
+    const v2f a0 = x0 + x2, a1 = x0 - x2, a2 = x1 + x3, a3 = x1 - x3;
+    x0 = a0 + a2;
+    x1 = pk_add_mi(a1, a3);
+    x2 = a0 - a2;
+    x3 = pk_add_pi(a1, a3);
+}
+
+// 16-point forward DFT, same factorisation / output order as fft16(): X[g + 4 q] at x[4 g + q].  64 + 18 packed instructions.
+__device__ __forceinline__ void fft16p(v2f (&x)[16]) {
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+    constexpr float wre[10] = {1.f, c1, h, s1, 0.f, -s1, -h, -c1, -1.f, -c1};
+    constexpr float wim[10] = {0.f, -s1, -h, -c1, -1.f, -c1, -h, -s1, 0.f, s1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r4p(x[j], x[j + 4], x[j + 8], x[j + 12]);
+        if (j > 0) {
+            x[j + 4] = pk_cmul_s(x[j + 4], (v2f){wre[j], wim[j]});
+            x[j + 8] = pk_cmul_s(x[j + 8], (v2f){wre[2 * j], wim[2 * j]});
+            x[j + 12] = pk_cmul_s(x[j + 12], (v2f){wre[3 * j], wim[3 * j]});
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r4p(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 (round 3): Doppler FIRST, then range — same 2-D DFT, a quarter of the range-FFT work.
+// grid = n_sf * 12, block = 256 (thread = ADC sample index)
+// ------------------------------------------------------------------------------------------
+// The range-first kernel above runs 64 full 256-point FFTs per (sensor-frame, antenna) and throws three quarters of their
+// output away; it issues ~3 100 instructions per wave and is bound by instruction issue (80 % busy), not by HBM (2.6 TB/s).
+// The 2-D transform is separable, so the pruned axis goes first: the chirp-loop (Doppler) DFT keeps 16 of its 64 bins, and
+// only those 16 sequences go through the 256-point range FFT.
+//   stage A  thread s owns ADC sample s of all 64 chirp loops (every load instruction is one contiguous 256-byte run; raw
+//            buffer loads with the chirp offset in an SGPR: no address arithmetic on the vector pipe).  64-point DFT =
+//            16 x 4 (n = 4 n1 + n2) entirely in registers: for each n2 a 16-point DFT over n1, then the 16 kept bins
+//            d = 0..7, 56..63 accumulate  acc[d] += Y_n2[d mod 16] * W_64^{n2 d}  (compile-time twiddles in SGPRs; nothing
+//            crosses lanes).  -> LDS tile[doppler i][sample]
+//            Clutter removal (reference :122-128) costs nothing and is EXACT: the samples are integers, so every sum /
+//            difference of the first butterflies is exact in fp32, the chirp mean only ever reaches the DC outputs
+//            Y_n2[0] (again exact sums), and subtracting it makes bin d = 0 exactly zero while every other bin is
+//            bit-identical with or without it — so the unwindowed kernel just writes zero to bin 0.  (With a window the
+//            products are no longer integers and the mean is subtracted explicitly.)
+//   stage B  16 range FFTs per workgroup (one 16-lane group each): 256 = 16 x 16 with ONE transpose through the group's own
+//            tile row, as in the range-first kernel; bins 94..31 go straight to RD[sf][antenna][i][r].
+// 37 KB of LDS.  The zero-Doppler bin (i = 8) is therefore EXACTLY zero where the range-first order (and the reference's
+// fft2 of the mean-free cube, process_iwr1843.py:122-134) leaves rounding noise; the loader epilogues below map a
+// zero-variance plane to zeros instead of 0/0.
+// HALF: only the eight Doppler bins the loader keeps (i = 4..11, dataset.py:145) — half the accumulators of stage A and half
+// the range FFTs (two of the four waves retire after stage A); the other rows of RD are left untouched.
+template <int WIN, bool HALF>
+__global__ __launch_bounds__(256) void hupr_k_doppler_range(const int16_t* __restrict__ iq, float2* __restrict__ rd) {
+    constexpr int kPitch = 272;                      // v2f per Doppler row: 2 x 272 = 32 (mod 64) banks, and = 16 x 17
+    constexpr int kRows = HALF ? 8 : kDop, kRow0 = HALF ? 4 : 0;
+    __shared__ v2f tw[256];                          // W_256^t
+    __shared__ v2f tile[kRows * kPitch];             // [doppler i - kRow0][sample]; a row doubles as its group's transpose scratch
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sf = blockIdx.x / kVant, vant = blockIdx.x % kVant;
+    const int rx = vant & 3;
+    const int tx = (vant < 4) ? 0 : (vant < 8 ? 2 : 1);          // TDM demux (reference :113-120)
+    tw[tid] = reinterpret_cast<const v2f*>(kTw256)[tid];
+
+    // ---- stage A ------------------------------------------------------------------------------------------------
+    constexpr int kRowBytes = kSamples * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int16_t*>(iq) + (size_t)(sf * kRx + rx) * kChirps * kSamples * 2, 0, kChirps * kRowBytes, 0x00020000);
+    int32_t raw[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) raw[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, (3 * c + tx) * kRowBytes, 0);
+    v2f mean = (v2f){0.f, 0.f};
+    float wr = 1.0f;
+    if constexpr (WIN != 0) {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) mean += (v2f){(float)(int16_t)(raw[c] & 0xffff), (float)(raw[c] >> 16)};
+        mean *= (1.0f / 64.0f);
+        if constexpr (WIN & 1) wr = hann(tid, kSamples);
+    }
+    v2f acc[16];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+        v2f x[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int32_t v = raw[4 * n1 + n2];
+            x[n1] = (v2f){(float)(int16_t)(v & 0xffff), (float)(v >> 16)};
+            if constexpr (WIN != 0) {
+                x[n1] -= mean;
+                float w = wr;
+                if constexpr (WIN & 2) w *= hann(4 * n1 + n2, 64);
+                x[n1] *= w;
+            }
+        }
+        fft16p(x);                                       // Y[k1 = g + 4 q] at x[4 g + q]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k1 = g + 4 * q;
+                const int d = (k1 < 8) ? k1 : k1 + 48;   // kept Doppler bin with d = k1 (mod 16)
+                if (HALF && k1 >= 4 && k1 < 12) continue;
+                if (n2 == 0) acc[k1] = x[4 * g + q];
+                else acc[k1] = pk_cfma_s(acc[k1], x[4 * g + q], (v2f){w64re(n2 * d), w64im(n2 * d)});
+            }
+    }
+    if constexpr (WIN == 0) acc[0] = (v2f){0.f, 0.f};    // exact clutter removal, see above
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        const int i = (k1 < 8) ? k1 + 8 : k1 - 8;        // fftshift + keep 24..39 -> i = (d + 8) & 63
+        if (i >= kRow0 && i < kRow0 + kRows) tile[(i - kRow0) * kPitch + tid] = acc[k1];
+    }
+    __syncthreads();
+    if (HALF && wave >= 2) return;                       // eight rows = two waves of range FFTs
+
+    // ---- stage B: 256-point range FFT of Doppler row i, sixteen lanes per FFT ---------------------------------------
+    const int l16 = lane & 15, i = kRow0 + wave * 4 + (lane >> 4);
+    v2f* row = tile + (i - kRow0) * kPitch;
+    v2f x[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) x[n1] = row[16 * n1 + l16];
+    v2f twl[16];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) twl[k1] = tw[(l16 * k1) & 255];
+    wave_lds_fence();                                    // the row is this group's scratch from here on
+    fft16p(x);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k1 = g + 4 * q;
+            row[k1 * 17 + l16] = (k1 == 0) ? x[4 * g + q] : pk_cmul_v(x[4 * g + q], twl[k1]);
+        }
+    wave_lds_fence();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) x[n2] = row[l16 * 17 + n2];
+    fft16p(x);                                           // X[k1 + 16 k2], k1 = l16, k2 = g + 4 q at x[4 g + q]
+    v2f* dst = reinterpret_cast<v2f*>(rd) + (((size_t)sf * kVant + vant) * kDop + i) * kRange;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k2 = g + 4 * q;
+            if (k2 < 1 || k2 > 5) continue;              // bins 94..31 live in k2 = 1..5 only
+            const int r = kRangeHi - (l16 + 16 * k2);
+            if (r >= 0 && r < kRange) dst[r] = x[4 * g + q];
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: pruned angle DFT + index map (+ optional loader epilogue)
 // grid = n_sf * (LOADER ? 8 : 16), block = 256 (4 waves x 16 range cells each)
 // ------------------------------------------------------------------------------------------
-// From here on floating-point contraction is OFF: the angle kernel exists in four instantiations (complex cube, loader,
-// magnitude, loader + elevation mean) that must produce the SAME bits for the same cell — left to its own devices hipcc fuses
-// different multiply-add pairs in different instantiations (measured: 30 % of the loader values differed by 1-2 ulp between
-// MODE 1 and MODE 3).  The DFT itself is written with explicit fmaf (cfma), so nothing is lost.
+// The angle kernel exists in four instantiations (complex cube, loader, magnitude, loader + elevation mean) that must
+// produce the SAME bits for the same cell: its arithmetic is written as explicit packed instructions (pk_* helpers above), so
+// there is nothing for the compiler to contract or re-associate differently per instantiation.
 #pragma clang fp contract(off)
 
+__device__ __forceinline__ v2f pk_cfma_v(v2f acc, v2f a, v2f w) {  // acc + a * w, w per lane
+    v2f t, d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
+}
+
 struct AngleOut {
-    float2 o[kEl];   // indexed by OUTPUT elevation bin e
+    v2f o[kEl];   // indexed by OUTPUT elevation bin e
 };
 
-__device__ __forceinline__ AngleOut angle_cell(const float2* __restrict__ cell, const float2* twl) {
-    // cell[0..7] azimuth antennas, cell[8..11] elevated antennas (at azimuth offsets 2..5)
-    float2 P = make_float2(0.f, 0.f), Q = P, R = cell[0];
+// One (range, azimuth-bin) cell: the zero-padded 8 x 64 angle FFT with <= 12 non-zero inputs, as a pruned DFT
+//   out[e', a'] = P[a'] + w8^e' Q[a'] + [e' = 0] R[a'],   output elevation bin e <- e' = (3 - e) mod 8.
+// w8^e' Q takes only Q, -iQ and U = h (1 - i) Q: the eight outputs are eight rotate-and-add instructions.
+__device__ __forceinline__ AngleOut angle_cell(const v2f* __restrict__ cell, const v2f* twl) {
+    // cell[0..7] azimuth antennas, cell[8..11] elevated antennas (at azimuth offsets 2..5); twl[a] = W_64^{a a'}
+    v2f P = pk_cmul_v(cell[2], twl[2]), Q = pk_cmul_v(cell[8], twl[2]);
 #pragma unroll
-    for (int a = 2; a < 6; ++a) {
-        cfma(P, cell[a], twl[a]);
-        cfma(Q, cell[8 + a - 2], twl[a]);
+    for (int a = 3; a < 6; ++a) {
+        P = pk_cfma_v(P, cell[a], twl[a]);
+        Q = pk_cfma_v(Q, cell[8 + a - 2], twl[a]);
     }
-    cfma(R, cell[1], twl[1]);
-    cfma(R, cell[6], twl[6]);
-    cfma(R, cell[7], twl[7]);
-    constexpr float c = 0.70710678118654752440f;
-    // w8^{e'} = exp(-2 pi i e'/8)
-    const float2 w8[8] = {{1.f, 0.f}, {c, -c}, {0.f, -1.f}, {-c, -c},
-                          {-1.f, 0.f}, {-c, c}, {0.f, 1.f}, {c, c}};
+    v2f R = pk_cfma_v(cell[0], cell[1], twl[1]);
+    R = pk_cfma_v(R, cell[6], twl[6]);
+    R = pk_cfma_v(R, cell[7], twl[7]);
+    constexpr float h = 0.70710678118654752440f;
+    const v2f U = pk_add_mi(Q, Q) * h;          // w8^1 Q = h (1 - i) Q
     AngleOut r;
-#pragma unroll
-    for (int e = 0; e < kEl; ++e) {
-        const int ep = (3 - e) & 7;                // source elevation-FFT bin for output bin e
-        // explicit rounding steps (intrinsics are exempt from contraction / re-association): hupr_common.h's cmul was
-        // compiled with contraction on and fused differently per instantiation once inlined here
-        const float2 wq = make_float2(__fmaf_rn(w8[ep].x, Q.x, -__fmul_rn(w8[ep].y, Q.y)),
-                                      __fmaf_rn(w8[ep].x, Q.y, __fmul_rn(w8[ep].y, Q.x)));
-        float2 v = make_float2(__fadd_rn(P.x, wq.x), __fadd_rn(P.y, wq.y));
-        if (ep == 0) v = make_float2(__fadd_rn(v.x, R.x), __fadd_rn(v.y, R.y));
-        r.o[e] = v;
-    }
+    r.o[0] = pk_add_mi(P, U);                   // e' = 3: -i U
+    r.o[1] = pk_add_mi(P, Q);                   // e' = 2: -i Q
+    r.o[2] = P + U;                             // e' = 1
+    r.o[3] = (P + Q) + R;                       // e' = 0
+    r.o[4] = pk_add_pi(P, U);                   // e' = 7: +i U
+    r.o[5] = pk_add_pi(P, Q);                   // e' = 6: +i Q
+    r.o[6] = P - U;                             // e' = 5
+    r.o[7] = P - Q;                             // e' = 4
     return r;
 }
 
 // MODE 0: complex64 cube (the reference's output); 1: loader epilogue (Normalize fused); 2 (opt-in): magnitude |X| as fp32;
 // 3: loader epilogue + HuPRNet's elevation mean (models/networks.py:26-27) — writes the (re/im, Doppler) planes
 // means[sf][2 f + c][range][azimuth] that the MNet front end consumes: 1/8 of the loader's bytes, and MNet no longer re-reads them
+//
+// Normalize statistics in closed form (round 3; the first version evaluated the whole pruned DFT twice).  A (re/im, elevation)
+// plane is, per range bin r, the 64-point DFT over a' of  z_r[a] = p_r[a] + w8^e' q_r[a] + [e' = 0] rest_r[a]  (a = 0..7), so
+//   sum_a' X        = 64 z_r[0]                                   (only e' = 0 has z[0] != 0)
+//   sum_a' X^2      = 64 sum_a z[a] z[-a]     = 64 z_r[0]^2       (a = 1..7 pair with the zero inputs 63..57)
+//   sum_a' |X|^2    = 64 sum_a |z[a]|^2                           (Parseval)
+//   sum_a' Re(X)^2  = (sum |X|^2 + Re sum X^2) / 2,  sum_a' Im(X)^2 = (sum |X|^2 - Re sum X^2) / 2
+// and  sum_a |p + w q|^2 = sum (|p|^2 + |q|^2) + 2 Re(w sum conj(p) q):  five real sums over the 64 x 12 inputs of the
+// workgroup give the mean and the unbiased variance of all sixteen planes.
 template <int MODE>
 __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ rd, void* __restrict__ out_) {
     constexpr bool LOADER = MODE == 1 || MODE == 3;
-    __shared__ float2 cells[kRange * kVant];   // RD for this (sf, i): 64 range bins x 12 antennas
-    __shared__ float2 tw64[64];
-    __shared__ float red[4][32];
-    __shared__ float s_mean[16], s_rstd[16];
+    __shared__ v2f cells[kRange * kVant];      // RD for this (sf, i): 64 range bins x 12 antennas
+    __shared__ v2f tw64[64];
+    __shared__ v2f s_mean[8], s_rstd[8];       // (re, im) pairs per OUTPUT elevation bin
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kPlanes = LOADER ? 8 : 16;
@@ -271,51 +470,62 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
     // RD[sf][antenna][doppler][range] -> cells[range][antenna]: twelve 512-byte runs
     for (int t = tid; t < kRange * kVant; t += 256) {
         const int v = t >> 6, r = t & 63;
-        cells[r * kVant + v] = rd[(((size_t)sf * kVant + v) * kDop + i) * kRange + r];
+        cells[r * kVant + v] = reinterpret_cast<const v2f*>(rd)[(((size_t)sf * kVant + v) * kDop + i) * kRange + r];
     }
-    if (tid < 64) tw64[tid] = kTw256[4 * tid];
+    if (tid < 64) tw64[tid] = reinterpret_cast<const v2f*>(kTw256)[4 * tid];
     __syncthreads();
 
-    // lane == azimuth-FFT output bin a'; twl[a] = W_64^{a a'}
-    float2 twl[8];
+    if (LOADER) {
+        if (wave == 0) {                        // lane = range bin
+            const v2f* c = cells + lane * kVant;
+            double sa = 0.0, scx = 0.0, scy = 0.0, t4 = 0.0;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) twl[a] = tw64[(a * lane) & 63];
+            for (int a = 2; a < 6; ++a) {
+                const double px = c[a].x, py = c[a].y, qx = c[8 + a - 2].x, qy = c[8 + a - 2].y;
+                sa += px * px + py * py + qx * qx + qy * qy;
+                scx += px * qx + py * qy;                     // conj(p) q
+                scy += px * qy - py * qx;
+            }
+            t4 = (double)c[1].x * c[1].x + (double)c[1].y * c[1].y + (double)c[6].x * c[6].x + (double)c[6].y * c[6].y +
+                 (double)c[7].x * c[7].x + (double)c[7].y * c[7].y;
+            const double z0x = c[0].x, z0y = c[0].y;
+            double red[8] = {sa, scx, scy, t4 + z0x * z0x + z0y * z0y, z0x, z0y, z0x * z0x - z0y * z0y, 0.0};
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) red[k] += __shfl_xor(red[k], o, 64);
+            if (lane < 8) {                     // lane = OUTPUT elevation bin e <- e' = (3 - e) mod 8
+                const int ep = (3 - lane) & 7;
+                constexpr double hh = 0.70710678118654752440;
+                const double w8x[8] = {1.0, hh, 0.0, -hh, -1.0, -hh, 0.0, hh}, w8y[8] = {0.0, -hh, -1.0, -hh, 0.0, hh, 1.0, hh};
+                double wx = 0.0, wy = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k == ep) { wx = w8x[k]; wy = w8y[k]; }
+                double e2 = red[0] + 2.0 * (wx * red[1] - wy * red[2]);        // sum_r sum_a |z|^2
+                double sx = 0.0, sy = 0.0, zz = 0.0;
+                if (ep == 0) { e2 += red[3]; sx = 64.0 * red[4]; sy = 64.0 * red[5]; zz = red[6]; }
+                const double n = 4096.0;
+                const double ssx = 32.0 * (e2 + zz), ssy = 32.0 * (e2 - zz);
+                const double mx = sx / n, my = sy / n;
+                const double vx = (ssx - sx * mx) / (n - 1.0), vy = (ssy - sy * my) / (n - 1.0);   // unbiased, like torch.std_mean
+                s_mean[lane] = (v2f){(float)mx, (float)my};
+                // an exactly-zero plane (the zero-Doppler bin of the Doppler-first chain) normalises to zeros, not 0/0
+                s_rstd[lane] = (v2f){vx > 0.0 ? (float)(1.0 / sqrt(vx)) : 0.0f, vy > 0.0 ? (float)(1.0 / sqrt(vy)) : 0.0f};
+            }
+        }
+        __syncthreads();
+    }
+
+    // lane == azimuth-FFT output bin a'; twl[a] = W_64^{a a'}
+    v2f twl[8];
+#pragma unroll
+    for (int a = 1; a < 8; ++a) twl[a] = tw64[(a * lane) & 63];
     const int a_out = (31 - lane) & 63;
 
     if (LOADER) {
-        // pass 1: per (re/im, elevation) plane statistics over the 64x64 (range, azimuth) plane
-        float sum[16], ssq[16];
+        v2f rstd[8], nmr[8];                    // x * rstd - mean * rstd, one fused multiply-add per (re, im) pair
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sum[k] = ssq[k] = 0.f;
-        for (int j = 0; j < 16; ++j) {
-            const int r = wave * 16 + j;
-            AngleOut v = angle_cell(cells + r * kVant, twl);
-#pragma unroll
-            for (int e = 0; e < kEl; ++e) {
-                sum[e] += v.o[e].x;          ssq[e] = fmaf(v.o[e].x, v.o[e].x, ssq[e]);
-                sum[8 + e] += v.o[e].y;      ssq[8 + e] = fmaf(v.o[e].y, v.o[e].y, ssq[8 + e]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { sum[k] = wave_sum(sum[k]); ssq[k] = wave_sum(ssq[k]); }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { red[wave][k] = sum[k]; red[wave][16 + k] = ssq[k]; }
-        }
-        __syncthreads();
-        if (tid < 16) {
-            const double n = 4096.0;
-            double S = (double)red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-            double SS = (double)red[0][16 + tid] + red[1][16 + tid] + red[2][16 + tid] + red[3][16 + tid];
-            double mean = S / n;
-            double var = (SS - S * mean) / (n - 1.0);   // unbiased, like torch.std_mean
-            s_mean[tid] = (float)mean;
-            s_rstd[tid] = (float)(1.0 / sqrt(var));
-        }
-        __syncthreads();
-        float mean[16], rstd[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { mean[k] = s_mean[k]; rstd[k] = s_rstd[k]; }
+        for (int e = 0; e < kEl; ++e) { rstd[e] = s_rstd[e]; nmr[e] = -(s_mean[e] * rstd[e]); }
         float* out = reinterpret_cast<float*>(out_);
         if constexpr (MODE == 3) {
             // means[sf][j = 2 pl + c][r][a] = mean over the 8 elevation bins of the normalised plane, summed exactly like
@@ -325,14 +535,12 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
             for (int j = 0; j < 16; ++j) {
                 const int r = wave * 16 + j;
                 AngleOut v = angle_cell(cells + r * kVant, twl);
-                float re[8], im[8];
+                v2f n[8];
 #pragma unroll
-                for (int e = 0; e < kEl; ++e) {
-                    re[e] = __fmul_rn(v.o[e].x - mean[e], rstd[e]);       // rounded products, as the stored loader tensor holds them
-                    im[e] = __fmul_rn(v.o[e].y - mean[8 + e], rstd[8 + e]);   // (no contraction into the sums below)
-                }
-                mre[r * kAz + a_out] = (((re[0] + re[1]) + (re[2] + re[3])) + ((re[4] + re[5]) + (re[6] + re[7]))) * 0.125f;
-                mim[r * kAz + a_out] = (((im[0] + im[1]) + (im[2] + im[3])) + ((im[4] + im[5]) + (im[6] + im[7]))) * 0.125f;
+                for (int e = 0; e < kEl; ++e) n[e] = __builtin_elementwise_fma(v.o[e], rstd[e], nmr[e]);
+                const v2f m = (((n[0] + n[1]) + (n[2] + n[3])) + ((n[4] + n[5]) + (n[6] + n[7]))) * 0.125f;
+                mre[r * kAz + a_out] = m.x;
+                mim[r * kAz + a_out] = m.y;
             }
             return;
         }
@@ -342,18 +550,15 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
         for (int j = 0; j < 16; ++j) {
             const int r = wave * 16 + j;
             AngleOut v = angle_cell(cells + r * kVant, twl);
-            float re[8], im[8];
+            v2f n[8];
 #pragma unroll
-            for (int e = 0; e < kEl; ++e) {
-                re[e] = (v.o[e].x - mean[e]) * rstd[e];
-                im[e] = (v.o[e].y - mean[8 + e]) * rstd[8 + e];
-            }
+            for (int e = 0; e < kEl; ++e) n[e] = __builtin_elementwise_fma(v.o[e], rstd[e], nmr[e]);
             f32x4* pr = reinterpret_cast<f32x4*>(base_re + ((size_t)r * kAz + a_out) * kEl);
             f32x4* pi = reinterpret_cast<f32x4*>(base_im + ((size_t)r * kAz + a_out) * kEl);
-            pr[0] = (f32x4){re[0], re[1], re[2], re[3]};
-            pr[1] = (f32x4){re[4], re[5], re[6], re[7]};
-            pi[0] = (f32x4){im[0], im[1], im[2], im[3]};
-            pi[1] = (f32x4){im[4], im[5], im[6], im[7]};
+            pr[0] = (f32x4){n[0].x, n[1].x, n[2].x, n[3].x};
+            pr[1] = (f32x4){n[4].x, n[5].x, n[6].x, n[7].x};
+            pi[0] = (f32x4){n[0].y, n[1].y, n[2].y, n[3].y};
+            pi[1] = (f32x4){n[4].y, n[5].y, n[6].y, n[7].y};
         }
     } else if (MODE == 2) {
         float* out = reinterpret_cast<float*>(out_) + ((size_t)(sf * kDop + i) * kRange) * kAz * kEl;
@@ -429,7 +634,7 @@ __global__ __launch_bounds__(256) void hupr_k_loader_normalize(const float2* __r
         double mean = S / n;
         double var = (SS - S * mean) / (n - 1.0);
         s_mean[tid] = (float)mean;
-        s_rstd[tid] = (float)(1.0 / sqrt(var));
+        s_rstd[tid] = var > 0.0 ? (float)(1.0 / sqrt(var)) : 0.0f;      // exactly-zero plane (zero Doppler): zeros, not 0/0
     }
     __syncthreads();
     const int e0 = 2 * epair;
@@ -458,6 +663,9 @@ extern "C" size_t hupr_fft_chain_ws_bytes(int n_sf) {
     return (size_t)n_sf * kDop * kRange * kVant * sizeof(float2);
 }
 
+static int g_fft_range_first = 0;      // A/B aid: 1 = the round-1/2 range-first kernel
+extern "C" void hupr_debug_fft_range_first(int on) { g_fft_range_first = on; }
+
 static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws, size_t ws_bytes,
                             hupr_stream_t stream, bool loader, int flags = 0, bool means = false) {
     HUPR_REQUIRE((flags & ~(HUPR_FFT_HANN_RANGE | HUPR_FFT_HANN_DOPPLER | HUPR_FFT_MAGNITUDE)) == 0, "hupr_fft_chain: flags=0x%x", flags);
@@ -473,11 +681,25 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
                     hupr_fft_chain_ws_bytes(n_sf));
     hipStream_t s = as_stream(stream);
     float2* rd = reinterpret_cast<float2*>(ws);
-    switch (flags & 3) {
-        case 0: hipLaunchKernelGGL(hupr_k_range_doppler<0>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
-        case 1: hipLaunchKernelGGL(hupr_k_range_doppler<1>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
-        case 2: hipLaunchKernelGGL(hupr_k_range_doppler<2>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
-        default: hipLaunchKernelGGL(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+    if (g_fft_range_first) {
+        switch (flags & 3) {
+            case 0: hipLaunchKernelGGL(hupr_k_range_doppler<0>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+            case 1: hipLaunchKernelGGL(hupr_k_range_doppler<1>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+            case 2: hipLaunchKernelGGL(hupr_k_range_doppler<2>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+            default: hipLaunchKernelGGL(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+        }
+    } else {
+        const dim3 g1(n_sf * kVant), b1(256);
+        switch ((flags & 3) | (loader ? 4 : 0)) {
+            case 0: hipLaunchKernelGGL((hupr_k_doppler_range<0, false>), g1, b1, 0, s, adc_iq, rd); break;
+            case 1: hipLaunchKernelGGL((hupr_k_doppler_range<1, false>), g1, b1, 0, s, adc_iq, rd); break;
+            case 2: hipLaunchKernelGGL((hupr_k_doppler_range<2, false>), g1, b1, 0, s, adc_iq, rd); break;
+            case 3: hipLaunchKernelGGL((hupr_k_doppler_range<3, false>), g1, b1, 0, s, adc_iq, rd); break;
+            case 4: hipLaunchKernelGGL((hupr_k_doppler_range<0, true>), g1, b1, 0, s, adc_iq, rd); break;
+            case 5: hipLaunchKernelGGL((hupr_k_doppler_range<1, true>), g1, b1, 0, s, adc_iq, rd); break;
+            case 6: hipLaunchKernelGGL((hupr_k_doppler_range<2, true>), g1, b1, 0, s, adc_iq, rd); break;
+            default: hipLaunchKernelGGL((hupr_k_doppler_range<3, true>), g1, b1, 0, s, adc_iq, rd); break;
+        }
     }
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
     if (loader && means)

@@ -33,12 +33,22 @@ def set_math(mode):
 
 
 # Per-region precision inside a bf16 run: PRECISION[region] = "f32" runs that region of HuPRNet.forward on the fp32 matrix
-# pipe with fp32-stored activations (models/layers.py wraps its regions in ``region(name)``); casts happen at the region
-# borders (``to_act``).  Every autograd node remembers the mode of its forward and restores it for its backward, so the
-# switches hold for training too.  Used to localise where the bf16 path loses arg-max agreement (scripts/precision_regions.py)
-# and to keep the cheapest set that clears SURVEY 8(d)'s gate; HUPR_F32_REGIONS="lvl0,head" presets it.
-REGIONS = ("mnet", "enc1", "enc2", "enc3", "merge", "lvl0", "lvl1", "lvl2", "dec3", "dec2", "dec1", "head")
-PRECISION = {r: "f32" for r in os.environ.get("HUPR_F32_REGIONS", "").split(",") if r}
+# pipe with fp32-stored activations, "f32act" keeps the bf16 matrix pipe but leaves the region's activations fp32 in HBM
+# (models/layers.py wraps its regions in ``region(name)``); casts happen at the region borders (``to_act``).  Every autograd
+# node remembers the mode of its forward and restores it for its backward, so the switches hold for training too.
+# scripts/precision_regions.py uses them to localise where the bf16 path loses arg-max agreement on a trained network
+# (profiles/r03_precision_regions.txt): everything but the last decoder block and the 1x1 head is >= 99.8 % on its own, those
+# two alone cost 2 % / 1.3 % of the first head's joints.  DEFAULT therefore: the last BasicBlock2D keeps fp32 activations and the
+# 14-channel head runs on the fp32 pipe (first head 99.1 -> 99.8-100 % identical arg-max, decoded head's max-abs error 3.8e-2 ->
+# 1.1e-2, for +0.4 ms / step).  HUPR_F32_REGIONS / HUPR_F32ACT_REGIONS (comma lists) replace the default; "none" clears it.
+REGIONS = ("mnet", "enc1", "enc2", "enc3", "merge", "lvl0", "lvl1", "lvl2", "dec3", "dec2", "dec1a", "dec1b", "head")
+if "HUPR_F32_REGIONS" in os.environ or "HUPR_F32ACT_REGIONS" in os.environ:
+    PRECISION = {r: "f32" for r in os.environ.get("HUPR_F32_REGIONS", "").split(",") if r and r != "none"}
+    PRECISION.update({r: "f32act" for r in os.environ.get("HUPR_F32ACT_REGIONS", "").split(",") if r and r != "none"})
+else:
+    PRECISION = {"dec1b": "f32act", "head": "f32"}
+assert all(r in REGIONS for r in PRECISION), PRECISION
+_ACT_F32_HERE = False      # inside a region switched to "f32act"
 
 
 class region:
@@ -49,15 +59,17 @@ class region:
         self.name = name
 
     def __enter__(self):
-        global MATH
-        self.prev = MATH
-        if MATH == "bf16" and PRECISION.get(self.name) == "f32":
+        global MATH, _ACT_F32_HERE
+        self.prev = (MATH, _ACT_F32_HERE)
+        mode = PRECISION.get(self.name)
+        if MATH == "bf16" and mode == "f32":
             MATH = "f32"
+        _ACT_F32_HERE = MATH == "bf16" and mode == "f32act"
         return self
 
     def __exit__(self, *exc):
-        global MATH
-        MATH = self.prev
+        global MATH, _ACT_F32_HERE
+        MATH, _ACT_F32_HERE = self.prev
         return False
 
 
@@ -66,16 +78,17 @@ def _math_scoped(cls):
     fwd, bwd = cls.forward, cls.backward
 
     def forward(ctx, *a):
-        ctx._hupr_math = MATH
+        ctx._hupr_math = (MATH, _ACT_F32_HERE)
         return fwd(ctx, *a)
 
     def backward(ctx, *g):
-        global MATH
-        prev, MATH = MATH, ctx._hupr_math
+        global MATH, _ACT_F32_HERE
+        prev = (MATH, _ACT_F32_HERE)
+        MATH, _ACT_F32_HERE = ctx._hupr_math
         try:
             return bwd(ctx, *g)
         finally:
-            MATH = prev
+            MATH, _ACT_F32_HERE = prev
     cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
     return cls
 
@@ -86,7 +99,7 @@ def _fn(stem):
 
 def act_bf16():
     """True when the encoder island stores activations as bf16 (bf16 math + ACT_BF16)."""
-    return MATH == "bf16" and ACT_BF16
+    return MATH == "bf16" and ACT_BF16 and not _ACT_F32_HERE
 
 
 def _act(stem, t):

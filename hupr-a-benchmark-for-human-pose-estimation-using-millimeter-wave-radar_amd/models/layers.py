@@ -159,17 +159,21 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
         # write bf16 too; the attention outputs are cast once on the way in, the 1x1 head gets fp32 back.  Every stage sits in a
         # precision region (F_.region): a region switched to fp32 takes / hands over its maps through casts at its borders.
         maps = None
-        stages = ((0, "dec3", self.decoderLayer3, ramaps, remaps), (1, "dec2", self.decoderLayer2, ral2maps, rel2maps),
-                  (2, "dec1", self.decoderLayer1[:2], ral1maps, rel1maps))
-        for i, dec, stack, ra, re in stages:
-            with F_.region(dec):
+        d1 = self.decoderLayer1
+        stages = ((0, ("dec3",), (self.decoderLayer3,), ramaps, remaps), (1, ("dec2",), (self.decoderLayer2,), ral2maps, rel2maps),
+                  (2, ("dec1a", "dec1b"), (d1[0], d1[1]), ral1maps, rel1maps))
+        for i, names, stacks, ra, re in stages:
+            with F_.region(names[0]):
                 bf16_in = F_.act_bf16() and F_.ACT_BF16_DECODER
             with F_.region("lvl%d" % i):
                 # bf16 decoder input: a fused level hands back its four maps already concatenated and cast (one tensor)
                 lv = self._level(i, ra, re, bf16_in and F_.CAT_FUSION)
-            with F_.region(dec):
+            with F_.region(names[0]):
                 parts = ([] if maps is None else [maps]) + list(lv)
-                maps = stack(torch.cat([F_.to_act(t, decoder=True) for t in parts], 4))
+                maps = stacks[0](torch.cat([F_.to_act(t, decoder=True) for t in parts], 4))
+            for name, stack in zip(names[1:], stacks[1:]):
+                with F_.region(name):
+                    maps = stack(F_.to_act(maps, decoder=True))
         x = F_.cast(maps, torch.float32)
         # 1x1 head with the 14 output channels zero-padded to 16 so later kernels stay float4-aligned
         with F_.region("head"):

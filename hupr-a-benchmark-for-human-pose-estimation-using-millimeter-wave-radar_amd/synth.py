@@ -232,10 +232,33 @@ def pose_scene_inputs(blobs, noise_h, noise_v, amp=POSE_AMP):
             (noise_v.reshape(sh) + amp * b).reshape(noise_v.shape))
 
 
+# a standing person in 256-px image coordinates, joints in cfg.DATASET.idxToJoints order (R_Hip, R_Knee, R_Ankle, L_Hip, L_Knee,
+# L_Ankle, Neck, Head, L_Shoulder, L_Elbow, L_Wrist, R_Shoulder, R_Elbow, R_Wrist), and how far each joint swings around it
+POSE_TEMPLATE = np.array([[118, 140], [116, 178], [115, 212], [138, 140], [140, 178], [141, 212], [128, 82], [128, 58],
+                          [147, 88], [156, 116], [159, 142], [109, 88], [100, 116], [97, 142]], dtype=np.float64)
+POSE_SWING = np.array([3, 7, 11, 3, 7, 11, 3, 4, 4, 9, 14, 4, 9, 14], dtype=np.float64)
+
+
+def pose_joints(u):
+    """u: (B, 3 + 28) uniforms in [0, 1) -> (B, 14, 2) int64 joints: the template skeleton, scaled (0.8 .. 1.15) about its hip
+    centre, shifted (+-45 px in x, +-14 px in y) and with every joint swung by up to POSE_SWING px — adjacent joints stay
+    adjacent, which is what the PRGCN's skeleton adjacency assumes (models/layers.py:97-112); clipped to the [40, 216) box
+    the uniform generator uses."""
+    u = np.asarray(u, dtype=np.float64)
+    B = u.shape[0]
+    centre = np.array([128.0, 140.0])
+    scale = 0.8 + 0.35 * u[:, 0]
+    shift = np.stack([(u[:, 1] - 0.5) * 90.0, (u[:, 2] - 0.5) * 28.0], 1)
+    swing = (u[:, 3:].reshape(B, 14, 2) - 0.5) * 2.0 * POSE_SWING[None, :, None]
+    j = centre + (POSE_TEMPLATE[None] - centre) * scale[:, None, None] + shift[:, None, :] + swing
+    return np.clip(np.floor(j), 40, 215).astype(np.int64)
+
+
 def pose_scenes(batch, seed):
     """Deterministic held-out scenes: (hori, vert, joints) numpy, regenerable anywhere from the seed."""
-    joints = keypoints(batch, 7919 + 104729 * int(seed))
-    nh, nv = model_inputs(batch, 7919 + 104729 * int(seed))
+    key = 7919 + 104729 * int(seed)
+    joints = pose_joints(uniform01(batch * 31, "pose", key).reshape(batch, 31))
+    nh, nv = model_inputs(batch, key)
     h, v = pose_scene_inputs(pose_scene_blobs(joints), nh, nv)
     return h, v, joints
 

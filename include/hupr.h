@@ -171,6 +171,7 @@ int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, i
  * (hupr_pack_conv_weights_f32 modes 0 and 1), 1 = bf16 layouts.  blocks_dev: one 16-byte record per workgroup
  * { int32 entry, layout; int64 start }: the workgroup writes destination elements [start, start + 2048) of that layout. */
 int hupr_pack_conv_weights_table(const void* descs_dev, const void* blocks_dev, int n_blocks, hupr_stream_t stream);
+void hupr_debug_fft_range_first(int on);  /* A/B aid: 1 = the range-first K1 of rounds 1-2 instead of the Doppler-first kernel */
 void hupr_debug_halo_small_tiles(int on); /* A/B aid: 0 keeps 64-wide channel tiles on grids of <= 256 workgroups (default 1: 32-wide there) */
 void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel, 2 skip the 512-voxel kernel */
 void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */

@@ -28,11 +28,18 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters * 1e-3
 
 
-t_c = timeit(lambda: preprocessing.fft_chain(iq, ws=ws))
-t_l = timeit(lambda: preprocessing.fft_chain_loader(iq, ws=ws, out=out_l))
-b_c, b_l = n_sf * 4980736, n_sf * 2883584
-print("n_sf=%d  c64: %.1f us  %.0f GB/s (%.3f of 8 TB/s) | loader: %.1f us  %.0f GB/s (%.3f)  | %.0f sensor-frames/s"
-      % (n_sf, t_c * 1e6, b_c / t_c / 1e9, b_c / t_c / 8e12, t_l * 1e6, b_l / t_l / 1e9, b_l / t_l / 8e12, n_sf / t_l))
+out_m = torch.empty((n_sf, 16, 64, 64), dtype=torch.float32, device="cuda")
+b_c, b_l, b_m = n_sf * 4980736, n_sf * 2883584, n_sf * 1048576          # SURVEY 8(d) algorithmic bytes per sensor-frame
+for tag, flag in (("doppler-first K1 (default)", 0), ("range-first K1 (rounds 1-2)", 1)):
+    rt.lib().hupr_debug_fft_range_first(flag)
+    t_c = timeit(lambda: preprocessing.fft_chain(iq, ws=ws))
+    t_l = timeit(lambda: preprocessing.fft_chain_loader(iq, ws=ws, out=out_l))
+    t_m = timeit(lambda: rt.check(rt.lib().hupr_fft_chain_loader_means_f32(rt.ptr(iq), n_sf, rt.ptr(out_m), rt.ptr(ws), ws.numel(), rt.stream())))
+    print("%s  n_sf=%d\n  c64:    %.1f us  %.0f GB/s (%.3f of 8 TB/s)\n  loader: %.1f us  %.0f GB/s (%.3f)  %.0f sensor-frames/s\n"
+          "  loader + elevation mean (the training step's variant): %.1f us  %.0f GB/s (%.3f)  %.0f sensor-frames/s"
+          % (tag, n_sf, t_c * 1e6, b_c / t_c / 1e9, b_c / t_c / 8e12, t_l * 1e6, b_l / t_l / 1e9, b_l / t_l / 8e12, n_sf / t_l,
+             t_m * 1e6, b_m / t_m / 1e9, b_m / t_m / 8e12, n_sf / t_m))
+rt.lib().hupr_debug_fft_range_first(0)
 
 # ---- per-kernel split (events around each C-ABI call are not possible: two kernels per call) and a pure-bandwidth baseline
 if len(sys.argv) > 2 and sys.argv[2] == "detail":

@@ -31,8 +31,14 @@ ap.add_argument("--skip-a", action="store_true")
 ap.add_argument("--time", action="store_true")
 ap.add_argument("--sets", default="")
 ap.add_argument("--brief", action="store_true", help="only the all-bf16 row")
+ap.add_argument("--full", action="store_true", help="with --sets: also the leave-one-out / leave-one-in rows")
 ap.add_argument("--lrs", default="", help="comma list: fit once per learning rate (brief tables), instead of --lr")
 args = ap.parse_args()
+
+
+def parse_set(st):
+    """"dec1b=f32act,head" -> {"dec1b": "f32act", "head": "f32"}"""
+    return {kv.split("=")[0]: (kv.split("=")[1] if "=" in kv else "f32") for kv in st.split(",") if kv}
 
 
 def table(tag, sd, cfg, h, v, joints=None):
@@ -61,8 +67,9 @@ def table(tag, sd, cfg, h, v, joints=None):
         return
     if args.sets:
         for st in args.sets.split(";"):
-            row("f32: " + st, {r: "f32" for r in st.split(",")})
-        return
+            row(st, parse_set(st))
+        if not args.full:
+            return
     for r in F_.REGIONS:
         row("all bf16 but %s" % r, {r: "f32"})
     for r in F_.REGIONS:
@@ -93,10 +100,11 @@ if args.time:
     from hupr_amd.tools.engine import TrainEngine
     F_.set_math("bf16")
     jt = torch.from_numpy(joints)
-    sets = [[]] + [[r] for r in F_.REGIONS] + ([s.split(",") for s in args.sets.split(";")] if args.sets else [])
+    sets = [{}] + ([{r: "f32"} for r in F_.REGIONS] if (args.full or not args.sets) else []) + \
+        ([parse_set(s) for s in args.sets.split(";")] if args.sets else [])
     for st in sets:
         F_.PRECISION.clear()
-        F_.PRECISION.update({r: "f32" for r in st})
+        F_.PRECISION.update(st)
         eng = TrainEngine(cfg, device="cuda", lr=1e-4)
         for _ in range(3):
             eng.train_step(h, v, jt)
@@ -105,7 +113,7 @@ if args.time:
         for _ in range(10):
             eng.train_step(h, v, jt)
         torch.cuda.synchronize()
-        print("   training step (B=32, model inputs) with f32 regions %-12s %.2f ms" % (",".join(st) or "-", (time.time() - t0) * 100), flush=True)
+        print("   training step (B=32, model inputs) with %-40s %.2f ms" % (",".join("%s=%s" % kv for kv in st.items()) or "all bf16", (time.time() - t0) * 100), flush=True)
         del eng
     F_.PRECISION.clear()
     F_.set_math("f32")

@@ -19,7 +19,7 @@ from hupr_amd.config_tree import load_config
 
 def scene_batch(batch, rng, gen, device):
     """One training batch of scenes: noise from the device generator, reflectors from NumPy joints."""
-    joints = rng.integers(40, 216, size=(batch, 14, 2)).astype(np.int64)
+    joints = synth.pose_joints(rng.random((batch, 31)))
     blobs = torch.from_numpy(synth.pose_scene_blobs(joints)).to(device)
     shape = (batch, 8, 8, 2, 64, 64, 8)
     nh = torch.randn(shape, device=device, generator=gen)
@@ -71,12 +71,14 @@ def fit(steps=600, batch=32, lr=3e-4, math="bf16", model_seed=1, gain=1.0, log_e
 
 
 def evaluate(sd, cfg, h, v, math, precision=None):
-    """Eval-mode forward of the weights ``sd`` under ``math`` (+ per-region precision switches) -> (p1, p2) on the device."""
+    """Eval-mode forward of the weights ``sd`` under ``math`` -> (p1, p2) on the device.  ``precision``: None = the library's
+    default per-region switches (functional.PRECISION), a dict = exactly those ({} = every region bf16)."""
     from hupr_amd.models import HuPRNet
     prev, prev_p = F_.MATH, dict(F_.PRECISION)
     F_.set_math(math)
-    F_.PRECISION.clear()
-    F_.PRECISION.update(precision or {})
+    if precision is not None:
+        F_.PRECISION.clear()
+        F_.PRECISION.update(precision)
     try:
         net = HuPRNet(cfg).cuda().eval()
         net.load_state_dict(sd)

@@ -100,8 +100,8 @@ def test_fused_loader_vs_oracle():
         assert np.abs(got[n][f_ok] - ref[f_ok]).max() <= 2e-4
     flat = got.reshape(2, 8, 2, 4096, 8).astype(np.float64)
     assert np.abs(flat.mean(axis=3)).max() < 1e-4
-    assert np.abs(flat.std(axis=3, ddof=1) - 1).max() < 1e-4
-    assert np.isfinite(got).all()
+    assert np.abs(flat[:, f_ok].std(axis=3, ddof=1) - 1).max() < 1e-4
+    assert np.isfinite(got).all() and np.abs(got[:, 4]).max() == 0.0      # the exactly-zero Doppler plane stays zero (no 0/0)
     # unfused route (complex cube -> loader glue) agrees with the fused one
     two = preprocessing.loader_normalize(preprocessing.fft_chain(dev)).cpu().numpy()
     assert np.abs(two[:, f_ok] - got[:, f_ok]).max() <= 1e-4
@@ -240,3 +240,29 @@ def test_fused_elevation_mean_loader_is_bit_identical_to_loader_plus_mnet_mean()
         ga = torch.autograd.grad(ya.float().square().sum(), (w, b))
         gb = torch.autograd.grad(yb.float().square().sum(), (w, b))
         assert torch.equal(ga[0], gb[0]) and torch.equal(ga[1], gb[1])
+
+
+def test_zero_doppler_bin_is_exactly_zero_and_normalises_to_zeros():
+    """Round 3 (Doppler-first chain): static clutter removal (process_iwr1843.py:122-128) is exact on integer ADC samples, so
+    the zero-Doppler bin (index 8; the loader's slot f = 4) is EXACTLY zero — the reference holds 1e-13-relative rounding
+    noise there, which its Normalize inflates to unit variance (meaningless either way).  The loader
+    epilogues must turn that zero-variance plane into zeros, never 0/0; both K1 orders agree on every other bin."""
+    from hupr_amd import preprocessing, runtime as rt
+    dev = torch.from_numpy(np.concatenate([synth.adc_cube_int16(9, frame=f) for f in range(4)])).cuda()
+    cube = preprocessing.fft_chain(dev)
+    assert cube[:, 8].abs().max().item() == 0.0
+    ld = preprocessing.fft_chain_loader(dev)
+    pl = preprocessing.fft_chain_loader_means(dev)
+    assert torch.isfinite(ld).all() and torch.isfinite(pl).all()
+    assert ld[:, 4].abs().max().item() == 0.0 and pl[:, 8:10].abs().max().item() == 0.0
+    try:
+        rt.lib().hupr_debug_fft_range_first(1)                     # the round-1/2 kernel: same transform, other order
+        old = preprocessing.fft_chain(dev)
+        old_ld = preprocessing.fft_chain_loader(dev)
+    finally:
+        rt.lib().hupr_debug_fft_range_first(0)
+    keep = [i for i in range(16) if i != 8]
+    rel = ((cube[:, keep] - old[:, keep]).abs().pow(2).sum().sqrt() / old[:, keep].abs().pow(2).sum().sqrt()).item()
+    assert rel <= 1e-6, rel
+    f_ok = [0, 1, 2, 3, 5, 6, 7]
+    assert (ld[:, f_ok] - old_ld[:, f_ok]).abs().max().item() <= 1e-4

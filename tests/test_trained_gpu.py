@@ -11,6 +11,7 @@ regenerated on the GPU box either.  What IS portable:
     maps — fp32: north_star's 1e-3 / identical arg-max; bf16: SURVEY 8(d)'s arg-max on >= 99 % of the joints + tolerance.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -20,6 +21,7 @@ from hupr_amd import synth
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 _CACHE = {}
 
 
@@ -78,11 +80,10 @@ def _oracle_eval(sd, h, v):
         return omodel.forward({k: t.detach().cpu() for k, t in sd.items()}, h.cpu(), v.cpu(), train=False)
 
 
-def test_both_paths_match_the_oracle_on_trained_peaky_maps():
-    """The oracle (= the reference's arithmetic) evaluates the weights trained above; fp32 path: heat-maps within 1e-3,
-    arg-max identical (north_star); bf16 path: arg-max identical on >= 99 % of 224 joints, heat-maps within 3e-2."""
-    from hupr_amd import functional as F_
-    from hupr_amd.models import HuPRNet
+def test_fp32_path_matches_the_oracle_on_memorised_peaky_maps():
+    """The oracle (= the reference's arithmetic) evaluates the weights trained above on the training batch + 14 unseen noise
+    samples (multi-modal maps with saturated blobs): fp32 path heat-maps within 1e-3, arg-max identical (north_star) — a flipped
+    joint must be an exact tie inside the path's tolerance."""
     c = _trained()
     B = 16
     xh, xv = (torch.from_numpy(t).cuda() for t in synth.model_inputs(B, int(c["g"]["extra_seed"])))
@@ -95,55 +96,94 @@ def test_both_paths_match_the_oracle_on_trained_peaky_maps():
     e1, e2 = (f1.cpu() - o1).abs().max().item(), (f2.cpu() - o2).abs().max().item()
     a1 = (f1.reshape(B, 14, -1).argmax(-1).cpu() == am1).float().mean().item()
     a2 = (f2.reshape(B, 14, -1).argmax(-1).cpu() == am2).float().mean().item()
-    print("fp32 path vs oracle on trained weights (%d joints, median max/mean %.1f): max-abs %.3e / %.3e, arg-max agreement "
+    print("fp32 path vs oracle on memorised weights (%d joints, median max/mean %.1f): max-abs %.3e / %.3e, arg-max agreement "
           "%.4f / %.4f" % (B * 14, pk, e1, e2, a1, a2))
     assert pk >= 10.0
     assert e1 <= 1e-3 and e2 <= 1e-3 and a1 >= 0.99 and a2 >= 0.99
-    # identical arg-max wherever the oracle's own map has a decisive maximum: a flipped joint must be a tie inside the
-    # path's 1e-3 tolerance (trained sigmoid maps saturate: several pixels of a blob sit at 0.99..)
+    _ties_only(f1, f2, o1, o2, B)
+
+
+def _ties_only(f1, f2, o1, o2, B):
+    """fp32 path: identical arg-max wherever the oracle's own map has a decisive maximum — a flipped joint must be a tie inside
+    1e-4 (trained sigmoid maps saturate: several pixels of a blob sit at 0.99..)."""
     for name, f, o in (("head", f1, o1), ("gcn", f2, o2)):
         fo, oo = f.reshape(B, 14, -1).cpu(), o.reshape(B, 14, -1)
         for b, k in zip(*np.nonzero((fo.argmax(-1) != oo.argmax(-1)).numpy())):
             assert (oo[b, k].max() - oo[b, k, fo[b, k].argmax()]).item() <= 1e-4, (name, b, k)
-    try:
-        F_.set_math("bf16")
-        net16 = HuPRNet(c["cfg"]).cuda().eval()
-        net16.load_state_dict(c["net"].state_dict())
-        with torch.no_grad():
-            b1, b2 = net16(xh, xv)
-    finally:
-        F_.set_math("f32")
-    e1, e2 = (b1.cpu() - o1).abs().max().item(), (b2.cpu() - o2).abs().max().item()
-    a1 = (b1.reshape(B, 14, -1).argmax(-1).cpu() == am1).float().mean().item()
-    a2 = (b2.reshape(B, 14, -1).argmax(-1).cpu() == am2).float().mean().item()
-    print("bf16 path vs oracle on trained weights: max-abs %.3e / %.3e, arg-max agreement %.4f / %.4f" % (e1, e2, a1, a2))
-    _bf16_gates(b1.cpu(), b2.cpu(), o1, o2, B)
 
 
-def test_bf16_path_on_trained_weights_meets_the_argmax_gate_at_batch32():
-    """SURVEY 8(d) at the bench batch: bf16 vs the fp32 path on the same trained weights, 448 joints."""
-    from hupr_amd import functional as F_
-    from hupr_amd.models import HuPRNet
-    c = _trained()
-    h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(32, 123))
-    with torch.no_grad():
-        f1, f2 = c["net"](h, v)
-    try:
-        F_.set_math("bf16")
-        net16 = HuPRNet(c["cfg"]).cuda().eval()
-        net16.load_state_dict(c["net"].state_dict())
-        with torch.no_grad():
-            b1, b2 = net16(h, v)
-    finally:
-        F_.set_math("f32")
-    e1, e2 = (f1 - b1).abs().max().item(), (f2 - b2).abs().max().item()
-    agree1 = (f1.reshape(32, 14, -1).argmax(-1) == b1.reshape(32, 14, -1).argmax(-1)).float().mean().item()
-    agree2 = (f2.reshape(32, 14, -1).argmax(-1) == b2.reshape(32, 14, -1).argmax(-1)).float().mean().item()
-    pk = (f2.reshape(448, -1).max(1)[0] / f2.reshape(448, -1).mean(1)).median().item()
-    print("bf16 vs fp32 on trained weights, B=32 (448 joints, median max/mean %.1f): max-abs %.3e / %.3e, arg-max agreement "
-          "%.4f / %.4f" % (pk, e1, e2, agree1, agree2))
-    assert pk >= 10.0
-    _bf16_gates(b1, b2, f1, f2, 32)
+# ---- the reduced-precision gate on a network that GENERALISES (VERDICT r2 item 1) --------------------------------------------
+# The memorised fixture above answers unseen noise with multi-modal maps; every bf16 flip on it is a tie, and no precision
+# switch short of the whole fp32 path changes that (profiles/r03_precision_regions.txt, part A).  SURVEY 8(d)'s gate is about a
+# trained network's uni-modal maps, so the fixture is a fit to the learnable pose-scene task (tests/pose_fit.py): trained on the
+# benched bf16 path, evaluated on held-out scenes by the oracle, the fp32 path and the bf16 path.
+_POSE = {}
+
+
+def _pose_trained():
+    if "sd" not in _POSE:
+        import pose_fit
+        sd, cfg, log = pose_fit.fit(steps=3000, lr=3e-4, verbose=False)
+        print("pose-scene fit: loss %.4f -> %.4f (gcn %.4f)" % (log[0][1], log[-1][1], log[-1][2]))
+        hn, vn, joints = synth.pose_scenes(32, 1)
+        _POSE.update(sd=sd, cfg=cfg, log=log, h=torch.from_numpy(hn).cuda(), v=torch.from_numpy(vn).cuda(), joints=joints, fit=pose_fit)
+    return _POSE
+
+
+def test_pose_fit_generalises_to_uni_modal_maps():
+    """Fixture sanity: the fit learns the task (loss / 20), and on 32 HELD-OUT scenes the fp32 path's maps are peaky and put the
+    first head's maximum on the target centre — a trained network in SURVEY's sense, not a memorised batch."""
+    p = _pose_trained()
+    pf = p["fit"]
+    assert min(l[1] for l in p["log"][-3:]) < 0.05 * p["log"][0][1]        # (single steps can spike: bf16 Adam at 3e-4)
+    r1, r2 = pf.evaluate(p["sd"], p["cfg"], p["h"], p["v"], "f32")
+    n = 32 * 14
+    pk1 = (r1.reshape(n, -1).max(1)[0] / r1.reshape(n, -1).mean(1)).median().item()
+    pk2 = (r2.reshape(n, -1).max(1)[0] / r2.reshape(n, -1).mean(1)).median().item()
+    hit = pf.hit_rate(r1, torch.from_numpy(p["joints"]))
+    ap = pf.decode_ap(r2, p["joints"])
+    t2 = r2.reshape(n, -1).topk(2, dim=1)[0]
+    tie = ((t2[:, 0] - t2[:, 1]) < 1e-3).float().mean().item()
+    print("held-out scenes, fp32 path: median max/mean %.1f / %.1f, first head on the target centre %.3f, OKS AP of the decoded "
+          "head %.3f; decoded-head joints whose two best pixels are within 1e-3: %.3f" % (pk1, pk2, hit, ap, tie))
+    assert pk1 >= 40.0 and pk2 >= 40.0 and hit >= 0.8 and ap >= 0.3
+    p.update(r1=r1, r2=r2, ap=ap)
+
+
+def test_both_paths_match_the_oracle_on_trained_uni_modal_maps():
+    """16 held-out scenes through the ORACLE (the reference's arithmetic, on the host): fp32 path within 1e-3 / identical
+    arg-max; bf16 path (the benched one, library-default precision switches) inside the reduced-precision gate."""
+    p = _pose_trained()
+    pf = p["fit"]
+    B = 16
+    h, v = p["h"][:B], p["v"][:B]
+    o1, o2 = _oracle_eval(p["sd"], h, v)
+    f1, f2 = pf.evaluate(p["sd"], p["cfg"], h, v, "f32")
+    e1, e2 = (f1.cpu() - o1).abs().max().item(), (f2.cpu() - o2).abs().max().item()
+    a1, a2 = pf.agreement(f1, o1)[0], pf.agreement(f2, o2)[0]
+    print("fp32 path vs oracle, held-out scenes (%d joints): max-abs %.3e / %.3e, arg-max agreement %.4f / %.4f" % (B * 14, e1, e2, a1, a2))
+    assert e1 <= 1e-3 and e2 <= 1e-3 and a1 >= 0.99 and a2 >= 0.99
+    _ties_only(f1, f2, o1, o2, B)
+    b1, b2 = pf.evaluate(p["sd"], p["cfg"], h, v, "bf16")
+    print("bf16 path vs oracle, held-out scenes:")
+    _bf16_gates(b1.cpu(), b2.cpu(), o1, o2)
+
+
+def test_bf16_path_meets_the_argmax_and_ap_gates_at_batch32():
+    """SURVEY 8(d) at the bench batch: bf16 vs the fp32 path on the same trained weights, 448 joints of 32 held-out scenes, and
+    the AP-level check north_star asks for (OKS AP of the decoded key-points against the scenes' joints, misc/oks_eval.py ==
+    the reference's COCOeval: +-0.2 AP points)."""
+    p = _pose_trained()
+    pf = p["fit"]
+    if "r1" not in p:
+        p["r1"], p["r2"] = pf.evaluate(p["sd"], p["cfg"], p["h"], p["v"], "f32")
+        p["ap"] = pf.decode_ap(p["r2"], p["joints"])
+    b1, b2 = pf.evaluate(p["sd"], p["cfg"], p["h"], p["v"], "bf16")
+    print("bf16 vs fp32 path, 32 held-out scenes:")
+    _bf16_gates(b1, b2, p["r1"], p["r2"])
+    ap16 = pf.decode_ap(b2, p["joints"])
+    print("  OKS AP of the decoded key-points: fp32 path %.4f, bf16 path %.4f" % (p["ap"], ap16))
+    assert abs(ap16 - p["ap"]) <= 0.002
 
 
 def test_bf16_training_forward_on_the_fitted_batch_decodes_identically():
@@ -176,19 +216,21 @@ def test_bf16_training_forward_on_the_fitted_batch_decodes_identically():
         assert torch.equal(af, ab)
 
 
-def _bf16_gates(b1, b2, r1, r2, B):
-    """Reduced-precision gate on peaky maps (arg-max identical on >= 99 % of the joints + tolerance).
-    Measured on this fixture at B = 32: first head 99.6 %, decoded (PRGCN) head 97.5 %, 98.7 % within one pixel (99.1 / 96.9 /
-    98.2 % before the BatchNorm statistics were made bit-reproducible: the 120 training steps are chaotic, and LDS fp64 atomics
-    used to change the last bit of a mean now and then, so the trained weights — and with them these counts — varied from run to
-    run; they are now identical on every run).  The eval-mode maps of a 120-step fit to two samples are multi-modal with saturated
-    blobs (median peak 0.96, several pixels within 2 % of it), and EVERY flip is a tie inside the bf16 tolerance.  The gates state exactly
-    that: >= 99 % on the first head, >= 96 % identical / >= 98 % within one pixel on the decoded head, and no flip whose
-    reference map prefers its own maximum by more than the tolerance."""
-    n = B * 14
-    tol = (3e-2, 6e-2)
+def _bf16_gates(b1, b2, r1, r2):
+    """Reduced-precision gate on a trained network's uni-modal maps (arg-max identical on >= 99 % of the joints +
+    the AP gate), one threshold set for every batch size:
+      first head    identical arg-max on >= 99 % of the joints;
+      decoded head  (PRGCN; the one key-points and AP come from) identical on >= 97.5 %, EVERY joint within one pixel, and the AP
+                    gate in the caller.  Measured 98.7-99.3 % over four fits (profiles/r03_precision_regions.txt): this head's
+                    map is a 2x align_corners up-sampling of a 32 x 32 map, so its two best pixels are interpolations of the same
+                    two source nodes and sit within 1e-3 of each other on 5-8 % of the joints OF THE FP32 MAP ITSELF; bf16
+                    arithmetic (max-abs 1e-2) decides some of those ties the other way, by one pixel.  Only the fp32 path can
+                    promise more — no set of per-region switches below +23 % step time changes it, see DESIGN.md section 6;
+      both          no flip whose reference map prefers its own maximum by more than the tolerance; max-abs inside the tolerance."""
+    n = b1.shape[0] * 14
+    tol = (5e-2, 3e-2)
     for hd, (b, r) in enumerate(((b1, r1), (b2, r2))):
-        bb, rr = b.reshape(n, -1), r.reshape(n, -1)
+        bb, rr = b.reshape(n, -1).float().cpu(), r.reshape(n, -1).float().cpu()
         ab, ar = bb.argmax(1), rr.argmax(1)
         d = torch.maximum((ab % 64 - ar % 64).abs(), (ab // 64 - ar // 64).abs())
         same, near = (d == 0).float().mean().item(), (d <= 1).float().mean().item()
@@ -198,7 +240,5 @@ def _bf16_gates(b1, b2, r1, r2, B):
               (hd, same, near, gap.max().item(), err))
         assert err <= tol[hd]
         assert gap.max().item() <= 1.5e-2
-        if hd == 0:
-            assert same >= (0.99 if B >= 32 else 0.97)          # 224 joints: one flip is 0.45 %
-        else:
-            assert same >= 0.96 and near >= 0.98
+        assert near == 1.0
+        assert same >= (0.99 if hd == 0 else 0.975)
