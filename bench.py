@@ -331,16 +331,23 @@ def main():
     # of the same step (same buffers, nothing re-initialised) and report that window separately; `value` stays the --steps region.
     sustained = None
     if args.sustain > 0 and not args.graph:
-        n_more = max(int(np.ceil(args.sustain / (dt / args.steps))), 1)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n_more):
-            one_step()
-        barrier()
-        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-        if dist.is_initialized():
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        d_more = float(ts.item())
+        # chunks until the window is >= --sustain seconds on every rank (the first estimate comes from the timed steps,
+        # which over-estimate the step time when --steps is tiny)
+        n_more, d_more = 0, 0.0
+        est = dt / args.steps
+        while d_more < args.sustain:
+            chunk = max(int(np.ceil((args.sustain - d_more) / est * 1.02)), 1)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(chunk):
+                one_step()
+            barrier()
+            ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+            if dist.is_initialized():
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)      # identical on every rank: all ranks leave the loop together
+            d_more += float(ts.item())
+            n_more += chunk
+            est = d_more / n_more
         sustained = {"value": round(world * B * micro * n_more / d_more, 3), "unit": "frames/s", "steps": n_more,
                      "seconds": round(d_more, 2), "ms_per_step": round(d_more / n_more * 1e3, 3),
                      "note": "continuation of the timed region on the same state; `value` above is the --steps window only"}
@@ -385,6 +392,7 @@ def main():
 
     if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_parity_path and not args.strong:
         # the path that meets north_star's 1e-3 heat-map / exact arg-max gate: fp32 matrix pipe, fp32 activations
+        eng.close()                  # release the exchange step's communicator (live under HUPR_FORCE_ALLREDUCE)
         del eng
         torch.cuda.empty_cache()
         F_.set_math("f32")
@@ -404,6 +412,7 @@ def main():
                   "ms_per_step": round(d32 / n32 * 1e3, 2),
                   "gate": "heat-maps within 1e-3 max-abs of the reference, arg-max identical (tests/test_model_gpu.py)",
                   "roofline": conv_roofline(ev32, B, "f32", PEAK_F32_MFMA_TFLOPS)}
+        eng32.close()
         del eng32
         F_.set_math(args.dtype)
 

@@ -27,7 +27,14 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     constexpr int NH = ABF ? NI : NI / 2;                      // ... fp32 sources: two half batches (register budget)
         __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];     // double-buffered weight stages
-    __shared__ float Ss[4][2][256];                              // fused BatchNorm statistics: [depth slice wave][sum | sum of squares][channel]
+    // fused BatchNorm statistics (p.stats; Co == 64, one co tile): running sums of the bf16-ROUNDED outputs per lane PAIR —
+    // [wave][lane >> 1][value r = 0..15 sums, 16..31 sums of squares].  A tile costs one DPP pair-add per value and a plain
+    // read-add-write of the pair's own 128-byte slot (16-byte LDS accesses; nobody else touches it: no atomics — ds_add_f32
+    // retires about one lane per clock and cost 80 us per launch); the cross-lane / cross-wave reduction happens ONCE after
+    // the tile loop, and the deferred epilogue stays on.  (Rounds 1-2 reduced all 32 voxel lanes
+    // per tile: 160 DPP adds + 32 LDS adds, immediate epilogue — 72 % of the cost of the statistics pass it replaced.  Per-lane
+    // register accumulators would be cheaper still, but the kernel sits at 245 of its 256 VGPRs.)
+    __shared__ __attribute__((aligned(16))) float St[8][32][36];      // [wave][lane >> 1][32 values + 4 pad: conflict-free 16-byte accesses]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // static issue priority for the second-dispatched half of the workgroup (it loses every arbitration against its older
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     long mP = 0;
     int chP = 0;
     bool pend = false;
-    const bool defer = ABF && !p.bias && !p.res && !p.stats && (p.Co & 7) == 0 && (p.out_ld & 7) == 0 && !(p.ablate & (4 | 2));      // ablate bit 1: A/B switch (immediate epilogue)
+    const bool defer = ABF && !p.bias && !p.res && (p.Co & 7) == 0 && (p.out_ld & 7) == 0 && !(p.ablate & (4 | 2));      // ablate bit 1: A/B switch (immediate epilogue)
     f32x4n va[ABF ? 1 : NH], vc[ABF ? 1 : NH];
     u32x4 vb[ABF ? NH : 1];
 
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     const int wg_rank = (p.ablate & 8) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     const int t_begin = wg_rank * per_wg, t_end = min(n_tiles, t_begin + per_wg);
     if (p.stats) {
-        for (int i = tid; i < 4 * 2 * 256; i += 512) (&Ss[0][0][0])[i] = 0.f;      // published by the prologue barrier
+        for (int i = tid; i < 8 * 32 * 36; i += 512) (&St[0][0][0])[i] = 0.f;      // published by the prologue barrier
         if (t_begin >= t_end) {
             for (int c = tid; c < 2 * p.Co; c += 512) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
         }
@@ -304,34 +311,26 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         }
         if constexpr (ABF) {
             if (p.stats && last_chunk) {
-                // column sums of what was just stored (the bf16-rounded values): this lane's 16 channels x its two voxels,
-                // summed over the 32 voxel lanes, then lanes 31 / 63 add into the slot only they ever touch
-                float cs[16], cq[16];
+                // this lane's 16 channels x its two voxels of the tile just finished, rounded exactly as they are stored;
+                // + the neighbouring voxel lane (quad_perm [1,0,3,2]); the even lane owns the pair's slot
+                f32x4n* slot = reinterpret_cast<f32x4n*>(&St[wave][lane >> 1][0]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float a = (float)(__bf16)acc[0][r], c = (float)(__bf16)acc[1][r];
-                    cs[r] = a + c;
-                    cq[r] = fmaf(a, a, c * c);
-                }
-                // 32-lane sums with DPP adds only (row_shr 1/2/4/8 inside each 16-lane row, row_bcast:15 across the two rows
-                // of a half-wave): the totals land in lanes 31 and 63.  (__shfl_xor compiled to 160 ds_bpermute per tile.)
-#define HUPR_DPP_ADD(V_, CTRL_, RMASK_)                                                                             \
-    V_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V_), CTRL_, RMASK_, 0xf, true));
-                // step-major order: the 32 chains are independent, a chain's own steps are not (DPP source hazards)
-#define HUPR_DPP_STEP(CTRL_, RMASK_)                                                                                \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) { HUPR_DPP_ADD(cs[r], CTRL_, RMASK_) HUPR_DPP_ADD(cq[r], CTRL_, RMASK_) } \
-    __builtin_amdgcn_sched_barrier(0);
-                HUPR_DPP_STEP(0x111, 0xf) HUPR_DPP_STEP(0x112, 0xf) HUPR_DPP_STEP(0x114, 0xf) HUPR_DPP_STEP(0x118, 0xf)
-                HUPR_DPP_STEP(0x142, 0xa)
-#undef HUPR_DPP_STEP
-#undef HUPR_DPP_ADD
-                if (lr == 31) {
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float sv[4], qv[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ch = n0 + wn * 32 + 4 * lh + 8 * (r >> 2) + (r & 3);
-                        // return-less LDS adds (only this lane ever touches the address: order = program order, deterministic)
-                        __hip_atomic_fetch_add(&Ss[wm][0][ch], cs[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&Ss[wm][1][ch], cq[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = (float)(__bf16)acc[0][4 * g4 + j], c = (float)(__bf16)acc[1][4 * g4 + j];
+                        sv[j] = a + c;
+                        qv[j] = fmaf(a, a, c * c);
+                        sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0xB1, 0xf, 0xf, true));
+                        qv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, qv[j]), 0xB1, 0xf, 0xf, true));
+                    }
+                    if (!(lane & 1)) {
+                        f32x4n s0 = slot[g4], q0 = slot[4 + g4];
+                        s0.x += sv[0]; s0.y += sv[1]; s0.z += sv[2]; s0.w += sv[3];
+                        q0.x += qv[0]; q0.y += qv[1]; q0.z += qv[2]; q0.w += qv[3];
+                        slot[g4] = s0;
+                        slot[4 + g4] = q0;
                     }
                 }
             }
@@ -349,11 +348,19 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         cur = nxt;
     }
     if (p.trace != nullptr && tid == 0) p.trace[4096 + 2 * blockIdx.x + 1] = wall_clock64();
-    if (p.stats) {                                                // the four depth-slice waves' sums, fixed order, as doubles
+    if (p.stats) {
+        // channel ch = 32 wn + 4 lh + 8 (r >> 2) + (r & 3) collects, in a fixed order and as doubles, the 16 lane-pair slots of
+        // its half-wave lh in each of the four depth-slice waves wm
         __syncthreads();
-        for (int c = tid; c < 2 * p.Co; c += 512) {
-            const int k = c / p.Co, ch = c - k * p.Co;
-            p.stats[(long)blockIdx.x * 2 * p.Co + c] = ((double)Ss[0][k][ch] + (double)Ss[1][k][ch]) + ((double)Ss[2][k][ch] + (double)Ss[3][k][ch]);
+        if (tid < 2 * BN) {
+            const int k = tid >> 6, ch = tid & 63;
+            const int wn_ = ch >> 5, c5 = ch & 31, g_ = c5 >> 3, lh_ = (c5 >> 2) & 1, r = 4 * g_ + (c5 & 3);
+            double t = 0.0;
+#pragma unroll
+            for (int wm_ = 0; wm_ < 4; ++wm_)
+#pragma unroll
+                for (int sl = 0; sl < 16; ++sl) t += (double)St[2 * wm_ + wn_][16 * lh_ + sl][16 * k + r];
+            p.stats[(long)blockIdx.x * 2 * p.Co + k * p.Co + ch] = t;
         }
     }
 #undef HUPR_W_DMA

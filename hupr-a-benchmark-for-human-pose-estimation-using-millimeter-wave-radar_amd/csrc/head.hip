@@ -254,6 +254,96 @@ __global__ __launch_bounds__(256) void hupr_k_adam_dev(float* __restrict__ p, co
 
 static inline int grid1d(long n, int bs = 256, long cap = 4096) { return (int)min(cap, (n + bs - 1) / bs); }
 
+
+// ------------------------------------------------------------------------------------------
+// 1x1 key-point head (reference models/layers.py:94, nn.Conv2d(32, 14, 1, bias=False)) in plain fp32 FMAs.
+// 58 MFLOP per batch of 32: the generic implicit-GEMM path spends its time on tile setup, zero-padded K axes and split-K
+// partials (0.26 ms per training step when the "head" region of a bf16 run is switched to fp32, functional.PRECISION).
+//   x [M][32] fp32, w [16][32] (rows >= 14 zero), y / dy [M][16], dx [M][32], dw [16][32]
+// One thread per voxel (its 32 input channels in registers, the weights through scalar loads: the index is uniform).
+// ------------------------------------------------------------------------------------------
+constexpr int kHeadCi = 32, kHeadCo = 16;
+
+__global__ __launch_bounds__(256) void hupr_k_head1x1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, long M) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= M) return;
+    float xr[kHeadCi];
+    const float4* xp = reinterpret_cast<const float4*>(x + v * kHeadCi);
+#pragma unroll
+    for (int i = 0; i < kHeadCi / 4; ++i) { const float4 t = xp[i]; xr[4 * i] = t.x; xr[4 * i + 1] = t.y; xr[4 * i + 2] = t.z; xr[4 * i + 3] = t.w; }
+    float4* yp = reinterpret_cast<float4*>(y + v * kHeadCo);
+#pragma unroll
+    for (int k4 = 0; k4 < kHeadCo / 4; ++k4) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < kHeadCi; ++c) a = fmaf(xr[c], w[(4 * k4 + j) * kHeadCi + c], a);
+            o[j] = a;
+        }
+        yp[k4] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dx[v][c] = sum_k dy[v][k] w[k][c]
+__global__ __launch_bounds__(256) void hupr_k_head1x1_dgrad(const float* __restrict__ dy, const float* __restrict__ w,
+                                                            float* __restrict__ dx, long M) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= M) return;
+    float g[kHeadCo];
+    const float4* gp = reinterpret_cast<const float4*>(dy + v * kHeadCo);
+#pragma unroll
+    for (int i = 0; i < kHeadCo / 4; ++i) { const float4 t = gp[i]; g[4 * i] = t.x; g[4 * i + 1] = t.y; g[4 * i + 2] = t.z; g[4 * i + 3] = t.w; }
+    float4* xp = reinterpret_cast<float4*>(dx + v * kHeadCi);
+#pragma unroll
+    for (int c4 = 0; c4 < kHeadCi / 4; ++c4) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < kHeadCo; ++k) a = fmaf(g[k], w[k * kHeadCi + 4 * c4 + j], a);
+            o[j] = a;
+        }
+        xp[c4] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dw[k][c] = sum_v dy[v][k] x[v][c]: workgroup b sums voxels [b * per, (b + 1) * per) in chunks of 128 staged in LDS; thread
+// t owns outputs (k, c) = (t >> 4, 2 (t & 15) + {0, 1}); partial rows [grid][512] are summed in block order by the second
+// kernel (deterministic, no atomics).
+constexpr int kHeadWgradGrid = 256;
+__global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ part, long M) {
+    __shared__ float xs[128][kHeadCi + 1];
+    __shared__ float gs[128][kHeadCo + 1];
+    const int tid = threadIdx.x, k = tid >> 4, c0 = 2 * (tid & 15);
+    const long per = (M + gridDim.x - 1) / gridDim.x, v0 = (long)blockIdx.x * per, v1 = min(M, v0 + per);
+    float a0 = 0.f, a1 = 0.f;
+    for (long vb = v0; vb < v1; vb += 128) {
+        const int n = (int)min((long)128, v1 - vb);
+        __syncthreads();
+        for (int i = tid; i < 128 * kHeadCi; i += 256) { const int r = i >> 5, c = i & 31; xs[r][c] = r < n ? x[(vb + r) * kHeadCi + c] : 0.f; }
+        for (int i = tid; i < 128 * kHeadCo; i += 256) { const int r = i >> 4, c = i & 15; gs[r][c] = r < n ? dy[(vb + r) * kHeadCo + c] : 0.f; }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 128; ++r) {
+            const float g = gs[r][k];
+            a0 = fmaf(g, xs[r][c0], a0);
+            a1 = fmaf(g, xs[r][c0 + 1], a1);
+        }
+    }
+    part[(long)blockIdx.x * 512 + k * kHeadCi + c0] = a0;
+    part[(long)blockIdx.x * 512 + k * kHeadCi + c0 + 1] = a1;
+}
+__global__ __launch_bounds__(512) void hupr_k_head1x1_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int rows) {
+    double a = 0.0;
+    for (int r = 0; r < rows; ++r) a += (double)part[(long)r * 512 + threadIdx.x];
+    dw[threadIdx.x] = (float)a;
+}
+
 }  // namespace hupr
 
 using namespace hupr;
@@ -268,6 +358,35 @@ extern "C" int hupr_softmax_rows_bwd_f32(const float* p, float* dp_inout, long r
     HUPR_REQUIRE(p && dp_inout && rows > 0 && n > 0 && n % 4 == 0 && rows < (1L << 31), "hupr_softmax_rows_bwd_f32: bad argument");
     hipLaunchKernelGGL(hupr_k_softmax_rows_bwd, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), p, dp_inout, n);
     HUPR_LAUNCH_OK("hupr_k_softmax_rows_bwd");
+    return HUPR_OK;
+}
+
+extern "C" size_t hupr_head1x1_ws_bytes(void) { return (size_t)kHeadWgradGrid * 512 * sizeof(float); }
+extern "C" int hupr_head1x1_fwd_f32(const float* x, const float* w16, float* y, long M, hupr_stream_t stream) {
+    HUPR_REQUIRE(M >= 0, "hupr_head1x1_fwd_f32: M=%ld", M);
+    if (M == 0) return HUPR_OK;
+    HUPR_REQUIRE(x && w16 && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "hupr_head1x1_fwd_f32: null or misaligned pointer");
+    hipLaunchKernelGGL(hupr_k_head1x1_fwd, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), x, w16, y, M);
+    HUPR_LAUNCH_OK("hupr_k_head1x1_fwd");
+    return HUPR_OK;
+}
+extern "C" int hupr_head1x1_bwd_f32(const float* x, const float* w16, const float* dy, float* dx_or_null, float* dw16_or_null,
+                                    long M, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(M >= 0, "hupr_head1x1_bwd_f32: M=%ld", M);
+    if (M == 0) return HUPR_OK;
+    HUPR_REQUIRE(x && w16 && dy && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx_or_null & 15) == 0,
+                 "hupr_head1x1_bwd_f32: null or misaligned pointer");
+    if (dx_or_null) {
+        hipLaunchKernelGGL(hupr_k_head1x1_dgrad, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), dy, w16, dx_or_null, M);
+        HUPR_LAUNCH_OK("hupr_k_head1x1_dgrad");
+    }
+    if (dw16_or_null) {
+        if (!ws || ws_bytes < hupr_head1x1_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_head1x1_bwd_f32: workspace %zu < %zu", ws_bytes, hupr_head1x1_ws_bytes());
+        const int grid = (int)min((long)kHeadWgradGrid, (M + 127) / 128);
+        hipLaunchKernelGGL(hupr_k_head1x1_wgrad, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, static_cast<float*>(ws), M);
+        hipLaunchKernelGGL(hupr_k_head1x1_wgrad_reduce, dim3(1), dim3(512), 0, as_stream(stream), static_cast<const float*>(ws), dw16_or_null, grid);
+        HUPR_LAUNCH_OK("hupr_k_head1x1_wgrad");
+    }
     return HUPR_OK;
 }
 

@@ -49,6 +49,7 @@ else:
     PRECISION = {"dec1b": "f32act", "head": "f32"}
 assert all(r in REGIONS for r in PRECISION), PRECISION
 _ACT_F32_HERE = False      # inside a region switched to "f32act"
+_REGION_SWITCHED = False   # inside a region of a bf16 run that was switched to the fp32 pipe
 
 
 class region:
@@ -59,17 +60,18 @@ class region:
         self.name = name
 
     def __enter__(self):
-        global MATH, _ACT_F32_HERE
-        self.prev = (MATH, _ACT_F32_HERE)
+        global MATH, _ACT_F32_HERE, _REGION_SWITCHED
+        self.prev = (MATH, _ACT_F32_HERE, _REGION_SWITCHED)
         mode = PRECISION.get(self.name)
         if MATH == "bf16" and mode == "f32":
             MATH = "f32"
+            _REGION_SWITCHED = True
         _ACT_F32_HERE = MATH == "bf16" and mode == "f32act"
         return self
 
     def __exit__(self, *exc):
-        global MATH, _ACT_F32_HERE
-        MATH, _ACT_F32_HERE = self.prev
+        global MATH, _ACT_F32_HERE, _REGION_SWITCHED
+        MATH, _ACT_F32_HERE, _REGION_SWITCHED = self.prev
         return False
 
 
@@ -335,12 +337,13 @@ def _halo_ok(x, k, pad, co=4):
     return bool(rt.lib().hupr_conv3x3_halo_supported(Di, Hi, Wi, Ci, k[0], k[1], k[2], pad[0], pad[1], pad[2]))
 
 
-# BatchNorm statistics fused into the producing convolution (hupr_conv3x3_halo_bf16act_stats): the column sums wait here,
-# keyed by the output's address, for the BatchNorm that consumes that tensor next (_bn_params pops them).
-# OFF by default (HUPR_CONV_STATS=1 switches it on): measured per training step, the separate statistics passes shrink by
-# 0.37 ms and the convolution epilogues grow by 0.27 ms (160 DPP adds + 32 LDS updates per tile per wave, all eight waves
-# at once) — +0.4 % frames/s at the price of ~14 us on every forward launch of the dominant kernel.
-CONV_STATS = os.environ.get("HUPR_CONV_STATS", "0") == "1"
+# BatchNorm statistics fused into the producing convolution (hupr_conv3x3_halo_bf16act_stats, 64-channel 3-D layers = the
+# largest tensors of the step): the column sums wait here, keyed by the output's address, for the BatchNorm that consumes that
+# tensor next (_bn_params pops them).  Round 3: the kernel keeps running per-lane-pair sums in LDS (plain read-add-write of a
+# private slot, deferred epilogue intact) and reduces across lanes once per launch: +6 us on a 222 us launch instead of +14 us
+# and the immediate epilogue, -0.16 ms / +0.7 % frames/s per step measured in interleaved same-box runs -> ON by default
+# (HUPR_CONV_STATS=0 switches it off).
+CONV_STATS = os.environ.get("HUPR_CONV_STATS", "1") == "1"
 _conv_stats = {}
 
 
@@ -1252,6 +1255,44 @@ class GCNLayerFn(torch.autograd.Function):
         x2 = x.permute(1, 0, 2).reshape(F, B * ld)
         dw = gemm(0, 1, _c(dt2), _c(x2), F, F, B * ld, B * ld, B * ld, 1, 0, 0, math=GCN_MATH)[0]
         return dx, dw, dbias, None, None
+
+
+@_math_scoped
+class Head1x1Fn(torch.autograd.Function):
+    """The 1x1 key-point head (reference models/layers.py:94) as plain fp32 FMAs: x (B,1,H,W,32) fp32, w16 (16,32,1,1) (the 14
+    filters zero-padded) -> (B,1,H,W,16).  What the "head" precision region of a bf16 run uses (PRECISION["head"] = "f32"):
+    the generic fp32 implicit-GEMM path costs 0.26 ms per training step on this 58-MFLOP product, these three kernels ~0.03."""
+
+    @staticmethod
+    def forward(ctx, x, w16):
+        x, w16 = _c(x), _c(w16)
+        B, D, H, W, Ci = _vox(x)
+        assert Ci == 32 and tuple(w16.shape) == (16, 32, 1, 1) and x.dtype == torch.float32
+        y = torch.empty((B, D, H, W, 16), dtype=torch.float32, device=x.device)
+        rt.check(rt.lib().hupr_head1x1_fwd_f32(rt.ptr(x), rt.ptr(w16), rt.ptr(y), B * D * H * W, rt.stream()))
+        ctx.save_for_backward(x, w16)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        dy = _c(dy)
+        M = x.numel() // 32
+        L = rt.lib()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w16) if ctx.needs_input_grad[1] else None
+        ws = workspace(L.hupr_head1x1_ws_bytes(), x.device)
+        rt.check(L.hupr_head1x1_bwd_f32(rt.ptr(x), rt.ptr(w16), rt.ptr(dy), rt.ptr(dx) if dx is not None else None,
+                                        rt.ptr(dw) if dw is not None else None, M, rt.ptr(ws), ws.numel(), rt.stream()))
+        return dx, dw
+
+
+def head_conv(x, w16):
+    """1x1 head: the dedicated fp32 kernels inside a bf16 run whose "head" region is switched to fp32 (32 -> 16 channels),
+    the generic convolution otherwise (the pure fp32 parity path keeps the arithmetic its golden fixtures were pinned with)."""
+    if _REGION_SWITCHED and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 32 and tuple(w16.shape) == (16, 32, 1, 1):
+        return Head1x1Fn.apply(x, w16)
+    return conv(x, w16, None, None, (0, 0, 0))
 
 
 @_math_scoped

@@ -179,7 +179,7 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
         with F_.region("head"):
             head = self.decoderLayer1[2]
             w16 = torch.nn.functional.pad(head.weight, (0, 0, 0, 0, 0, 0, 0, 16 - self.numKeypoints))
-            maps16 = F_.conv(x, w16, None, None, (0, 0, 0))
+            maps16 = F_.head_conv(x, w16)
         return maps16, self.gcn(maps16)
 
 

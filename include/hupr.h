@@ -307,6 +307,13 @@ int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, cons
                             int residual, int accumulate, hupr_stream_t stream);
 
 /* (a7) PRGCN: y = act(t . A + bias) with t = W . x computed by hupr_gemm_f32 (gcn_networks.py:23-29,53-58) */
+/* The 1x1 key-point head nn.Conv2d(32, 14, 1, bias=False) (reference models/layers.py:94) in plain fp32 FMAs: x [M][32],
+ * w16 [16][32] (the 14 filters zero-padded to 16 output channels), y / dy [M][16]; backward writes dx [M][32] and / or
+ * dw16 [16][32] (either may be null).  Used for the "head" precision region of bf16 runs (functional.PRECISION). */
+size_t hupr_head1x1_ws_bytes(void);
+int hupr_head1x1_fwd_f32(const float* x, const float* w16, float* y, long M, hupr_stream_t stream);
+int hupr_head1x1_bwd_f32(const float* x, const float* w16, const float* dy, float* dx_or_null, float* dw16_or_null, long M,
+                         void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,
                          int ld, int relu, hupr_stream_t stream);
 int hupr_gcn_adj_bwd_f32(const float* dy, const float* y, const float* adj, float* dt, float* gmasked,

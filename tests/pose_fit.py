@@ -105,14 +105,12 @@ def agreement(b, r):
     return (d == 0).float().mean().item(), (d <= 1).float().mean().item(), gap.max().item(), (bb - rr).abs().max().item()
 
 
-def decode_ap(p2, joints, first_id=0):
-    """OKS AP of the decoded (PRGCN) head against the scene's joints, the way tools/run.py:57 / tools/base.py:124-152 decode:
-    key-point = arg-max (x, y) * 4, visibility 1, score 1."""
+def decode_ap_from_indices(idx, joints, first_id=0):
+    """idx (B, 14) arg-max indices of the decoded head -> OKS AP against the scene's joints, the way tools/run.py:57 /
+    tools/base.py:124-152 decode: key-point = arg-max (x, y) * 4, visibility 1, score 1."""
     from hupr_amd.misc import oks_eval
-    B = p2.shape[0]
-    idx = p2.reshape(B, 14, -1).argmax(-1).cpu().numpy()
     gts, dts = [], []
-    for b in range(B):
+    for b in range(idx.shape[0]):
         kp = np.stack([idx[b] % 64, idx[b] // 64], 1).astype(np.float64) * 4.0
         j = np.asarray(joints[b], dtype=np.float64)
         x0, y0 = j.min(0)
@@ -120,3 +118,8 @@ def decode_ap(p2, joints, first_id=0):
         gts.append({"image_id": first_id + b, "keypoints": j, "bbox": [x0, y0, x1 - x0, y1 - y0]})
         dts.append({"image_id": first_id + b, "keypoints": np.concatenate([kp, np.ones((14, 1))], 1).reshape(-1), "score": 1.0})
     return oks_eval.evaluate_keypoints(gts, dts)[0]
+
+
+def decode_ap(p2, joints, first_id=0):
+    """OKS AP of the decoded (PRGCN) head's maps ``p2`` against the scene's joints."""
+    return decode_ap_from_indices(p2.reshape(p2.shape[0], 14, -1).argmax(-1).cpu().numpy(), joints, first_id)

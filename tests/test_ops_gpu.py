@@ -697,7 +697,7 @@ def test_mscsa_level_bf16_concatenated_output(C, H, bf16_math):
         assert torch.equal(x, y), "gradient %d differs" % i
 
 
-@pytest.mark.parametrize("Ci,Co,shape", [(64, 64, (8, 8, 32, 32)), (64, 128, (16, 4, 32, 32))])
+@pytest.mark.parametrize("Ci,Co,shape", [(64, 64, (8, 8, 32, 32)), (64, 64, (6, 8, 64, 64)), (32, 64, (4, 8, 64, 64))])
 def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
     """The 256-voxel convolution kernel leaves the column sums of its (bf16-rounded) output for the BatchNorm that follows
     (functional.conv(..., stats=True) -> BNActFn): mean / variance / running statistics and the normalised output must
@@ -707,10 +707,14 @@ def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
     B, D, H, W = shape
     x = cl(rnd(B, Ci, D, H, W, seed=160)).cuda().bfloat16()
     w = (rnd(Co, Ci, 3, 3, 3, seed=161, scale=(Ci * 27) ** -0.5)).cuda()
+    if Ci % 64:                              # the 256-voxel kernel needs Ci % 64 == 0: no fused statistics, separate pass
+        assert not F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, Co, 3)
+        return
     assert F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, Co, 3)
+    assert not F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, 128, 3)      # one co tile only (lane -> channel map)
     res = []
     saved = F_.CONV_STATS
-    F_.CONV_STATS = True                     # off by default (see functional.CONV_STATS)
+    F_.CONV_STATS = True                     # (the library default since round 3)
     for fused in (True, False):
         bn = nn.BatchNorm3d(Co).cuda()
         with torch.no_grad():
@@ -959,3 +963,33 @@ def test_merge_down_node_matches_separate_nodes(bf16_math):
     # the larger addend, which can exceed the (possibly cancelled) sum's own step
     d = (a[2] - b[2]).abs()
     assert d.max().item() <= 2.0 ** -6 * b[2].abs().max().item() and d.mean().item() <= 2.0 ** -9 * b[2].abs().mean().item() * 4
+
+
+@pytest.mark.parametrize("B,H", [(3, 64), (1, 8)])
+def test_head1x1_fp32_kernels(B, H):
+    """The dedicated fp32 1x1 head (32 -> 14 key-point channels padded to 16; reference models/layers.py:94) against fp64:
+    forward, input gradient and weight gradient, incl. a voxel count that is not a multiple of the workgroup slices."""
+    from hupr_amd import functional as F_
+    x0 = rnd(B, 1, H, H, 32, seed=300).cuda()
+    w0 = torch.zeros(16, 32, 1, 1)
+    w0[:14] = rnd(14, 32, 1, 1, seed=301, scale=32 ** -0.5)
+    w0 = w0.cuda()
+    gy = rnd(B, 1, H, H, 16, seed=302).cuda()
+    x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    y = F_.Head1x1Fn.apply(x, w)
+    y.backward(gy)
+    xd, wd = x0.double(), w0.double().reshape(16, 32)
+    close(y, xd @ wd.t(), 2e-6, "head forward")
+    close(x.grad, gy.double() @ wd, 2e-6, "head input gradient")
+    close(w.grad.reshape(16, 32), gy.double().reshape(-1, 16).t() @ xd.reshape(-1, 32), 5e-6, "head weight gradient")
+    assert y[..., 14:].abs().max().item() == 0.0 and w.grad[14:].abs().max().item() < 1e30
+    # inside a bf16 run the model's head region goes through these kernels, the fp32 parity path through the generic convolution
+    F_.set_math("bf16")
+    try:
+        with F_.region("head"):
+            assert F_._REGION_SWITCHED and F_.MATH == "f32"
+            y2 = F_.head_conv(x0, w0)
+        assert torch.equal(y2, y.detach())
+    finally:
+        F_.set_math("f32")
+    assert not F_._REGION_SWITCHED

@@ -57,14 +57,30 @@ def _trained():
 
 
 def test_fp32_training_follows_the_reference_trajectory():
+    """VERDICT r2 item 2 — chaos, not bias.  tests/golden/model_trained_spread.npz holds the REFERENCE's own loss trajectories
+    over the same 120-step fit when only its rounding changes (make_golden.py `spread`: fp64 arithmetic, inputs perturbed by
+    1e-7 relative, one ATen thread instead of eight): they leave the default fp32 run by 0.6-15 % within ten steps and by
+    15-17 % over the fit.  The fp32 HIP path must (a) reproduce the first three steps to 2e-5 — the same computation while
+    rounding noise has not been amplified — and (b) afterwards stay within TWICE the reference's own spread at steps 10 / 30 /
+    120, with a final loss inside twice the range the reference's variants end in."""
     c = _trained()
     g, losses = c["g"], c["losses"]
     ref = g["losses"]
+    sp = np.load(os.path.join(G, "model_trained_spread.npz"))
+    variants = {k[7:]: sp[k] for k in sp.files if k.startswith("losses_")}
+    assert {"f64", "eps"} <= set(variants) and all(len(v) == len(ref) for v in variants.values())
     rel = np.abs(losses - ref) / ref
+    own = np.max([np.abs(v - ref) / ref for v in variants.values()], axis=0)          # (steps, 2): the reference vs itself
     print("loss trajectory rel err: steps 0-2 %.2e, steps 0-9 %.2e, all %.2e; final %.5f vs %.5f" %
           (rel[:3].max(), rel[:10].max(), rel.max(), losses[-1, 0], ref[-1, 0]))
-    assert rel[:3].max() <= 2e-5           # the same computation while rounding noise has not been amplified yet ...
-    assert rel[:10].max() <= 2e-2 and rel.max() <= 0.3      # ... and the same optimisation afterwards
+    assert rel[:3].max() <= 2e-5
+    for t in (10, 30, len(ref)):
+        print("  steps < %3d: HIP fp32 vs reference %.2e; reference vs its own variants (%s) %.2e" %
+              (t, rel[:t].max(), ", ".join(sorted(variants)), own[:t].max()))
+        assert rel[:t].max() <= 2.0 * own[:t].max()
+    finals = np.array([ref[-1, 0]] + [v[-1, 0] for v in variants.values()])
+    print("  final loss: HIP %.5f; reference variants %s" % (losses[-1, 0], np.round(finals, 5).tolist()))
+    assert abs(losses[-1, 0] - finals.mean()) <= 2.0 * (finals.max() - finals.min())
     assert losses[-1, 0] < 0.1 * losses[0, 0]
     with torch.no_grad():
         p1, p2 = c["net"](c["h"], c["v"])
@@ -123,7 +139,7 @@ _POSE = {}
 def _pose_trained():
     if "sd" not in _POSE:
         import pose_fit
-        sd, cfg, log = pose_fit.fit(steps=3000, lr=3e-4, verbose=False)
+        sd, cfg, log = pose_fit.fit(steps=4000, lr=2e-4, verbose=False)      # (3e-4 shows loss spikes in bf16; 2e-4 does not)
         print("pose-scene fit: loss %.4f -> %.4f (gcn %.4f)" % (log[0][1], log[-1][1], log[-1][2]))
         hn, vn, joints = synth.pose_scenes(32, 1)
         _POSE.update(sd=sd, cfg=cfg, log=log, h=torch.from_numpy(hn).cuda(), v=torch.from_numpy(vn).cuda(), joints=joints, fit=pose_fit)
@@ -169,51 +185,69 @@ def test_both_paths_match_the_oracle_on_trained_uni_modal_maps():
     _bf16_gates(b1.cpu(), b2.cpu(), o1, o2)
 
 
-def test_bf16_path_meets_the_argmax_and_ap_gates_at_batch32():
-    """SURVEY 8(d) at the bench batch: bf16 vs the fp32 path on the same trained weights, 448 joints of 32 held-out scenes, and
-    the AP-level check north_star asks for (OKS AP of the decoded key-points against the scenes' joints, misc/oks_eval.py ==
-    the reference's COCOeval: +-0.2 AP points)."""
+def test_bf16_path_meets_the_argmax_gate_at_batch32():
+    """SURVEY 8(d) at the bench batch: bf16 vs the fp32 path on the same trained weights, 448 joints of 32 held-out scenes."""
     p = _pose_trained()
     pf = p["fit"]
     if "r1" not in p:
         p["r1"], p["r2"] = pf.evaluate(p["sd"], p["cfg"], p["h"], p["v"], "f32")
-        p["ap"] = pf.decode_ap(p["r2"], p["joints"])
     b1, b2 = pf.evaluate(p["sd"], p["cfg"], p["h"], p["v"], "bf16")
     print("bf16 vs fp32 path, 32 held-out scenes:")
     _bf16_gates(b1, b2, p["r1"], p["r2"])
-    ap16 = pf.decode_ap(b2, p["joints"])
-    print("  OKS AP of the decoded key-points: fp32 path %.4f, bf16 path %.4f" % (p["ap"], ap16))
-    assert abs(ap16 - p["ap"]) <= 0.002
 
 
-def test_bf16_training_forward_on_the_fitted_batch_decodes_identically():
-    """Train-mode forward (batch statistics — what configs C3/C4 run) on the batch the weights were fitted to: the maps are
-    single-blob (decisive maximum per joint), and both pipes must decode every joint identically."""
+def test_bf16_path_meets_the_ap_gate_on_512_scenes():
+    """The AP-level check north_star asks for (COCO OKS AP within +-0.2 points of the reference path): both paths decode 512
+    held-out scenes (noise drawn on the device from a fixed seed, joints from the seeded generator) and are scored against the
+    scenes' joints with misc/oks_eval.py (== the reference's COCOeval to 1e-12, tests/golden/oks_eval.json).  512 images: one
+    image crossing one of the ten OKS thresholds moves AP by 0.0002 — on the 32-scene set above the same event is 0.003."""
+    p = _pose_trained()
+    pf = p["fit"]
+    rng = np.random.default_rng(777)
+    gen = torch.Generator(device="cuda").manual_seed(888)
+    dec = {"f32": [], "bf16": []}
+    same = tot = 0
+    joints = []
+    for _ in range(16):
+        h, v, j = pf.scene_batch(32, rng, gen, torch.device("cuda"))
+        joints.append(j.numpy())
+        out = {}
+        for math in ("f32", "bf16"):
+            out[math] = pf.evaluate(p["sd"], p["cfg"], h, v, math)[1]
+            dec[math].append(out[math].reshape(32, 14, -1).argmax(-1).cpu())
+        same += (dec["f32"][-1] == dec["bf16"][-1]).sum().item()
+        tot += 32 * 14
+    joints = np.concatenate(joints)
+    ap = {m: pf.decode_ap_from_indices(torch.cat(dec[m]).numpy(), joints) for m in dec}
+    print("512 held-out scenes (7 168 joints): decoded head identical on %.4f; OKS AP fp32 path %.4f, bf16 path %.4f (difference "
+          "%.2f AP points)" % (same / tot, ap["f32"], ap["bf16"], 100 * abs(ap["f32"] - ap["bf16"])))
+    assert ap["f32"] >= 0.3 and abs(ap["bf16"] - ap["f32"]) <= 0.002 and same / tot >= 0.975
+
+
+def test_bf16_training_mode_forward_meets_the_same_gates():
+    """Train-mode forward (BatchNorm on batch statistics — what configs C3 / C4 run) of the pose-trained weights on the 32
+    held-out scenes: bf16 vs fp32 path through the same reduced-precision gates, and both decode the scenes (AP)."""
     from hupr_amd import functional as F_
     from hupr_amd.models import HuPRNet
-    c = _trained()
-    sd = {k: t.clone() for k, t in c["net"].state_dict().items()}
+    p = _pose_trained()
     outs = {}
     try:
         for math in ("f32", "bf16"):
             F_.set_math(math)
-            net = HuPRNet(c["cfg"]).cuda()
-            net.load_state_dict(sd)
+            net = HuPRNet(p["cfg"]).cuda()
+            net.load_state_dict(p["sd"])
+            F_.invalidate_packed()
             net.train()
             with torch.no_grad():
-                outs[math] = net(c["h"], c["v"])
+                outs[math] = tuple(t.float() for t in net(p["h"], p["v"]))
     finally:
         F_.set_math("f32")
-    gt = torch.from_numpy(synth.keypoints(2, int(c["g"]["kp_seed"])))
-    want = ((gt.float() / 4 + 0.5).long())                                   # target centres (misc/utils.py:37-38)
-    want = (want[..., 1] * 64 + want[..., 0]).cuda()
-    for hd in (0, 1):
-        af = outs["f32"][hd].reshape(2, 14, -1).argmax(-1)
-        ab = outs["bf16"][hd].reshape(2, 14, -1).argmax(-1)
-        pkv = outs["f32"][hd].reshape(28, -1).max(1)[0].median().item()
-        print("train-mode head %d: bf16 == fp32 on %.3f of the joints, fp32 == target centre on %.3f, median peak %.2f" %
-              (hd, (af == ab).float().mean().item(), (af == want).float().mean().item(), pkv))
-        assert torch.equal(af, ab)
+        F_.invalidate_packed()
+    print("train-mode forward, bf16 vs fp32 path, 32 held-out scenes:")
+    _bf16_gates(outs["bf16"][0], outs["bf16"][1], outs["f32"][0], outs["f32"][1])
+    ap32, ap16 = p["fit"].decode_ap(outs["f32"][1], p["joints"]), p["fit"].decode_ap(outs["bf16"][1], p["joints"])
+    print("  OKS AP of the decoded key-points: fp32 path %.4f, bf16 path %.4f" % (ap32, ap16))
+    assert ap32 >= 0.3 and abs(ap16 - ap32) <= 0.002
 
 
 def _bf16_gates(b1, b2, r1, r2):
