@@ -48,3 +48,31 @@ if len(sys.argv) > 2 and sys.argv[2] == "detail":
     src = torch.empty_like(big)
     t_copy = timeit(lambda: big.copy_(src))
     print("baseline: fill %.0f GB/s, copy (r+w) %.0f GB/s" % (big.numel() * 4 / t_fill / 1e9, 2 * big.numel() * 4 / t_copy / 1e9))
+
+# ---- cache-cold check: the training step calls the chain once per sensor per step, with ~25 GB of other traffic in between, so
+# its inputs never sit in the 256 MB Infinity Cache and its TLB entries are gone.  Per-call times of the fused-mean variant,
+# warm (back to back on the same two buffers) and cold (a 4 GB fill between calls).
+if len(sys.argv) > 2 and sys.argv[2] in ("cold", "detail"):
+    half = n_sf // 2
+    a, b = iq[:half].contiguous(), iq[half:].contiguous()
+    om = torch.empty((half, 16, 64, 64), dtype=torch.float32, device="cuda")
+    trash = torch.empty(1 << 30, dtype=torch.float32, device="cuda")
+
+    def one(x):
+        rt.check(rt.lib().hupr_fft_chain_loader_means_f32(rt.ptr(x), half, rt.ptr(om), rt.ptr(ws), ws.numel(), rt.stream()))
+
+    for cold in (False, True):
+        ts = []
+        for i in range(12):
+            if cold:
+                trash.fill_(float(i))
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            one(a if i % 2 == 0 else b)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e) * 1e3)
+        med = sorted(ts[2:])[len(ts[2:]) // 2]
+        print("%s, %d sensor-frames per call: per-call us %s  median %.1f us = %.0f GB/s (%.3f of 8 TB/s)" %
+              ("cold (4 GB fill between calls)" if cold else "warm (back to back)", half, " ".join("%.0f" % t for t in ts), med,
+               half * b_m / n_sf / med / 1e3, half * b_m / n_sf / med / 1e3 / 8000))
