@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void hupr_k_head1x1_dgrad(const float* __restr
 // dw[k][c] = sum_v dy[v][k] x[v][c]: workgroup b sums voxels [b * per, (b + 1) * per) in chunks of 128 staged in LDS; thread
 // t owns outputs (k, c) = (t >> 4, 2 (t & 15) + {0, 1}); partial rows [grid][512] are summed in block order by the second
 // kernel (deterministic, no atomics).
-constexpr int kHeadWgradGrid = 256;
+constexpr int kHeadWgradGrid = 64;       // partial rows: the second kernel's reduction walks them with 16 loads in flight
 __global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, long M) {
     __shared__ float xs[128][kHeadCi + 1];
@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad(const float* __restr
 }
 __global__ __launch_bounds__(512) void hupr_k_head1x1_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int rows) {
     double a = 0.0;
+#pragma unroll 16
     for (int r = 0; r < rows; ++r) a += (double)part[(long)r * 512 + threadIdx.x];
     dw[threadIdx.x] = (float)a;
 }

@@ -37,8 +37,10 @@ class BasicBlock2D(nn.Module):
             raise NotImplementedError("decoder activation must be nn.PReLU (networks.py:21)")
 
     def forward(self, x):
-        residual = _conv(x, self.downsample[0])
-        out = _conv(x, self.main[0])
+        # the two convolutions of x as one node where the halo kernels apply (bf16 math): the second input gradient is
+        # accumulated onto the first in the kernel's residual epilogue instead of by a separate add over the widest maps
+        p = self.main[0].padding
+        out, residual = F_.dual_conv(x, self.main[0].weight, self.downsample[0].weight, (0, p[0], p[1]))
         out = F_.PReLUFn.apply(out, self.main[1].weight)
         out = _conv(out, self.main[2], res=residual)          # main(x) + residual fused in the epilogue
         return F_.PReLUFn.apply(out, self.relu.weight)
