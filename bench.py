@@ -392,10 +392,17 @@ def main():
                 ts.append(ev[0].elapsed_time(ev[1]) * 1e-3)
             return sorted(ts)[len(ts) // 2] / (B * G)
 
-        def fft_obj(per_sf, nbytes, kernel, per_sf_cold):
+        try:      # HBM bytes per sensor-frame of the same kernels, measured offline with rocprofv3 --pmc (profiles/)
+            fft_pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_fft.json")))
+        except Exception:      # noqa: BLE001
+            fft_pmc = {}
+
+        def fft_obj(per_sf, nbytes, kernel, per_sf_cold, pmc_key):
             gbs, cold = nbytes / per_sf / 1e9, nbytes / per_sf_cold / 1e9
             return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_sensor_frame": nbytes,
+                    "traffic": fft_pmc.get(pmc_key, {}).get("traffic_bytes_per_sensor_frame"),
+                    "traffic_note": "HBM bytes per sensor-frame, 2 x FETCH_SIZE + WRITE_SIZE of both kernels (profiles/pmc_fft.json)",
                     "sensor_frames_per_s": round(1.0 / per_sf, 1), "share_of_step_ms": round(per_sf_cold * 2 * B * G * 1e3, 3),
                     "measured": "20 back-to-back calls alternating the two sensors' cubes (as in rounds 1-2)",
                     "cold": {"achieved": round(cold, 1), "frac": round(cold / PEAK_HBM_GBS, 4),
@@ -404,10 +411,10 @@ def main():
                                      "hits on the int16 cubes); share_of_step_ms uses this figure"}}
         fused_mean = fft_obj(fft_time(fft_chain_loader_means), FFT_MEANS_BYTES_PER_SF,
                              "hupr_k_doppler_range + hupr_k_angle<loader + elevation mean> (FFT chain, Normalize, HuPRNet's elevation mean)",
-                             fft_time_cold(fft_chain_loader_means))
+                             fft_time_cold(fft_chain_loader_means), "fused_mean")
         loader = fft_obj(fft_time(fft_chain_loader), FFT_LOADER_BYTES_PER_SF,
                          "hupr_k_doppler_range + hupr_k_angle<loader> (FFT chain fused with the loader glue)",
-                         fft_time_cold(fft_chain_loader))
+                         fft_time_cold(fft_chain_loader), "loader")
         del trash
         fft_roof = dict(fused_mean if fused_step else loader)
         fft_roof["loader_variant" if fused_step else "fused_mean_variant"] = loader if fused_step else fused_mean

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void hupr_k_head1x1_dgrad(const float* __restr
 // dw[k][c] = sum_v dy[v][k] x[v][c]: workgroup b sums voxels [b * per, (b + 1) * per) in chunks of 128 staged in LDS; thread
 // t owns outputs (k, c) = (t >> 4, 2 (t & 15) + {0, 1}); partial rows [grid][512] are summed in block order by the second
 // kernel (deterministic, no atomics).
-constexpr int kHeadWgradGrid = 64;       // partial rows: the second kernel's reduction walks them with 16 loads in flight
+constexpr int kHeadWgradGrid = 512;      // partial rows (a workgroup's slice is a serial load -> barrier -> multiply chain: keep it short)
 __global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ part, long M) {
     __shared__ float xs[128][kHeadCi + 1];
@@ -338,11 +338,16 @@ __global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad(const float* __restr
     part[(long)blockIdx.x * 512 + k * kHeadCi + c0] = a0;
     part[(long)blockIdx.x * 512 + k * kHeadCi + c0 + 1] = a1;
 }
-__global__ __launch_bounds__(512) void hupr_k_head1x1_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int rows) {
+// dw[i] = sum over the partial rows, in a fixed order: 8 workgroups x (64 outputs x 4 row groups), 16 loads in flight per thread
+__global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int rows) {
+    __shared__ double red[4][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double a = 0.0;
 #pragma unroll 16
-    for (int r = 0; r < rows; ++r) a += (double)part[(long)r * 512 + threadIdx.x];
-    dw[threadIdx.x] = (float)a;
+    for (int r = g; r < rows; r += 4) a += (double)part[(long)r * 512 + i];
+    red[g][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (g == 0) dw[i] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 }  // namespace hupr
@@ -385,7 +390,7 @@ extern "C" int hupr_head1x1_bwd_f32(const float* x, const float* w16, const floa
         if (!ws || ws_bytes < hupr_head1x1_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_head1x1_bwd_f32: workspace %zu < %zu", ws_bytes, hupr_head1x1_ws_bytes());
         const int grid = (int)min((long)kHeadWgradGrid, (M + 127) / 128);
         hipLaunchKernelGGL(hupr_k_head1x1_wgrad, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, static_cast<float*>(ws), M);
-        hipLaunchKernelGGL(hupr_k_head1x1_wgrad_reduce, dim3(1), dim3(512), 0, as_stream(stream), static_cast<const float*>(ws), dw16_or_null, grid);
+        hipLaunchKernelGGL(hupr_k_head1x1_wgrad_reduce, dim3(8), dim3(256), 0, as_stream(stream), static_cast<const float*>(ws), dw16_or_null, grid);
         HUPR_LAUNCH_OK("hupr_k_head1x1_wgrad");
     }
     return HUPR_OK;
