@@ -10,6 +10,7 @@ bf16), and print the arg-max agreement of both heads at B = 32 (448 joints).  Th
 usage: python scripts/precision_regions.py [--steps 600] [--skip-a] [--time]
 """
 import argparse
+import gc
 import os
 import sys
 import time
@@ -123,6 +124,9 @@ if args.time:
             eng.train_step(h, v, jt)
         torch.cuda.synchronize()
         print("   training step (B=32, model inputs) with %-40s %.2f ms" % (",".join("%s=%s" % kv for kv in st.items()) or "all bf16", (time.time() - t0) * 100), flush=True)
+        eng.close()
         del eng
+        gc.collect()                  # dead engines' weights would otherwise stay in the packed-weight table and be refreshed every step
+        torch.cuda.empty_cache()
     F_.PRECISION.clear()
     F_.set_math("f32")
