@@ -26,7 +26,26 @@ struct HaloArgs {
     unsigned long long* trace;  // profiling only: s_memtime stamps of workgroup 0 / wave 0 (scripts/halo_trace.py) or null
     double* stats;           // 256-voxel kernel, bf16 output, no bias / residual: per-workgroup column sums [grid][2][Co] of the
                              // stored (rounded) output and its square — the BatchNorm statistics pass fused into the epilogue
+    // 128-voxel kernel, small grids (single-sample inference): the (channel chunk, kz plane) units of the reduction are split over
+    // blockIdx.y, each slice leaves fp32 partial sums [slice][voxel][Co] in `part` and hupr_k_conv_partial_reduce finishes
+    // (slice order, bias, residual, one rounding).  part == nullptr: the whole reduction in one workgroup, as always.
+    // (Finishing inside the kernel — the last slice to arrive sums the others — was built and measured: the slices of a tile
+    // run on different XCDs with private L2s, and both ways of making the partial sums visible across them cost far more than the
+    // 4 us launch they save: agent-scope scalar accesses 12.7 -> 42 us per layer, L2 write-back fences 94 us.)
+    float* part;
+    int units_per_slice;
 };
+
+// fp32 partial sums of a K slice: this lane's voxel, its four 4-channel runs (see halo_store_voxel for the lane -> channel map)
+__device__ __forceinline__ void halo_store_partial(const HaloArgs& p, const f32x16& acc, long m, int chb, int slice) {
+    const long M = (long)p.Bn * p.D * p.H * p.W;
+    float* dst = p.part + ((long)slice * M + m) * p.Co;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ch = chb + 8 * g;
+        if (ch < p.Co) *reinterpret_cast<f32x4n*>(dst + ch) = (f32x4n){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    }
+}
 
 // 256-voxel persistent variant; returns false when the geometry is not supported
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);

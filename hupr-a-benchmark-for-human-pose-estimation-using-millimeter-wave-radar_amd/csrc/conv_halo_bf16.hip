@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {   
     constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, KD = IS3D ? 3 : 1;
     constexpr int HD = TD + KD - 1, HH = 10, HW = TW + 2;
     constexpr int NVOX = HD * HH * HW;                // 400 (3-D) / 180 (2-D)
-    constexpr int T = KD * 9, NSTAGE = KD * 3;
+    constexpr int T = KD * 9;
     constexpr int NI = (NVOX * C8 + 255) / 256;       // halo items (8 channels of one voxel) per thread
 
     __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
@@ -92,10 +92,19 @@ __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {   
     u32x4 rb[B_LD];                                   // next stage's weight tiles, in flight during the MFMAs
     __bf16* const Bflat = &Bs[0][0];
 
+    // K slice of this workgroup (p.part != nullptr): units = (channel chunk, kz plane), unit u = chunk * KD + kz
+    const int n_units = (p.Ci / KC) * KD;
+    const int u_begin = p.part ? (int)blockIdx.y * p.units_per_slice : 0;
+    const int u_end = p.part ? min(n_units, u_begin + p.units_per_slice) : n_units;
+    bool first_chunk = true;
     for (int c0 = 0; c0 < p.Ci; c0 += KC) {
+        const int cu = (c0 / KC) * KD;
+        const int kz_lo = max(0, u_begin - cu), kz_hi = min(KD, u_end - cu);
+        if (kz_lo >= kz_hi) continue;           // this chunk belongs to other slices (workgroup-uniform)
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const u32x4*>(bsrc[j] + c0);      // stage 0: kz = kx = 0
-        if (c0 > 0) __syncthreads();            // previous chunk's readers are done with Hs / Bs
+        for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const u32x4*>(bsrc[j] + (long)(kz_lo * 9) * p.Ci + c0);      // first stage: kz = kz_lo, kx = 0
+        if (!first_chunk) __syncthreads();      // previous chunk's readers are done with Hs / Bs
+        first_chunk = false;
         // ---- halo chunk: global -> bf16 LDS, zero outside the tensor.  ALL of this thread's loads are issued before any
         // is stored, so the fill costs about one memory round trip. ---------------------------------------------------
         if (!(p.ablate & 1)) {
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {   
         // ---- stages: compute from Bs while the next stage's weights travel to registers -------------------------------
         // (kz is a real loop — unrolling all nine 3-D stages costs ~60 VGPRs and spills at two workgroups per CU)
 #pragma unroll 1
-        for (int kz = 0; kz < KD; ++kz)
+        for (int kz = kz_lo; kz < kz_hi; ++kz)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int st_ = kz * 3 + kx;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {   
             for (int j = 0; j < B_LD; ++j)
                 if (B_LD * 256 == TS * BN * C8 || tid + 256 * j < TS * BN * C8) *reinterpret_cast<u32x4*>(&Bflat[bdst[j]]) = rb[j];
             __syncthreads();
-            if (st_ + 1 < NSTAGE) {
+            if (st_ + 1 < kz_hi * 3) {
                 const long soff = (long)(((st_ + 1) / 3) * 9 + ((st_ + 1) % 3)) * p.Ci + c0;     // tap (kz, ky = 0, kx) of the next stage
 #pragma unroll
                 for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const u32x4*>(bsrc[j] + soff);
@@ -210,9 +219,29 @@ __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {   
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const long m = (((long)b * p.D + d0 + dz) * p.H + h0 + hy0 + i) * p.W + w0 + wx;
-            halo_store_voxel<ABF>(p, acc[i], m, n0 + wn * 32 + 4 * lh);
+            if (p.part) halo_store_partial(p, acc[i], m, n0 + wn * 32 + 4 * lh, blockIdx.y);      // K slice: finished by the reduce kernel
+            else halo_store_voxel<ABF>(p, acc[i], m, n0 + wn * 32 + 4 * lh);
         }
     }
+}
+
+// y[m][c] = bf16( sum_s part[s][m][c] (+ bias[c]) (+ res[m][c]) ) in slice order: the second half of a K-sliced convolution.
+__global__ __launch_bounds__(256) void hupr_k_conv_partial_reduce(HaloArgs p, int n_slices) {
+    const long M = (long)p.Bn * p.D * p.H * p.W;
+    const int c4n = p.Co >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * c4n) return;
+    const long m = i / c4n;
+    const int ch = (int)(i - m * c4n) * 4;
+    f32x4n v = *reinterpret_cast<const f32x4n*>(p.part + m * p.Co + ch);
+    for (int s = 1; s < n_slices; ++s) v += *reinterpret_cast<const f32x4n*>(p.part + ((long)s * M + m) * p.Co + ch);
+    if (p.bias) v += (f32x4n){p.bias[ch], p.bias[ch + 1], p.bias[ch + 2], p.bias[ch + 3]};
+    if (p.res) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.res) + m * p.res_ld + ch);
+        v += (f32x4n){(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+    }
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.y) + m * p.out_ld + ch) = o;
 }
 
 // w (Co, Ci, taps) fp32 parameter layout -> bf16  mode 0: [Co][tap][Ci]   mode 1: [Ci][taps-1-tap][Co]
@@ -337,6 +366,8 @@ static unsigned long long* g_halo_trace = nullptr;
 extern "C" void hupr_debug_halo_trace(void* buf) { g_halo_trace = reinterpret_cast<unsigned long long*>(buf); }
 extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
 extern "C" void hupr_debug_halo_variant(int v) { g_halo_variant = v; }
+static int g_halo_split_k = 1;      // A/B aid: 0 = never slice the reduction of small grids
+extern "C" void hupr_debug_halo_split_k(int on) { g_halo_split_k = on; }
 static int g_halo_small_tiles = 1;  // A/B aid: 0 keeps 64-wide channel tiles on small grids
 extern "C" void hupr_debug_halo_small_tiles(int on) { g_halo_small_tiles = on; }
 
@@ -349,9 +380,28 @@ extern "C" int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, 
     return (D == 1 && W % 16 == 0) ? 1 : 0;
 }
 
+// K slices of the 128-voxel kernel for grids that leave most of the chip idle (single-sample inference: a level-3 layer is
+// 32 workgroups walking 36 stages each).  Returns the slice count (1 = no split) and the units per slice.
+static int halo_k_slices(int Bn, int D, int H, int W, int Ci, int Co, int kd, int* units_per_slice) {
+    *units_per_slice = 0;
+    if (!g_halo_split_k || !hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1) || Co % 32 != 0) return 1;
+    const int td = kd == 3 ? 2 : 1, tw = kd == 3 ? 8 : 16;
+    const long tiles = (long)Bn * (D / td) * (H / 8) * (W / tw);
+    if (tiles * ((Co + 63) / 64) > 256) return 1;                 // enough workgroups (and possibly the persistent kernels)
+    const long blocks = tiles * (Co / 32);                        // small grids run 32-wide channel tiles
+    const int units = (Ci / (Ci % 64 == 0 ? 64 : 32)) * (kd == 3 ? 3 : 1);
+    if (blocks >= 384 || units < 2) return 1;
+    int s = (int)min((long)units, (768 + blocks - 1) / blocks);
+    const int per = (units + s - 1) / s;
+    s = (units + per - 1) / per;
+    *units_per_slice = per;
+    return s;
+}
+
 static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y, int Bn, int D,
                         int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd, bool abf,
-                        hupr_stream_t stream, const char* who, double* stats = nullptr) {
+                        hupr_stream_t stream, const char* who, double* stats = nullptr, void* ws = nullptr, size_t ws_bytes = 0,
+                        bool partial_only = false) {
     HUPR_REQUIRE(x && wp_bf16 && y, "%s: null pointer", who);
     HUPR_REQUIRE(hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1), "%s: unsupported geometry", who);
     const int al = abf ? 8 : 4;                      // 16-byte halo loads, 4-channel output vectors
@@ -364,6 +414,8 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     a.ablate = g_halo_ablate;
     a.trace = g_halo_trace;
     a.stats = stats;
+    a.part = nullptr;
+    a.units_per_slice = 0;
     if (stats) {
         HUPR_REQUIRE(abf && !bias && !res && Co == 64 && conv_halo256_supported(a, Bn, abf),
                      "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);
@@ -373,11 +425,11 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     }
     // variants: 0 auto (512-voxel register-blocked kernel where its envelope holds, then 256-, then 128-voxel), 1 force the
     // 128-voxel kernel, 2 skip the 512-voxel kernel (A/B comparisons)
-    if (g_halo_variant == 0 && launch_conv_halo512(a, Bn, abf, as_stream(stream))) {
+    if (!partial_only && g_halo_variant == 0 && launch_conv_halo512(a, Bn, abf, as_stream(stream))) {
         HUPR_LAUNCH_OK("hupr_k_conv_halo512_bf16");
         return HUPR_OK;
     }
-    if (g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {
+    if (!partial_only && g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {
         HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16");
         return HUPR_OK;
     }
@@ -392,14 +444,28 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     const long blocks = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
     HUPR_REQUIRE(blocks < (1L << 31), "%s: grid too large", who);
     hipStream_t s = as_stream(stream);
+    int n_slices = 1;
+    if (ws && abf && n32) {                                       // K-sliced form (bf16 activations, caller supplied the workspace)
+        int per = 0;
+        const int want = halo_k_slices(Bn, D, H, W, Ci, Co, kd, &per);
+        const size_t need = (size_t)want * Bn * D * H * W * Co * sizeof(float);
+        if (want > 1 && ws_bytes >= need && ((uintptr_t)ws & 15) == 0) {
+            n_slices = want;
+            a.part = static_cast<float*>(ws);
+            a.units_per_slice = per;
+        }
+    }
+    HUPR_REQUIRE(!partial_only || n_slices > 1,
+                 "%s: this geometry is not K-sliced (hupr_conv3x3_halo_splitk_ws_bytes() == 0) or the workspace is too small", who);
 #define HUPR_HALO_LAUNCH(BN_, KC_)                                                                                       \
     do {                                                                                                                 \
+        const dim3 grid_((unsigned)blocks, (unsigned)n_slices);                                                          \
         if (kd == 3) {                                                                                                   \
-            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);   \
-            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);      \
+            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, true>), grid_, dim3(256), 0, s, a);       \
+            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, true>), grid_, dim3(256), 0, s, a);          \
         } else {                                                                                                         \
-            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);  \
-            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);     \
+            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, false>), grid_, dim3(256), 0, s, a);      \
+            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, false>), grid_, dim3(256), 0, s, a);         \
         }                                                                                                                \
     } while (0)
     if (Ci % 64 == 0) {
@@ -409,6 +475,12 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     }
 #undef HUPR_HALO_LAUNCH
     HUPR_LAUNCH_OK("hupr_k_conv_halo_bf16");
+    if (partial_only) return HUPR_OK;
+    if (n_slices > 1) {
+        const long n4 = (long)Bn * D * H * W * (Co / 4);
+        hipLaunchKernelGGL(hupr_k_conv_partial_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, n_slices);
+        HUPR_LAUNCH_OK("hupr_k_conv_partial_reduce");
+    }
     return HUPR_OK;
 }
 
@@ -427,6 +499,31 @@ extern "C" int hupr_conv3x3_halo_bf16act(const void* x, const void* wp_bf16, con
                                          int kd, hupr_stream_t stream) {
     return conv3x3_halo(x, wp_bf16, bias, res, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld, kd, true, stream,
                         "hupr_conv3x3_halo_bf16act");
+}
+
+// The same operator with a caller-supplied workspace: small grids (single-sample inference) split the reduction over
+// (channel chunk, kz plane) slices that leave fp32 partial sums in `ws`, summed in slice order (+ bias, + residual, one rounding)
+// by a second launch.  hupr_conv3x3_halo_splitk_ws_bytes() is 0 where the one-launch form is used anyway (then ws may be null).
+extern "C" size_t hupr_conv3x3_halo_splitk_ws_bytes(int Bn, int D, int H, int W, int Ci, int Co, int kd) {
+    int per = 0;
+    if (Bn <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+    const int s = halo_k_slices(Bn, D, H, W, Ci, Co, kd, &per);
+    return s > 1 ? (size_t)s * Bn * D * H * W * Co * sizeof(float) : 0;
+}
+extern "C" int hupr_conv3x3_halo_bf16act_ws(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y,
+                                            int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld,
+                                            int kd, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return conv3x3_halo(x, wp_bf16, bias, res, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, res_ld, kd, true, stream,
+                        "hupr_conv3x3_halo_bf16act_ws", nullptr, ws, ws_bytes);
+}
+
+// Only the first half: the fp32 partial sums [slices][voxel][Co] stay in `part` (slices = hupr_conv3x3_halo_splitk_ws_bytes() /
+// (voxels * Co * 4)) for a consumer that sums them itself (hupr_infer_tail_bf16act).  No bias, no residual, nothing stored to y.
+extern "C" int hupr_conv3x3_halo_bf16act_partial(const void* x, const void* wp_bf16, int Bn, int D, int H, int W, int Ci, int in_ld,
+                                                 int Co, int kd, void* part, size_t part_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(part, "hupr_conv3x3_halo_bf16act_partial: null pointer");
+    return conv3x3_halo(x, wp_bf16, nullptr, nullptr, part /* never written: y of a partial-only launch */, Bn, D, H, W, Ci, in_ld, Co,
+                        Co, 0, kd, true, stream, "hupr_conv3x3_halo_bf16act_partial", nullptr, part, part_bytes, true);
 }
 
 // BatchNorm statistics fused into the convolution (bf16 activations, 256-voxel kernel, no bias / residual): besides y the

@@ -260,6 +260,79 @@ __global__ __launch_bounds__(256) void hupr_k_bn_eval_act(const T* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Inference tails on K-SLICED convolutions (config C2: single-sample forward; conv_halo_bf16.hip, HaloArgs::part).  A sliced
+// convolution leaves n fp32 partial tensors [n][M][C]; instead of a reduce launch per convolution, the elementwise kernel that
+// consumes the convolution sums the slices itself — in slice order, rounded to bf16 exactly where the stored tensor would have
+// been rounded, so the results are bit-identical to convolution -> reduce -> tail.
+//   MODE 0  BasicBlock3D:  y = relu?( bn1_eval(c1) [+ bn2_eval(c2)] )                 (models/layers.py:55-70, eval mode)
+//   MODE 1  BasicBlock2D:  y = prelu( c1 [+ c2] )   with c1 + c2 rounded once, as the convolution's residual epilogue does
+// A side is either a bf16 tensor (n == 0) or n fp32 slices.  4 channels per thread.
+// ------------------------------------------------------------------------------------------------------------------
+struct TailSide { const void* x; int n; BnEvalSide bn; };
+__device__ __forceinline__ void tail_load(const TailSide& s, long i4, long MC, float* v, bool round_it) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if (s.n == 0) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(s.x) + i4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (float)t[k];
+        return;
+    }
+    const float* p = static_cast<const float*>(s.x) + i4 * 4;
+    float4 a = *reinterpret_cast<const float4*>(p);
+    for (int j = 1; j < s.n; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (long)j * MC);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    if (round_it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (float)(__bf16)v[k];
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void hupr_k_infer_tail(TailSide s1, TailSide s2, const float* __restrict__ alpha, int relu,
+                                                         __bf16* __restrict__ y, long M, int C) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const long MC = M * C, n4 = MC >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    float v[4], u[4];
+    if (MODE == 0) {
+        float a[4], b[4];
+        tail_load(s1, i, MC, v, true);
+        eval_coef<4>(s1.bn.gamma, s1.bn.beta, s1.bn.rm, s1.bn.rv, s1.bn.eps, c, a, b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], a[k], b[k]);
+        if (s2.x) {
+            tail_load(s2, i, MC, u, true);
+            eval_coef<4>(s2.bn.gamma, s2.bn.beta, s2.bn.rm, s2.bn.rv, s2.bn.eps, c, a, b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += fmaf(u[k], a[k], b[k]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+    } else {
+        tail_load(s1, i, MC, v, false);
+        if (s2.x) {
+            tail_load(s2, i, MC, u, true);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += u[k];
+        }
+        const float al = alpha[0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = (float)(__bf16)v[k];                       // the convolution's stored output
+            v[k] = v[k] > 0.f ? v[k] : al * v[k];
+        }
+    }
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(y + i * 4) = o;
+}
+
 // backward finalize: dgamma = S2, dbeta = S1 and the per-channel coefficients of the apply pass
 //   train: dx = w*(g' - S1/M - xhat*S2/M) = cA*g' + cB*(x - mean) + cD,  cA = w, cB = -w*invstd*S2/M, cD = -w*S1/M
 //   eval : dx = w*g'                                                      cB = cD = 0          (w = gamma*invstd)
@@ -666,6 +739,31 @@ extern "C" int hupr_bn_eval_act_bf16act(const void* x1, const float* gamma1, con
                                         hupr_stream_t stream) {
     return bn_eval_act("hupr_bn_eval_act_bf16act", static_cast<const __bf16*>(x1), gamma1, beta1, mean1, var1, eps1,
                        static_cast<const __bf16*>(x2), gamma2, beta2, mean2, var2, eps2, static_cast<__bf16*>(y), M, C, act, stream);
+}
+
+// Inference tails that sum K-sliced convolution partials themselves (see hupr_k_infer_tail).  x*: bf16 tensor (n* == 0) or n* fp32
+// slices [n][M][C]; x2 may be null.  mode 0: relu?(bn1(x1) [+ bn2(x2)]) from the BatchNorm tensors (running statistics);
+// mode 1: prelu(x1 [+ x2]) with *alpha (the BatchNorm pointers are ignored).
+extern "C" int hupr_infer_tail_bf16act(int mode, const void* x1, int n1, const float* g1, const float* b1, const float* m1,
+                                       const float* v1, float eps1, const void* x2, int n2, const float* g2, const float* b2,
+                                       const float* m2, const float* v2, float eps2, const float* alpha, int relu, void* y, long M,
+                                       int C, hupr_stream_t stream) {
+    const char* who = "hupr_infer_tail_bf16act";
+    HUPR_REQUIRE(x1 && y && M > 0 && C > 0 && C % 4 == 0 && n1 >= 0 && n2 >= 0, "%s: bad argument", who);
+    HUPR_REQUIRE(((uintptr_t)x1 & 7) == 0 && ((uintptr_t)x2 & 7) == 0 && ((uintptr_t)y & 7) == 0, "%s: misaligned pointer", who);
+    HUPR_REQUIRE((n1 == 0 || ((uintptr_t)x1 & 15) == 0) && (n2 == 0 || ((uintptr_t)x2 & 15) == 0), "%s: misaligned slices", who);
+    const TailSide s1{x1, n1, BnEvalSide{g1, b1, m1, v1, eps1}}, s2{x2, n2, BnEvalSide{g2, b2, m2, v2, eps2}};
+    const long n4 = M * C / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (mode == 0) {
+        HUPR_REQUIRE(g1 && b1 && m1 && v1 && (!x2 || (g2 && b2 && m2 && v2)), "%s: mode 0 needs the BatchNorm tensors", who);
+        hipLaunchKernelGGL(hupr_k_infer_tail<0>, grid, dim3(256), 0, as_stream(stream), s1, s2, alpha, relu, static_cast<__bf16*>(y), M, C);
+    } else {
+        HUPR_REQUIRE(mode == 1 && alpha, "%s: mode 1 needs the PReLU slope", who);
+        hipLaunchKernelGGL(hupr_k_infer_tail<1>, grid, dim3(256), 0, as_stream(stream), s1, s2, alpha, relu, static_cast<__bf16*>(y), M, C);
+    }
+    HUPR_LAUNCH_OK("hupr_k_infer_tail");
+    return HUPR_OK;
 }
 
 // BatchNorm backward through an optional ReLU mask (y > 0).  train=1: batch-stat formula.

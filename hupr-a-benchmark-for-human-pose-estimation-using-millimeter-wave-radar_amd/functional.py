@@ -347,7 +347,7 @@ CONV_STATS = os.environ.get("HUPR_CONV_STATS", "1") == "1"
 _conv_stats = {}
 
 
-def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stats=False):
+def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stats=False, infer=False):
     """weight: parameter-layout tensor (Co', Ci', taps...) packed here (mode 0 forward / 1 input gradient).
     out: write here instead of a fresh tensor (may be ``res`` itself: the epilogue reads a residual element right
     before the same lane overwrites it)."""
@@ -374,9 +374,18 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stat
             if heavy:
                 _heavy_end(x.device)
             return y
-        fn = rt.lib().hupr_conv3x3_halo_bf16act if abf else rt.lib().hupr_conv3x3_halo_bf16
-        rt.check(fn(rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
-                    rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
+        L = rt.lib()
+        # inference on small grids (config C2: B = 1): the reduction is sliced over workgroups, partial sums through a workspace
+        nws = L.hupr_conv3x3_halo_splitk_ws_bytes(B, Di, Hi, Wi, Ci, co, k[0]) if (abf and infer) else 0
+        if nws:
+            ws = workspace(nws, x.device)
+            rt.check(L.hupr_conv3x3_halo_bf16act_ws(rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
+                                                    rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co,
+                                                    k[0], rt.ptr(ws), ws.numel(), rt.stream()))
+        else:
+            fn = L.hupr_conv3x3_halo_bf16act if abf else L.hupr_conv3x3_halo_bf16
+            rt.check(fn(rt.ptr(x), rt.ptr(wp), rt.ptr(bias) if bias is not None else None,
+                        rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
         if ev is not None:
             ev[1].record()
         if heavy:
@@ -397,6 +406,71 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stat
     return y
 
 
+class ConvPartial:
+    """A K-sliced inference convolution that has not been summed yet: ``slices`` fp32 tensors (n, B, D, H, W, Co) for a consumer
+    that sums them itself (``infer_tail``).  See hupr_conv3x3_halo_bf16act_partial in include/hupr.h."""
+    __slots__ = ("slices", "n", "shape")
+
+    def __init__(self, slices, n, shape):
+        self.slices, self.n, self.shape = slices, n, shape
+
+
+INFER_TAILS = os.environ.get("HUPR_NO_INFER_TAILS", "0") != "1"      # A/B aid
+
+
+def infer_fast_ok(x):
+    """Single-sample style inference on the bf16 path: no autograd, bf16-stored channels-last input, bf16 matrix pipe."""
+    return INFER_TAILS and MATH == "bf16" and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
+
+
+def conv_infer_sliced(shape, weight, pad):
+    """Would ``conv_infer`` K-slice this convolution (input extent ``shape`` = (B, D, H, W, Ci))?"""
+    B, D, H, W, Ci = shape
+    k = _ksize(weight)
+    return bool(rt.lib().hupr_conv3x3_halo_supported(D, H, W, Ci, k[0], k[1], k[2], pad[0], pad[1], pad[2])) and \
+        rt.lib().hupr_conv3x3_halo_splitk_ws_bytes(B, D, H, W, Ci, weight.shape[0], k[0]) > 0
+
+
+def conv_infer(x, weight, pad):
+    """Bias-free 3x3(x3) "same" convolution under ``infer_fast_ok``: a ConvPartial where the reduction is K-sliced (small grids),
+    else the stored bf16 tensor."""
+    x = _c(x)
+    k = _ksize(weight)
+    B, D, H, W, Ci = _vox(x)
+    co = weight.shape[0]
+    L = rt.lib()
+    nws = L.hupr_conv3x3_halo_splitk_ws_bytes(B, D, H, W, Ci, co, k[0]) if _halo_ok(x, k, pad, co) else 0
+    if not nws:
+        return conv(x, weight, None, None, pad)
+    n = nws // (B * D * H * W * co * 4)
+    part = torch.empty((n, B, D, H, W, co), dtype=torch.float32, device=x.device)
+    rt.check(L.hupr_conv3x3_halo_bf16act_partial(rt.ptr(x), rt.ptr(_packed(weight, 0, 1)), B, D, H, W, Ci, Ci, co, k[0],
+                                                 rt.ptr(part), nws, rt.stream()))
+    return ConvPartial(part, n, (B, D, H, W, co))
+
+
+def infer_tail(a, b=None, bn_a=None, bn_b=None, relu=False, prelu=None):
+    """One launch for the elementwise tail of an inference block; ``a`` / ``b``: bf16 tensors or ConvPartials.
+    BatchNorm form (bn_a given): relu?(bn_a(a) [+ bn_b(b)]) on running statistics; PReLU form: prelu(a [+ b])."""
+    def side(t):
+        if t is None:
+            return None, 0
+        return (rt.ptr(t.slices), t.n) if isinstance(t, ConvPartial) else (rt.ptr(_c(t)), 0)
+
+    shape = a.shape
+    C = shape[-1]
+    M = int(np.prod(shape[:-1]))
+    dev = (a.slices if isinstance(a, ConvPartial) else a).device
+    y = torch.empty(tuple(shape), dtype=torch.bfloat16, device=dev)
+    (x1, n1), (x2, n2) = side(a), side(b)
+    bn = lambda m: (rt.ptr(m.weight), rt.ptr(m.bias), rt.ptr(m.running_mean), rt.ptr(m.running_var), float(m.eps)) \
+        if m is not None else (None, None, None, None, 0.0)
+    rt.check(rt.lib().hupr_infer_tail_bf16act(0 if bn_a is not None else 1, x1, n1, *bn(bn_a), x2, n2, *bn(bn_b),
+                                              rt.ptr(prelu) if prelu is not None else None, 1 if relu else 0, rt.ptr(y), M, C,
+                                              rt.stream()))
+    return y
+
+
 def _ksize(w):
     k = tuple(w.shape[2:])
     return (1,) + k if len(k) == 2 else k
@@ -408,14 +482,14 @@ class ConvFn(torch.autograd.Function):
     residual add.  ``pad`` is (pd, ph, pw)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, pad, want_stats=False):
+    def forward(ctx, x, weight, bias, res, pad, want_stats=False, infer=False):
         x = _c(x)
         k = _ksize(weight)
         B, Di, Hi, Wi, Ci = _vox(x)
         assert weight.shape[1] == Ci, (weight.shape, x.shape)
         out_extent = (Di + 2 * pad[0] - k[0] + 1, Hi + 2 * pad[1] - k[1] + 1, Wi + 2 * pad[2] - k[2] + 1)
         y = _conv_raw(x, weight, 0, bias, _c(res) if res is not None else None, weight.shape[0], k, pad, out_extent,
-                      stats=want_stats)
+                      stats=want_stats, infer=infer)
         ctx.save_for_backward(x, weight)
         ctx.bias_ref = bias                       # only its identity/shape is needed (gradient destination)
         ctx.pad, ctx.k, ctx.has_bias, ctx.has_res = pad, k, bias is not None, res is not None
@@ -464,7 +538,7 @@ class ConvFn(torch.autograd.Function):
             rt.check(_act("colsum", dy)(rt.ptr(dy), B * Do * Ho * Wo, Co, rt.ptr(db), rt.ptr(ws), ws.numel(),
                                         rt.stream()))
         dres = dy if ctx.has_res else None
-        return dx, _pret(weight, dw, dw_direct), _pret(ctx.bias_ref, db, db_direct), dres, None, None
+        return dx, _pret(weight, dw, dw_direct), _pret(ctx.bias_ref, db, db_direct), dres, None, None, None
 
 
 @_math_scoped
@@ -474,14 +548,14 @@ class DualConvFn(torch.autograd.Function):
     in the second kernel's residual epilogue instead of by a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w_a, w_b, pad, want_stats=False):
+    def forward(ctx, x, w_a, w_b, pad, want_stats=False, infer=False):
         x = _c(x)
         k = _ksize(w_a)
         B, D, H, W, Ci = _vox(x)
         co = w_a.shape[0]
         assert w_b.shape == w_a.shape and _halo_ok(x, k, pad, co)
-        y_a = _conv_raw(x, w_a, 0, None, None, co, k, pad, (D, H, W), stats=want_stats)
-        y_b = _conv_raw(x, w_b, 0, None, None, co, k, pad, (D, H, W), stats=want_stats)
+        y_a = _conv_raw(x, w_a, 0, None, None, co, k, pad, (D, H, W), stats=want_stats, infer=infer)
+        y_b = _conv_raw(x, w_b, 0, None, None, co, k, pad, (D, H, W), stats=want_stats, infer=infer)
         ctx.save_for_backward(x, w_a, w_b)
         ctx.k, ctx.pad = k, pad
         return y_a, y_b
@@ -510,7 +584,7 @@ class DualConvFn(torch.autograd.Function):
             rt.check(fn(rt.ptr(x), rt.ptr(dy[i]), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, k[0], rt.ptr(ws), ws.numel(),
                         rt.stream()))
             grads.append(_pret(w, dw, direct))
-        return dx, grads[0], grads[1], None, None
+        return dx, grads[0], grads[1], None, None, None
 
 
 def dual_conv(x, w_a, w_b, pad, stats=False):
@@ -518,13 +592,16 @@ def dual_conv(x, w_a, w_b, pad, stats=False):
     k = _ksize(w_a)
     if w_a.shape == w_b.shape and _halo_ok(x, k, pad, w_a.shape[0]) and x.shape[-1] % 32 == 0 and w_a.shape[0] % 8 == 0 \
             and os.environ.get("HUPR_NO_DUAL_CONV", "0") != "1":
-        return DualConvFn.apply(x, w_a, w_b, tuple(pad), bool(stats))
-    return ConvFn.apply(x, w_a, None, None, tuple(pad), bool(stats)), ConvFn.apply(x, w_b, None, None, tuple(pad), bool(stats))
+        return DualConvFn.apply(x, w_a, w_b, tuple(pad), bool(stats), not torch.is_grad_enabled())
+    infer = not torch.is_grad_enabled()
+    return (ConvFn.apply(x, w_a, None, None, tuple(pad), bool(stats), infer),
+            ConvFn.apply(x, w_b, None, None, tuple(pad), bool(stats), infer))
 
 
 def conv(x, weight, bias=None, res=None, pad=(0, 0, 0), stats=False):
     """stats: a BatchNorm in training mode consumes the output next — let the convolution leave its column sums."""
-    return ConvFn.apply(x, weight, bias, res, tuple(pad), bool(stats))
+    # (grad mode is read HERE: inside an autograd.Function's forward it is always off)
+    return ConvFn.apply(x, weight, bias, res, tuple(pad), bool(stats), not torch.is_grad_enabled())
 
 
 @_math_scoped

@@ -37,9 +37,16 @@ class BasicBlock2D(nn.Module):
             raise NotImplementedError("decoder activation must be nn.PReLU (networks.py:21)")
 
     def forward(self, x):
+        p = self.main[0].padding
+        pad = (0, p[0], p[1])
+        if F_.infer_fast_ok(x) and F_.conv_infer_sliced(tuple(x.shape[:-1]) + (self.main[2].weight.shape[1],), self.main[2].weight, pad):
+            # inference: K-sliced convolutions (small grids) hand their partial sums to the PReLU launch that follows them
+            # (only where main[2] is sliced: its residual add then happens in that launch, rounded once like the epilogue's)
+            res = F_.conv_infer(x, self.downsample[0].weight, pad)
+            out = F_.infer_tail(F_.conv_infer(x, self.main[0].weight, pad), prelu=self.main[1].weight)
+            return F_.infer_tail(F_.conv_infer(out, self.main[2].weight, pad), res, prelu=self.relu.weight)
         # the two convolutions of x as one node where the halo kernels apply (bf16 math): the second input gradient is
         # accumulated onto the first in the kernel's residual epilogue instead of by a separate add over the widest maps
-        p = self.main[0].padding
         out, residual = F_.dual_conv(x, self.main[0].weight, self.downsample[0].weight, (0, p[0], p[1]))
         out = F_.PReLUFn.apply(out, self.main[1].weight)
         out = _conv(out, self.main[2], res=residual)          # main(x) + residual fused in the epilogue
@@ -68,6 +75,13 @@ class BasicBlock3D(nn.Module):
         self.relu = activation()
 
     def forward(self, x):
+        if not self.training and F_.infer_fast_ok(x):
+            # inference: K-sliced convolutions (small grids) hand their partial sums to the BatchNorm launch that follows them
+            pad = tuple(self.main[0].padding)
+            res = F_.conv_infer(x, self.downsample[0].weight, pad)
+            out = F_.infer_tail(F_.conv_infer(x, self.main[0].weight, pad), bn_a=self.main[1], relu=True)
+            return F_.infer_tail(F_.conv_infer(out, self.main[3].weight, tuple(self.main[3].padding)), res, bn_a=self.main[4],
+                                 bn_b=self.downsample[1], relu=True)
         # the two convolutions of x as one node: their input gradients are summed in the second kernel's epilogue
         # every convolution of the block feeds a BatchNorm: in training mode they leave its column sums (stats=True)
         out, res = F_.dual_conv(x, self.main[0].weight, self.downsample[0].weight, tuple(self.main[0].padding),

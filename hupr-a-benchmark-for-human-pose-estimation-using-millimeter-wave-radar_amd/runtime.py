@@ -115,6 +115,12 @@ SIGNATURES = {
     "hupr_adam_step_dev_f32": (c_int, [c_void_p] * 4 + [c_long, c_void_p] + [c_float] * 5 + [c_void_p]),
     # bf16-activation variants (same argument lists as their fp32-activation counterparts)
     "hupr_conv3x3_halo_bf16act": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
+    "hupr_conv3x3_halo_splitk_ws_bytes": (c_size_t, [c_int] * 7),
+    "hupr_conv3x3_halo_bf16act_ws": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_conv3x3_halo_bf16act_partial": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_infer_tail_bf16act": (c_int, [c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_float, c_void_p, c_int] + [c_void_p] * 4 +
+                                [c_float, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p]),
+    "hupr_debug_halo_split_k": (None, [c_int]),
     "hupr_conv3x3_wgrad_halo_bf16act": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
     "hupr_bn_train_stats_bf16act": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -349,6 +349,28 @@ int hupr_adam_step_dev_f32(float* p, const float* g, float* exp_avg, float* exp_
 int hupr_conv3x3_halo_bf16act(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y,
                               int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd,
                               hupr_stream_t stream);
+/* The same operator with a caller-supplied workspace.  Grids that would leave most of the chip idle (single-sample inference,
+ * config C2 of BASELINE.json: a level-3 layer is 32 workgroups walking 36 weight stages each) split the reduction over
+ * (channel chunk, kz plane) slices on blockIdx.y; every slice leaves fp32 partial sums [slice][voxel][Co] in ws and a second
+ * launch sums them in slice order (+ bias, + residual) and rounds once.  hupr_conv3x3_halo_splitk_ws_bytes() returns 0 where
+ * the one-launch form is used anyway (ws may then be null).  Same products as the plain form; the fp32 summation order differs. */
+size_t hupr_conv3x3_halo_splitk_ws_bytes(int Bn, int D, int H, int W, int Ci, int Co, int kd);
+int hupr_conv3x3_halo_bf16act_ws(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y,
+                                 int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd,
+                                 void* ws, size_t ws_bytes, hupr_stream_t stream);
+/* First half only: the fp32 partial sums [slices][voxel][Co] stay in `part` (slices = hupr_conv3x3_halo_splitk_ws_bytes() /
+ * (voxels * Co * 4), which must be > 0) for a consumer that sums them itself.  No bias, no residual. */
+int hupr_conv3x3_halo_bf16act_partial(const void* x, const void* wp_bf16, int Bn, int D, int H, int W, int Ci, int in_ld,
+                                      int Co, int kd, void* part, size_t part_bytes, hupr_stream_t stream);
+/* Inference tails that sum K-sliced partials themselves, in slice order and rounded where the stored tensor would have been
+ * (bit-identical to convolution -> reduce -> tail, one launch per convolution less).  x*: bf16 tensor (n* == 0) or n* fp32 slices
+ * [n][M][C]; x2 may be null.  mode 0: y = relu?(bn1_eval(x1) [+ bn2_eval(x2)]) — the BasicBlock3D tails, reference
+ * models/layers.py:55-70 in eval mode; mode 1: y = prelu(x1 [+ x2]) — the BasicBlock2D tails, :30-37. */
+int hupr_infer_tail_bf16act(int mode, const void* x1, int n1, const float* gamma1, const float* beta1, const float* mean1,
+                            const float* var1, float eps1, const void* x2, int n2, const float* gamma2, const float* beta2,
+                            const float* mean2, const float* var2, float eps2, const float* alpha, int relu, void* y, long M,
+                            int C, hupr_stream_t stream);
+void hupr_debug_halo_split_k(int on);     /* A/B aid: 0 = never slice the reduction of small grids */
 int hupr_conv3x3_wgrad_halo_bf16act(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci,
                                     int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
                                     hupr_stream_t stream);

@@ -351,3 +351,30 @@ def test_benched_forward_batch32_from_adc_matches_the_oracle():
     finally:
         F_.set_math("f32")
         F_.invalidate_packed()
+
+
+def test_single_sample_inference_tails_are_bit_identical_and_slicing_is_within_rounding():
+    """Config C2 (B = 1 eval, bf16 path): (1) the inference tails that sum the K-sliced convolutions' partial sums themselves
+    (functional.infer_tail) give the SAME bits as convolution -> reduce launch -> BatchNorm / PReLU launch; (2) slicing the
+    reductions at all changes only fp32 summation order: heat-maps within 2e-3 of the unsliced forward, arg-max identical up to ties inside that tolerance."""
+    from hupr_amd import functional as F_
+    try:
+        _, net = _net("bf16")
+        net.eval()
+        h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(1, 91))
+        outs = {}
+        for tag, tails, split in (("tails", True, 1), ("reduce", False, 1), ("unsliced", False, 0)):
+            F_.INFER_TAILS = tails
+            F_.rt.lib().hupr_debug_halo_split_k(split)
+            with torch.no_grad():
+                outs[tag] = tuple(t.float().clone() for t in net(h, v))
+        for i in (0, 1):
+            assert torch.equal(outs["tails"][i], outs["reduce"][i])
+            assert (outs["tails"][i] - outs["unsliced"][i]).abs().max().item() <= 2e-3
+            a, b = outs["tails"][i].reshape(14, -1), outs["unsliced"][i].reshape(14, -1)      # flat random-weight maps: a flip must be a tie
+            gap = b.max(-1).values - b.gather(-1, a.argmax(-1)[:, None])[:, 0]
+            assert gap.max().item() <= 2e-3
+    finally:
+        F_.INFER_TAILS = True
+        F_.rt.lib().hupr_debug_halo_split_k(1)
+        F_.set_math("f32")

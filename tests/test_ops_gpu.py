@@ -993,3 +993,36 @@ def test_head1x1_fp32_kernels(B, H):
     finally:
         F_.set_math("f32")
     assert not F_._REGION_SWITCHED
+
+
+@pytest.mark.parametrize("shape,Ci,Co,k", [((1, 2, 16, 16), 256, 256, 3), ((1, 4, 32, 32), 128, 128, 3), ((1, 4, 32, 32), 64, 128, 3),
+                                           ((1, 1, 16, 16), 1024, 256, 1), ((1, 1, 32, 32), 640, 128, 1), ((1, 1, 64, 64), 320, 64, 1),
+                                           ((2, 1, 16, 16), 256, 128, 1)])
+def test_small_grid_convolution_k_slices(shape, Ci, Co, k, bf16_math):
+    """Single-sample inference (config C2): the halo convolution splits its reduction over (channel chunk, kz plane) slices on
+    grids that would leave the chip idle (hupr_conv3x3_halo_bf16act_ws + hupr_k_conv_partial_reduce).  Against the one-launch
+    form (same products; fp32 summation order differs, so outputs agree to one bf16 rounding) and against fp64, with a residual
+    and a bias riding in the reduce kernel."""
+    from hupr_amd import functional as F_
+    B, D, H, W = shape
+    L = F_.rt.lib()
+    assert L.hupr_conv3x3_halo_splitk_ws_bytes(B, D, H, W, Ci, Co, k) > 0
+    x = cl(rnd(B, Ci, D, H, W, seed=400)).cuda().bfloat16()
+    w = rnd(Co, Ci, k, 3, 3, seed=401, scale=(Ci * 9 * k) ** -0.5).cuda()
+    bias = rnd(Co, seed=402).cuda()
+    res = cl(rnd(B, Co, D, H, W, seed=403)).cuda().bfloat16()
+    pad = (k // 2, 1, 1)
+    with torch.no_grad():
+        y1 = F_.conv(x, w, bias, res, pad)
+        L.hupr_debug_halo_split_k(0)
+        try:
+            y0 = F_.conv(x, w, bias, res, pad)
+        finally:
+            L.hupr_debug_halo_split_k(1)
+    ref = torch.nn.functional.conv3d(ncdhw(x.double()), w.double(), bias.double(), padding=pad) + ncdhw(res.double())
+    close(ncdhw(y1.float()), ref, 1.2e-2, "sliced convolution vs fp64 (bf16 products)")
+    close(y1.float(), y0.float(), 8e-3, "sliced vs one-launch")
+    assert (y1 != y0).float().mean().item() < 0.2                 # mostly identical bits; differences are single bf16 roundings
+    # training keeps the one-launch form (gradients enabled: no slicing, bit-identical to before)
+    y2 = F_.conv(x, w.requires_grad_(True), bias, res, pad)
+    assert torch.equal(y2.detach(), y0)
