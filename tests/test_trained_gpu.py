@@ -192,36 +192,46 @@ def test_bf16_path_meets_the_argmax_gate_at_batch32():
     if "r1" not in p:
         p["r1"], p["r2"] = pf.evaluate(p["sd"], p["cfg"], p["h"], p["v"], "f32")
     b1, b2 = pf.evaluate(p["sd"], p["cfg"], p["h"], p["v"], "bf16")
-    print("bf16 vs fp32 path, 32 held-out scenes:")
-    _bf16_gates(b1, b2, p["r1"], p["r2"])
+    print("bf16 vs fp32 path, 32 held-out scenes (448 joints: one joint is 0.22 %; the 99 % gate proper runs on 7 168 joints below):")
+    _bf16_gates(b1, b2, p["r1"], p["r2"], first_head_min=0.985)
 
 
-def test_bf16_path_meets_the_ap_gate_on_512_scenes():
-    """The AP-level check north_star asks for (COCO OKS AP within +-0.2 points of the reference path): both paths decode 512
-    held-out scenes (noise drawn on the device from a fixed seed, joints from the seeded generator) and are scored against the
-    scenes' joints with misc/oks_eval.py (== the reference's COCOeval to 1e-12, tests/golden/oks_eval.json).  512 images: one
-    image crossing one of the ten OKS thresholds moves AP by 0.0002 — on the 32-scene set above the same event is 0.003."""
+def test_bf16_path_meets_the_argmax_and_ap_gates_on_512_scenes():
+    """The gates on a sample large enough to mean something: 512 held-out scenes (noise drawn on the device from a fixed seed,
+    joints from the seeded generator), 7 168 joints per head.  SURVEY 8(d): arg-max identical on >= 99 % of the joints — asserted
+    for the first head (measured 99.8 %); the decoded head is held to >= 97.5 % with >= 99.5 % within one pixel (measured
+    99.0-99.1 % / 100 %, see _bf16_gates for why it cannot promise more).  And the AP-level check north_star asks for (COCO OKS AP
+    within +-0.2 points of the reference path): both paths' decoded key-points are scored against the scenes' joints with
+    misc/oks_eval.py (== the reference's COCOeval to 1e-12, tests/golden/oks_eval.json); one image crossing one of the ten OKS
+    thresholds moves AP by 0.0002 here — on a 32-scene set the same event is 0.003."""
     p = _pose_trained()
     pf = p["fit"]
     rng = np.random.default_rng(777)
     gen = torch.Generator(device="cuda").manual_seed(888)
     dec = {"f32": [], "bf16": []}
-    same = tot = 0
+    same = [0, 0]
+    near = tot = 0
     joints = []
     for _ in range(16):
         h, v, j = pf.scene_batch(32, rng, gen, torch.device("cuda"))
         joints.append(j.numpy())
-        out = {}
-        for math in ("f32", "bf16"):
-            out[math] = pf.evaluate(p["sd"], p["cfg"], h, v, math)[1]
-            dec[math].append(out[math].reshape(32, 14, -1).argmax(-1).cpu())
-        same += (dec["f32"][-1] == dec["bf16"][-1]).sum().item()
+        out = {math: pf.evaluate(p["sd"], p["cfg"], h, v, math) for math in ("f32", "bf16")}
+        for hd in (0, 1):
+            a, b = (out[m][hd].reshape(32, 14, -1).argmax(-1) for m in ("f32", "bf16"))
+            same[hd] += (a == b).sum().item()
+            if hd == 1:
+                near += (torch.maximum((a % 64 - b % 64).abs(), (a // 64 - b // 64).abs()) <= 1).sum().item()
+                dec["f32"].append(a.cpu())
+                dec["bf16"].append(b.cpu())
         tot += 32 * 14
     joints = np.concatenate(joints)
     ap = {m: pf.decode_ap_from_indices(torch.cat(dec[m]).numpy(), joints) for m in dec}
-    print("512 held-out scenes (7 168 joints): decoded head identical on %.4f; OKS AP fp32 path %.4f, bf16 path %.4f (difference "
-          "%.2f AP points)" % (same / tot, ap["f32"], ap["bf16"], 100 * abs(ap["f32"] - ap["bf16"])))
-    assert ap["f32"] >= 0.3 and abs(ap["bf16"] - ap["f32"]) <= 0.002 and same / tot >= 0.975
+    print("512 held-out scenes (7 168 joints per head): identical arg-max first head %.4f, decoded head %.4f (%.4f within one pixel); "
+          "OKS AP fp32 path %.4f, bf16 path %.4f (difference %.2f AP points)" %
+          (same[0] / tot, same[1] / tot, near / tot, ap["f32"], ap["bf16"], 100 * abs(ap["f32"] - ap["bf16"])))
+    assert same[0] / tot >= 0.99
+    assert same[1] / tot >= 0.975 and near / tot >= 0.995
+    assert ap["f32"] >= 0.3 and abs(ap["bf16"] - ap["f32"]) <= 0.002
 
 
 def test_bf16_training_mode_forward_meets_the_same_gates():
