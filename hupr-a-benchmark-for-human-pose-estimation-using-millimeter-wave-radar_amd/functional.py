@@ -604,6 +604,22 @@ def conv(x, weight, bias=None, res=None, pad=(0, 0, 0), stats=False):
     return ConvFn.apply(x, weight, bias, res, tuple(pad), bool(stats), not torch.is_grad_enabled())
 
 
+TMERGE_STREAM = os.environ.get("HUPR_NO_TMERGE_STREAM", "0") != "1"      # A/B aid
+
+
+def _tmerge_fwd(x, weight, y):
+    """merged map y (B,1,H,W,Co) fp32 of x (B,G,H,W,Ci): the LDS-DMA streaming kernel for bf16 64-channel maps (level 1),
+    the generic mixed-storage convolution otherwise."""
+    B, G, H, W, Ci = _vox(x)
+    Co = weight.shape[0]
+    L = rt.lib()
+    if TMERGE_STREAM and x.dtype == torch.bfloat16 and L.hupr_tmerge_stream_supported(G, H * W, Ci, Co):
+        rt.check(L.hupr_tmerge_fwd_stream_bf16(rt.ptr(x), rt.ptr(_packed(weight, 0, 1)), rt.ptr(y), B, G, H * W, Ci, Co, rt.stream()))
+        return
+    rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), int(x.dtype == torch.bfloat16), rt.ptr(_packed(weight, 0, 0)), None, rt.ptr(y), 0,
+                                        B, G, H, W, Ci, Ci, 1, H, W, Co, Co, G, 1, 1, 0, 0, 0, rt.stream()))
+
+
 @_math_scoped
 class TemporalMergeFn(torch.autograd.Function):
     """Frame-axis merge: Conv3d with kernel (G,1,1), no padding and no bias on a (B,G,H,W,C) map (the
@@ -618,9 +634,7 @@ class TemporalMergeFn(torch.autograd.Function):
         Co = weight.shape[0]
         assert tuple(weight.shape[1:]) == (Ci, G, 1, 1), (weight.shape, x.shape)
         y = torch.empty((B, 1, H, W, Co), dtype=torch.float32, device=x.device)
-        rt.check(rt.lib().hupr_conv_fwd_bf16_mixed(
-            rt.ptr(x), int(x.dtype == torch.bfloat16), rt.ptr(_packed(weight, 0, 0)), None, rt.ptr(y), 0,
-            B, G, H, W, Ci, Ci, 1, H, W, Co, Co, G, 1, 1, 0, 0, 0, rt.stream()))
+        _tmerge_fwd(x, weight, y)
         ctx.save_for_backward(x, weight)
         return y
 
@@ -662,8 +676,7 @@ class MergeDownFn(torch.autograd.Function):
         assert tuple(weight.shape[1:]) == (Ci, G, 1, 1) and x.dtype == torch.bfloat16
         L = rt.lib()
         merged = torch.empty((B, 1, H, W, Co), dtype=torch.float32, device=x.device)
-        rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 1, rt.ptr(_packed(weight, 0, 0)), None, rt.ptr(merged), 0,
-                                            B, G, H, W, Ci, Ci, 1, H, W, Co, Co, G, 1, 1, 0, 0, 0, rt.stream()))
+        _tmerge_fwd(x, weight, merged)
         Do, Ho, Wo = size
         down = torch.empty((B, Do, Ho, Wo, Ci), dtype=x.dtype, device=x.device)
         rt.check(L.hupr_interp_linear_fwd_bf16act(rt.ptr(x), rt.ptr(down), B, G, H, W, Do, Ho, Wo, Ci, Ci, Ci, rt.stream()))

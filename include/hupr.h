@@ -136,6 +136,13 @@ int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int
                          int in_ld, int Do, int Ho, int Wo, int Co, int dy_ld, int kd, int kh, int kw, int pd,
                          int ph, int pw, void* ws, size_t ws_bytes, hupr_stream_t stream);
 
+/* Streaming form of the temporal merge Conv3d(C, C, (G,1,1)) for 64-channel maps (reference models/layers.py:208,218: the
+ * level-1 merge): x bf16 (Bn, G, HW, 64) -> y fp32 (Bn, HW, 64).  The operand travels global -> LDS by LDS-DMA through a ring of
+ * four 16 KB stages per persistent workgroup (three in flight while one is multiplied); the generic engine keeps one 8 KB tile
+ * in flight and ran this 64 flop/B product at 2.2 TB/s.  wp_bf16: the weight packed [Co][G][Ci] (hupr_pack_conv_weights_bf16). */
+int hupr_tmerge_stream_supported(int G, int HW, int Ci, int Co);
+int hupr_tmerge_fwd_stream_bf16(const void* x, const void* wp_bf16, float* y, int Bn, int G, int HW, int Ci, int Co,
+                                hupr_stream_t stream);
 /* Mixed-storage variants for the temporal merges of Encoder3D (reference models/layers.py:195-197: Conv3d with
  * kernel (G,1,1) collapsing the frame axis): the feature maps arrive bf16-stored from the bf16-activation encoder,
  * the merged maps and all gradients of the parameters stay fp32.  x_bf16 / y_bf16 / dx_bf16 select the HBM storage

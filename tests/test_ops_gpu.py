@@ -1026,3 +1026,24 @@ def test_small_grid_convolution_k_slices(shape, Ci, Co, k, bf16_math):
     # training keeps the one-launch form (gradients enabled: no slicing, bit-identical to before)
     y2 = F_.conv(x, w.requires_grad_(True), bias, res, pad)
     assert torch.equal(y2.detach(), y0)
+
+
+@pytest.mark.parametrize("B,H", [(3, 64), (1, 16), (32, 64)])
+def test_streaming_temporal_merge_matches_the_generic_kernel(B, H, bf16_math):
+    """hupr_tmerge_fwd_stream_bf16 (LDS-DMA ring, persistent workgroups; the level-1 merge Conv3d(64, 64, (8,1,1)), reference
+    models/layers.py:208,218) against fp64 on the bf16-rounded operands and against the generic mixed-storage convolution it
+    replaces (same bf16 products, fp32 accumulation in another order)."""
+    from hupr_amd import functional as F_
+    G, C = 8, 64
+    x = rnd(B, G, H, H, C, seed=500).cuda().bfloat16()
+    w = rnd(C, C, G, 1, 1, seed=501, scale=(C * G) ** -0.5).cuda().requires_grad_(True)
+    assert F_.rt.lib().hupr_tmerge_stream_supported(G, H * H, C, C)
+    y1 = F_.TemporalMergeFn.apply(x, w).detach()
+    F_.TMERGE_STREAM = False
+    try:
+        y0 = F_.TemporalMergeFn.apply(x, w).detach()
+    finally:
+        F_.TMERGE_STREAM = True
+    ref = torch.einsum("bghwc,ocg->bhwo", x.double().cpu(), w.detach().reshape(C, C, G).to(torch.bfloat16).double().cpu())
+    close(y1.reshape(B, H, H, C), ref, 1e-5, "streaming merge vs fp64 (bf16-rounded operands)")
+    close(y1, y0, 2e-6, "streaming vs generic")
