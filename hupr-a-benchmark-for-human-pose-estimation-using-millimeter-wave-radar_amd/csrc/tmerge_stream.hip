@@ -108,6 +108,245 @@ __global__ __launch_bounds__(256) void hupr_k_tmerge_fwd_stream(const __bf16* __
 #undef HUPR_VMCNT
 }
 
+
+// ---- input gradient: dx[b][g][v][ci] = sum_co dy[b][v][co] * W[co][ci][g] -------------------------------------------------------------
+// Write-bound (134 MB of bf16 dx against 34 MB of fp32 dy at B = 32): a persistent workgroup converts a 128-voxel dy tile to bf16 in
+// LDS once (the next tile's 32 KB already on their way into registers), multiplies it by the G resident weight slices
+// (D' = W_g^T dy^T: a lane holds one voxel and 4 x 4 input channels) and stores G x 16 KB with 16-byte stores (lanes l / l + 32
+// exchange their 4-channel halves, as in the halo convolution's bf16 epilogue).
+template <int G>
+__global__ __launch_bounds__(256) void hupr_k_tmerge_dgrad_stream(const float* __restrict__ dy, const __bf16* __restrict__ wp1,
+                                                                  __bf16* __restrict__ dx, int Bn, int HW) {
+    constexpr int C = 64, ROW = C;
+    __shared__ __attribute__((aligned(16))) __bf16 Wt[G][C * ROW];               // [g][ci][co]
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[2][128 * ROW];             // [buffer][voxel][co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+
+    // weights: mode-1 packed [ci][G - 1 - g][co] bf16 -> Wt[g][ci][chunk ^ ((ci >> 1) & 7)]
+    for (int it = tid; it < G * C * 8; it += 256) {
+        const int c8 = it & 7, ci = (it >> 3) % C, g = it / (8 * C);
+        *reinterpret_cast<u32x4*>(&Wt[g][ci * ROW + ((c8 ^ ((ci >> 1) & 7)) << 3)]) =
+            *reinterpret_cast<const u32x4*>(wp1 + ((long)ci * G + (G - 1 - g)) * C + c8 * 8);
+    }
+
+    const int tiles_per_b = HW / 128, n_tiles = Bn * tiles_per_b;
+    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (my_tiles == 0) return;
+
+    f32x4n pre[8];                                                // a dy tile: 128 x 64 fp32 = 8 float4 per thread, contiguous in HBM
+    auto fetch = [&](int i) {
+        const int t = (int)blockIdx.x + i * (int)gridDim.x;
+        const float* src = dy + ((long)(t / tiles_per_b) * HW + (long)(t % tiles_per_b) * 128) * C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[j] = *reinterpret_cast<const f32x4n*>(src + (long)(j * 256 + tid) * 4);
+    };
+    fetch(0);
+    const int arow = (wave * 32 + lr) * ROW, akey = ((wave * 32 + lr) >> 1) & 7;
+    for (int i = 0; i < my_tiles; ++i) {
+        __bf16* Dt = &Ds[i & 1][0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = j * 256 + tid, row = f >> 4, c4 = f & 15;
+            const bf16x4 o = {(__bf16)pre[j][0], (__bf16)pre[j][1], (__bf16)pre[j][2], (__bf16)pre[j][3]};
+            *reinterpret_cast<bf16x4*>(&Dt[row * ROW + (((c4 >> 1) ^ ((row >> 1) & 7)) << 3) + ((c4 & 1) << 2)]) = o;
+        }
+        if (i + 1 < my_tiles) fetch(i + 1);
+        __syncthreads();                                          // buffer i & 1 complete; buffer (i + 1) & 1 was last read two tiles ago
+        const int t = (int)blockIdx.x + i * (int)gridDim.x;
+        const int b = t / tiles_per_b, v = (t % tiles_per_b) * 128 + wave * 32 + lr;
+        bf16x8 af[C / 16];
+#pragma unroll
+        for (int ks = 0; ks < C / 16; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(&Dt[arow + (((ks * 2 + lh) ^ akey) << 3)]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            const __bf16* Wg = &Wt[g][0];
+#pragma unroll
+            for (int ks = 0; ks < C / 16; ++ks) {
+                const int cw = ks * 2 + lh;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int ci = 32 * ct + lr;
+                    const bf16x8 bq = *reinterpret_cast<const bf16x8*>(&Wg[ci * ROW + ((cw ^ ((ci >> 1) & 7)) << 3)]);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, af[ks], acc[ct], 0, 0, 0);
+                }
+            }
+            __bf16* drow = dx + (((long)b * G + g) * HW + v) * C;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                unsigned pk[8];
+                halo_pack_tile(acc[ct], pk);
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp], pk[2 * gp + 2], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp + 1], pk[2 * gp + 3], false, false);
+                    *reinterpret_cast<u32x4*>(drow + 32 * ct + 8 * (gp + lh)) = (u32x4){r0[0], r1[0], r0[1], r1[1]};
+                }
+            }
+        }
+    }
+}
+
+// ---- weight gradient: dW[co][ci][g] = sum_{b,v} dy[b][v][co] * x[b][g][v][ci] ------------------------------------------------------------
+// The reduction axis (voxels) has to run along the MFMA K of BOTH operands: ds_read_b64_tr_b16 produces those transposed fragments
+// from the row-major [voxel][channel] LDS images (the idiom of wgrad_halo_bf16.hip).  Everything arrives by LDS-DMA through the
+// same ring of four 16 KB stages as the forward kernel: per 128-voxel tile two stages carry the fp32 dy tile (converted LDS -> LDS
+// to one bf16 image, its eight K-step fragments then live in registers for the tile) and G stages the frame slices of x.  Wave w
+// owns the 32 x 32 block (co half w >> 1, ci half w & 1) of every frame's 64 x 64 gradient: G accumulator tiles, 16 G registers.
+// Each workgroup leaves one fp32 partial in the parameter layout (Co, Ci, G); hupr_k_tmerge_wgrad_reduce sums them in a fixed order.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tm_tr_pair(const char* base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_stream(const __bf16* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ part, int Bn, int HW) {
+    constexpr int C = 64, S = G + 2, SLOT = 128 * C * 2;          // stages per tile; bytes per ring slot
+    __shared__ __attribute__((aligned(16))) char Ring[kTmStages][SLOT];
+    __shared__ __attribute__((aligned(16))) char Db[128 * C * 2];                // bf16 dy tile [voxel][co], 16-byte chunks swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5;
+
+    const int tiles_per_b = HW / 128, n_tiles = Bn * tiles_per_b;
+    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_stage = my_tiles * S;
+    const int ct = wave >> 1, it = wave & 1;
+
+    f32x16 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+    if (n_stage > 0) {
+        const u32x4 xrs = {(unsigned)(unsigned long)x, (unsigned)((unsigned long)x >> 32) & 0xffffu,
+                           (unsigned)((long)Bn * G * HW * C * 2), 0x00020000u};
+        const u32x4 drs = {(unsigned)(unsigned long)dy, (unsigned)((unsigned long)dy >> 32) & 0xffffu,
+                           (unsigned)((long)Bn * HW * C * 4), 0x00020000u};
+        const unsigned ring_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&Ring[0][0];
+        // stage n = (tile n / S, s = n % S): s < 2 -> half s of the fp32 dy tile (64 voxels = 16 KB, copied linearly), else frame s - 2 of
+        // the x tile (128 voxels = 16 KB, 16-byte chunks swizzled by the row on the source side as in the forward kernel)
+        auto dma = [&](int n) {
+            const int t = (int)blockIdx.x + (n / S) * (int)gridDim.x, s = n % S;
+            const int b = t / tiles_per_b, v0 = (t % tiles_per_b) * 128;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int piece = 4 * wave + j;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (n % kTmStages) * SLOT + piece * 1024);
+                unsigned keep_;
+                if (s < 2) {
+                    const unsigned voff = (unsigned)(((long)b * HW + v0 + 64 * s) * C * 4) + piece * 1024 + lane * 16;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(keep_)
+                                 : "s"(dst), "v"(voff), "s"(drs)
+                                 : "memory");
+                } else {
+                    const int row = piece * 8 + (lane >> 3);
+                    const unsigned voff = (unsigned)((((long)b * G + (s - 2)) * HW + v0) * C * 2) + row * (C * 2) +
+                                          ((((lane & 7) ^ ((row >> 1) & 7)) & 7) << 4);
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(keep_)
+                                 : "s"(dst), "v"(voff), "s"(xrs)
+                                 : "memory");
+                }
+            }
+        };
+#define HUPR_VMCNT(N_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N_) & 15) | (((N_) >> 4) << 14))
+        for (int n = 0; n < kTmStages - 1 && n < n_stage; ++n) dma(n);
+
+        // transpose-read supplier role of this lane (wgrad_halo_bf16.hip): 16-lane group q, index sq inside it -> rows 8 lh + 4 t + (sq >> 2)
+        // of a 16-voxel K step, the 8-byte segment at channel 16 (q & 1) + 4 (sq & 3) of this wave's 32-channel half
+        const int q = lane >> 4, sq = lane & 15;
+        int offa[2], offb[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = 8 * lh + 4 * tt + (sq >> 2), key = (row >> 1) & 7;       // K steps advance rows by 16: the key is unchanged
+            const int ca = (32 * ct + 16 * (q & 1) + 4 * (sq & 3)) * 2, cb = (32 * it + 16 * (q & 1) + 4 * (sq & 3)) * 2;
+            offa[tt] = row * 128 + ((((ca >> 4) ^ key) & 7) << 4) + (ca & 15);
+            offb[tt] = row * 128 + ((((cb >> 4) ^ key) & 7) << 4) + (cb & 15);
+        }
+
+        bf16x8 a[8];
+        for (int i = 0; i < my_tiles; ++i) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int n = i * S + s;
+                const int younger = min(kTmStages - 2, n_stage - 1 - n) * 4;
+                if (younger >= 8) HUPR_VMCNT(8); else if (younger == 4) HUPR_VMCNT(4); else HUPR_VMCNT(0);
+                __syncthreads();                                  // stage n is in LDS; slot (n - 1) % 4 is free
+                if (n + kTmStages - 1 < n_stage) dma(n + kTmStages - 1);
+                const char* slot = &Ring[n % kTmStages][0];
+                if (s < 2) {
+                    // fp32 (64 voxels x 64 co) -> bf16 rows 64 s .. of Db (read by everyone from stage 2 on, behind that stage's barrier;
+                    // the previous tile's last reads of Db are behind this stage's barrier)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = j * 256 + tid, row = 64 * s + (f >> 4), c4 = f & 15;
+                        const f32x4n v = *reinterpret_cast<const f32x4n*>(slot + (long)f * 16);
+                        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(Db + row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) << 4) + ((c4 & 1) << 3)) = o;
+                    }
+                } else {
+                    if (s == 2) {
+#pragma unroll
+                        for (int ks = 0; ks < 8; ++ks) a[ks] = tm_tr_pair(Db + ks * 16 * 128, offa[0], offa[1]);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const bf16x8 bq = tm_tr_pair(slot + ks * 16 * 128, offb[0], offb[1]);
+                        acc[s - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bq, acc[s - 2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#undef HUPR_VMCNT
+    }
+    // partial [workgroup][co][ci][g]: a lane holds, for its column ci and 16 rows co, the G frame values = 4 G contiguous bytes
+    float* dst = part + (long)blockIdx.x * (C * C * G);
+    const int ci = 32 * it + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 32 * ct + 8 * (r >> 2) + 4 * lh + (r & 3);
+        float* d = dst + ((long)co * C + ci) * G;
+        if constexpr (G % 4 == 0) {
+#pragma unroll
+            for (int g = 0; g < G; g += 4) *reinterpret_cast<f32x4n*>(d + g) = (f32x4n){acc[g][r], acc[g + 1][r], acc[g + 2][r], acc[g + 3][r]};
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) d[g] = acc[g][r];
+        }
+    }
+}
+
+// dw[e] (+)= sum over workgroups of part[w][e] in a fixed order: 16 slices of the partial list per block, 16 float4 columns each
+__global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int n_part,
+                                                                  int n4) {
+    __shared__ f32x4n sm[16][16];
+    const int sl = threadIdx.x >> 4, c = threadIdx.x & 15, col = blockIdx.x * 16 + c;
+    f32x4n s = {0.f, 0.f, 0.f, 0.f};
+    if (col < n4)
+        for (int w = sl; w < n_part; w += 16) s += reinterpret_cast<const f32x4n*>(part)[(long)w * n4 + col];
+    sm[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && col < n4) {
+        f32x4n t = sm[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sm[k][c];
+        reinterpret_cast<f32x4n*>(dw)[col] = t;
+    }
+}
+
 }  // namespace hupr
 
 using namespace hupr;
@@ -133,5 +372,50 @@ extern "C" int hupr_tmerge_fwd_stream_bf16(const void* x, const void* wp_bf16, f
     else if (G == 4) hipLaunchKernelGGL(hupr_k_tmerge_fwd_stream<4>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
     else hipLaunchKernelGGL(hupr_k_tmerge_fwd_stream<2>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
     HUPR_LAUNCH_OK("hupr_k_tmerge_fwd_stream");
+    return HUPR_OK;
+}
+
+// dy fp32 (Bn, HW, 64); wp1_bf16: the merge weight packed in mode 1 ([Ci][G - 1 - g][Co] bf16); dx bf16 (Bn, G, HW, 64).
+extern "C" int hupr_tmerge_dgrad_stream_bf16(const float* dy, const void* wp1_bf16, void* dx, int Bn, int G, int HW, int Ci, int Co,
+                                             hupr_stream_t stream) {
+    HUPR_REQUIRE(dy && wp1_bf16 && dx && Bn > 0, "hupr_tmerge_dgrad_stream_bf16: bad argument");
+    HUPR_REQUIRE(hupr_tmerge_stream_supported(G, HW, Ci, Co), "hupr_tmerge_dgrad_stream_bf16: unsupported geometry (G=%d HW=%d Ci=%d Co=%d)", G, HW, Ci, Co);
+    HUPR_REQUIRE(((uintptr_t)dy & 15) == 0 && ((uintptr_t)wp1_bf16 & 15) == 0 && ((uintptr_t)dx & 15) == 0, "hupr_tmerge_dgrad_stream_bf16: misaligned pointer");
+    const int tiles = Bn * (HW / 128);
+    const dim3 grid((unsigned)min(tiles, 256));
+    const __bf16* wb = static_cast<const __bf16*>(wp1_bf16);
+    __bf16* dxb = static_cast<__bf16*>(dx);
+    hipStream_t s = as_stream(stream);
+    if (G == 8) hipLaunchKernelGGL(hupr_k_tmerge_dgrad_stream<8>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
+    else if (G == 4) hipLaunchKernelGGL(hupr_k_tmerge_dgrad_stream<4>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
+    else hipLaunchKernelGGL(hupr_k_tmerge_dgrad_stream<2>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
+    HUPR_LAUNCH_OK("hupr_k_tmerge_dgrad_stream");
+    return HUPR_OK;
+}
+
+// Workspace of the streaming weight gradient: one fp32 partial (Co, Ci, G) per persistent workgroup.
+extern "C" size_t hupr_tmerge_wgrad_stream_ws_bytes(int Bn, int G, int HW, int Ci, int Co) {
+    if (!hupr_tmerge_stream_supported(G, HW, Ci, Co) || Bn <= 0) return 0;
+    return (size_t)min(Bn * (HW / 128), 256) * Co * Ci * G * sizeof(float);
+}
+
+// x bf16 (Bn, G, HW, 64), dy fp32 (Bn, HW, 64) -> dw fp32 in the parameter layout (Co, Ci, G) (overwritten).  Deterministic.
+extern "C" int hupr_tmerge_wgrad_stream_bf16(const void* x, const float* dy, float* dw, int Bn, int G, int HW, int Ci, int Co,
+                                             void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(x && dy && dw && ws && Bn > 0, "hupr_tmerge_wgrad_stream_bf16: bad argument");
+    HUPR_REQUIRE(hupr_tmerge_stream_supported(G, HW, Ci, Co), "hupr_tmerge_wgrad_stream_bf16: unsupported geometry (G=%d HW=%d Ci=%d Co=%d)", G, HW, Ci, Co);
+    HUPR_REQUIRE(ws_bytes >= hupr_tmerge_wgrad_stream_ws_bytes(Bn, G, HW, Ci, Co), "hupr_tmerge_wgrad_stream_bf16: workspace too small");
+    HUPR_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dw & 15) == 0 && ((uintptr_t)ws & 15) == 0, "hupr_tmerge_wgrad_stream_bf16: misaligned pointer");
+    HUPR_REQUIRE((long)Bn * G * HW * Ci * 2 < 0x7fffffffL, "hupr_tmerge_wgrad_stream_bf16: tensor too large for 32-bit buffer offsets");
+    const int tiles = Bn * (HW / 128), n_part = min(tiles, 256), n4 = Co * Ci * G / 4;
+    const __bf16* xb = static_cast<const __bf16*>(x);
+    float* part = static_cast<float*>(ws);
+    hipStream_t s = as_stream(stream);
+    if (G == 8) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<8>, dim3(n_part), dim3(256), 0, s, xb, dy, part, Bn, HW);
+    else if (G == 4) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<4>, dim3(n_part), dim3(256), 0, s, xb, dy, part, Bn, HW);
+    else hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<2>, dim3(n_part), dim3(256), 0, s, xb, dy, part, Bn, HW);
+    HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_stream");
+    hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce, dim3((n4 + 15) / 16), dim3(256), 0, s, part, dw, n_part, n4);
+    HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_reduce");
     return HUPR_OK;
 }

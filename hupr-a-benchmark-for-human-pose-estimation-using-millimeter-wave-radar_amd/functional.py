@@ -620,6 +620,35 @@ def _tmerge_fwd(x, weight, y):
                                         B, G, H, W, Ci, Ci, 1, H, W, Co, Co, G, 1, 1, 0, 0, 0, rt.stream()))
 
 
+def _tmerge_dgrad(dy, weight, dx):
+    """dx (B,G,H,W,Ci) of the merge from the merged map's gradient dy (B,1,H,W,Co) fp32."""
+    B, G, H, W, Ci = _vox(dx)
+    Co = weight.shape[0]
+    L = rt.lib()
+    if TMERGE_STREAM and dx.dtype == torch.bfloat16 and L.hupr_tmerge_stream_supported(G, H * W, Ci, Co):
+        rt.check(L.hupr_tmerge_dgrad_stream_bf16(rt.ptr(dy), rt.ptr(_packed(weight, 1, 1)), rt.ptr(dx), B, G, H * W, Ci, Co, rt.stream()))
+        return
+    rt.check(L.hupr_tmerge_dgrad_bf16(rt.ptr(dy), rt.ptr(_packed(weight, 1, 0)), rt.ptr(dx), int(dx.dtype == torch.bfloat16), B, G,
+                                      H * W, Ci, Co, rt.stream()))
+
+
+def _tmerge_wgrad(x, dy, weight):
+    """-> (dw in the parameter layout, written directly into the gradient sink?)."""
+    B, G, H, W, Ci = _vox(x)
+    Co = weight.shape[0]
+    L = rt.lib()
+    dw, direct = _pgrad(weight)
+    if TMERGE_STREAM and x.dtype == torch.bfloat16 and L.hupr_tmerge_stream_supported(G, H * W, Ci, Co):
+        ws = workspace(L.hupr_tmerge_wgrad_stream_ws_bytes(B, G, H * W, Ci, Co), x.device)
+        rt.check(L.hupr_tmerge_wgrad_stream_bf16(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, G, H * W, Ci, Co, rt.ptr(ws), ws.numel(),
+                                                 rt.stream()))
+        return dw, direct
+    ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, Ci, Co, G, 1, 1), x.device)
+    rt.check(L.hupr_conv_wgrad_bf16_mixed(rt.ptr(x), int(x.dtype == torch.bfloat16), rt.ptr(dy), rt.ptr(dw), B, G, H, W, Ci, Ci, 1,
+                                          H, W, Co, Co, G, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
+    return dw, direct
+
+
 @_math_scoped
 class TemporalMergeFn(torch.autograd.Function):
     """Frame-axis merge: Conv3d with kernel (G,1,1), no padding and no bias on a (B,G,H,W,C) map (the
@@ -645,18 +674,13 @@ class TemporalMergeFn(torch.autograd.Function):
         B, G, H, W, Ci = _vox(x)
         Co = weight.shape[0]
         L = rt.lib()
-        xbf = int(x.dtype == torch.bfloat16)
         dx = dw = None
         direct = False
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            rt.check(L.hupr_tmerge_dgrad_bf16(rt.ptr(dy), rt.ptr(_packed(weight, 1, 0)), rt.ptr(dx), xbf, B, G, H * W,
-                                              Ci, Co, rt.stream()))
+            _tmerge_dgrad(dy, weight, dx)
         if ctx.needs_input_grad[1]:
-            dw, direct = _pgrad(weight)
-            ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, Ci, Co, G, 1, 1), x.device)
-            rt.check(L.hupr_conv_wgrad_bf16_mixed(rt.ptr(x), xbf, rt.ptr(dy), rt.ptr(dw), B, G, H, W, Ci, Ci, 1, H, W,
-                                                  Co, Co, G, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
+            dw, direct = _tmerge_wgrad(x, dy, weight)
         return dx, _pret(weight, dw, direct)
 
 
@@ -693,16 +717,12 @@ class MergeDownFn(torch.autograd.Function):
         L = rt.lib()
         d_merged, d_down = _c(d_merged), _c(d_down)
         dx = torch.empty_like(x)
-        rt.check(L.hupr_tmerge_dgrad_bf16(rt.ptr(d_merged), rt.ptr(_packed(weight, 1, 0)), rt.ptr(dx), 1, B, G, H * W, Ci, Co,
-                                          rt.stream()))
+        _tmerge_dgrad(d_merged, weight, dx)
         rt.check(L.hupr_interp_linear_bwd_acc_bf16act(rt.ptr(d_down), rt.ptr(dx), B, G, H, W, Do, Ho, Wo, Ci, Ci, Ci, rt.stream()))
         dw = None
         direct = False
         if ctx.needs_input_grad[1]:
-            dw, direct = _pgrad(weight)
-            ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, Ci, Co, G, 1, 1), x.device)
-            rt.check(L.hupr_conv_wgrad_bf16_mixed(rt.ptr(x), 1, rt.ptr(d_merged), rt.ptr(dw), B, G, H, W, Ci, Ci, 1, H, W,
-                                                  Co, Co, G, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
+            dw, direct = _tmerge_wgrad(x, d_merged, weight)
         return dx, _pret(weight, dw, direct), None
 
 

@@ -143,6 +143,16 @@ int hupr_conv_wgrad_bf16(const float* x, const float* dy, float* dw, int Bn, int
 int hupr_tmerge_stream_supported(int G, int HW, int Ci, int Co);
 int hupr_tmerge_fwd_stream_bf16(const void* x, const void* wp_bf16, float* y, int Bn, int G, int HW, int Ci, int Co,
                                 hupr_stream_t stream);
+/* Its input gradient dx (bf16, (Bn,G,HW,64)) from dy (fp32, (Bn,HW,64)) — write-bound: the dy tile is converted to bf16 in LDS
+ * once and multiplied by the G resident weight slices; wp1_bf16 = the mode-1 bf16 packing ([Ci][taps reversed][Co]) — and its
+ * weight gradient dw (fp32, parameter layout (Co,Ci,G), overwritten; deterministic): x and dy both stream through the LDS-DMA
+ * ring, the voxel axis is put along the MFMA K of both operands by ds_read_b64_tr_b16, every persistent workgroup leaves one
+ * fp32 partial in `ws` (hupr_tmerge_wgrad_stream_ws_bytes) and a second kernel sums them in a fixed order. */
+int hupr_tmerge_dgrad_stream_bf16(const float* dy, const void* wp1_bf16, void* dx, int Bn, int G, int HW, int Ci, int Co,
+                                  hupr_stream_t stream);
+size_t hupr_tmerge_wgrad_stream_ws_bytes(int Bn, int G, int HW, int Ci, int Co);
+int hupr_tmerge_wgrad_stream_bf16(const void* x, const float* dy, float* dw, int Bn, int G, int HW, int Ci, int Co, void* ws,
+                                  size_t ws_bytes, hupr_stream_t stream);
 /* Mixed-storage variants for the temporal merges of Encoder3D (reference models/layers.py:195-197: Conv3d with
  * kernel (G,1,1) collapsing the frame axis): the feature maps arrive bf16-stored from the bf16-activation encoder,
  * the merged maps and all gradients of the parameters stay fp32.  x_bf16 / y_bf16 / dx_bf16 select the HBM storage

@@ -1047,3 +1047,29 @@ def test_streaming_temporal_merge_matches_the_generic_kernel(B, H, bf16_math):
     ref = torch.einsum("bghwc,ocg->bhwo", x.double().cpu(), w.detach().reshape(C, C, G).to(torch.bfloat16).double().cpu())
     close(y1.reshape(B, H, H, C), ref, 1e-5, "streaming merge vs fp64 (bf16-rounded operands)")
     close(y1, y0, 2e-6, "streaming vs generic")
+    # backward: dx (bf16 store) and dW (fp32) of the streaming kernels against fp64 on the bf16-rounded operands, and against
+    # the generic kernels (same products, other summation order)
+    dy = rnd(B, 1, H, H, C, seed=502).cuda()
+    xg = x.clone().requires_grad_(True)
+
+    def grads():
+        w.grad = None
+        xg.grad = None
+        F_.TemporalMergeFn.apply(xg, w).backward(dy)
+        return xg.grad.float().cpu(), w.grad.detach().clone().cpu()
+    dx1, dw1 = grads()
+    F_.TMERGE_STREAM = False
+    try:
+        dx0, dw0 = grads()
+    finally:
+        F_.TMERGE_STREAM = True
+    dyr = dy.to(torch.bfloat16).double().cpu().reshape(B, H, H, C)
+    wr = w.detach().reshape(C, C, G).to(torch.bfloat16).double().cpu()
+    dx_ref = torch.einsum("bhwo,ocg->bghwc", dyr, wr)
+    dw_ref = torch.einsum("bhwo,bghwc->ocg", dyr, x.double().cpu()).reshape(C, C, G, 1, 1)
+    close(dx1, dx_ref, 6e-3, "streaming dgrad vs fp64 (one bf16 rounding of the result)")
+    close(dx1, dx0, 6e-3, "streaming vs generic dgrad")
+    close(dw1, dw_ref, 5e-5, "streaming wgrad vs fp64 (bf16-rounded operands)")
+    close(dw1, dw0, 5e-5, "streaming vs generic wgrad")
+    dx2, dw2 = grads()
+    assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2), "the streaming backward is deterministic"
