@@ -219,6 +219,9 @@ struct Lin {
     float w0, w1;
 };
 __device__ __forceinline__ Lin lin_coord(int o, int in, int out) {
+    // src is the ROUNDED product, as in ATen's area_pixel_compute_source_index: fused into the subtraction below (fma) the weights
+    // move by up to 2e-6 against the reference's, 1e-5 on the output (HIP's __fmul_rn is a plain, contractable multiply)
+#pragma clang fp contract(off)
     Lin l;
     const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
     const float src = scale * (float)o;
@@ -266,6 +269,7 @@ __device__ __forceinline__ void lin_range(int i, const LinAxis& a, int& lo, int&
     hi = min(a.out - 1, (int)floorf((float)(i + 1) * a.inv + 0.03125f));
 }
 __device__ __forceinline__ float lin_weight(int o, int i, const LinAxis& a) {
+#pragma clang fp contract(off)      // same rounding as lin_coord: the backward is the exact adjoint of the forward
     const float src = a.scale * (float)o;
     const int i0 = (int)src;
     const int i1 = i0 + ((i0 < a.in - 1) ? 1 : 0);
@@ -277,7 +281,7 @@ __device__ __forceinline__ float lin_weight(int o, int i, const LinAxis& a) {
 }
 
 // forward: y[o] = sum over the 8 corner voxels
-template <typename T>
+template <typename T, bool PK = false>
 __global__ __launch_bounds__(256) void hupr_k_interp_fwd(const T* __restrict__ src, T* __restrict__ dst, int Bn,
                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                                                          int in_ld, int out_ld) {
@@ -308,8 +312,21 @@ __global__ __launch_bounds__(256) void hupr_k_interp_fwd(const T* __restrict__ s
                     const float wgt = wd * wh * (cq ? lw.w1 : lw.w0);
                     const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
                     const float4 xv = ld_act4(src + ivox * in_ld + c4 * 4);
-                    acc.x = fmaf(wgt, xv.x, acc.x); acc.y = fmaf(wgt, xv.y, acc.y);
-                    acc.z = fmaf(wgt, xv.z, acc.z); acc.w = fmaf(wgt, xv.w, acc.w);
+                    if constexpr (PK) {                     // probe only (hupr_debug_interp_packed, scripts/interp_race.py builds this file
+                        acc.x = fmaf(wgt, xv.x, acc.x); acc.y = fmaf(wgt, xv.y, acc.y);     // WITHOUT -fno-slp-vectorize): the form hipcc's SLP
+                        acc.z = fmaf(wgt, xv.z, acc.z); acc.w = fmaf(wgt, xv.w, acc.w);     // vectoriser turns into op_sel'ed v_pk_mul / v_pk_fma
+                    } else {
+                        // scalar FMAs on purpose.  Under plain -O3 hipcc's SLP vectoriser turns the weight products and the four
+                        // accumulations into op_sel'ed v_pk_mul_f32 / v_pk_fma_f32, and with the two encoder branches on two streams that
+                        // build returned wrong even-channel sums (2-40 % low, ~1e-4 of the elements) in most launches that shared the chip
+                        // with hupr_k_conv_halo_bf16<64, 64> — never alone, not behind poisoned registers, also with full vmcnt(0) waits;
+                        // a hand-written v_pk_fma_f32 form does not (scripts/interp_race.py, DESIGN.md section 7 "A two-stream step that
+                        // was not reproducible").  The library is built with -fno-slp-vectorize for the same reason.
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc.x) : "v"(wgt), "v"(xv.x));
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc.y) : "v"(wgt), "v"(xv.y));
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc.z) : "v"(wgt), "v"(xv.z));
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc.w) : "v"(wgt), "v"(xv.w));
+                    }
                 }
             }
         }
@@ -461,6 +478,9 @@ static int interp_check(const char* who, int Bn, int Di, int Hi, int Wi, int Do,
     return HUPR_OK;
 }
 
+static int g_interp_packed = 0;      // probe aid (scripts/interp_race.py): 1 = the compiler-packed accumulation
+extern "C" void hupr_debug_interp_packed(int on) { g_interp_packed = on; }
+
 template <typename T>
 static int interp_fwd(const char* who, const T* x, T* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                       int in_ld, int out_ld, hupr_stream_t stream) {
@@ -468,8 +488,12 @@ static int interp_fwd(const char* who, const T* x, T* y, int Bn, int Di, int Hi,
     int rc = interp_check(who, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     if (rc) return rc;
     const long total = (long)Bn * Do * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(hupr_k_interp_fwd<T>, dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
-                       as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    if (g_interp_packed)
+        hipLaunchKernelGGL((hupr_k_interp_fwd<T, true>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    else
+        hipLaunchKernelGGL((hupr_k_interp_fwd<T, false>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     HUPR_LAUNCH_OK("hupr_k_interp_fwd");
     return HUPR_OK;
 }

@@ -121,6 +121,7 @@ SIGNATURES = {
     "hupr_infer_tail_bf16act": (c_int, [c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_float, c_void_p, c_int] + [c_void_p] * 4 +
                                 [c_float, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p]),
     "hupr_debug_halo_split_k": (None, [c_int]),
+    "hupr_debug_interp_packed": (None, [c_int]),
     "hupr_tmerge_stream_supported": (c_int, [c_int] * 4),
     "hupr_tmerge_fwd_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "hupr_tmerge_dgrad_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),

@@ -387,6 +387,7 @@ int hupr_infer_tail_bf16act(int mode, const void* x1, int n1, const float* gamma
                             const float* var1, float eps1, const void* x2, int n2, const float* gamma2, const float* beta2,
                             const float* mean2, const float* var2, float eps2, const float* alpha, int relu, void* y, long M,
                             int C, hupr_stream_t stream);
+void hupr_debug_interp_packed(int on);   /* probe aid: 1 = the resampling forward with hipcc's packed-fp32 accumulation (scripts/interp_race.py) */
 void hupr_debug_halo_split_k(int on);     /* A/B aid: 0 = never slice the reduction of small grids */
 int hupr_conv3x3_wgrad_halo_bf16act(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci,
                                     int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,

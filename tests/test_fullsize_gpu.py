@@ -198,6 +198,42 @@ def test_two_stream_branches_match_one_stream():
         F_.set_math("f32")
 
 
+def test_two_stream_branches_match_one_stream_at_batch32():
+    """The same at the benched batch, where the two branches' kernels really share the chip (at B = 4 most launches are alone on it):
+    two optimisation steps on two streams, on one stream, and on two streams again land on identical losses, parameters and
+    BatchNorm statistics.  Round 3 regression: the resampling forward, in the packed-fp32 form hipcc gave it, returned wrong sums
+    in ~1e-4 of its elements whenever it shared the chip with the other branch's level-3 convolution — a two-stream step was not
+    reproducible, the pose fit of test_trained_gpu.py landed somewhere else on every run (scripts/interp_race.py,
+    scripts/step_determinism.py)."""
+    import pose_fit
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    saved = F_.TWO_STREAMS
+    try:
+        F_.set_math("bf16")
+        cfg = load_config()
+        dev = torch.device("cuda", 0)
+        h, v, joints = pose_fit.scene_batch(32, np.random.default_rng(5), torch.Generator(device=dev).manual_seed(6), dev)
+        states, losses = [], []
+        for two in (True, False, True, True):
+            F_.TWO_STREAMS = two
+            eng = TrainEngine(cfg, device=dev, seed=0, lr=2e-4)
+            for _ in range(2):
+                loss, _ = eng.train_step(h, v, joints)
+            torch.cuda.synchronize()
+            states.append({k: t.detach().clone() for k, t in eng.model.state_dict().items()})
+            losses.append(float(loss.detach()))
+            eng.close()
+        for other in (1, 2, 3):
+            assert losses[0] == losses[other], losses
+            bad = [k for k in states[0] if not torch.equal(states[0][k], states[other][k])]
+            assert not bad, (other, bad[:8])
+    finally:
+        F_.TWO_STREAMS = saved
+        F_.set_math("f32")
+
+
 def test_bf16_path_argmax_agreement_b32():
     """SURVEY 8(d) bf16 gate at scale (2 heads x 448 joints, eval, B = 32): the bf16 path (bf16 matrix pipe + bf16-stored
     activations) against the fp32 parity path on the same weights/inputs.  The random-weight fixture has flat heat-maps
