@@ -60,9 +60,10 @@ def test_fp32_training_follows_the_reference_trajectory():
     """VERDICT r2 item 2 — chaos, not bias.  tests/golden/model_trained_spread.npz holds the REFERENCE's own loss trajectories
     over the same 120-step fit when only its rounding changes (make_golden.py `spread`: fp64 arithmetic, inputs perturbed by
     1e-7 relative, one ATen thread instead of eight): they leave the default fp32 run by 0.6-15 % within ten steps and by
-    15-17 % over the fit.  The fp32 HIP path must (a) reproduce the first three steps to 2e-5 — the same computation while
-    rounding noise has not been amplified — and (b) afterwards stay within TWICE the reference's own spread at steps 10 / 30 /
-    120, with a final loss inside twice the range the reference's variants end in."""
+    15-17 % over the fit; after three steps they already differ by 2-6e-5.  The fp32 HIP path must (a) reproduce the first
+    loss to 5e-6 — the same forward pass, nothing amplified yet — and (b) stay within TWICE the reference's own spread at steps
+    3 / 10 / 30 / 120 (measured 1-3e-5 at step 3: which side of 2e-5 it lands on moved with one rounding inside the resampling
+    weights, round 3), with a final loss inside twice the range the reference's variants end in."""
     c = _trained()
     g, losses = c["g"], c["losses"]
     ref = g["losses"]
@@ -73,8 +74,8 @@ def test_fp32_training_follows_the_reference_trajectory():
     own = np.max([np.abs(v - ref) / ref for v in variants.values()], axis=0)          # (steps, 2): the reference vs itself
     print("loss trajectory rel err: steps 0-2 %.2e, steps 0-9 %.2e, all %.2e; final %.5f vs %.5f" %
           (rel[:3].max(), rel[:10].max(), rel.max(), losses[-1, 0], ref[-1, 0]))
-    assert rel[:3].max() <= 2e-5
-    for t in (10, 30, len(ref)):
+    assert rel[0].max() <= 5e-6                       # step 0: the same forward pass on the same weights, nothing amplified yet
+    for t in (3, 10, 30, len(ref)):
         print("  steps < %3d: HIP fp32 vs reference %.2e; reference vs its own variants (%s) %.2e" %
               (t, rel[:t].max(), ", ".join(sorted(variants)), own[:t].max()))
         assert rel[:t].max() <= 2.0 * own[:t].max()
