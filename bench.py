@@ -352,6 +352,30 @@ def main():
                      "seconds": round(d_more, 2), "ms_per_step": round(d_more / n_more * 1e3, 3),
                      "note": "continuation of the timed region on the same state; `value` above is the --steps window only"}
 
+    # The library's default of two branch streams, beside the headline: `value` / `roofline` are measured on ONE stream so that a
+    # per-launch duration is that of a kernel owning the GPU; this window repeats the same step with the vertical encoder on a side
+    # stream (bit-identical results: tests/test_fullsize_gpu.py::test_two_stream_branches_match_one_stream_at_batch32).
+    two_streams = None
+    if args.sustain > 0 and not args.graph and not F_.TWO_STREAMS and os.environ.get("HUPR_ONE_STREAM", "0") != "1":
+        F_.TWO_STREAMS = True
+        try:
+            for _ in range(3):
+                one_step()
+            n2 = max(int(np.ceil(1.5 / (dt / args.steps))), 10)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n2):
+                one_step()
+            barrier()
+            ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+            if dist.is_initialized():
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            d2 = float(ts.item())
+            two_streams = {"value": round(world * B * micro * n2 / d2, 3), "unit": "frames/s", "steps": n2, "ms_per_step": round(d2 / n2 * 1e3, 3),
+                           "note": "same step, functional.TWO_STREAMS = True (python bench.py --two-streams times the whole run this way)"}
+        finally:
+            F_.TWO_STREAMS = False
+
     if args.graph:      # roofline probe on a few eager steps (events cannot be read back from inside a graph replay)
         eng._graph = None
         F_.CONV_PROBE = conv_probe_factory(probe_events)
@@ -488,6 +512,7 @@ def main():
             "host_enqueue_ms_per_step_by_rank": [round(float(x), 2) for x in enq_ranks],
             "rccl_ranks": rccl_ranks,
             "sustained": sustained,
+            "two_streams": two_streams,
             "roofline": conv_roofline(probe_events, B, args.dtype, peak),
             "fft_roofline": fft_roof,
         }

@@ -33,6 +33,9 @@ wrap("hupr_conv_fwd_bf16_mixed", lambda a: "B%d in(%d,%d,%d) Ci%d Co%d k(%d,%d,%
 wrap("hupr_conv_wgrad_bf16", lambda a: "B%d in(%d,%d,%d) Ci%d Co%d k(%d,%d,%d)" % (a[3], a[4], a[5], a[6], a[7], a[12], a[14], a[15], a[16]))
 wrap("hupr_conv_wgrad_bf16_mixed", lambda a: "B%d in(%d,%d,%d) Ci%d Co%d k(%d,%d,%d)" % (a[4], a[5], a[6], a[7], a[8], a[13], a[15], a[16], a[17]))
 wrap("hupr_tmerge_dgrad_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d" % (a[4], a[5], a[6], a[7], a[8]))
+wrap("hupr_tmerge_fwd_stream_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d" % (a[3], a[4], a[5], a[6], a[7]))
+wrap("hupr_tmerge_dgrad_stream_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d" % (a[3], a[4], a[5], a[6], a[7]))
+wrap("hupr_tmerge_wgrad_stream_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d (incl. the partial reduce)" % (a[3], a[4], a[5], a[6], a[7]))
 eng.train_step_from_adc(adc_h, adc_v, joints, decode="device")
 torch.cuda.synchronize()
 agg = collections.OrderedDict()

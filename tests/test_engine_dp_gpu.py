@@ -66,6 +66,48 @@ def test_rccl_exchange_single_rank_is_bit_transparent(monkeypatch):
         F_.set_math("f32")
 
 
+def test_rccl_exchange_at_batch32_with_two_streams_is_bit_transparent(monkeypatch):
+    """The regime a data-parallel rank really runs in: B = 32, both encoder branches in flight on two streams AND the bucket
+    all-reduces on the communication stream beside the backward kernels.  Two steps that way == two steps on one stream without
+    any collective, bit for bit.  (Round 3: at B = 32 kernels of different streams really share the chip, and one kernel turned
+    out to return wrong sums beside another stream's convolution — DESIGN.md section 7; the B = 4 test above never saw it.)"""
+    import numpy as np
+    import pose_fit
+    from hupr_amd import functional as F_
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.tools.engine import TrainEngine
+    saved = F_.TWO_STREAMS
+    try:
+        F_.set_math("bf16")
+        cfg = load_config()
+        dev = torch.device("cuda", 0)
+        h, v, joints = pose_fit.scene_batch(32, np.random.default_rng(7), torch.Generator(device=dev).manual_seed(8), dev)
+        F_.TWO_STREAMS = False
+        monkeypatch.delenv("HUPR_FORCE_ALLREDUCE", raising=False)
+        e0 = TrainEngine(cfg, device=dev, seed=0, lr=2e-4)
+        for _ in range(2):
+            l0, _ = e0.train_step(h, v, joints)
+        torch.cuda.synchronize()
+        ref = {k: t.detach().clone() for k, t in e0.model.state_dict().items()}
+        e0.close()
+        F_.TWO_STREAMS = True
+        monkeypatch.setenv("HUPR_FORCE_ALLREDUCE", "1")
+        for attempt in range(2):
+            e1 = TrainEngine(cfg, device=dev, seed=0, lr=2e-4)
+            assert e1.buckets.active and e1.buckets.transport.name.startswith("rccl"), e1.buckets.transport.name
+            for _ in range(2):
+                l1, _ = e1.train_step(h, v, joints)
+            torch.cuda.synchronize()
+            assert all(b.launched for b in e1.buckets.buckets)
+            assert float(l0.detach()) == float(l1.detach())
+            bad = [k for k, t in e1.model.state_dict().items() if not torch.equal(t, ref[k])]
+            assert not bad, (attempt, bad[:8])
+            e1.close()
+    finally:
+        F_.TWO_STREAMS = saved
+        F_.set_math("f32")
+
+
 def test_graph_captures_the_exchange_step(monkeypatch):
     """The data-parallel step as ONE hipGraph: the fork to the communication stream, ncclAllReduce and the join before Adam
     are captured; 2 eager + 1 warm-up + 2 replays == 5 eager steps."""
