@@ -1,4 +1,4 @@
-python -m pytest tests/test_trained_gpu.py -q -m gpu -s 2>&1 | grep -v "pose fit step" > gpurun_out/trained.txt; tail -3 gpurun_out/trained.txt
+# usage (GPU box, repo root): bash scripts/final_measurements.sh  -> gpurun_out/{b_*.json, final_kernels.md, gemm_path_calls.txt, tmerge.txt}
 python bench.py > gpurun_out/b_default.json 2>gpurun_out/b_default.err
 python bench.py --steps 20 --warmup 5 > gpurun_out/b_driver.json 2>/dev/null
 python bench.py --two-streams --no-cpu-baseline --no-parity-path --no-c2 > gpurun_out/b_two.json 2>/dev/null
