@@ -200,6 +200,39 @@ def test_interp_align_corners(shape, size):
     close(ncdhw(xg.grad), xr.grad, 1e-5, "interp bwd")
 
 
+def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(bf16_math):
+    """Round 3 regression (scripts/interp_race.py): the build of hupr_k_interp_fwd that hipcc's SLP vectoriser
+    produced returned wrong sums in >90 % of the launches that shared the chip with the level-3 convolution kernel
+    (hupr_k_conv_halo_bf16<64, 64>, B = 32) running on another stream — and in none alone.  The library's kernel (scalar FMAs,
+    -fno-slp-vectorize) must give the bits of the launch alone in every one of 600 launches beside that convolution."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    dev = torch.device("cuda")
+    x = torch.randn(32, 4, 32, 32, 128, device=dev).relu().bfloat16()
+    B, G, H, W, C = x.shape
+
+    def interp():
+        y = torch.empty((B, 2, 16, 16, C), dtype=x.dtype, device=dev)
+        rt.check(L.hupr_interp_linear_fwd_bf16act(rt.ptr(x), rt.ptr(y), B, G, H, W, 2, 16, 16, C, C, C, rt.stream()))
+        return y
+    ref = interp()
+    torch.cuda.synchronize()
+    x3 = torch.randn(32, 2, 16, 16, 256, device=dev).bfloat16()
+    w3 = (torch.randn(256, 256, 3, 3, 3, device=dev) * 0.02).requires_grad_(True)
+    side = F_.side_stream(dev)
+    bad = 0
+    for _ in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(100):
+                F_.conv(x3, w3, None, None, (1, 1, 1))
+        outs = [interp() for _ in range(200)]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(o, ref)) for o in outs)
+    assert bad == 0, "%d of 600 launches differ from the launch alone" % bad
+
+
 def test_mnet_front_end():
     from hupr_amd import functional as F_
     B, G = 2, 3
