@@ -82,6 +82,9 @@ AGG = [
     ("temporal merge (LDS-DMA stream kernel)", rep(lambda: F_.TemporalMergeFn.apply(xa, wm), 60)),
     ("the whole RE encoder", rep(lambda: net.REradarEncoder(net.REchirpNet(v)), 1)),
 ]
+if os.environ.get("ABLATE"):      # narrow the aggressor down: bit0 = no halo fill, bit2 = no epilogue stores (hupr_debug_halo_ablate)
+    L.hupr_debug_halo_ablate(int(os.environ["ABLATE"]))
+    AGG = [a for a in AGG if "level 3: conv" in a[0]]
 for name, agg in AGG:
     bad = tot = 0
     first = ""
