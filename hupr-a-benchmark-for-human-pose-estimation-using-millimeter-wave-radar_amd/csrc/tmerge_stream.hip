@@ -208,18 +208,26 @@ __device__ __forceinline__ bf16x8 tm_tr_pair(const char* base, int off0, int off
     return u.v;
 }
 
+// Wider maps (C = 128 / 256: the level-2 / level-3 merges) run through the SAME kernel: a frame of C channels is SUB = C / 64 "virtual
+// frames" of 64 channels (rows of 128 bytes at a pitch of 2 C bytes — the DMA does not care), G here = real frames x SUB (8 at all
+// three levels), and the Co / 64 output-channel blocks are spread over the workgroups (workgroup w: block w % NB, tile slot w / NB), each
+// of which reads its 64-channel column block of dy (rows of 256 bytes at a pitch of 4 Co) and ALL of x — x is read NB times, which
+// still beats the generic engine 2-3x at these sizes.  Partials are [workgroup][co 64][ci 64][virtual frame]; the reduce kernel
+// scatters them to the parameter layout (Co, Ci, frames).
 template <int G>
 __global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_stream(const __bf16* __restrict__ x, const float* __restrict__ dy,
-                                                                  float* __restrict__ part, int Bn, int HW) {
+                                                                  float* __restrict__ part, int Bn, int HW, int SUB, int NB) {
     constexpr int C = 64, S = G + 2, SLOT = 128 * C * 2;          // stages per tile; bytes per ring slot
     __shared__ __attribute__((aligned(16))) char Ring[kTmStages][SLOT];
     __shared__ __attribute__((aligned(16))) char Db[128 * C * 2];                // bf16 dy tile [voxel][co], 16-byte chunks swizzled
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5;
 
     const int tiles_per_b = HW / 128, n_tiles = Bn * tiles_per_b;
-    const int my_tiles = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int cob = (int)blockIdx.x % NB, slot_id = (int)blockIdx.x / NB, n_slots = (int)gridDim.x / NB;
+    const int my_tiles = (slot_id < n_tiles) ? (n_tiles - 1 - slot_id) / n_slots + 1 : 0;
     const int n_stage = my_tiles * S;
     const int ct = wave >> 1, it = wave & 1;
+    const int Gr = G / SUB, xpitch = SUB * C * 2, dpitch = NB * C * 4;           // real frames; bytes per voxel row of x / of dy
 
     f32x16 acc[G];
 #pragma unroll
@@ -229,14 +237,15 @@ __global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_stream(const __bf16* 
 
     if (n_stage > 0) {
         const u32x4 xrs = {(unsigned)(unsigned long)x, (unsigned)((unsigned long)x >> 32) & 0xffffu,
-                           (unsigned)((long)Bn * G * HW * C * 2), 0x00020000u};
+                           (unsigned)((long)Bn * Gr * HW * xpitch), 0x00020000u};
         const u32x4 drs = {(unsigned)(unsigned long)dy, (unsigned)((unsigned long)dy >> 32) & 0xffffu,
-                           (unsigned)((long)Bn * HW * C * 4), 0x00020000u};
+                           (unsigned)((long)Bn * HW * dpitch), 0x00020000u};
         const unsigned ring_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&Ring[0][0];
-        // stage n = (tile n / S, s = n % S): s < 2 -> half s of the fp32 dy tile (64 voxels = 16 KB, copied linearly), else frame s - 2 of
-        // the x tile (128 voxels = 16 KB, 16-byte chunks swizzled by the row on the source side as in the forward kernel)
+        // stage n = (tile n / S, s = n % S): s < 2 -> half s of the fp32 dy tile (64 voxels x 64 co = 16 KB, four 256-byte rows per 1 KB
+        // piece), else virtual frame s - 2 of the x tile (128 voxels = 16 KB, 16-byte chunks swizzled by the row on the source side as
+        // in the forward kernel)
         auto dma = [&](int n) {
-            const int t = (int)blockIdx.x + (n / S) * (int)gridDim.x, s = n % S;
+            const int t = slot_id + (n / S) * n_slots, s = n % S;
             const int b = t / tiles_per_b, v0 = (t % tiles_per_b) * 128;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -244,15 +253,15 @@ __global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_stream(const __bf16* 
                 const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (n % kTmStages) * SLOT + piece * 1024);
                 unsigned keep_;
                 if (s < 2) {
-                    const unsigned voff = (unsigned)(((long)b * HW + v0 + 64 * s) * C * 4) + piece * 1024 + lane * 16;
+                    const unsigned voff = (unsigned)(((long)b * HW + v0 + 64 * s + 4 * piece + (lane >> 4)) * dpitch) + cob * 256 + (lane & 15) * 16;
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
                                  "s_mov_b32 m0, %0"
                                  : "=&s"(keep_)
                                  : "s"(dst), "v"(voff), "s"(drs)
                                  : "memory");
                 } else {
-                    const int row = piece * 8 + (lane >> 3);
-                    const unsigned voff = (unsigned)((((long)b * G + (s - 2)) * HW + v0) * C * 2) + row * (C * 2) +
+                    const int row = piece * 8 + (lane >> 3), f = s - 2;
+                    const unsigned voff = (unsigned)((((long)b * Gr + f / SUB) * HW + v0 + row) * xpitch) + (f % SUB) * 128 +
                                           ((((lane & 7) ^ ((row >> 1) & 7)) & 7) << 4);
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
                                  "s_mov_b32 m0, %0"
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_stream(const __bf16* 
         }
 #undef HUPR_VMCNT
     }
-    // partial [workgroup][co][ci][g]: a lane holds, for its column ci and 16 rows co, the G frame values = 4 G contiguous bytes
+    // partial [workgroup][co][ci][virtual frame]: a lane holds, for its column ci and 16 rows co, the G frame values = 4 G contiguous bytes
     float* dst = part + (long)blockIdx.x * (C * C * G);
     const int ci = 32 * it + (lane & 31);
 #pragma unroll
@@ -329,21 +338,28 @@ __global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_stream(const __bf16* 
     }
 }
 
-// dw[e] (+)= sum over workgroups of part[w][e] in a fixed order: 16 slices of the partial list per block, 16 float4 columns each
-__global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int n_part,
-                                                                  int n4) {
-    __shared__ f32x4n sm[16][16];
-    const int sl = threadIdx.x >> 4, c = threadIdx.x & 15, col = blockIdx.x * 16 + c;
-    f32x4n s = {0.f, 0.f, 0.f, 0.f};
-    if (col < n4)
-        for (int w = sl; w < n_part; w += 16) s += reinterpret_cast<const f32x4n*>(part)[(long)w * n4 + col];
+// dw (Co, Ci, Gr) = sum over the workgroups of an output-channel block of their partials [co 64][ci 64][F], in a fixed order; element
+// (co, ci, g) lives in block co / 64 at [co % 64][ci % 64][g * SUB + ci / 64].  16 slices of the workgroup list per thread block.
+__global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int n_slots,
+                                                                  int NB, int SUB, int F, int n_out) {
+    __shared__ float sm[16][16];
+    const int sl = threadIdx.x >> 4, c = threadIdx.x & 15, e = blockIdx.x * 16 + c;
+    float s = 0.f;
+    if (e < n_out) {
+        const int Gr = F / SUB, Ci = SUB * 64;
+        const int g = e % Gr, ci = (e / Gr) % Ci, co = e / (Gr * Ci);
+        const long src = ((long)(co & 63) * 64 + (ci & 63)) * F + g * SUB + (ci >> 6);
+        const long stride = (long)NB * 64 * 64 * F;               // workgroups of one block are NB apart
+        const float* p = part + (long)(co >> 6) * 64 * 64 * F + src;
+        for (int w = sl; w < n_slots; w += 16) s += p[w * stride];
+    }
     sm[sl][c] = s;
     __syncthreads();
-    if (sl == 0 && col < n4) {
-        f32x4n t = sm[0][c];
+    if (sl == 0 && e < n_out) {
+        float t = sm[0][c];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t += sm[k][c];
-        reinterpret_cast<f32x4n*>(dw)[col] = t;
+        dw[e] = t;
     }
 }
 
@@ -393,29 +409,46 @@ extern "C" int hupr_tmerge_dgrad_stream_bf16(const float* dy, const void* wp1_bf
     return HUPR_OK;
 }
 
-// Workspace of the streaming weight gradient: one fp32 partial (Co, Ci, G) per persistent workgroup.
-extern "C" size_t hupr_tmerge_wgrad_stream_ws_bytes(int Bn, int G, int HW, int Ci, int Co) {
-    if (!hupr_tmerge_stream_supported(G, HW, Ci, Co) || Bn <= 0) return 0;
-    return (size_t)min(Bn * (HW / 128), 256) * Co * Ci * G * sizeof(float);
+// The streaming weight gradient also takes the wider merges: C = 64, 128 or 256 channels (Ci == Co) with G * C / 64 in {2, 4, 8}.
+extern "C" int hupr_tmerge_wgrad_stream_supported(int G, int HW, int Ci, int Co) {
+    if (Ci != Co || Ci % 64 != 0 || Ci > 256 || HW % 128 != 0 || G < 1) return 0;
+    const int F = G * (Ci / 64);
+    return (F == 8 || F == 4 || F == 2) ? 1 : 0;
 }
 
-// x bf16 (Bn, G, HW, 64), dy fp32 (Bn, HW, 64) -> dw fp32 in the parameter layout (Co, Ci, G) (overwritten).  Deterministic.
+static void tm_wgrad_grid(int Bn, int HW, int Co, int* nb, int* n_slots) {
+    *nb = Co / 64;
+    *n_slots = min(Bn * (HW / 128), 256 / *nb);
+}
+
+// Workspace of the streaming weight gradient: one fp32 partial [64][64][G * Ci / 64] per persistent workgroup.
+extern "C" size_t hupr_tmerge_wgrad_stream_ws_bytes(int Bn, int G, int HW, int Ci, int Co) {
+    if (!hupr_tmerge_wgrad_stream_supported(G, HW, Ci, Co) || Bn <= 0) return 0;
+    int nb, n_slots;
+    tm_wgrad_grid(Bn, HW, Co, &nb, &n_slots);
+    return (size_t)nb * n_slots * 64 * 64 * (G * (Ci / 64)) * sizeof(float);
+}
+
+// x bf16 (Bn, G, HW, C), dy fp32 (Bn, HW, C) -> dw fp32 in the parameter layout (Co, Ci, G) (overwritten).  Deterministic.
 extern "C" int hupr_tmerge_wgrad_stream_bf16(const void* x, const float* dy, float* dw, int Bn, int G, int HW, int Ci, int Co,
                                              void* ws, size_t ws_bytes, hupr_stream_t stream) {
     HUPR_REQUIRE(x && dy && dw && ws && Bn > 0, "hupr_tmerge_wgrad_stream_bf16: bad argument");
-    HUPR_REQUIRE(hupr_tmerge_stream_supported(G, HW, Ci, Co), "hupr_tmerge_wgrad_stream_bf16: unsupported geometry (G=%d HW=%d Ci=%d Co=%d)", G, HW, Ci, Co);
+    HUPR_REQUIRE(hupr_tmerge_wgrad_stream_supported(G, HW, Ci, Co), "hupr_tmerge_wgrad_stream_bf16: unsupported geometry (G=%d HW=%d Ci=%d Co=%d)", G, HW, Ci, Co);
     HUPR_REQUIRE(ws_bytes >= hupr_tmerge_wgrad_stream_ws_bytes(Bn, G, HW, Ci, Co), "hupr_tmerge_wgrad_stream_bf16: workspace too small");
     HUPR_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dw & 15) == 0 && ((uintptr_t)ws & 15) == 0, "hupr_tmerge_wgrad_stream_bf16: misaligned pointer");
-    HUPR_REQUIRE((long)Bn * G * HW * Ci * 2 < 0x7fffffffL, "hupr_tmerge_wgrad_stream_bf16: tensor too large for 32-bit buffer offsets");
-    const int tiles = Bn * (HW / 128), n_part = min(tiles, 256), n4 = Co * Ci * G / 4;
+    HUPR_REQUIRE((long)Bn * G * HW * Ci * 2 < 0x7fffffffL && (long)Bn * HW * Co * 4 < 0x7fffffffL, "hupr_tmerge_wgrad_stream_bf16: tensor too large for 32-bit buffer offsets");
+    int nb, n_slots;
+    tm_wgrad_grid(Bn, HW, Co, &nb, &n_slots);
+    const int SUB = Ci / 64, F = G * SUB, n_out = Co * Ci * G;
     const __bf16* xb = static_cast<const __bf16*>(x);
     float* part = static_cast<float*>(ws);
     hipStream_t s = as_stream(stream);
-    if (G == 8) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<8>, dim3(n_part), dim3(256), 0, s, xb, dy, part, Bn, HW);
-    else if (G == 4) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<4>, dim3(n_part), dim3(256), 0, s, xb, dy, part, Bn, HW);
-    else hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<2>, dim3(n_part), dim3(256), 0, s, xb, dy, part, Bn, HW);
+    const dim3 grid((unsigned)(nb * n_slots));
+    if (F == 8) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<8>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
+    else if (F == 4) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<4>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
+    else hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<2>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
     HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_stream");
-    hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce, dim3((n4 + 15) / 16), dim3(256), 0, s, part, dw, n_part, n4);
+    hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, part, dw, n_slots, nb, SUB, F, n_out);
     HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_reduce");
     return HUPR_OK;
 }

@@ -605,6 +605,7 @@ def conv(x, weight, bias=None, res=None, pad=(0, 0, 0), stats=False):
 
 
 TMERGE_STREAM = os.environ.get("HUPR_NO_TMERGE_STREAM", "0") != "1"      # A/B aid
+TMERGE_WIDE = os.environ.get("HUPR_NO_TMERGE_WIDE", "0") != "1"          # A/B aid: the streaming weight gradient for C = 128 / 256 too
 
 
 def _tmerge_fwd(x, weight, y):
@@ -638,7 +639,7 @@ def _tmerge_wgrad(x, dy, weight):
     Co = weight.shape[0]
     L = rt.lib()
     dw, direct = _pgrad(weight)
-    if TMERGE_STREAM and x.dtype == torch.bfloat16 and L.hupr_tmerge_stream_supported(G, H * W, Ci, Co):
+    if TMERGE_STREAM and x.dtype == torch.bfloat16 and (Ci == 64 or TMERGE_WIDE) and L.hupr_tmerge_wgrad_stream_supported(G, H * W, Ci, Co):
         ws = workspace(L.hupr_tmerge_wgrad_stream_ws_bytes(B, G, H * W, Ci, Co), x.device)
         rt.check(L.hupr_tmerge_wgrad_stream_bf16(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, G, H * W, Ci, Co, rt.ptr(ws), ws.numel(),
                                                  rt.stream()))

@@ -125,6 +125,7 @@ SIGNATURES = {
     "hupr_tmerge_stream_supported": (c_int, [c_int] * 4),
     "hupr_tmerge_fwd_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "hupr_tmerge_dgrad_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "hupr_tmerge_wgrad_stream_supported": (c_int, [c_int] * 4),
     "hupr_tmerge_wgrad_stream_ws_bytes": (c_size_t, [c_int] * 5),
     "hupr_tmerge_wgrad_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "hupr_conv3x3_wgrad_halo_bf16act": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),

@@ -150,6 +150,8 @@ int hupr_tmerge_fwd_stream_bf16(const void* x, const void* wp_bf16, float* y, in
  * fp32 partial in `ws` (hupr_tmerge_wgrad_stream_ws_bytes) and a second kernel sums them in a fixed order. */
 int hupr_tmerge_dgrad_stream_bf16(const float* dy, const void* wp1_bf16, void* dx, int Bn, int G, int HW, int Ci, int Co,
                                   hupr_stream_t stream);
+int hupr_tmerge_wgrad_stream_supported(int G, int HW, int Ci, int Co);  /* the weight gradient also takes C = 128 / 256 (Ci == Co, G * C / 64 in {2,4,8}):
+                                                                        a frame is C / 64 virtual 64-channel frames, the Co / 64 output blocks go to different workgroups */
 size_t hupr_tmerge_wgrad_stream_ws_bytes(int Bn, int G, int HW, int Ci, int Co);
 int hupr_tmerge_wgrad_stream_bf16(const void* x, const float* dy, float* dw, int Bn, int G, int HW, int Ci, int Co, void* ws,
                                   size_t ws_bytes, hupr_stream_t stream);

@@ -200,6 +200,35 @@ def test_interp_align_corners(shape, size):
     close(ncdhw(xg.grad), xr.grad, 1e-5, "interp bwd")
 
 
+@pytest.mark.parametrize("B,G,H,C", [(32, 4, 32, 128), (32, 2, 16, 256), (3, 4, 16, 128), (1, 2, 16, 256), (2, 1, 16, 128)])
+def test_streaming_merge_weight_gradient_on_wider_maps(B, G, H, C, bf16_math):
+    """hupr_tmerge_wgrad_stream_bf16 on the level-2 / level-3 merges (C = 128 / 256: virtual 64-channel frames, output-channel blocks
+    spread over the workgroups, partials scattered to (Co, Ci, G) by the reduce kernel) against fp64 on the bf16-rounded operands and
+    against the generic kernel; run twice for determinism."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    if not L.hupr_tmerge_wgrad_stream_supported(G, H * H, C, C):
+        pytest.skip("geometry not covered by the streaming kernel")
+    x = rnd(B, G, H, H, C, seed=510).cuda().bfloat16().requires_grad_(True)
+    w = rnd(C, C, G, 1, 1, seed=511, scale=(C * G) ** -0.5).cuda().requires_grad_(True)
+    dy = rnd(B, 1, H, H, C, seed=512).cuda()
+
+    def dw():
+        w.grad = None
+        F_.TemporalMergeFn.apply(x, w).backward(dy)
+        return w.grad.detach().clone()
+    d1, d2 = dw(), dw()
+    F_.TMERGE_STREAM = False
+    try:
+        d0 = dw()
+    finally:
+        F_.TMERGE_STREAM = True
+    ref = torch.einsum("bhwo,bghwc->ocg", dy.to(torch.bfloat16).double().cpu().reshape(B, H, H, C), x.detach().double().cpu()).reshape(C, C, G, 1, 1)
+    close(d1, ref, 5e-5, "streaming wgrad vs fp64 (bf16-rounded operands)")
+    close(d1, d0, 5e-5, "streaming vs generic wgrad")
+    assert torch.equal(d1, d2)
+
+
 def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(bf16_math):
     """Round 3 regression (scripts/interp_race.py): the build of hupr_k_interp_fwd that hipcc's SLP vectoriser
     produced returned wrong sums in >90 % of the launches that shared the chip with the level-3 convolution kernel
