@@ -338,6 +338,25 @@ __global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_stream(const __bf16* 
     }
 }
 
+// 64-channel maps: the partial layout IS the parameter layout — 16 slices of the partial list per block, 16 float4 columns each
+// (same summation order as the general kernel below: slice sl adds partials sl, sl + 16, ..., then the slices are added in order)
+__global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_reduce4(const float* __restrict__ part, float* __restrict__ dw, int n_part,
+                                                                   int n4) {
+    __shared__ f32x4n sm[16][16];
+    const int sl = threadIdx.x >> 4, c = threadIdx.x & 15, col = blockIdx.x * 16 + c;
+    f32x4n s = {0.f, 0.f, 0.f, 0.f};
+    if (col < n4)
+        for (int w = sl; w < n_part; w += 16) s += reinterpret_cast<const f32x4n*>(part)[(long)w * n4 + col];
+    sm[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && col < n4) {
+        f32x4n t = sm[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += sm[k][c];
+        reinterpret_cast<f32x4n*>(dw)[col] = t;
+    }
+}
+
 // dw (Co, Ci, Gr) = sum over the workgroups of an output-channel block of their partials [co 64][ci 64][F], in a fixed order; element
 // (co, ci, g) lives in block co / 64 at [co % 64][ci % 64][g * SUB + ci / 64].  16 slices of the workgroup list per thread block.
 __global__ __launch_bounds__(256) void hupr_k_tmerge_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int n_slots,
@@ -448,7 +467,10 @@ extern "C" int hupr_tmerge_wgrad_stream_bf16(const void* x, const float* dy, flo
     else if (F == 4) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<4>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
     else hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<2>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
     HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_stream");
-    hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, part, dw, n_slots, nb, SUB, F, n_out);
+    if (SUB == 1 && nb == 1 && n_out % 4 == 0)
+        hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce4, dim3((n_out / 4 + 15) / 16), dim3(256), 0, s, part, dw, n_slots, n_out / 4);
+    else
+        hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, part, dw, n_slots, nb, SUB, F, n_out);
     HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_reduce");
     return HUPR_OK;
 }
