@@ -312,6 +312,9 @@ __global__ __launch_bounds__(256) void hupr_k_interp_fwd(const T* __restrict__ s
                     const float wgt = wd * wh * (cq ? lw.w1 : lw.w0);
                     const long ivox = (((long)b * Di + id) * Hi + ih) * Wi + iw;
                     const float4 xv = ld_act4(src + ivox * in_ld + c4 * 4);
+#ifdef HUPR_PROBE_WHOLE_SIMD                              // probe builds only: claim all 512 registers -> no other wave shares this wave's SIMD
+                    asm volatile("" ::: "v255", "a255");
+#endif
                     if constexpr (PK) {                     // probe only (hupr_debug_interp_packed, scripts/interp_race.py builds this file
                         acc.x = fmaf(wgt, xv.x, acc.x); acc.y = fmaf(wgt, xv.y, acc.y);     // WITHOUT -fno-slp-vectorize): the form hipcc's SLP
                         acc.z = fmaf(wgt, xv.z, acc.z); acc.w = fmaf(wgt, xv.w, acc.w);     // vectoriser turns into op_sel'ed v_pk_mul / v_pk_fma

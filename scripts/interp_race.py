@@ -18,8 +18,10 @@ from hupr_amd.models import HuPRNet
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "hupr-a-benchmark-for-human-pose-estimation-using-millimeter-wave-radar_amd", "csrc")
 so = "/tmp/libhupr_interp_slp.so"
+# WHOLE_SIMD=1: the victim claims all 512 registers of a lane, so that no other wave can be resident on the SIMD it runs on
+extra = ["-DHUPR_PROBE_WHOLE_SIMD"] if os.environ.get("WHOLE_SIMD", "0") == "1" else []
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(root, "include"),
-                       "-I" + csrc, os.path.join(csrc, "spatial.hip"), os.path.join(csrc, "core.hip"), "-o", so])
+                       "-I" + csrc, os.path.join(csrc, "spatial.hip"), os.path.join(csrc, "core.hip"), "-o", so] + extra)
 V = ctypes.CDLL(so)
 V.hupr_interp_linear_fwd_bf16act.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] * 10 + [ctypes.c_void_p]
 V.hupr_debug_interp_packed.argtypes = [ctypes.c_int]
@@ -82,6 +84,32 @@ AGG = [
     ("temporal merge (LDS-DMA stream kernel)", rep(lambda: F_.TemporalMergeFn.apply(xa, wm), 60)),
     ("the whole RE encoder", rep(lambda: net.REradarEncoder(net.REchirpNet(v)), 1)),
 ]
+if os.environ.get("SPIN", "0") == "1":
+    # aggressors that only occupy registers: spin_<N> claims N VGPRs per lane and loops on four v_add_f32 (scripts/probes/vgpr_spin.hip)
+    spin_so = "/tmp/libvgpr_spin.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(root, "scripts", "probes", "vgpr_spin.hip"), "-o", spin_so])
+    SP = ctypes.CDLL(spin_so)
+    SP.spin_launch.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+    sink = torch.zeros(4, device=dev)
+    blocks = int(os.environ.get("SPIN_BLOCKS", "2048"))
+
+    def spin(nv):
+        def f():
+            assert SP.spin_launch(nv, 20000, blocks, rt.ptr(sink), rt.stream()) == 0
+        return f
+    AGG = [("nothing", None)] + [("a spin kernel holding %3d VGPRs" % nv, spin(nv)) for nv in (56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 160, 192, 224)]
+    SP.spin_class_launch.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_void_p]
+    srcbuf = torch.arange(64 << 20, device=dev, dtype=torch.int32)
+
+    def cls(which, iters):
+        def f():
+            assert SP.spin_class_launch(which, iters, blocks, rt.ptr(sink), rt.ptr(srcbuf), srcbuf.numel(), rt.stream()) == 0
+        return f
+    AGG += [("112 VGPRs, loop of v_mfma_f32_32x32x16_bf16", cls(0, 4000)), ("112 VGPRs + 47 KB LDS, loop of ds_read_b128", cls(1, 20000)),
+            ("112 VGPRs + 47 KB LDS, loop of ds_write_b128", cls(2, 20000)), ("112 VGPRs, loop of s_barrier", cls(3, 20000)),
+            ("112 VGPRs, loop of global_load_dwordx4", cls(4, 2000)), ("112 VGPRs, loop of v_cvt_pk_bf16_f32 + v_permlane32_swap", cls(5, 20000))]
+    if os.environ.get("SPIN_ONLY_CLASSES", "0") == "1":
+        AGG = AGG[-6:]
 if os.environ.get("ABLATE"):      # narrow the aggressor down: bit0 = no halo fill, bit2 = no epilogue stores (hupr_debug_halo_ablate)
     L.hupr_debug_halo_ablate(int(os.environ["ABLATE"]))
     AGG = [a for a in AGG if "level 3: conv" in a[0]]
