@@ -162,7 +162,7 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
         if F_.mscsa_level_fused_ok(ra):         # bf16 math: projections + attentions of the level as one autograd node
             w = [m[i].weight for m in (self.phi_cross_hori, self.theta_cross_hori, self.phi_self_hori, self.theta_self_hori,
                                        self.phi_cross_vert, self.theta_cross_vert, self.phi_self_vert, self.theta_self_vert)]
-            return list(F_.MSCSALevelFn.apply(ra, re, cat_bf16, *w))
+            return list(F_.MSCSALevelFn.apply(ra, re, int(bool(cat_bf16)) | (0 if torch.is_grad_enabled() else 2), *w))
         k_c_h, q_c_v = _conv(ra, self.phi_cross_hori[i]), _conv(re, self.theta_cross_vert[i])
         k_c_v, q_c_h = _conv(re, self.phi_cross_vert[i]), _conv(ra, self.theta_cross_hori[i])
         k_h, q_h = _conv(ra, self.phi_self_hori[i]), _conv(ra, self.theta_self_hori[i])
