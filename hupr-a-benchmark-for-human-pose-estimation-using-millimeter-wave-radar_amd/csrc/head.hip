@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void hupr_k_softmax_rows_bwd(const float* __re
 // the RUN-TIME K — private arrays in scratch memory: 14.6 us for 64 KB of data, three times per single-sample forward.)
 __global__ __launch_bounds__(256) void hupr_k_gcn_adj_fwd(const float* __restrict__ t, const float* __restrict__ adj,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          long rows, int F, int K, int ld, int relu) {
+                                                          long rows, int F, int K, int ld, int relu, int slices) {
+    // slices > 1 (single-sample inference): t is [slices][rows][ld], the K slices of the product W x — summed here, in slice order
     __shared__ float sa[16 * 16];
     for (int i = threadIdx.x; i < 256; i += 256) sa[i] = (i / 16 < K && i % 16 < K) ? adj[(i / 16) * K + (i % 16)] : 0.f;
     __syncthreads();
@@ -82,14 +83,22 @@ __global__ __launch_bounds__(256) void hupr_k_gcn_adj_fwd(const float* __restric
             const float4* row = reinterpret_cast<const float4*>(t + r * 16);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = row[q];
+                float4 v = row[q];
+                for (int sl = 1; sl < slices; ++sl) {
+                    const float4 u = row[(long)sl * rows * 4 + q];
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
                 s = fmaf(v.x, sa[(4 * q) * 16 + kp], s);
                 s = fmaf(v.y, sa[(4 * q + 1) * 16 + kp], s);
                 s = fmaf(v.z, sa[(4 * q + 2) * 16 + kp], s);
                 s = fmaf(v.w, sa[(4 * q + 3) * 16 + kp], s);
             }
         } else {
-            for (int k = 0; k < K; ++k) s = fmaf(t[r * ld + k], sa[k * 16 + kp], s);
+            for (int k = 0; k < K; ++k) {
+                float v = t[r * ld + k];
+                for (int sl = 1; sl < slices; ++sl) v += t[((long)sl * rows + r) * ld + k];
+                s = fmaf(v, sa[k * 16 + kp], s);
+            }
         }
         if (kp < ld) y[r * ld + kp] = kp < K ? (relu ? fmaxf(s, 0.f) : s) : 0.f;
     }
@@ -411,7 +420,17 @@ extern "C" int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const floa
                                     int ld, int relu, hupr_stream_t stream) {
     HUPR_REQUIRE(t && adj && bias && y && Bn > 0 && F > 0 && K > 0 && K <= 16 && ld >= K && ld <= 16, "hupr_gcn_adj_fwd_f32: bad argument");
     const long rows = (long)Bn * F;
-    hipLaunchKernelGGL(hupr_k_gcn_adj_fwd, dim3((unsigned)min((long)4096, (rows + 15) / 16)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu);
+    hipLaunchKernelGGL(hupr_k_gcn_adj_fwd, dim3((unsigned)min((long)4096, (rows + 15) / 16)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu, 1);
+    HUPR_LAUNCH_OK("hupr_k_gcn_adj_fwd");
+    return HUPR_OK;
+}
+// the same with t given as `slices` partial products [slices][Bn * F][ld] (K slices of W x: single-sample inference), summed in slice order
+extern "C" int hupr_gcn_adj_fwd_sliced_f32(const float* t, int slices, const float* adj, const float* bias, float* y, int Bn, int F,
+                                           int K, int ld, int relu, hupr_stream_t stream) {
+    HUPR_REQUIRE(t && adj && bias && y && Bn > 0 && F > 0 && K > 0 && K <= 16 && ld >= K && ld <= 16 && slices >= 1 && slices <= 64,
+                 "hupr_gcn_adj_fwd_sliced_f32: bad argument");
+    const long rows = (long)Bn * F;
+    hipLaunchKernelGGL(hupr_k_gcn_adj_fwd, dim3((unsigned)min((long)4096, (rows + 15) / 16)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu, slices);
     HUPR_LAUNCH_OK("hupr_k_gcn_adj_fwd");
     return HUPR_OK;
 }

@@ -1180,6 +1180,21 @@ def _cat_weights(ws, C, cache):
     return t
 
 
+def head_weight16(weight, num_keypoints):
+    """The 1x1 head's filters zero-padded to 16 output channels (later kernels stay float4-aligned).  Under no_grad the padded copy is
+    kept across calls like the concatenated projection weights (one pad launch less per inference forward)."""
+    pad = lambda: torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, 16 - num_keypoints))      # noqa: E731
+    if torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        return pad()
+    key = (PACK_EPOCH, "head16", weight.data_ptr(), weight._version)
+    t = _wc_cache.get(key)
+    if t is None:
+        if len(_wc_cache) >= 64:
+            _wc_cache.clear()
+        t = _wc_cache[key] = pad()
+    return t
+
+
 @_math_scoped
 class MSCSALevelFn(torch.autograd.Function):
     """One level of the multi-scale cross/self attention (models/layers.py:150-163 of the reference): eight 1x1
@@ -1359,14 +1374,19 @@ class GCNLayerFn(torch.autograd.Function):
         L = rt.lib()
         if B == 1 and F % 1024 == 0:
             # single-sample inference: F / 128 = 8 workgroups would each walk K = F alone (37 us of latency for 34 MFLOP);
-            # eight K slices side by side as a batched GEMM, summed afterwards
+            # eight K slices side by side as a batched GEMM; the adjacency kernel sums them
             S = 8
-            t = gemm(0, 0, weight, x, F, ld, F // S, F, ld, S, F // S, (F // S) * ld, math=GCN_MATH).sum(0, keepdim=True)
+            t = gemm(0, 0, weight, x, F, ld, F // S, F, ld, S, F // S, (F // S) * ld, math=GCN_MATH)
         else:
+            S = 1
             t = gemm(0, 0, weight, x, F, ld, F, F, ld, B, 0, F * ld, math=GCN_MATH)
         y = torch.empty_like(x)
-        rt.check(L.hupr_gcn_adj_fwd_f32(rt.ptr(t), rt.ptr(adj), rt.ptr(_c(bias)), rt.ptr(y), B, F, K, ld, 1 if relu else 0,
-                                        rt.stream()))
+        if S > 1:
+            rt.check(L.hupr_gcn_adj_fwd_sliced_f32(rt.ptr(t), S, rt.ptr(adj), rt.ptr(_c(bias)), rt.ptr(y), B, F, K, ld, 1 if relu else 0,
+                                                   rt.stream()))
+        else:
+            rt.check(L.hupr_gcn_adj_fwd_f32(rt.ptr(t), rt.ptr(adj), rt.ptr(_c(bias)), rt.ptr(y), B, F, K, ld, 1 if relu else 0,
+                                            rt.stream()))
         ctx.save_for_backward(x, weight, y, adj)
         ctx.relu, ctx.K = relu, K
         return y

@@ -194,7 +194,7 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
         # 1x1 head with the 14 output channels zero-padded to 16 so later kernels stay float4-aligned
         with F_.region("head"):
             head = self.decoderLayer1[2]
-            w16 = torch.nn.functional.pad(head.weight, (0, 0, 0, 0, 0, 0, 0, 16 - self.numKeypoints))
+            w16 = F_.head_weight16(head.weight, self.numKeypoints)
             maps16 = F_.head_conv(x, w16)
         return maps16, self.gcn(maps16)
 

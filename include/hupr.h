@@ -335,6 +335,9 @@ int hupr_head1x1_bwd_f32(const float* x, const float* w16, const float* dy, floa
                          void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,
                          int ld, int relu, hupr_stream_t stream);
+/* t as `slices` partial products [slices][Bn*F][ld] (the K slices of W x of a single-sample forward), summed here in slice order */
+int hupr_gcn_adj_fwd_sliced_f32(const float* t, int slices, const float* adj, const float* bias, float* y, int Bn, int F,
+                                int K, int ld, int relu, hupr_stream_t stream);
 int hupr_gcn_adj_bwd_f32(const float* dy, const float* y, const float* adj, float* dt, float* gmasked,
                          float* dbias, int Bn, int F, int K, int ld, int relu, hupr_stream_t stream);
 
