@@ -272,16 +272,44 @@ __device__ __forceinline__ void store_ct_add16(float* dst_row, const f32x16* acc
 // SPLIT (few workgroups: small batches, e.g. the B = 1 inference of BASELINE config C2): blockIdx.z walks only its share of the
 // keys and leaves the un-normalised O^T tile, the running maximum and the running sum in part_o / part_ml
 // ([split][B N][D] / [split][B N][2]); hupr_k_attn_combine merges the shares (flash-decoding).
+// Up to four independent attentions of equal shape in ONE split launch (the four of an MSCSA level in single-sample inference, where
+// launches, not work, set the time): n > 0 only with SPLIT; blockIdx.z = item * splits + split.
+struct AttnBatch {
+    int n, splits;
+    const void* K[4];
+    const void* Q[4];
+    const void* V[4];
+    const float* Vres[4];
+    float* out[4];
+    float* lse[4];
+    __bf16* out16[4];
+};
+
 template <int D, typename TI, bool SPLIT = false>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
                                                        float* __restrict__ out, float* __restrict__ lse, int N, int ldk,
                                                        int ldq, __bf16* __restrict__ out16, int ld16,
-                                                       float* __restrict__ part_o = nullptr, float* __restrict__ part_ml = nullptr) {
+                                                       float* __restrict__ part_o = nullptr, float* __restrict__ part_ml = nullptr,
+                                                       const AttnBatch batch = AttnBatch()) {
     // ldk / ldq: row strides (elements) of K and Q — the projections of one map may sit side by side in one tensor;
     // out16 (optional): a bf16 copy of the output with row stride ld16 (a column block of the decoder's input)
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
+    int zs = SPLIT ? (int)blockIdx.z : 0, nzs = SPLIT ? (int)gridDim.z : 1;      // this workgroup's key share and their number
+    if constexpr (SPLIT) {
+        if (batch.n > 0) {
+            const int item = (int)blockIdx.z / batch.splits;
+            nzs = batch.splits;
+            zs = (int)blockIdx.z - item * nzs;
+            K = static_cast<const TI*>(batch.K[item]);
+            Q = static_cast<const TI*>(batch.Q[item]);
+            V = static_cast<const TI*>(batch.V[item]);
+            const long rows = (long)gridDim.y * N;                               // partials: [item][split][B N]
+            part_o += (long)item * nzs * rows * D;
+            part_ml += (long)item * nzs * rows * 2;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const long base = (long)blockIdx.y * N * D;
     const int q = blockIdx.x * 128 + wave * 32 + lr;         // this lane's query
@@ -296,8 +324,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
     float m_run = -INFINITY, l_run = 0.f;
     constexpr bool PF = (D <= 128);                           // D = 256 has no registers to spare for the prefetch
     StageRegs<PF ? D : 64, 64, TI> kr, vr;
-    const int jb = SPLIT ? (int)blockIdx.z * (N / (int)gridDim.z) : 0;      // this workgroup's key range [jb, je)
-    const int je = SPLIT ? jb + N / (int)gridDim.z : N;
+    const int jb = SPLIT ? zs * (N / nzs) : 0;                              // this workgroup's key range [jb, je)
+    const int je = SPLIT ? jb + N / nzs : N;
     if (PF) {
         kr.load(K + (long)jb * ldk, ldk, tid);
         vr.load(V + base + (long)jb * D, D, tid);
@@ -348,7 +376,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (SPLIT) {
-        const long row = ((long)blockIdx.z * gridDim.y + blockIdx.y) * N + q;
+        const long row = ((long)zs * gridDim.y + blockIdx.y) * N + q;
         store_ct<D>(part_o + row * D, o, 1.f, nullptr, lh);
         if (lh == 0) {
             part_ml[2 * row] = m_run;
@@ -368,8 +396,18 @@ template <int D>
 __global__ __launch_bounds__(256) void hupr_k_attn_combine(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                           int S, long rows, const float* __restrict__ Vres,
                                                           float* __restrict__ out, float* __restrict__ lse,
-                                                          __bf16* __restrict__ out16, int ld16) {
+                                                          __bf16* __restrict__ out16, int ld16,
+                                                          const AttnBatch batch = AttnBatch()) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if (batch.n > 0) {                                        // blockIdx.y = item
+        const int item = blockIdx.y;
+        part_o += (long)item * S * rows * D;
+        part_ml += (long)item * S * rows * 2;
+        Vres = batch.Vres[item];
+        out = batch.out[item];
+        lse = batch.lse[item];
+        out16 = batch.out16[item];
+    }
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const long row = t / (D / 4);
     const int c = (int)(t % (D / 4)) * 4;
@@ -600,16 +638,16 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
         hipStream_t s = as_stream(stream);
 #define HUPR_ATTN_SPLIT(D_)                                                                                                \
         hipLaunchKernelGGL((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, \
-                           part_o, part_ml);                                                                               \
-        hipLaunchKernelGGL((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, Vres, out, lse, o16, ld16);
+                           part_o, part_ml, AttnBatch());                                                                  \
+        hipLaunchKernelGGL((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, Vres, out, lse, o16, ld16, AttnBatch());
         if (C == 64) { HUPR_ATTN_SPLIT(64) } else if (C == 128) { HUPR_ATTN_SPLIT(128) } else { HUPR_ATTN_SPLIT(256) }
 #undef HUPR_ATTN_SPLIT
         HUPR_LAUNCH_OK("hupr_k_attn_fwd (split)");
         return HUPR_OK;
     }
-    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np);
-    else if (C == 128) hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np);
-    else hipLaunchKernelGGL((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np);
+    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    else if (C == 128) hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    else hipLaunchKernelGGL((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
@@ -634,6 +672,48 @@ extern "C" int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, in
     return attn_fwd("hupr_attn_fwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
                     static_cast<const __bf16*>(V), Vres, out, lse, out16, ld16, Bn, N, C, stream);
 }
+// Up to four independent attentions of the same shape and strides in ONE split launch + ONE merge launch (the four attentions of an MSCSA
+// level in single-sample inference: 8 launches -> 2).  Only where the split form applies (hupr_attn_fwd_split_ws_bytes(Bn, N, C) > 0);
+// ws: n_items times that many bytes.  items: host array of hupr_attn_item (bf16 K / Q / V, fp32 Vres or null, fp32 out, lse, bf16 out16 or null).
+extern "C" int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N,
+                                                int C, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    const char* who = "hupr_attn_fwd_bf16in_ld_ws_batch";
+    HUPR_REQUIRE(items && n_items >= 1 && n_items <= 4 && Bn > 0 && ws, "%s: bad argument", who);
+    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
+    HUPR_REQUIRE(ldk >= C && ldq >= C && ldk % 8 == 0 && ldq % 8 == 0, "%s: bad row strides %d %d", who, ldk, ldq);
+    const int S = attn_splits(Bn, N);
+    HUPR_REQUIRE(S > 1, "%s: the split form does not apply to Bn=%d N=%d (use hupr_attn_fwd_bf16in_ld_ws per attention)", who, Bn, N);
+    HUPR_REQUIRE(ws_bytes >= (size_t)n_items * hupr_attn_fwd_split_ws_bytes(Bn, N, C), "%s: workspace too small", who);
+    AttnBatch b = AttnBatch();
+    b.n = n_items;
+    b.splits = S;
+    bool any16 = false;
+    for (int i = 0; i < n_items; ++i) {
+        HUPR_REQUIRE(items[i].K && items[i].Q && items[i].V && items[i].out && items[i].lse, "%s: null pointer in item %d", who, i);
+        b.K[i] = items[i].K; b.Q[i] = items[i].Q; b.V[i] = items[i].V; b.Vres[i] = items[i].Vres;
+        b.out[i] = items[i].out; b.lse[i] = items[i].lse; b.out16[i] = static_cast<__bf16*>(items[i].out16);
+        any16 = any16 || items[i].out16;
+    }
+    HUPR_REQUIRE(!any16 || (ld16 >= C && ld16 % 4 == 0), "%s: bad bf16 output stride %d", who, ld16);
+    const long rows = (long)Bn * N;
+    float* part_o = static_cast<float*>(ws);
+    float* part_ml = part_o + (long)n_items * S * rows * C;
+    const dim3 grid(N / 128, Bn, S * n_items);
+    const dim3 cgrid((unsigned)((rows * (C / 4) + 255) / 256), n_items);
+    hipStream_t s = as_stream(stream);
+    typedef __bf16 TI;
+    const TI* const nk = nullptr;
+    float* const nf = nullptr;
+    __bf16* const nh = nullptr;
+#define HUPR_ATTN_BATCH(D_)                                                                                                          \
+    hipLaunchKernelGGL((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, nk, nk, nk, nf, nf, nf, N, ldk, ldq, nh, ld16, part_o, part_ml, b); \
+    hipLaunchKernelGGL((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, nf, nf, nf, nh, ld16, b);
+    if (C == 64) { HUPR_ATTN_BATCH(64) } else if (C == 128) { HUPR_ATTN_BATCH(128) } else { HUPR_ATTN_BATCH(256) }
+#undef HUPR_ATTN_BATCH
+    HUPR_LAUNCH_OK("hupr_k_attn_fwd (split, batch)");
+    return HUPR_OK;
+}
+
 // the same with a workspace of hupr_attn_fwd_split_ws_bytes(Bn, N, C) bytes (0: the plain kernel already fills the GPU and ws may
 // be null): small batches split the keys over blockIdx.z and merge the shares in a second launch (flash-decoding)
 extern "C" int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres,

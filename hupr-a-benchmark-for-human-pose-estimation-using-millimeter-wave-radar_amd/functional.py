@@ -1161,6 +1161,7 @@ def mscsa_level_fused_ok(ra):
 
 
 _wc_cache = {}
+ATTN_BATCH = os.environ.get("HUPR_NO_ATTN_BATCH", "0") != "1"      # A/B aid: one launch pair per MSCSA level in single-sample inference
 
 
 def _cat_weights(ws, C, cache):
@@ -1248,7 +1249,20 @@ class MSCSALevelFn(torch.autograd.Function):
         else:
             vb = maps
             aux = [torch.empty((B, N, N), dtype=torch.float32, device=dev) for _ in range(4)]       # P[query][key]
+        # single-sample inference (config C2): the four attentions of the level as ONE split launch + ONE merge launch instead of eight
+        split_bytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C) if (infer and flash and ATTN_BATCH) else 0
+        if split_bytes:
+            items = (rt.AttnItem * 4)()
+            for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
+                items[i].K, items[i].Q = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
+                items[i].V, items[i].Vres = rt.ptr(vb[vs]), (rt.ptr(maps[vs]) if residual else None)
+                items[i].out, items[i].lse = rt.ptr(out), rt.ptr(a)
+                items[i].out16 = (cat.data_ptr() + i * C * 2) if cat_bf16 else None
+            ws = workspace(4 * split_bytes, dev)
+            rt.check(L.hupr_attn_fwd_bf16in_ld_ws_batch(items, 4, 4 * C, 4 * C, 4 * C, B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
         for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
+            if split_bytes:
+                break
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
             if flash:
                 ws = _attn_ws(B, N, C, dev)

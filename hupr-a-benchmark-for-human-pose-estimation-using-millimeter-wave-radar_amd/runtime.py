@@ -17,6 +17,12 @@ c_void_p, c_int, c_size_t, c_float, c_char_p = (ctypes.c_void_p, ctypes.c_int, c
 c_long = ctypes.c_long
 
 # name -> (restype, argtypes); must list every symbol declared in include/hupr.h
+class AttnItem(ctypes.Structure):
+    """hupr_attn_item (include/hupr.h): one attention of a batched single-sample launch."""
+    _fields_ = [("K", ctypes.c_void_p), ("Q", ctypes.c_void_p), ("V", ctypes.c_void_p), ("Vres", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("lse", ctypes.c_void_p), ("out16", ctypes.c_void_p)]
+
+
 SIGNATURES = {
     "hupr_version": (c_int, []),
     "hupr_last_error": (c_char_p, []),
@@ -92,6 +98,7 @@ SIGNATURES = {
     "hupr_attn_fwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_void_p, c_int] + [c_int] * 3
                                 + [c_void_p]),
     "hupr_attn_fwd_split_ws_bytes": (c_size_t, [c_int] * 3),
+    "hupr_attn_fwd_bf16in_ld_ws_batch": (c_int, [ctypes.POINTER(AttnItem)] + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "hupr_debug_attn_split": (None, [c_int]),
     "hupr_attn_fwd_bf16in_ld_ws": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_void_p, c_int] + [c_int] * 3
                                    + [c_void_p, c_size_t, c_void_p]),

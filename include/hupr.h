@@ -316,6 +316,12 @@ int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, cons
  * the workspace that needs, or 0 when the one-pass kernel is used (ws may then be null): by default the split is taken for
  * single-sample calls only, so that batched runs keep the rounding their parity gates were measured with. */
 size_t hupr_attn_fwd_split_ws_bytes(int Bn, int N, int C);
+/* Up to four independent attentions of one shape (the four of an MSCSA level, reference models/layers.py:150-163) in ONE split launch and
+ * ONE merge launch — single-sample inference is bound by launches, not work.  Applies where hupr_attn_fwd_split_ws_bytes() > 0; ws: n_items
+ * times that size.  K / Q / V: bf16 with row strides ldk / ldq / C; Vres (fp32 V for the residual) and out16 (bf16 copy, stride ld16) may be null. */
+typedef struct hupr_attn_item { const void* K; const void* Q; const void* V; const float* Vres; float* out; float* lse; void* out16; } hupr_attn_item;
+int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N, int C,
+                                     void* ws, size_t ws_bytes, hupr_stream_t stream);
 void hupr_debug_attn_split(int mode);    /* 0 (default): split for Bn == 1 only; 1: every grid below 128 workgroups; -1: never */
 int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres, float* out,
                                float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, void* ws, size_t ws_bytes,

@@ -229,6 +229,37 @@ def test_streaming_merge_weight_gradient_on_wider_maps(B, G, H, C, bf16_math):
     assert torch.equal(d1, d2)
 
 
+@pytest.mark.parametrize("H,C", [(64, 64), (32, 128), (16, 256)])
+@pytest.mark.parametrize("cat", [1, 0])
+def test_single_sample_attentions_of_a_level_in_one_launch(H, C, cat, bf16_math):
+    """hupr_attn_fwd_bf16in_ld_ws_batch: the four attentions of an MSCSA level (reference models/layers.py:150-163) at B = 1 as one
+    split launch + one merge launch — bit-identical to the four launch pairs it replaces (same key shares, same merge), at the three
+    levels' shapes, with and without the bf16 concatenation output."""
+    from hupr_amd import functional as F_
+    if not F_.rt.lib().hupr_attn_fwd_split_ws_bytes(1, H * H, C):
+        pytest.skip("the split form does not apply to this shape")
+    ra, re = rnd(1, 1, H, H, C, seed=160).cuda(), rnd(1, 1, H, H, C, seed=161).cuda()
+    ws = [rnd(C, C, 1, 1, seed=162 + i, scale=C ** -0.5).cuda().requires_grad_(True) for i in range(8)]
+
+    def run():
+        with torch.no_grad():
+            return [o.clone() for o in F_.MSCSALevelFn.apply(ra, re, cat | 2, *ws)]
+    assert F_.ATTN_BATCH
+    y1 = run()
+    F_.ATTN_BATCH = False
+    try:
+        y0 = run()
+    finally:
+        F_.ATTN_BATCH = True
+    assert len(y1) == len(y0) == (1 if cat else 4)
+    for a, b in zip(y1, y0):
+        assert torch.equal(a, b)
+    with torch.no_grad():                                     # and against the training form of the node (no key split)
+        ref = F_.MSCSALevelFn.apply(ra, re, cat, *ws)
+    for a, b in zip(y1, ref):
+        close(a.float(), b.float(), 1e-2 if cat else 2e-5, "split + batched vs one-pass attention")
+
+
 def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(bf16_math):
     """Round 3 regression (scripts/interp_race.py): the build of hupr_k_interp_fwd that hipcc's SLP vectoriser
     produced returned wrong sums in >90 % of the launches that shared the chip with the level-3 convolution kernel
