@@ -292,13 +292,30 @@ __device__ __forceinline__ void fft16p(v2f (&x)[16]) {
 //            products are no longer integers and the mean is subtracted explicitly.)
 //   stage B  16 range FFTs per workgroup (one 16-lane group each): 256 = 16 x 16 with ONE transpose through the group's own
 //            tile row, as in the range-first kernel; bins 94..31 go straight to RD[sf][antenna][i][r].
-// 37 KB of LDS.  The zero-Doppler bin (i = 8) is therefore EXACTLY zero where the range-first order (and the reference's
-// fft2 of the mean-free cube, process_iwr1843.py:122-134) leaves rounding noise; the loader epilogues below map a
-// zero-variance plane to zeros instead of 0/0.
+// 37 KB of LDS.  The zero-Doppler bin (i = 8) would therefore be EXACTLY zero where the range-first order (and the
+// reference's fft2 of the mean-free cube, process_iwr1843.py:122-134) leaves rounding noise that the reference's Normalize
+// inflates to a unit-variance channel (and an exact zero to 0/0 = NaN): by default the bin carries the dither defined
+// below instead (HUPR_FFT_ZERO_DOPPLER_EXACT keeps the exact zero; the loader epilogues map a zero-variance plane to zeros).
 // HALF: only the eight Doppler bins the loader keeps (i = 4..11, dataset.py:145) — half the accumulators of stage A and half
 // the range FFTs (two of the four waves retire after stage A); the other rows of RD are left untouched.
+// Zero-Doppler dither (round 4).  The reference's zero-Doppler bin is the fp64 rounding residue of fft2 over the mean-free
+// chirps (process_iwr1843.py:122-134: ~2e-16 of the other bins, white over range and antenna, a pure function of the frame)
+// and its Normalize (datasets/base.py:17-24) turns that plane into a unit-variance input channel — an exactly-zero plane
+// would be 0/0 there.  No other implementation can reproduce pocketfft's residue, so this chain carries a stand-in with the
+// same statistics: per (antenna, ADC sample) a pair of 16-bit integers hashed from the exact chirp sums T (the very
+// quantity clutter removal cancels) and the position, scaled by 2^-53 of an ADC LSB; the range FFT of stage B turns it
+// into a white, near-Gaussian row of rms ~5e-11 (the reference: 4e-11 on full-scale inputs) that the angle kernel and the
+// loader epilogues treat like every other Doppler bin.  oracle/fft_chain.py::zero_doppler_dither restates it bit for bit.
+__device__ __forceinline__ v2f zero_doppler_dither(v2f chirp_sum, int vant, int s) {
+    uint32_t h = (uint32_t)(int)chirp_sum.x * 0x9E3779B1u ^ (uint32_t)(int)chirp_sum.y * 0x85EBCA77u ^
+                 (uint32_t)(vant * 256 + s) * 0xC2B2AE3Du;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    constexpr float kScale = 1.1102230246251565e-16f;           // 2^-53
+    return (v2f){(float)(int16_t)(h & 0xffffu) * kScale, (float)((int32_t)h >> 16) * kScale};
+}
+
 template <int WIN, bool HALF>
-__global__ __launch_bounds__(256) void hupr_k_doppler_range(const int16_t* __restrict__ iq, float2* __restrict__ rd) {
+__global__ __launch_bounds__(256) void hupr_k_doppler_range(const int16_t* __restrict__ iq, float2* __restrict__ rd, int zd_exact) {
     constexpr int kPitch = 272;                      // v2f per Doppler row: 2 x 272 = 32 (mod 64) banks, and = 16 x 17
     constexpr int kRows = HALF ? 8 : kDop, kRow0 = HALF ? 4 : 0;
     __shared__ v2f tw[256];                          // W_256^t
@@ -352,7 +369,8 @@ __global__ __launch_bounds__(256) void hupr_k_doppler_range(const int16_t* __res
                 else acc[k1] = pk_cfma_s(acc[k1], x[4 * g + q], (v2f){w64re(n2 * d), w64im(n2 * d)});
             }
     }
-    if constexpr (WIN == 0) acc[0] = (v2f){0.f, 0.f};    // exact clutter removal, see above
+    if constexpr (WIN == 0)                              // exact clutter removal, see above: acc[0] holds the exact chirp sum
+        acc[0] = zd_exact ? (v2f){0.f, 0.f} : zero_doppler_dither(acc[0], vant, tid);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
         const int i = (k1 < 8) ? k1 + 8 : k1 - 8;        // fftshift + keep 24..39 -> i = (d + 8) & 63
@@ -668,7 +686,10 @@ extern "C" void hupr_debug_fft_range_first(int on) { g_fft_range_first = on; }
 
 static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws, size_t ws_bytes,
                             hupr_stream_t stream, bool loader, int flags = 0, bool means = false) {
-    HUPR_REQUIRE((flags & ~(HUPR_FFT_HANN_RANGE | HUPR_FFT_HANN_DOPPLER | HUPR_FFT_MAGNITUDE)) == 0, "hupr_fft_chain: flags=0x%x", flags);
+    HUPR_REQUIRE((flags & ~(HUPR_FFT_HANN_RANGE | HUPR_FFT_HANN_DOPPLER | HUPR_FFT_MAGNITUDE | HUPR_FFT_ZERO_DOPPLER_EXACT |
+                            HUPR_FFT_RANGE_FIRST)) == 0, "hupr_fft_chain: flags=0x%x", flags);
+    HUPR_REQUIRE(!((flags & HUPR_FFT_ZERO_DOPPLER_EXACT) && (flags & HUPR_FFT_RANGE_FIRST)),
+                 "hupr_fft_chain: the range-first order has no exact zero-Doppler form");
     HUPR_REQUIRE(!(loader && (flags & HUPR_FFT_MAGNITUDE)), "hupr_fft_chain: the loader epilogue splits re/im, it has no magnitude form");
     HUPR_REQUIRE(n_sf >= 0, "hupr_fft_chain: n_sf=%d", n_sf);
     if (n_sf == 0) return HUPR_OK;                      // empty batch is a no-op
@@ -681,7 +702,8 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
                     hupr_fft_chain_ws_bytes(n_sf));
     hipStream_t s = as_stream(stream);
     float2* rd = reinterpret_cast<float2*>(ws);
-    if (g_fft_range_first) {
+    const int zd = (flags & HUPR_FFT_ZERO_DOPPLER_EXACT) ? 1 : 0;
+    if (g_fft_range_first || (flags & HUPR_FFT_RANGE_FIRST)) {
         switch (flags & 3) {
             case 0: hipLaunchKernelGGL(hupr_k_range_doppler<0>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
             case 1: hipLaunchKernelGGL(hupr_k_range_doppler<1>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
@@ -691,14 +713,14 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
     } else {
         const dim3 g1(n_sf * kVant), b1(256);
         switch ((flags & 3) | (loader ? 4 : 0)) {
-            case 0: hipLaunchKernelGGL((hupr_k_doppler_range<0, false>), g1, b1, 0, s, adc_iq, rd); break;
-            case 1: hipLaunchKernelGGL((hupr_k_doppler_range<1, false>), g1, b1, 0, s, adc_iq, rd); break;
-            case 2: hipLaunchKernelGGL((hupr_k_doppler_range<2, false>), g1, b1, 0, s, adc_iq, rd); break;
-            case 3: hipLaunchKernelGGL((hupr_k_doppler_range<3, false>), g1, b1, 0, s, adc_iq, rd); break;
-            case 4: hipLaunchKernelGGL((hupr_k_doppler_range<0, true>), g1, b1, 0, s, adc_iq, rd); break;
-            case 5: hipLaunchKernelGGL((hupr_k_doppler_range<1, true>), g1, b1, 0, s, adc_iq, rd); break;
-            case 6: hipLaunchKernelGGL((hupr_k_doppler_range<2, true>), g1, b1, 0, s, adc_iq, rd); break;
-            default: hipLaunchKernelGGL((hupr_k_doppler_range<3, true>), g1, b1, 0, s, adc_iq, rd); break;
+            case 0: hipLaunchKernelGGL((hupr_k_doppler_range<0, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            case 1: hipLaunchKernelGGL((hupr_k_doppler_range<1, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            case 2: hipLaunchKernelGGL((hupr_k_doppler_range<2, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            case 3: hipLaunchKernelGGL((hupr_k_doppler_range<3, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            case 4: hipLaunchKernelGGL((hupr_k_doppler_range<0, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            case 5: hipLaunchKernelGGL((hupr_k_doppler_range<1, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            case 6: hipLaunchKernelGGL((hupr_k_doppler_range<2, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            default: hipLaunchKernelGGL((hupr_k_doppler_range<3, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
         }
     }
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
@@ -731,7 +753,8 @@ extern "C" int hupr_fft_chain_loader_means_f32(const int16_t* adc_iq, int n_sf, 
 
 extern "C" int hupr_fft_chain_opts(const int16_t* adc_iq, int n_sf, void* out, int flags, int loader, void* ws, size_t ws_bytes,
                                    hupr_stream_t stream) {
-    return fft_chain_common(adc_iq, n_sf, out, ws, ws_bytes, stream, loader != 0, flags);
+    HUPR_REQUIRE(loader >= 0 && loader <= 2, "hupr_fft_chain_opts: loader=%d", loader);
+    return fft_chain_common(adc_iq, n_sf, out, ws, ws_bytes, stream, loader != 0, flags, loader == 2);
 }
 
 extern "C" int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* out, hupr_stream_t stream) {

@@ -182,7 +182,9 @@ def refresh_packed(device):
         w = e.wref()
         if w is not None and w.device == device and e.stamp != (PACK_EPOCH, w._version):
             _pack_refresh_all(device)
-            return
+            break
+    if not torch.cuda.is_current_stream_capturing():
+        _wc_refresh(device)
 
 
 # Direct gradient sink (installed by tools.distributed.GradientBuckets): parameter gradients are written by the kernels
@@ -297,15 +299,24 @@ def _pack_refresh_all(dev):
 
 
 def _packed(weight, mode, kind):
-    """Packed layout ``mode`` (0 forward, 1 input gradient) of ``weight`` as fp32 (kind 0) or bf16 (kind 1)."""
+    """Packed layout ``mode`` (0 forward, 1 input gradient) of ``weight`` as fp32 (kind 0) or bf16 (kind 1).
+    During a hipGraph capture: a TRAINING graph (grad enabled) repacks inside the graph — its own optimiser node changes the
+    weights between replays; an INFERENCE graph (no_grad) reads the cached layouts when they are fresh — ~60 pack launches less
+    per replay — and those buffers are refreshed IN PLACE by the next eager refresh (``refresh_packed`` after a weight update
+    keeps a captured inference graph current, together with the in-place ``_wc_cache`` below)."""
     global _pack_table
+    capturing = torch.cuda.is_current_stream_capturing()
     if not (PACK_CACHE and weight.is_leaf and weight.requires_grad and weight.is_contiguous()) or \
-            torch.cuda.is_current_stream_capturing():
+            (capturing and torch.is_grad_enabled()):
         return pack_weights_bf16(weight, mode) if kind else pack_weights(weight, mode)
     key = (weight.data_ptr(), kind)
     e = _pack_entries.get(key)
     if e is not None and (e.wref() is None or e.shape != tuple(weight.shape)):     # the address was recycled by another tensor
         e = None
+    if capturing:
+        if e is None or e.stamp != (PACK_EPOCH, weight._version):                  # nothing cached is created or refreshed mid-capture
+            return pack_weights_bf16(weight, mode) if kind else pack_weights(weight, mode)
+        return e.wp[mode]
     if e is None:
         e = _PackEntry()
         e.wref, e.ptr, e.kind, e.shape = weakref.ref(weight), weight.data_ptr(), kind, tuple(weight.shape)
@@ -318,9 +329,10 @@ def _packed(weight, mode, kind):
         _pack_refresh_all(weight.device)
         if e.stamp != (PACK_EPOCH, weight._version):          # not covered by the table pass (should not happen)
             pk = pack_weights_bf16 if kind else pack_weights
-            e.wp = (pk(weight, 0), pk(weight, 1))
+            pk_into = (pk(weight, 0), pk(weight, 1))
+            e.wp[0].copy_(pk_into[0])                           # in place: captured inference graphs hold these addresses
+            e.wp[1].copy_(pk_into[1])
             e.stamp = (PACK_EPOCH, weight._version)
-            _pack_table = None
     return e.wp[mode]
 
 
@@ -1160,40 +1172,86 @@ def mscsa_level_fused_ok(ra):
     return LEVEL_FUSION and MATH == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
 
 
+# Derived inference constants (concatenated projection weights, the zero-padded head filter): one entry per set of source
+# parameters, keyed by their addresses, stamped like the packed layouts and REFRESHED IN PLACE when stale — a captured
+# inference graph that baked in an entry's address keeps reading current values once ``refresh_packed`` has run after a weight
+# update (the first version keyed entries by epoch, so an update orphaned the tensor a graph was still reading,
+# and ``clear()`` at 64 entries could free it).  Entries die with their parameters (weak references), never by count.
 _wc_cache = {}
 ATTN_BATCH = os.environ.get("HUPR_NO_ATTN_BATCH", "0") != "1"      # A/B aid: one launch pair per MSCSA level in single-sample inference
 
 
+class _WcEntry:
+    __slots__ = ("wrefs", "stamp", "build", "t")
+
+
+def _wc_stamp(ws):
+    return (PACK_EPOCH,) + tuple(w._version for w in ws)
+
+
+def _wc_get(tag, ws, build):
+    """-> the cached constant ``build(ws, out)`` derives from the parameters ``ws``.  ``build(ws, None)`` returns a fresh tensor,
+    ``build(ws, t)`` refills ``t`` in place.  Nothing is created or refreshed during a capture (a fresh entry would live in the
+    graph's private pool; a stale one means the caller skipped ``refresh_packed``): the capture then computes its own copy
+    inside the graph, which is always current."""
+    key = (tag,) + tuple(w.data_ptr() for w in ws)
+    e = _wc_cache.get(key)
+    if e is not None and any(r() is not w for r, w in zip(e.wrefs, ws)):            # an address recycled by another tensor
+        e = None
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing:
+        return e.t if e is not None and e.stamp == _wc_stamp(ws) else build(ws, None)
+    if e is None:
+        for k in [k for k, v in _wc_cache.items() if any(r() is None for r in v.wrefs)]:
+            del _wc_cache[k]
+        e = _WcEntry()
+        e.wrefs, e.build, e.t = tuple(weakref.ref(w) for w in ws), build, build(ws, None)
+        e.stamp = _wc_stamp(ws)
+        _wc_cache[key] = e
+    elif e.stamp != _wc_stamp(ws):
+        build(ws, e.t)
+        e.stamp = _wc_stamp(ws)
+    return e.t
+
+
+def _wc_refresh(device):
+    """Refill every stale derived constant on ``device`` in place (part of ``refresh_packed``)."""
+    for k in list(_wc_cache):
+        e = _wc_cache[k]
+        ws = [r() for r in e.wrefs]
+        if any(w is None for w in ws):
+            del _wc_cache[k]
+        elif ws[0].device == device and e.stamp != _wc_stamp(ws):
+            e.build(ws, e.t)
+            e.stamp = _wc_stamp(ws)
+
+
+def _cat_build(ws, out):
+    C = ws[0].shape[0]
+    return torch.cat([w.reshape(C, C) for w in ws], 0, out=out) if out is not None else torch.cat([w.reshape(C, C) for w in ws], 0)
+
+
 def _cat_weights(ws, C, cache):
-    """The four (C, C, 1, 1) projection weights of a map as one (4C, C) matrix.  Inference (``cache``): kept across calls, keyed by the
-    parameters' addresses, versions and the packed-weight epoch — six concatenation launches less per forward (37 us of config C2's 1.28 ms).  Never filled
-    during graph capture (the tensor would live in the graph's private pool)."""
+    """The four (C, C, 1, 1) projection weights of a map as one (4C, C) matrix.  Inference (``cache``): kept across calls
+    (``_wc_get``) — six concatenation launches less per forward (37 us of config C2's 1.28 ms)."""
     if not cache:
         return torch.cat([w.reshape(C, C) for w in ws], 0)
-    key = (PACK_EPOCH,) + tuple((w.data_ptr(), w._version) for w in ws)      # PACK_EPOCH: FusedAdam updates parameters in place
-    t = _wc_cache.get(key)
-    if t is None:
-        t = torch.cat([w.reshape(C, C) for w in ws], 0)
-        if not torch.cuda.is_current_stream_capturing():
-            if len(_wc_cache) >= 64:
-                _wc_cache.clear()
-            _wc_cache[key] = t
-    return t
+    return _wc_get("cat", tuple(ws), _cat_build)
 
 
 def head_weight16(weight, num_keypoints):
     """The 1x1 head's filters zero-padded to 16 output channels (later kernels stay float4-aligned).  Under no_grad the padded copy is
     kept across calls like the concatenated projection weights (one pad launch less per inference forward)."""
-    pad = lambda: torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, 16 - num_keypoints))      # noqa: E731
-    if torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
-        return pad()
-    key = (PACK_EPOCH, "head16", weight.data_ptr(), weight._version)
-    t = _wc_cache.get(key)
-    if t is None:
-        if len(_wc_cache) >= 64:
-            _wc_cache.clear()
-        t = _wc_cache[key] = pad()
-    return t
+    def build(ws, out):
+        w = ws[0]
+        if out is None:
+            return torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 16 - w.shape[0]))
+        out[:w.shape[0]].copy_(w)
+        return out
+    if torch.is_grad_enabled():
+        return build((weight,), None)
+    assert weight.shape[0] == num_keypoints
+    return _wc_get("head16", (weight,), build)
 
 
 @_math_scoped

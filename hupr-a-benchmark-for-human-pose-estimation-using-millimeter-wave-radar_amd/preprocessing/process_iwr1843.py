@@ -29,24 +29,39 @@ def _check_adc(adc_iq):
         raise ValueError("adc_iq must be int16 (n,4,192,256,2), got %s %r" % (adc_iq.dtype, tuple(adc_iq.shape)))
 
 
-HANN_RANGE, HANN_DOPPLER, MAGNITUDE = 1, 2, 4      # include/hupr.h HUPR_FFT_*
+HANN_RANGE, HANN_DOPPLER, MAGNITUDE, ZERO_DOPPLER_EXACT, RANGE_FIRST = 1, 2, 4, 8, 16      # include/hupr.h HUPR_FFT_*
+
+# What the zero-Doppler bin (Doppler index 8, loader slot f = 4) holds — include/hupr.h, "The zero-Doppler bin":
+#   "dither"      (default) a frame-keyed stand-in for the reference's fp64 rounding residue, normalised like every other bin,
+#                 so an unmodified reference Normalize / a reference-trained checkpoint sees what it was trained on;
+#   "exact"       exactly zero (round 3's chain; the loader emits zeros in slot f = 4);
+#   "range_first" the rounds-1/2 kernel order, whose own fp32 rounding residue fills the bin (slower).
+# HUPR_FFT_ZERO_DOPPLER selects the process default; tools.Runner records the mode in its checkpoints ("fft_zero_doppler").
+ZERO_DOPPLER_MODES = {"dither": 0, "exact": ZERO_DOPPLER_EXACT, "range_first": RANGE_FIRST}
+ZERO_DOPPLER = os.environ.get("HUPR_FFT_ZERO_DOPPLER", "dither")
+if ZERO_DOPPLER not in ZERO_DOPPLER_MODES:
+    raise ValueError("HUPR_FFT_ZERO_DOPPLER must be one of %s, got %r" % (sorted(ZERO_DOPPLER_MODES), ZERO_DOPPLER))
 
 
-def _flags(window, magnitude):
-    """window: None / False (the reference: rectangular), "hann" / True (range + Doppler), "range", "doppler"."""
+def _flags(window, magnitude, zero_doppler=None):
+    """window: None / False (the reference: rectangular), "hann" / True (range + Doppler), "range", "doppler";
+    zero_doppler: None (the process default ZERO_DOPPLER) or a key of ZERO_DOPPLER_MODES."""
     table = {None: 0, False: 0, "none": 0, True: 3, "hann": 3, "range": 1, "doppler": 2}
     if window not in table:
         raise ValueError("window must be one of None, 'hann', 'range', 'doppler'; got %r" % (window,))
-    return table[window] | (MAGNITUDE if magnitude else 0)
+    zd = ZERO_DOPPLER if zero_doppler is None else zero_doppler
+    if zd not in ZERO_DOPPLER_MODES:
+        raise ValueError("zero_doppler must be one of %s, got %r" % (sorted(ZERO_DOPPLER_MODES), zd))
+    return table[window] | (MAGNITUDE if magnitude else 0) | ZERO_DOPPLER_MODES[zd]
 
 
-def fft_chain(adc_iq, ws=None, window=None, magnitude=False):
+def fft_chain(adc_iq, ws=None, window=None, magnitude=False, zero_doppler=None):
     """adc_iq: int16 GPU tensor (n,4,192,256,2) -> complex64 GPU tensor (n,16,64,64,8).
     Opt-in (defaults = the reference: no window, complex output): ``window="hann"`` applies np.hanning windows over the
-    range samples and the chirp loops, ``magnitude=True`` returns |X| as fp32."""
+    range samples and the chirp loops, ``magnitude=True`` returns |X| as fp32.  ``zero_doppler``: see ZERO_DOPPLER_MODES."""
     _check_adc(adc_iq)
     n = adc_iq.shape[0]
-    flags = _flags(window, magnitude)
+    flags = _flags(window, magnitude, zero_doppler)
     out = torch.empty((n, 16, 64, 64, 8), dtype=torch.float32 if magnitude else torch.complex64, device=adc_iq.device)
     if ws is None:
         ws, nbytes = _workspace(n, adc_iq.device)
@@ -59,9 +74,10 @@ def fft_chain(adc_iq, ws=None, window=None, magnitude=False):
     return out
 
 
-def fft_chain_loader(adc_iq, ws=None, out=None, window=None):
+def fft_chain_loader(adc_iq, ws=None, out=None, window=None, zero_doppler=None):
     """adc_iq: int16 GPU tensor (n,4,192,256,2) -> fp32 GPU tensor (n, 8, 2, 64, 64, 8):
-    Doppler bins 4..11, re/im split, per-elevation Normalize (datasets glue fused in).  ``window``: see fft_chain."""
+    Doppler bins 4..11, re/im split, per-elevation Normalize (datasets glue fused in).  ``window`` / ``zero_doppler``: see
+    fft_chain."""
     _check_adc(adc_iq)
     n = adc_iq.shape[0]
     if out is None:
@@ -70,7 +86,7 @@ def fft_chain_loader(adc_iq, ws=None, out=None, window=None):
         ws, nbytes = _workspace(n, adc_iq.device)
     else:
         nbytes = ws.numel() * ws.element_size()
-    flags = _flags(window, False)
+    flags = _flags(window, False, zero_doppler)
     if flags == 0:
         rt.check(rt.lib().hupr_fft_chain_loader_f32(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
     else:
@@ -78,7 +94,7 @@ def fft_chain_loader(adc_iq, ws=None, out=None, window=None):
     return out
 
 
-def fft_chain_loader_means(adc_iq, ws=None):
+def fft_chain_loader_means(adc_iq, ws=None, zero_doppler=None):
     """adc_iq: int16 GPU tensor (n,4,192,256,2) -> fp32 GPU tensor (n, 16, 64, 64): the loader tensor of ``fft_chain_loader``
     averaged over its elevation axis, plane index 2 f + c — what ``HuPRNet.forward`` computes first (models/networks.py:26-27).
     The fused training loader hands these planes to the model instead of the 8x larger (n,8,2,64,64,8) tensor."""
@@ -89,7 +105,11 @@ def fft_chain_loader_means(adc_iq, ws=None):
         ws, nbytes = _workspace(n, adc_iq.device)
     else:
         nbytes = ws.numel() * ws.element_size()
-    rt.check(rt.lib().hupr_fft_chain_loader_means_f32(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
+    flags = _flags(None, False, zero_doppler)
+    if flags == 0:
+        rt.check(rt.lib().hupr_fft_chain_loader_means_f32(rt.ptr(adc_iq), n, rt.ptr(out), rt.ptr(ws), nbytes, rt.stream()))
+    else:
+        rt.check(rt.lib().hupr_fft_chain_opts(rt.ptr(adc_iq), n, rt.ptr(out), flags, 2, rt.ptr(ws), nbytes, rt.stream()))
     return out
 
 

@@ -98,7 +98,7 @@ class RcclTransport:
             got = uid.raw if self.L.hupr_comm_unique_id(uid) == 0 else _ID_ERROR
             err = rt.last_error() if got == _ID_ERROR else ""
         if multi:
-            got = self._exchange_id(got, group)
+            got = self._exchange_id(got, group, device)
         if got == _ID_ERROR:
             raise rt.HuprError("rank 0 could not create an RCCL communicator id" + (": " + err if self.rank == 0 else ""))
         uid = ctypes.create_string_buffer(got, 128)
@@ -115,18 +115,19 @@ class RcclTransport:
     _n_comms = 0
 
     @classmethod
-    def _exchange_id(cls, uid_bytes, group):
+    def _exchange_id(cls, uid_bytes, group, device):
         """Rank 0's 128-byte communicator id (or the error sentinel) to every rank.  Default group: through the rendezvous
-        key-value store (no collective, no device traffic: works whatever backends the group was initialised with);
-        sub-groups, or a store that cannot be reached ON ANY RANK (agreed, so nobody waits on a key the others never
-        write): object broadcast."""
+        key-value store (no device traffic for the id itself); sub-groups, or a store that cannot be reached ON ANY RANK
+        (agreed, so nobody waits on a key the others never write): object broadcast.  ``device`` = the transport's GPU: the
+        agreement flag falls back to it when the group has no CPU backend (plain ``init_process_group("nccl")``; ADVICE r3 —
+        with ``torch.device("cpu")`` here the fallback was a no-op and the constructor failed on every rank of such a group)."""
         if group is None:
             store = None
             try:
                 store = dist.distributed_c10d._get_default_store()
             except Exception as exc:      # noqa: BLE001 — private accessor
                 sys.stderr.write("hupr: no rendezvous store for the RCCL id (%s)\n" % exc)
-            if _all_ok(store is not None, group, torch.device("cpu")):
+            if _all_ok(store is not None, group, device):
                 key = "hupr_rccl_uid_%d" % cls._n_comms
                 cls._n_comms += 1
                 if uid_bytes is not None:

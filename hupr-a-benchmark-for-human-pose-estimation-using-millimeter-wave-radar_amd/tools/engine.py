@@ -159,6 +159,8 @@ class TrainEngine:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        from .. import functional as F_
+        F_.invalidate_packed()      # the graph's Adam node changed the parameters behind every host-side cache
         return self._g_out
 
     @torch.no_grad()

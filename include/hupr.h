@@ -69,11 +69,24 @@ int hupr_fft_chain_loader_means_f32(const int16_t* adc_iq, int n_sf, float* mean
  *        HUPR_FFT_HANN_RANGE    x[c,s] *= hann256[s]            before the range FFT   (np.hanning(256), symmetric)
  *        HUPR_FFT_HANN_DOPPLER  (x - mean_c x)[c] *= hann64[c]  before the Doppler FFT (after clutter removal :122-128)
  *        HUPR_FFT_MAGNITUDE     out = |X| as float [n_sf][16][64][64][8] (2 097 152 B) instead of complex64
- *      loader != 0 selects the fused loader epilogue of hupr_fft_chain_loader_f32 (window flags only).
- *      flags == 0 is exactly hupr_fft_chain_c64 / hupr_fft_chain_loader_f32. */
+ *      loader: 0 = complex cube, 1 = the fused loader epilogue of hupr_fft_chain_loader_f32, 2 = the elevation-mean planes of
+ *      hupr_fft_chain_loader_means_f32 (window / zero-Doppler / order flags only).
+ *      flags == 0 is exactly hupr_fft_chain_c64 / hupr_fft_chain_loader_f32 / hupr_fft_chain_loader_means_f32.
+ *
+ *      The zero-Doppler bin (Doppler index 8; the loader's slot f = 4).  Clutter removal (process_iwr1843.py:122-128) cancels
+ *      it analytically; the reference keeps the fp64 rounding residue of its fft2 there (~2e-16 of the other bins, white, a
+ *      pure function of the frame) and its Normalize (datasets/base.py:17-24) inflates that plane to a unit-variance input
+ *      channel — an exactly-zero plane would be 0/0 = NaN in that Normalize.  Default: the bin carries a frame-keyed dither
+ *      with the reference residue's statistics (integer hash of the exact chirp sums, 2^-53 of an ADC LSB per sample, restated
+ *      bit for bit by oracle/fft_chain.py::zero_doppler_dither), transformed and normalised like every other bin.
+ *        HUPR_FFT_ZERO_DOPPLER_EXACT  the bin is exactly 0 (round 3's behaviour; the loader epilogues then emit zeros in f = 4)
+ *        HUPR_FFT_RANGE_FIRST         the range-first order of rounds 1-2 (the reference's order of operations in fp32: the bin
+ *                                     holds that order's own fp32 rounding residue, ~1e-7 relative); slower (2.6 vs 4 TB/s) */
 #define HUPR_FFT_HANN_RANGE 1
 #define HUPR_FFT_HANN_DOPPLER 2
 #define HUPR_FFT_MAGNITUDE 4
+#define HUPR_FFT_ZERO_DOPPLER_EXACT 8
+#define HUPR_FFT_RANGE_FIRST 16
 int hupr_fft_chain_opts(const int16_t* adc_iq, int n_sf, void* out, int flags, int loader, void* ws, size_t ws_bytes,
                         hupr_stream_t stream);
 

@@ -60,6 +60,45 @@ def range_doppler(az, el, window=0):
     return az, el
 
 
+def zero_doppler_dither(iq):
+    """THE BUILD'S definition (not the reference's — pinned only against this restatement, like the opt-in windows): what the
+    HIP chain puts where clutter removal cancels the signal.  The reference's zero-Doppler bin is the fp64 rounding residue of
+    its fft2 (:122-134; ~2e-16 of the other bins, white over range and antenna, a pure function of the frame), which its
+    Normalize (datasets/base.py:17-24) inflates to a unit-variance channel; pocketfft's residue cannot be reproduced by another
+    implementation, so the chain substitutes a frame-keyed dither of the same statistics (csrc/fft_chain.hip,
+    ``zero_doppler_dither``): per (virtual antenna v, ADC sample s) two 16-bit integers hashed from the exact chirp sums
+    T[v, s] = sum over the 64 chirp loops of the int16 samples, scaled by 2^-53.
+
+    iq: int16 (4, 192, 256, 2)  ->  complex128 (12, 256): rows 0..7 azimuth antennas (TX1 rx0..3, TX3 rx0..3), 8..11 elevated.
+    """
+    iq = np.asarray(iq)
+    assert iq.dtype == np.int16 and iq.shape == (NUM_RX, NUM_CHIRP, NUM_SAMPLE, 2)
+    t = np.concatenate([iq[:, 0::3], iq[:, 2::3], iq[:, 1::3]], axis=0).astype(np.int64).sum(axis=1)      # (12, 256, 2)
+    m = np.uint64(0xFFFFFFFF)
+    pos = (np.arange(12, dtype=np.uint64)[:, None] * np.uint64(256) + np.arange(256, dtype=np.uint64)[None, :])
+    u = lambda x: x.astype(np.int64).astype(np.uint64) & m           # two's-complement uint32 image of an int
+    h = ((u(t[..., 0]) * np.uint64(0x9E3779B1)) & m) ^ ((u(t[..., 1]) * np.uint64(0x85EBCA77)) & m) ^ ((pos * np.uint64(0xC2B2AE3D)) & m)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7FEB352D)) & m
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x846CA68B)) & m
+    h ^= h >> np.uint64(16)
+    re = (h & np.uint64(0xFFFF)).astype(np.uint16).view(np.int16).astype(np.float64)
+    im = (h >> np.uint64(16)).astype(np.uint16).view(np.int16).astype(np.float64)
+    return (re + 1j * im) * 2.0 ** -53
+
+
+def generate_heatmap_dithered(iq):
+    """``generate_heatmap`` of the int16 cube ``iq`` (4,192,256,2) with the zero-Doppler row of the range-Doppler map replaced by
+    the range FFT of ``zero_doppler_dither`` — what the HIP chain computes by default.  Every other bin is the reference's."""
+    frame = np.asarray(iq)[..., 0].astype(np.float64) + 1j * np.asarray(iq)[..., 1].astype(np.float64)
+    az, el = demux(frame)
+    az, el = range_doppler(az, el)
+    d = np.fft.fft(zero_doppler_dither(iq), axis=1)
+    az[:, 0, :], el[:, 0, :] = d[:8], d[8:]
+    return _index_map(angle_cube(az, el))
+
+
 def angle_cube(az, el):
     """Zero-padded cube M[e, a, d, s] after elevation (rows a=2..5 only) and azimuth FFTs."""
     M = np.zeros((NUM_EL, NUM_AZ, NUM_LOOPS, NUM_SAMPLE), dtype=np.complex128)
@@ -78,16 +117,19 @@ def generate_heatmap(frame, window=0, magnitude=False):
     """
     az, el = demux(frame)
     az, el = range_doppler(az, el, window)
-    M5 = angle_cube(az, el)
-    # out[i, r, a, e] = M5[(3-e)%8, (31-a)%64, (56+i)%64, 94-r]   
+    out = _index_map(angle_cube(az, el))
+    return np.abs(out) if magnitude else out
+
+
+def _index_map(M5):
+    """out[i, r, a, e] = M5[(3-e)%8, (31-a)%64, (56+i)%64, 94-r]   (reference :154-171, :48-52)"""
     e_idx = (3 - np.arange(NUM_EL)) % NUM_EL
     a_idx = (31 - np.arange(NUM_AZ)) % NUM_AZ
     d_idx = (56 + np.arange(NUM_DOPPLER_KEEP)) % NUM_LOOPS
     r_idx = RANGE_HI - np.arange(64)
     out = M5[e_idx[None, None, None, :], a_idx[None, None, :, None],
              d_idx[:, None, None, None], r_idx[None, :, None, None]]
-    out = np.ascontiguousarray(out)
-    return np.abs(out) if magnitude else out
+    return np.ascontiguousarray(out)
 
 
 def generate_heatmap_percell(frame):

@@ -17,14 +17,29 @@ from hupr_amd import functional as F_, synth
 from hupr_amd.config_tree import load_config
 
 
-def scene_batch(batch, rng, gen, device):
-    """One training batch of scenes: noise from the device generator, reflectors from NumPy joints."""
+def scene_batch(batch, rng, gen, device, zero_doppler=None, gen4=None):
+    """One training batch of scenes: noise from the device generator, reflectors from NumPy joints.
+    ``zero_doppler``: what the clutter-nulled Doppler slot f = 4 of both inputs holds (the A/B of VERDICT r3 item 1) — None: the
+    fixture as it always was (noise + the reflectors of its Doppler half); "noise": unit noise and NO reflector, what the
+    reference's Normalize makes of its rounding residue and the chain's default dither reproduces; "zero": zeros, round 3's
+    exact clutter removal.  ``gen4``: with "noise", draw slot 4 from this generator instead — ANOTHER realisation of the same
+    noise in an otherwise identical scene (the reference's residue and the chain's dither are two such realisations)."""
     joints = synth.pose_joints(rng.random((batch, 31)))
     blobs = torch.from_numpy(synth.pose_scene_blobs(joints)).to(device)
     shape = (batch, 8, 8, 2, 64, 64, 8)
     nh = torch.randn(shape, device=device, generator=gen)
     nv = torch.randn(shape, device=device, generator=gen)
     h, v = synth.pose_scene_inputs(blobs, nh, nv)
+    if zero_doppler == "noise":
+        if gen4 is None:
+            h[:, :, 4], v[:, :, 4] = nh[:, :, 4], nv[:, :, 4]
+        else:
+            h[:, :, 4] = torch.randn(nh[:, :, 4].shape, device=device, generator=gen4)
+            v[:, :, 4] = torch.randn(nv[:, :, 4].shape, device=device, generator=gen4)
+    elif zero_doppler == "zero":
+        h[:, :, 4], v[:, :, 4] = 0.0, 0.0
+    elif zero_doppler is not None:
+        raise ValueError(zero_doppler)
     return h.contiguous(), v.contiguous(), torch.from_numpy(joints)
 
 
@@ -36,7 +51,8 @@ def hit_rate(p, joints):
     return (p.reshape(B, 14, -1).argmax(-1) == want).float().mean().item()
 
 
-def fit(steps=600, batch=32, lr=3e-4, math="bf16", model_seed=1, gain=1.0, log_every=100, verbose=True, drops=(0.7, 0.9)):
+def fit(steps=600, batch=32, lr=3e-4, math="bf16", model_seed=1, gain=1.0, log_every=100, verbose=True, drops=(0.7, 0.9),
+        zero_doppler=None):
     """-> (state_dict on the GPU, cfg, log list of (step, loss, loss2)).  Adam at ``lr``, divided by 3 at each fraction of
     ``drops`` of the run (the reference decays its rate too, tools/base.py:49-58)."""
     from hupr_amd.tools.engine import TrainEngine
@@ -57,7 +73,7 @@ def fit(steps=600, batch=32, lr=3e-4, math="bf16", model_seed=1, gain=1.0, log_e
                 for gr in eng.optimizer.param_groups:
                     gr["lr"] = gr["lr"] / 3.0
                 eng.sync_lr()
-            h, v, joints = scene_batch(batch, rng, gen, dev)
+            h, v, joints = scene_batch(batch, rng, gen, dev, zero_doppler)
             loss, loss2 = eng.train_step(h, v, joints)
             if it % log_every == 0 or it == steps - 1:
                 log.append((it, loss.item(), loss2.item()))

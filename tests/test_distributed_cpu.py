@@ -198,8 +198,8 @@ def _uid_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hupr_amd.tools.distributed import RcclTransport
     # two communicators in a row: the second exchange must not read the first one's key
-    a = RcclTransport._exchange_id(bytes([rank + 1] * 128) if rank == 0 else None, None)
-    b = RcclTransport._exchange_id(bytes([7] * 128) if rank == 0 else None, None)
+    a = RcclTransport._exchange_id(bytes([rank + 1] * 128) if rank == 0 else None, None, torch.device("cpu"))
+    b = RcclTransport._exchange_id(bytes([7] * 128) if rank == 0 else None, None, torch.device("cpu"))
     out[rank] = (a, b)
     dist.barrier()
     dist.destroy_process_group()
@@ -222,7 +222,7 @@ def _agree_worker(rank, world, port, out):
     cpu = torch.device("cpu")
     res = [D._all_ok(True, None, cpu), D._all_ok(rank == 0, None, cpu), D._all_ok(rank == 1, None, cpu), D._all_ok(False, None, cpu)]
     # rank 0 could not create an id: it publishes the sentinel, the waiting rank gets it instead of blocking forever
-    got = D.RcclTransport._exchange_id(D._ID_ERROR if rank == 0 else None, None)
+    got = D.RcclTransport._exchange_id(D._ID_ERROR if rank == 0 else None, None, cpu)
     out[rank] = (res, got == D._ID_ERROR)
     dist.barrier()
     dist.destroy_process_group()
@@ -236,3 +236,52 @@ def test_transport_choice_is_a_group_decision_world2():
     out = mp.Manager().dict()
     mp.spawn(_agree_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0] == out[1] == ([True, False, False, False], True)
+
+
+def _no_cpu_backend_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hupr_amd.tools import distributed as D
+    # a group WITHOUT a CPU backend (plain init_process_group("nccl")), imitated on gloo: collectives on ordinary CPU tensors
+    # raise; tensors that went through ``.to(the transport's device)`` — tagged here, the stand-in device being the CPU — pass
+    real_all_reduce, real_to = dist.all_reduce, torch.Tensor.to
+    moved, seen = set(), []
+
+    class _Dev:                                              # what RcclTransport passes as its device
+        type = "cuda"
+
+    def fake_all_reduce(t, *a, **k):
+        if id(t) not in moved:
+            raise RuntimeError("No backend type associated with device type cpu")
+        return real_all_reduce(t, *a, **k)
+
+    def fake_to(self, dev, *a, **k):
+        if isinstance(dev, _Dev):
+            seen.append("moved to the transport's device")
+            r = self.clone()
+            moved.add(id(r))
+            return r
+        return real_to(self, dev, *a, **k)
+
+    dist.all_reduce, torch.Tensor.to = fake_all_reduce, fake_to
+    try:
+        got = D.RcclTransport._exchange_id(bytes([9] * 128) if rank == 0 else None, None, _Dev())
+    finally:
+        dist.all_reduce, torch.Tensor.to = real_all_reduce, real_to
+    out[rank] = (got, list(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_id_exchange_on_a_group_without_a_cpu_backend_world2():
+    """on a group with no CPU backend the agreement flag of the id exchange must fall back to the
+    transport's GPU — it used to be handed torch.device("cpu"), so the fallback was a no-op, RcclTransport failed on every
+    rank, make_transport fell back to torch.distributed and TrainEngine.capture() then refused to run.  An nccl-only group
+    cannot exist on this CPU box; its behaviour (CPU collectives raise) is imitated on gloo and the exchange must still
+    deliver rank 0's id, having moved its flag to the device it was given."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_no_cpu_backend_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0][0] == out[1][0] == bytes([9] * 128)
+    assert out[0][1] == out[1][1] == ["moved to the transport's device"]

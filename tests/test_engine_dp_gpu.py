@@ -125,10 +125,22 @@ def test_graph_captures_the_exchange_step(monkeypatch):
         e2 = TrainEngine(cfg, device=dev, seed=0)
         for _ in range(2):
             e2.train_step_from_adc(adc_h, adc_v, joints)
+        hv = e2.preprocess(adc_h, adc_v)
+        e2.infer(*hv)                                   # fills the host-side inference constants with the weights of step 2
         e2.capture(adc_h, adc_v, joints, warmup=1, decode="device")
         for _ in range(2):
             l2, _ = e2.train_step_from_adc(adc_h, adc_v, joints)
         torch.cuda.synchronize()
+        # the replayed graph's Adam node moves the parameters behind every host-side cache; an evaluation after
+        # replayed steps must see the weights of step 5, not the constants cached at step 2
+        from hupr_amd.models import HuPRNet
+        got = e2.infer(*hv)
+        fresh = HuPRNet(cfg).to(dev).eval()
+        fresh.load_state_dict(e2.model.state_dict())
+        F_.invalidate_packed()
+        with torch.no_grad():
+            want = fresh(*hv)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
         p1, p2 = _flat(e1), _flat(e2)
         assert torch.isfinite(p2).all()
         rel = ((p1 - p2).norm() / p1.norm()).item()

@@ -414,3 +414,53 @@ def test_single_sample_inference_tails_are_bit_identical_and_slicing_is_within_r
         F_.INFER_TAILS = True
         F_.rt.lib().hupr_debug_halo_split_k(1)
         F_.set_math("f32")
+
+
+def test_inference_constants_follow_weight_updates_eager_and_captured():
+    """the host-side inference constants — packed convolution layouts, concatenated MSCSA projection weights,
+    the zero-padded head filter — must follow parameter updates made behind torch's version counters (FusedAdam, a replayed
+    training graph), in eager calls AND in an inference hipGraph captured earlier: its nodes read the cached buffers (no pack
+    launches inside the graph), and ``functional.refresh_packed`` refills exactly those buffers in place."""
+    from hupr_amd import functional as F_
+    from hupr_amd.models import HuPRNet
+    try:
+        cfg, net = _net("bf16")
+        net.eval()
+        h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(1, 17))
+        with torch.no_grad():
+            a0 = tuple(t.clone() for t in net(h, v))                 # fills every cache
+            n_wc = len(F_._wc_cache)
+            assert n_wc >= 7                                         # 6 concatenations + the head filter
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                net(h, v)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = net(h, v)
+            g.replay()
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, a) for o, a in zip(out, a0))
+            assert len(F_._wc_cache) == n_wc                         # the capture created nothing
+            for p in net.parameters():                               # an update torch's version counters do not see
+                p.data.mul_(1.02)
+            F_.invalidate_packed()
+            F_.refresh_packed(h.device)                              # what keeps a captured inference graph current
+            g.replay()
+            torch.cuda.synchronize()
+            got_graph = tuple(t.clone() for t in out)
+            got_eager = net(h, v)
+            fresh = HuPRNet(cfg).cuda().eval()
+            fresh.load_state_dict(net.state_dict())
+            F_.invalidate_packed()
+            want = fresh(h, v)
+            assert not torch.equal(want[1], a0[1])                   # the update is visible at all
+            for i in (0, 1):
+                assert torch.equal(got_eager[i], want[i])
+                assert torch.equal(got_graph[i], want[i])
+        # TrainEngine._replay bumps the epoch itself (its Adam node runs inside the graph): covered by
+        # tests/test_engine_dp_gpu.py::test_graph_captures_the_exchange_step + the eval that follows it there
+    finally:
+        F_.set_math("f32")
+        F_.invalidate_packed()
