@@ -590,6 +590,326 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     else store_ct<DV>(dV + base + (long)key * D + c0, dv, 1.f, dVadd ? dVadd + base + (long)key * D + c0 : nullptr, lh);
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Ping-pong kernels (round 4; D = 64, bf16 operands) — the MSCSA level-1 shape (N = 4096), 88 % of the attention flops
+// ------------------------------------------------------------------------------------------------------
+// What the measurements of rounds 2-3 said about the kernels above at D = 64: per 64-key tile a wave
+// issues 16 MFMAs (512 matrix-pipe cycles) and ~176 VALU instructions (~840 cycles); a second workgroup on the CU adds its own
+// 1 800 cycles per tile instead of hiding in the first one's stalls — the two waves of a SIMD run the same phases in step
+// (matrix beside matrix, soft-max beside soft-max), and a kernel without MFMAs and exponentials still takes 153 of 206 us:
+// register-staged K / V tiles (global -> VGPR -> ds_write, two barriers per tile) and fragment reads in front of their MFMAs.
+// Here a 512-thread workgroup owns 256 queries (32 per wave) and its two wave groups (waves 0-3 / 4-7 = the two waves of every
+// SIMD) are held in ANTI-PHASE by where they take the ONE barrier of a key tile: every wave alternates a soft-max segment (VALU;
+// it also reads its next fragments from LDS) and a matrix segment (S^T of the next key tile and O^T += V^T P^T of the current
+// one: 16 back-to-back MFMAs whose operands are already in registers); group 0 meets the barrier after its matrix segment,
+// group 1 between its two segments, so that one wave of a SIMD multiplies while its partner exponentiates.  (Two barriers per
+// tile — strict alternation — was the first build: the soft-max segments, 1 300-1 650 cycles against 600 for the MFMAs, then
+// run one after the other and the matrix pipe idles two thirds of the time; stamps in profiles/r04_attn_pp_trace.txt.)
+//   * K / V tiles travel global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, the swizzle applied on the source side) through
+//     a ring of eight 16 KB slots, four tiles ahead: no staging registers, no ds_write, no barrier of their own (each wave
+//     covers its own pieces with a counted vmcnt before the tile barrier; a slot is rewritten five tiles after its last read);
+//   * the soft-max works on score PAIRS (v_pk_fma_f32 / v_pk_add_f32, v_max3_f32) and exchanges the half-waves' maxima with one
+//     v_permlane32_swap instead of an LDS shuffle: ~105 VALU instructions per tile;
+//   * the workgroups of one sample share an XCD (one L2 fetches its K / V once: 1 MB per sample instead of up to 8);
+//   * same tile order, same running maximum and the same bf16 rounding of P as the kernels above: results equal up to the
+//     association of the row sums.
+typedef float v2fa __attribute__((ext_vector_type(2)));
+constexpr int kPPRing = 8, kPPAhead = 4;
+
+__device__ __forceinline__ void pp_dma(unsigned m0val, int voff, u32x4a rsrc, int soff) {
+    unsigned keep;
+    m0val = __builtin_amdgcn_readfirstlane(m0val);          // wave-uniform by construction; the "s" constraint does not enforce it
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(m0val), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+// all but the youngest N_ vector-memory operations of this wave have completed (vmcnt is 6 bits: [3:0] and [15:14])
+#define HUPR_PP_VMCNT(N_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N_) & 15) | (((N_) >> 4) << 14))
+#define HUPR_PP_BARRIER()                    \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ u32x4a pp_rsrc(const void* base, long bytes) {
+    return (u32x4a){(unsigned)(unsigned long)base, (unsigned)((unsigned long)base >> 32) & 0xffffu, (unsigned)bytes, 0x00020000u};
+}
+
+// lane -> (sample, query block) of a 1-D grid: workgroup id L runs on XCD L % 8; the query blocks of one sample stay on one XCD
+__device__ __forceinline__ void pp_block(int nqb, int Bn, int& b, int& qb) {
+    const int L = blockIdx.x;
+    if (Bn % 8 == 0) {
+        const int idx = L >> 3;
+        qb = idx % nqb;
+        b = (L & 7) + 8 * (idx / nqb);
+    } else {
+        qb = L % nqb;
+        b = L / nqb;
+    }
+}
+
+template <int abl>
+__global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __restrict__ K, const __bf16* __restrict__ Q,
+                                                              const __bf16* __restrict__ V, const float* __restrict__ Vres,
+                                                              float* __restrict__ out, float* __restrict__ lse, int N, int Bn, int ldk,
+                                                              int ldq, __bf16* __restrict__ out16, int ld16,
+                                                              unsigned long long* __restrict__ trace) {
+    // abl (compile-time; profiling only, wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no exponentials, 8 no maxima,
+    // 16 no MFMAs, 32 no tile barrier, 64 no epilogue stores (scripts/attn_pp_ablate.py)
+    constexpr int D = 64;
+    __shared__ __attribute__((aligned(1024))) __bf16 ring[kPPRing][2][64 * D];      // [slot][K image, V image]
+    // profiling (scripts/attn_pp_trace.py): s_memtime stamps of waves 0 and 4 of workgroup 0, five per key tile
+    const bool tracing = trace != nullptr && blockIdx.x == 0 && (threadIdx.x >> 6) % 4 == 0;
+    unsigned long long* tr = trace + (threadIdx.x >> 8) * 4096;
+    int tslot = 0;
+#define HUPR_PP_STAMP()                                                             \
+    if (tracing) {                                                                  \
+        const unsigned long long t__ = __builtin_amdgcn_s_memtime();                \
+        if ((threadIdx.x & 63) == 0 && tslot < 4096) tr[tslot] = t__;               \
+        ++tslot;                                                                    \
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int grp = wave >> 2;
+    // static issue priority for one of the two waves of each SIMD (abl 128: none, 256: waves 4-7 instead of 0-3).  Stamps of the
+    // equal-priority build: wave 0's tile 1 820 cycles + 860 at the barrier, wave 4's 2 470 + 220; measured 171.1 (waves 4-7) /
+    // 171.5 (none) / 167.4 us (waves 0-3)
+    if (!(abl & 128) && (grp == 0) == !(abl & 256)) __builtin_amdgcn_s_setprio(1);
+    int b, qb;
+    pp_block(N / 256, Bn, b, qb);
+    const long base = (long)b * N * D;
+    const int q = qb * 256 + wave * 32 + lr;                  // this lane's query
+    const int nt = N / 64;
+    bf16x8 qf[4];
+    load_frags<D, __bf16>(qf, Q + ((long)b * N + q) * ldq, lh);
+
+    // LDS-DMA: wave w deposits rows 8 w .. 8 w + 7 of the K image and of the V image of a tile (1 KiB each); lane l fills row
+    // 8 w + (l >> 3), chunk position l & 7, with source chunk (l & 7) ^ key(row)
+    const int prow = 8 * wave + (lane >> 3);
+    const int pchunk = (lane & 7) ^ Img<D>::key(prow);
+    const int kvoff = (prow * ldk + pchunk * 8) * 2, vvoff = (prow * D + pchunk * 8) * 2;
+    const u32x4a krs = pp_rsrc(K + (long)b * N * ldk, (long)N * ldk * 2), vrs = pp_rsrc(V + base, (long)N * D * 2);
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&ring[0][0][0];
+    const unsigned piece = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+#define HUPR_PP_ISSUE(TILE_)                                                                    \
+    {                                                                                           \
+        const int tl_ = min((TILE_), nt - 1), sl_ = (TILE_) & (kPPRing - 1);                    \
+        pp_dma(piece + sl_ * 16384, kvoff, krs, tl_ * 64 * ldk * 2);                            \
+        pp_dma(piece + sl_ * 16384 + 8192, vvoff, vrs, tl_ * 64 * D * 2);                       \
+    }
+    // per-lane fragment addresses inside a slot (bf16 elements)
+    int koff[4];                                              // K rows 32 t + lr, K-step ks: + t * 32 * D
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = Img<D>::off(lr, 2 * ks + lh);
+    const int g = lane >> 4, s16 = lane & 15, h = g >> 1;
+    const int col = 16 * (g & 1) + 4 * (s16 & 3), rsub = s16 >> 2;
+    int voff0[2], voff1[2];                                   // V rows row0 = 4 h + rsub (+ 32 t + 16 u), row1 = row0 + 8; channel tile ct
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int c = 32 * ct + col;
+        voff0[ct] = Img<D>::off(4 * h + rsub, c >> 3) + (c & 4);
+        voff1[ct] = Img<D>::off(4 * h + rsub + 8, c >> 3) + (c & 4);
+    }
+
+    f32x16 o[2], st[2][2];                                    // st[parity]: S^T of the current tile / of the next one
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    bf16x8 kf[2][4], vf[2][2][2], pb[2][2][2];                // pb[parity]: P^T of the current tile / of the previous one
+
+#define HUPR_PP_READ_K(SLOT_)                                                                                      \
+    {                                                                                                              \
+        const __bf16* ki_ = &ring[SLOT_][0][0];                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                           \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
+                kf[t][ks] = *reinterpret_cast<const bf16x8*>(ki_ + koff[ks] + t * 32 * D);                         \
+    }
+#define HUPR_PP_READ_V(SLOT_)                                                                                      \
+    {                                                                                                              \
+        const __bf16* vi_ = &ring[SLOT_][1][0];                                                                    \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                              \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                          \
+                _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                                 \
+                    const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                     \
+                        (__attribute__((address_space(3))) s16x4*)(vi_ + voff0[ct] + (32 * t + 16 * u) * D));     \
+                    const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                     \
+                        (__attribute__((address_space(3))) s16x4*)(vi_ + voff1[ct] + (32 * t + 16 * u) * D));     \
+                    union { struct { s16x4 a, b; } s2; bf16x8 v; } uu_;                                            \
+                    uu_.s2.a = lo_;                                                                                \
+                    uu_.s2.b = hi_;                                                                                \
+                    vf[t][u][ct] = uu_.v;                                                                          \
+                }                                                                                                  \
+    }
+#define HUPR_PP_S(DST_)                                                                                            \
+    {                                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                              \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) st[DST_][t][r] = 0.f;                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                           \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
+                st[DST_][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], st[DST_][t], 0, 0, 0);    \
+    }
+#define HUPR_PP_PV(SRC_)                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                              \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                       \
+                o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][u][ct], pb[SRC_][t][u], o[ct], 0, 0, 0);
+
+    // prologue: kPPAhead tiles in flight, the first two landed and published
+    HUPR_PP_ISSUE(0)
+    HUPR_PP_ISSUE(1)
+    HUPR_PP_ISSUE(2)
+    HUPR_PP_ISSUE(3)
+    HUPR_PP_VMCNT(4);
+    HUPR_PP_BARRIER();
+    HUPR_PP_READ_K(0)
+    HUPR_PP_S(0)
+
+    // One key tile j, software-pipelined INSIDE the wave: the soft-max of tile j (VALU: st[CUR_] -> pb[CUR_]) is interleaved,
+    // instruction group by instruction group, with the MFMAs of its neighbours, which do not depend on it — O^T += V^T P^T of
+    // tile j - 1 (pb[NXT_], V fragments read at the end of the previous iteration) under the row maxima, S^T of tile j + 1
+    // (-> st[NXT_]) under the exponentials.  A wave issues a VALU instruction every ~5 cycles at best (8.4 when dependent,
+    // v_exp_f32 9-12: scripts/probes/valu_issue_probe.hip) while a 32x32x16 MFMA occupies the matrix pipe for 32 cycles: five to
+    // six VALU instructions fit in the shadow of each MFMA of the SAME wave, whereas two waves that alternate whole phases each
+    // wait out their own issue latencies (the first builds of this kernel: soft-max segment 1 300-1 500 cycles, matrix segment
+    // 600, a tile 2 900).  hipcc does not build such a schedule from sched_group_barrier patterns here (it clumped the sixteen
+    // MFMAs behind the maxima, each behind its own lgkmcnt(0)), so the order is written out: one MFMA + its share of the VALU
+    // work per group, groups fenced with sched_barrier(0).  FIRST_ / LAST_ (compile-time): no previous tile / no next tile.
+#define HUPR_SB() __builtin_amdgcn_sched_barrier(0)
+#define HUPR_PVM(T_, U_, CT_)                                                                                              \
+    if (!(FIRST__) && !(abl & 16)) o[CT_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[T_][U_][CT_], pb[NXT__][T_][U_], o[CT_], 0, 0, 0);
+    // The MFMA of a group is pinned between two empty asm statements through its A operand: the first one "defines" the fragment
+    // (after the previous group's statement), the second one "redefines" it, so the MFMA that reads it sits in between — without
+    // the statements the instruction selector linearises all eight MFMAs behind the exponentials (their results are needed last).
+#define HUPR_SM(KS_, T_)                                                                                                   \
+    if (!(LAST__) && !(abl & 16)) {                                                                                        \
+        asm volatile("" : "+v"(kf[T_][KS_]));                                                                              \
+        if ((KS_) == 0) st[NXT__][T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T_][0], qf[0], zero16, 0, 0, 0);        \
+        else st[NXT__][T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T_][KS_], qf[KS_], st[NXT__][T_], 0, 0, 0);        \
+        asm volatile("" : "+v"(kf[T_][KS_]));                                                                              \
+    }
+#define HUPR_M3(A_, B_, C_) fmaxf(fmaxf(A_, B_), C_)
+    // scores 2 P_, 2 P_ + 1 of the current tile (P_ = 0..15: t = P_ >> 3, u = (P_ >> 2) & 1, i = 2 (P_ & 3))
+#define HUPR_PAIR(P_)                                                                                                      \
+    {                                                                                                                      \
+        constexpr int t_ = (P_) >> 3, u_ = ((P_) >> 2) & 1, i_ = 2 * ((P_) & 3);                                           \
+        v2fa s2_ = {st[CUR__][t_][8 * u_ + i_], st[CUR__][t_][8 * u_ + i_ + 1]};                                           \
+        asm volatile("" : "+v"(s2_));                                                                                      \
+        const v2fa e2_ = __builtin_elementwise_fma(s2_, l2e2, nm2);                                                        \
+        const float p0_ = (abl & 4) ? e2_.x : __builtin_amdgcn_exp2f(e2_.x);                                               \
+        const float p1_ = (abl & 4) ? e2_.y : __builtin_amdgcn_exp2f(e2_.y);                                               \
+        sum2[(P_) & 1] += (v2fa){p0_, p1_};                                                                                \
+        pb[CUR__][t_][u_][i_] = (__bf16)p0_;                                                                               \
+        pb[CUR__][t_][u_][i_ + 1] = (__bf16)p1_;                                                                           \
+        if (((P_) & 1) == 1) asm volatile("" : "+v"(sum2[0]), "+v"(sum2[1]));                                              \
+    }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define HUPR_PP_TILE(CUR_, NXT_, FIRST_, LAST_)                                                                            \
+    {                                                                                                                      \
+        constexpr int CUR__ = CUR_, NXT__ = NXT_;                                                                          \
+        constexpr bool FIRST__ = FIRST_, LAST__ = LAST_;                                                                   \
+        HUPR_PP_STAMP()                                                                                                    \
+        if (!(abl & 1)) { HUPR_PP_ISSUE(j + kPPAhead) }                                                                    \
+        if (!(abl & 2) && !LAST__) { HUPR_PP_READ_K((j + 1) & (kPPRing - 1)) }                                             \
+        HUPR_SB();                                                                                                         \
+        /* ---- row maxima of tile j under O^T += V^T P^T of tile j - 1 (four independent chains) ---- */                  \
+        const f32x16& s0_ = st[CUR__][0];                                                                                  \
+        const f32x16& s1_ = st[CUR__][1];                                                                                  \
+        float ma_, mb_, mc_, md_;                                                                                          \
+        HUPR_PVM(0, 0, 0) ma_ = HUPR_M3(s0_[0], s0_[1], s0_[2]); mb_ = HUPR_M3(s0_[8], s0_[9], s0_[10]); HUPR_SB();        \
+        HUPR_PVM(0, 0, 1) mc_ = HUPR_M3(s1_[0], s1_[1], s1_[2]); md_ = HUPR_M3(s1_[8], s1_[9], s1_[10]); HUPR_SB();        \
+        HUPR_PVM(0, 1, 0) ma_ = HUPR_M3(ma_, s0_[3], s0_[4]); mb_ = HUPR_M3(mb_, s0_[11], s0_[12]); HUPR_SB();             \
+        HUPR_PVM(0, 1, 1) mc_ = HUPR_M3(mc_, s1_[3], s1_[4]); md_ = HUPR_M3(md_, s1_[11], s1_[12]); HUPR_SB();             \
+        HUPR_PVM(1, 0, 0) ma_ = HUPR_M3(ma_, s0_[5], s0_[6]); mb_ = HUPR_M3(mb_, s0_[13], s0_[14]); HUPR_SB();             \
+        HUPR_PVM(1, 0, 1) mc_ = HUPR_M3(mc_, s1_[5], s1_[6]); md_ = HUPR_M3(md_, s1_[13], s1_[14]); HUPR_SB();             \
+        HUPR_PVM(1, 1, 0) ma_ = HUPR_M3(ma_, s0_[7], mb_); mc_ = HUPR_M3(mc_, s1_[7], md_); HUPR_SB();                     \
+        HUPR_PVM(1, 1, 1) ma_ = HUPR_M3(ma_, s0_[15], s1_[15]);                                                            \
+        float mx = (abl & 8) ? ma_ : fmaxf(ma_, mc_);                                                                      \
+        if (!(abl & 8)) {                                                                                                  \
+            /* the other half-wave holds the other 32 keys: v_permlane32_swap leaves the lower half-wave's maximum in every  */ \
+            /* lane of its first register and the upper one's in the second.  Written as asm: through the builtin hipcc       */ \
+            /* dropped the second result (max(r0, r1) compiled to r0 alone, the upper half-wave's maximum was lost — results  */ \
+            /* stayed normalised, P was rounded relative to the wrong maximum; found with scripts/attn_pp_ab.py)             */ \
+            unsigned ua_ = __builtin_bit_cast(unsigned, mx), ub_ = ua_;                                                    \
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ua_), "+v"(ub_));                       \
+            mx = fmaxf(__builtin_bit_cast(float, ua_), __builtin_bit_cast(float, ub_));                                    \
+        }                                                                                                                  \
+        const float m_new = fmaxf(m_run, mx);                                                                              \
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);                                              \
+        const float nm = -m_new * kLog2e;                     /* exp(s - m) = 2^(s log2e - m log2e) */                     \
+        const v2fa nm2 = {nm, nm}, l2e2 = {kLog2e, kLog2e};                                                                \
+        v2fa sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};                                                                           \
+        HUPR_SB();                                                                                                         \
+        /* ---- exponentials of tile j under S^T of tile j + 1: one MFMA + two score pairs per group ---- */               \
+        HUPR_SM(0, 0) HUPR_PAIR(0) HUPR_PAIR(1) HUPR_SB();                                                                 \
+        HUPR_SM(0, 1) HUPR_PAIR(2) HUPR_PAIR(3) HUPR_SB();                                                                 \
+        HUPR_SM(1, 0) HUPR_PAIR(4) HUPR_PAIR(5) HUPR_SB();                                                                 \
+        HUPR_SM(1, 1) HUPR_PAIR(6) HUPR_PAIR(7) HUPR_SB();                                                                 \
+        HUPR_SM(2, 0) HUPR_PAIR(8) HUPR_PAIR(9) HUPR_SB();                                                                 \
+        HUPR_SM(2, 1) HUPR_PAIR(10) HUPR_PAIR(11) HUPR_SB();                                                               \
+        HUPR_SM(3, 0) HUPR_PAIR(12) HUPR_PAIR(13) HUPR_SB();                                                               \
+        HUPR_SM(3, 1) HUPR_PAIR(14) HUPR_PAIR(15)                                                                          \
+        /* (the empty asm statements keep LLVM from sinking the exponentials into the NEXT iteration, next to the MFMAs that */ \
+        /* consume them: seen twice)                                                                                      */ \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                      \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(pb[CUR__][t][u]));                        \
+        asm volatile("" : "+v"(sum2[0]), "+v"(sum2[1]));                                                                   \
+        HUPR_SB();                                                                                                         \
+        /* ---- tail: the V fragments of tile j for the next iteration, the row sum, the (rare) rescale ---- */            \
+        if (!(abl & 2)) { HUPR_PP_READ_V(j & (kPPRing - 1)) }                                                              \
+        sum2[0] += sum2[1];                                                                                                \
+        l_run = l_run * alpha + (sum2[0].x + sum2[0].y);                                                                   \
+        m_run = m_new;                                                                                                     \
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {      /* rare after the first tiles; behind the MFMAs of tile j - 1 */ \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                               \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;                                          \
+        }                                                                                                                  \
+        HUPR_PP_STAMP()                                                                                                    \
+        if (!(abl & 32)) {                                                                                                 \
+            HUPR_PP_VMCNT(4);                                 /* this wave's pieces of tile j + 2 have landed */           \
+            HUPR_PP_BARRIER();                                                                                             \
+        }                                                                                                                  \
+    }
+    int j = 0;
+    HUPR_PP_TILE(0, 1, true, false)
+    for (j = 1; j < nt - 1; j += 2) {
+        HUPR_PP_TILE(1, 0, false, false)
+        ++j;
+        HUPR_PP_TILE(0, 1, false, false)
+        --j;
+    }
+    j = nt - 1;
+    HUPR_PP_TILE(1, 0, false, true)
+#undef HUPR_PP_TILE
+    {                                                         // the last tile's O^T += V^T P^T (its V fragments were read in its tail)
+        constexpr int NXT__ = 1;
+        constexpr bool FIRST__ = false;
+        HUPR_PVM(0, 0, 0) HUPR_PVM(0, 0, 1) HUPR_PVM(0, 1, 0) HUPR_PVM(0, 1, 1)
+        HUPR_PVM(1, 0, 0) HUPR_PVM(1, 0, 1) HUPR_PVM(1, 1, 0) HUPR_PVM(1, 1, 1)
+    }
+#undef HUPR_PVM
+#undef HUPR_SM
+#undef HUPR_M3
+#undef HUPR_PAIR
+#undef HUPR_SB
+    HUPR_PP_VMCNT(0);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (!(abl & 64)) {
+    store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
+    if (out16)
+        store_ct16<D>(out16 + ((long)b * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
+    }
+    if (lh == 0) lse[(long)b * N + q] = m_run + __logf(l_tot) + ((abl & 64) ? o[0][0] + o[1][5] : 0.f);
+#undef HUPR_PP_ISSUE
+#undef HUPR_PP_READ_K
+#undef HUPR_PP_READ_V
+#undef HUPR_PP_S
+#undef HUPR_PP_PV
+#undef HUPR_PP_STAMP
+}
+
 }  // namespace hupr
 
 using namespace hupr;
@@ -604,6 +924,10 @@ extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C =
 // widens it to every grid below 128 workgroups, -1 switches it off.
 static int g_attn_split = 0;
 extern "C" void hupr_debug_attn_split(int mode) { g_attn_split = mode; }
+static int g_attn_pp = 1;      // A/B aid: 0 = the rounds-1-3 kernels for the D = 64 shapes too; bits 4.. = phase ablations of the ping-pong kernels (timing only)
+extern "C" void hupr_debug_attn_pingpong(int on) { g_attn_pp = on; }
+static unsigned long long* g_attn_trace = nullptr;      // profiling: device buffer of 3 x 2 x 4096 s_memtime stamps (fwd, dQ, dK/dV) or null
+extern "C" void hupr_debug_attn_trace(void* buf) { g_attn_trace = static_cast<unsigned long long*>(buf); }
 static int attn_splits(int Bn, int N) {
     const long wgs = (long)Bn * (N / 128);
     if (wgs >= 128 || g_attn_split < 0 || (g_attn_split == 0 && Bn != 1)) return 1;
@@ -628,6 +952,32 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     __bf16* o16 = static_cast<__bf16*>(out16);
     float* const np = nullptr;
     const int S = ws ? attn_splits(Bn, N) : 1;
+    if constexpr (sizeof(TI) == 2) {
+        // level-1 shape: the ping-pong kernel (256 queries per 512-thread workgroup, LDS-DMA ring)
+        if (S <= 1 && C == 64 && N % 256 == 0 && N >= 256 && g_attn_pp && (long)N * ldk * 2 < (1L << 31)) {
+#define HUPR_PP_FWD(A_) hipLaunchKernelGGL(hupr_k_attn_fwd_pp64<A_>, dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, \
+                                           out, lse, N, Bn, ldk, ldq, o16, ld16, g_attn_trace)
+            switch (g_attn_pp >> 4) {
+                case 0: HUPR_PP_FWD(0); break;
+                case 1: HUPR_PP_FWD(1); break;
+                case 2: HUPR_PP_FWD(2); break;
+                case 4: HUPR_PP_FWD(4); break;
+                case 8: HUPR_PP_FWD(8); break;
+                case 16: HUPR_PP_FWD(16); break;
+                case 31: HUPR_PP_FWD(31); break;
+                case 27: HUPR_PP_FWD(27); break;
+                case 23: HUPR_PP_FWD(23); break;
+                case 64: HUPR_PP_FWD(64); break;
+                case 127: HUPR_PP_FWD(127); break;
+                case 128: HUPR_PP_FWD(128); break;
+                case 256: HUPR_PP_FWD(256); break;
+                default: return fail(HUPR_ERR_ARG, "hupr_k_attn_fwd_pp64: ablation %d is not instantiated", g_attn_pp >> 4);
+            }
+#undef HUPR_PP_FWD
+            HUPR_LAUNCH_OK("hupr_k_attn_fwd_pp64");
+            return HUPR_OK;
+        }
+    }
     if (S > 1) {
         HUPR_REQUIRE(ws_bytes >= hupr_attn_fwd_split_ws_bytes(Bn, N, C), "%s: workspace too small", who);
         const long rows = (long)Bn * N;

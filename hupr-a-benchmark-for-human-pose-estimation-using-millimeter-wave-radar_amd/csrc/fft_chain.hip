@@ -314,15 +314,27 @@ __device__ __forceinline__ v2f zero_doppler_dither(v2f chirp_sum, int vant, int 
     return (v2f){(float)(int16_t)(h & 0xffffu) * kScale, (float)((int32_t)h >> 16) * kScale};
 }
 
-template <int WIN, bool HALF>
-__global__ __launch_bounds__(256) void hupr_k_doppler_range(const int16_t* __restrict__ iq, float2* __restrict__ rd, int zd_exact) {
+template <int WIN, bool HALF, int AUX = 0>
+__global__ __launch_bounds__(256) void hupr_k_doppler_range(const int16_t* __restrict__ iq, float2* __restrict__ rd, int zd_exact, int n_items,
+                                                            int grouped) {
     constexpr int kPitch = 272;                      // v2f per Doppler row: 2 x 272 = 32 (mod 64) banks, and = 16 x 17
     constexpr int kRows = HALF ? 8 : kDop, kRow0 = HALF ? 4 : 0;
     __shared__ v2f tw[256];                          // W_256^t
     __shared__ v2f tile[kRows * kPitch];             // [doppler i - kRow0][sample]; a row doubles as its group's transpose scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sf = blockIdx.x / kVant, vant = blockIdx.x % kVant;
+    // work item = (sensor-frame, virtual antenna).  grouped: the three antennas that share a receiver (TX1 / TX3 / TX2 = chirps
+    // 3 c + 0 / 2 / 1 of the SAME 192 KB block of the cube, interleaved row by row) run back to back on ONE XCD (workgroup id ->
+    // XCD is id % 8), so that the three passes over a block reach the memory controller together instead of from three XCDs at
+    // three different times
+    int item = blockIdx.x;
+    if (grouped) {
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;       // XCD, position in the XCD's sequence
+        const int g = (k / 3) * 8 + x, t3 = k % 3;               // (sensor-frame, receiver) group, which of its three antennas
+        item = (g >> 2) * kVant + (g & 3) + 4 * t3;
+        if (item >= n_items) return;
+    }
+    const int sf = item / kVant, vant = item % kVant;
     const int rx = vant & 3;
     const int tx = (vant < 4) ? 0 : (vant < 8 ? 2 : 1);          // TDM demux (reference :113-120)
     tw[tid] = reinterpret_cast<const v2f*>(kTw256)[tid];
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256) void hupr_k_doppler_range(const int16_t* __res
         const_cast<int16_t*>(iq) + (size_t)(sf * kRx + rx) * kChirps * kSamples * 2, 0, kChirps * kRowBytes, 0x00020000);
     int32_t raw[64];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) raw[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, (3 * c + tx) * kRowBytes, 0);
+    for (int c = 0; c < 64; ++c) raw[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, (3 * c + tx) * kRowBytes, AUX);
     v2f mean = (v2f){0.f, 0.f};
     float wr = 1.0f;
     if constexpr (WIN != 0) {
@@ -681,6 +693,8 @@ extern "C" size_t hupr_fft_chain_ws_bytes(int n_sf) {
     return (size_t)n_sf * kDop * kRange * kVant * sizeof(float2);
 }
 
+static int g_fft_variant = 0;          // A/B aid: bit 0 = non-temporal ADC loads, bit 1 = antenna groups ordered per XCD
+extern "C" void hupr_debug_fft_variant(int v) { g_fft_variant = v; }
 static int g_fft_range_first = 0;      // A/B aid: 1 = the round-1/2 range-first kernel
 extern "C" void hupr_debug_fft_range_first(int on) { g_fft_range_first = on; }
 
@@ -711,17 +725,24 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
             default: hipLaunchKernelGGL(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
         }
     } else {
-        const dim3 g1(n_sf * kVant), b1(256);
+        // grouped order: (sensor-frame, receiver) groups x 3 antennas, one group per XCD slot; the grid is padded to a multiple of 24
+        const int n_items = n_sf * kVant, grouped = (g_fft_variant & 2) ? 1 : 0;
+        const int n_groups = n_sf * 4;
+        const dim3 g1(grouped ? ((n_groups + 7) / 8) * 24 : n_items), b1(256);
+#define HUPR_DR(W_, H_)                                                                                                      \
+        if (g_fft_variant & 1) hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 2>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped); \
+        else hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 0>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped)
         switch ((flags & 3) | (loader ? 4 : 0)) {
-            case 0: hipLaunchKernelGGL((hupr_k_doppler_range<0, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
-            case 1: hipLaunchKernelGGL((hupr_k_doppler_range<1, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
-            case 2: hipLaunchKernelGGL((hupr_k_doppler_range<2, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
-            case 3: hipLaunchKernelGGL((hupr_k_doppler_range<3, false>), g1, b1, 0, s, adc_iq, rd, zd); break;
-            case 4: hipLaunchKernelGGL((hupr_k_doppler_range<0, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
-            case 5: hipLaunchKernelGGL((hupr_k_doppler_range<1, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
-            case 6: hipLaunchKernelGGL((hupr_k_doppler_range<2, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
-            default: hipLaunchKernelGGL((hupr_k_doppler_range<3, true>), g1, b1, 0, s, adc_iq, rd, zd); break;
+            case 0: HUPR_DR(0, false); break;
+            case 1: HUPR_DR(1, false); break;
+            case 2: HUPR_DR(2, false); break;
+            case 3: HUPR_DR(3, false); break;
+            case 4: HUPR_DR(0, true); break;
+            case 5: HUPR_DR(1, true); break;
+            case 6: HUPR_DR(2, true); break;
+            default: HUPR_DR(3, true); break;
         }
+#undef HUPR_DR
     }
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
     if (loader && means)

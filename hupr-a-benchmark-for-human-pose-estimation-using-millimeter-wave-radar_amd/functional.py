@@ -1228,7 +1228,8 @@ def _wc_refresh(device):
 
 def _cat_build(ws, out):
     C = ws[0].shape[0]
-    return torch.cat([w.reshape(C, C) for w in ws], 0, out=out) if out is not None else torch.cat([w.reshape(C, C) for w in ws], 0)
+    parts = [w.detach().reshape(C, C) for w in ws]
+    return torch.cat(parts, 0, out=out) if out is not None else torch.cat(parts, 0)
 
 
 def _cat_weights(ws, C, cache):
@@ -1243,13 +1244,13 @@ def head_weight16(weight, num_keypoints):
     """The 1x1 head's filters zero-padded to 16 output channels (later kernels stay float4-aligned).  Under no_grad the padded copy is
     kept across calls like the concatenated projection weights (one pad launch less per inference forward)."""
     def build(ws, out):
-        w = ws[0]
+        w = ws[0].detach()
         if out is None:
             return torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 16 - w.shape[0]))
         out[:w.shape[0]].copy_(w)
         return out
-    if torch.is_grad_enabled():
-        return build((weight,), None)
+    if torch.is_grad_enabled():                                 # training: an ordinary differentiable pad
+        return torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, 16 - num_keypoints))
     assert weight.shape[0] == num_keypoints
     return _wc_get("head16", (weight,), build)
 

@@ -55,6 +55,9 @@ SIGNATURES = {
     "hupr_bn_train_finalize_f32": (c_int, [c_void_p, c_int, c_long, c_int] + [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 5),
     "hupr_pack_conv_weights_table": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hupr_debug_fft_range_first": (None, [c_int]),
+    "hupr_debug_fft_variant": (None, [c_int]),
+    "hupr_debug_attn_pingpong": (None, [c_int]),
+    "hupr_debug_attn_trace": (None, [c_void_p]),
     "hupr_debug_halo_ablate": (None, [c_int]),
     "hupr_debug_halo_variant": (None, [c_int]),
     "hupr_debug_halo_small_tiles": (None, [c_int]),

@@ -61,7 +61,8 @@ if len(sys.argv) > 2 and sys.argv[2] in ("cold", "detail"):
     def one(x):
         rt.check(rt.lib().hupr_fft_chain_loader_means_f32(rt.ptr(x), half, rt.ptr(om), rt.ptr(ws), ws.numel(), rt.stream()))
 
-    for cold in (False, True):
+    for variant, cold in [(vv, cc) for vv in (0, 1, 2, 3) for cc in (False, True)]:
+        rt.lib().hupr_debug_fft_variant(variant)
         ts = []
         for i in range(12):
             if cold:
@@ -73,6 +74,7 @@ if len(sys.argv) > 2 and sys.argv[2] in ("cold", "detail"):
             torch.cuda.synchronize()
             ts.append(s.elapsed_time(e) * 1e3)
         med = sorted(ts[2:])[len(ts[2:]) // 2]
-        print("%s, %d sensor-frames per call: per-call us %s  median %.1f us = %.0f GB/s (%.3f of 8 TB/s)" %
-              ("cold (4 GB fill between calls)" if cold else "warm (back to back)", half, " ".join("%.0f" % t for t in ts), med,
+        print("variant %d (bit 0 nt loads, bit 1 per-XCD antenna groups) %s, %d sensor-frames per call: per-call us %s  median %.1f us = %.0f GB/s (%.3f of 8 TB/s)" %
+              (variant, "cold (4 GB fill between calls)" if cold else "warm (back to back)", half, " ".join("%.0f" % t for t in ts), med,
                half * b_m / n_sf / med / 1e3, half * b_m / n_sf / med / 1e3 / 8000))
+    rt.lib().hupr_debug_fft_variant(0)

@@ -375,6 +375,65 @@ def make_contract(net, cfg):
     print("contract ok", len(contract["state_dict"]), "keys")
 
 
+def make_plot():
+    """plotHumanPose (misc/plot.py:14-80) on a black camera frame: cv2 and torchvision are not installed here, so this is a
+    RESTATEMENT of the reference's call sequence with OpenCV's rasterisation written out from its documented algorithm —
+      make_grid(single image, padding 2, normalize=True) -> the image itself, 256 x 256, no border        (:31; torchvision.utils)
+      joint += padding; cv2.circle(ndarr, joint, 2, [255, 0, 0], 2)                                        (:41-46)
+        thickness > 1 -> EllipseEx: ellipse2Poly with delta 90 for radius 2 = the diamond (x+-2, y), (x, y+-2), drawn as a
+        closed poly-line with a 2-pixel pen: the pixels at L1 distance 1..3 from the centre
+      cv2.line(ndarr, a, b, [255, 0, 0], 1) for the 14 edges, [0, 255, 0] for the four box sides          (:48-74)
+        LINE_8 LineIterator: dx + 1 points along the major axis, err = dx - 2 dy, diagonal step while err < 0
+    independent of hupr_amd/misc/plot.py (which is what the fixture pins).  Stored: joints, box, and the red / green pixel sets."""
+    import numpy as np
+    from hupr_amd import synth
+
+    def line(p0, p1):
+        (x0, y0), (x1, y1) = p0, p1
+        dx, dy = abs(x1 - x0), abs(y1 - y0)
+        sx, sy = (1 if x1 >= x0 else -1), (1 if y1 >= y0 else -1)
+        swap = dy > dx
+        if swap:
+            dx, dy = dy, dx
+        err, plus, minus = dx - (dy + dy), dx + dx, -(dy + dy)
+        x, y, pts = x0, y0, []
+        for _ in range(dx + 1):
+            pts.append((x, y))
+            mask = err < 0
+            err += minus + (plus if mask else 0)
+            if swap:
+                y += sy
+                x += sx if mask else 0
+            else:
+                x += sx
+                y += sy if mask else 0
+        return pts
+
+    joints = synth.pose_joints(synth.uniform01(2 * 31, "plot_fixture").reshape(2, 31)).astype(np.float64)
+    bbox = np.array([[20., 30., 200., 180.], [60.5, 41.2, 120.7, 190.9]])
+    edges = [(0, 1), (1, 2), (0, 3), (3, 4), (4, 5), (0, 6), (3, 6), (6, 7), (6, 8), (6, 11), (8, 9), (9, 10), (11, 12), (12, 13)]
+    out = {"joints": joints, "bbox": bbox}
+    for b in range(2):
+        img = np.zeros((256, 256, 3), np.uint8)
+        def put(pts, col):
+            for x, y in pts:
+                if 0 <= x < 256 and 0 <= y < 256:
+                    img[y, x] = col
+        jj = [(int(2 + x), int(2 + y)) for x, y in joints[b]]
+        for x, y in jj:
+            put([(x + u, y + v) for u in range(-3, 4) for v in range(-3, 4) if 1 <= abs(u) + abs(v) <= 3], (255, 0, 0))
+        for i, k in edges:
+            put(line(jj[i], jj[k]), (255, 0, 0))
+        x0, y0, w, h = bbox[b]
+        tl, tr, bl, br = (int(x0), int(y0)), (int(x0 + w), int(y0)), (int(x0), int(y0 + h)), (int(x0 + w), int(y0 + h))
+        for p, q in ((tl, tr), (tl, bl), (tr, br), (bl, br)):
+            put(line(p, q), (0, 255, 0))
+        out["red_%d" % b] = np.argwhere((img == (255, 0, 0)).all(-1)).astype(np.int16)
+        out["green_%d" % b] = np.argwhere((img == (0, 255, 0)).all(-1)).astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, "plot_fixture.npz"), **out)
+    print("plot fixture: %d / %d red pixels, %d / %d green" % (len(out["red_0"]), len(out["red_1"]), len(out["green_0"]), len(out["green_1"])))
+
+
 def make_oks():
     """200-image synthetic GT + detections through the reference's pycocotools fork
     (misc/coco.py + misc/cocoeval.py loaded as a package with an empty ``mask`` submodule)."""
@@ -434,6 +493,9 @@ def make_oks():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "plot":
+        make_plot()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "oks":
         make_oks()
         sys.exit(0)

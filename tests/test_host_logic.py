@@ -215,26 +215,50 @@ def test_dca1000_encode_is_the_inverse_of_the_parser():
     assert np.array_equal(dca1000.frames_int16(synth.dca1000_encode(frames)), frames)
 
 
-def test_plot_human_pose_writes_skeleton_overlays(tmp_path):
-    """misc/plot.py:14-80 without cv2: file naming single_<seq>/<frame>.png from the image id, 2-pixel make_grid border,
-    red joints / edges at the padded coordinates, green box, black canvas when the camera frame is absent."""
+def test_plot_human_pose_matches_the_reference_call_sequence(tmp_path):
+    """misc/plot.py:14-80 without cv2 / torchvision: file naming single_<seq>/<frame>.png
+    from the image id; the 256 x 256 picture make_grid returns for a single image (no border) with the joints shifted by the
+    2-pixel padding all the same; red joint markers and Bresenham edges, green un-shifted box, black canvas when the camera
+    frame is absent — pixel for pixel against tests/golden/plot_fixture.npz, an independent restatement of the reference's
+    cv2 / make_grid calls (make_golden.py `plot`; OpenCV's rasterisation restated from its algorithm: cv2 is not installed here)."""
     import numpy as np
     from PIL import Image
     from hupr_amd.config_tree import load_config
-    from hupr_amd.misc.plot import EDGES, plotHumanPose
+    from hupr_amd.misc.plot import EDGES, bresenham, plotHumanPose
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "plot_fixture.npz"))
     cfg = load_config()
-    joints = np.stack([np.stack([np.linspace(30, 220, 14), np.linspace(40, 200, 14)[::-1]], 1),
-                       np.full((14, 2), 100.0)])
-    files = plotHumanPose(joints, cfg, str(tmp_path), torch.tensor([1200034, 7]), bbox=torch.tensor([[20., 30., 200., 180.], [5., 5., 50., 60.]]))
+    files = plotHumanPose(g["joints"], cfg, str(tmp_path), torch.tensor([1200034, 7]), bbox=torch.from_numpy(g["bbox"]))
     assert [os.path.relpath(f, tmp_path) for f in files] == ["single_12/000000034.png", "single_0/000000007.png"]
-    img = np.asarray(Image.open(files[0]))
-    assert img.shape == (260, 260, 3)                       # 256 + 2 x 2 padding
-    x, y = int(2 + joints[0, 3, 0]), int(2 + joints[0, 3, 1])
-    assert tuple(img[y, x + 3]) == (255, 0, 0)              # the joint ring, offset by the padding
-    assert tuple(img[30, 120]) == (0, 255, 0)               # top edge of the box
     assert len(EDGES) == 14 and sorted(set(i for e in EDGES for i in e)) == list(range(14))
-    red = (img[..., 0] == 255) & (img[..., 1] == 0)
-    assert red.sum() > 14 * 20                               # joints + connecting lines drawn
+    for b, f in enumerate(files):
+        img = np.asarray(Image.open(f))
+        assert img.shape == (256, 256, 3)                    # a single image passes through make_grid unchanged: no border
+        red = np.argwhere((img == (255, 0, 0)).all(-1))
+        green = np.argwhere((img == (0, 255, 0)).all(-1))
+        assert np.array_equal(red, g["red_%d" % b]) and np.array_equal(green, g["green_%d" % b])
+        assert ((img == 0).all(-1) | (img == (255, 0, 0)).all(-1) | (img == (0, 255, 0)).all(-1)).all()
+        x, y = int(2 + g["joints"][b, 3, 0]), int(2 + g["joints"][b, 3, 1])      # the marker sits at joint + padding
+        assert tuple(img[y, x + 2]) == (255, 0, 0) and tuple(img[y + 3, x]) == (255, 0, 0)
+    # the line iterator: end points inclusive, one pixel per major-axis step, symmetric octants
+    assert bresenham((0, 0), (5, 2)) == [(0, 0), (1, 0), (2, 1), (3, 1), (4, 2), (5, 2)]
+    assert bresenham((3, 3), (3, 3)) == [(3, 3)] and len(bresenham((10, 4), (2, 20))) == 17
+    assert [(-x, y) for x, y in bresenham((0, 0), (5, 2))] == bresenham((0, 0), (-5, 2))
+    # with a camera frame: resized, min-max normalised, drawn over
+    import yaml  # noqa: F401
+    frames = tmp_path / "frames" / str(cfg.TEST.plotImgDir) / "single_0" / "processed" / "images"
+    frames.mkdir(parents=True)
+    rgb = (np.linspace(40, 200, 480 * 640 * 3).reshape(480, 640, 3)).astype(np.uint8)
+    Image.fromarray(rgb).save(frames / "000000007.jpg", quality=95)
+    cwd = os.getcwd()
+    os.makedirs(tmp_path / "run")
+    os.chdir(tmp_path / "run")                               # the reference's path is relative: ../frames/...
+    try:
+        f2 = plotHumanPose(g["joints"][1:], cfg, str(tmp_path / "vis"), torch.tensor([7]), bbox=torch.from_numpy(g["bbox"][1:]))
+    finally:
+        os.chdir(cwd)
+    img = np.asarray(Image.open(f2[0]))
+    assert img.shape == (256, 256, 3) and img[..., 2].min() <= 2 and img.max() >= 253      # normalised to the full range
+    assert np.array_equal(np.argwhere((img == (255, 0, 0)).all(-1)), g["red_1"])
 
 
 def test_sequence_grouped_sampler_keeps_the_raw_capture_cache_hot():

@@ -293,6 +293,65 @@ def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(bf1
     assert bad == 0, "%d of 600 launches differ from the launch alone" % bad
 
 
+@pytest.mark.parametrize("victim", ["fft_chain", "halo_conv_epilogue", "attention_forward"])
+def test_packed_fp32_kernels_are_unaffected_by_co_resident_kernels(victim, bf16_math):
+    """VERDICT r3 item 7.  Round 3's corruption needed one compiler-formed packed-fp32 sequence and one
+    co-resident kernel, and its mechanism inside the chip was never established.  The library still carries HAND-WRITTEN packed
+    fp32 arithmetic — the FFT butterflies (hupr_k_doppler_range / hupr_k_angle: 6 000 v_pk_*_f32), the 4-vector adds of the halo
+    convolution epilogue, and since round 4 the score pairs of the attention soft-max (v_pk_fma_f32 / v_pk_add_f32) — two compute
+    streams are the library default and data parallel adds an RCCL kernel on a third.  Each of those kernels, on a FIXED input,
+    must return the bits of its launch alone in every one of 2 400 launches that share the chip with round 3's aggressor
+    (hupr_k_conv_halo_bf16<64, 64>: the level-3 convolution at B = 32) on a second stream AND an all-reduce through
+    hupr_allreduce_bucket (the C ABI's RCCL communicator, one rank) on a third."""
+    from hupr_amd import functional as F_, preprocessing, synth
+    from hupr_amd.tools.distributed import RcclTransport
+    L, rt = F_.rt.lib(), F_.rt
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    if victim == "fft_chain":
+        iq = torch.from_numpy(np.concatenate([synth.adc_cube_int16(31, frame=f) for f in range(32)])).cuda()
+        ws = torch.empty(L.hupr_fft_chain_ws_bytes(32), dtype=torch.uint8, device=dev)
+        run = lambda: preprocessing.fft_chain_loader_means(iq, ws=ws)
+    elif victim == "halo_conv_epilogue":
+        xa = torch.randn(4, 8, 64, 64, 64, device=dev, generator=gen).bfloat16()
+        wa = (torch.randn(64, 64, 3, 3, 3, device=dev, generator=gen) * 0.02).requires_grad_(True)
+        def run():
+            with torch.no_grad():
+                return F_.conv(xa, wa, None, None, (1, 1, 1))
+    else:
+        k, q, v = (torch.randn(2, 1024, 64, device=dev, generator=gen) for _ in range(3))
+        kb, qb, vb = (k * 0.5).bfloat16(), (q * 0.5).bfloat16(), v.bfloat16()
+        def run():
+            out, lse = torch.empty(2, 1024, 64, device=dev), torch.empty(2, 1024, device=dev)
+            rt.check(L.hupr_attn_fwd_bf16in(rt.ptr(kb), rt.ptr(qb), rt.ptr(vb), rt.ptr(v), rt.ptr(out), rt.ptr(lse), 2, 1024, 64, rt.stream()))
+            return out
+    ref = run().clone()
+    torch.cuda.synchronize()
+    x3 = torch.randn(32, 2, 16, 16, 256, device=dev, generator=gen).bfloat16()
+    w3 = (torch.randn(256, 256, 3, 3, 3, device=dev, generator=gen) * 0.02).requires_grad_(True)
+    side, third = F_.side_stream(dev), torch.cuda.Stream(device=dev)
+    comm = RcclTransport(dev)
+    bucket = torch.randn(12 << 20, device=dev, generator=gen)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    try:
+        for _ in range(12):
+            side.wait_stream(torch.cuda.current_stream())
+            third.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(100):
+                    F_.conv(x3, w3, None, None, (1, 1, 1))
+            for _ in range(4):
+                comm.all_reduce(bucket, stream=third)
+            for _ in range(200):
+                bad += (run() != ref).any().to(torch.int64)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(third)
+        torch.cuda.synchronize()
+    finally:
+        comm.close()
+    assert bad.item() == 0, "%d of 2 400 launches of %s differ from the launch alone" % (bad.item(), victim)
+
+
 def test_mnet_front_end():
     from hupr_amd import functional as F_
     B, G = 2, 3
