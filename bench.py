@@ -422,17 +422,20 @@ def main():
             fft_pmc = {}
 
         def fft_obj(per_sf, nbytes, kernel, per_sf_cold, pmc_key):
+            # `achieved` / `frac` = the COLD figure: one call per sensor behind 1 GiB of unrelated traffic, which
+            # is how the training step sees the chain; the back-to-back figure of rounds 1-3 (part of the int16 cube still in the
+            # 256 MB Infinity Cache) is kept as the `warm` sub-object.
             gbs, cold = nbytes / per_sf / 1e9, nbytes / per_sf_cold / 1e9
-            return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_sensor_frame": nbytes,
+            return {"bound": "hbm", "kernel": kernel, "achieved": round(cold, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(cold / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_sensor_frame": nbytes,
                     "traffic": fft_pmc.get(pmc_key, {}).get("traffic_bytes_per_sensor_frame"),
                     "traffic_note": "HBM bytes per sensor-frame, 2 x FETCH_SIZE + WRITE_SIZE of both kernels (profiles/pmc_fft.json)",
-                    "sensor_frames_per_s": round(1.0 / per_sf, 1), "share_of_step_ms": round(per_sf_cold * 2 * B * G * 1e3, 3),
-                    "measured": "20 back-to-back calls alternating the two sensors' cubes (as in rounds 1-2)",
-                    "cold": {"achieved": round(cold, 1), "frac": round(cold / PEAK_HBM_GBS, 4),
-                             "sensor_frames_per_s": round(1.0 / per_sf_cold, 1),
-                             "note": "per call with 1 GiB of unrelated traffic in front (how the step sees it: no Infinity-Cache "
-                                     "hits on the int16 cubes); share_of_step_ms uses this figure"}}
+                    "sensor_frames_per_s": round(1.0 / per_sf_cold, 1), "share_of_step_ms": round(per_sf_cold * 2 * B * G * 1e3, 3),
+                    "measured": "cold: per call with 1 GiB of unrelated traffic in front (how the step sees it: no Infinity-Cache hits "
+                                "on the int16 cubes), median of 6 calls, HIP events; share_of_step_ms uses this figure",
+                    "warm": {"achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4),
+                             "sensor_frames_per_s": round(1.0 / per_sf, 1),
+                             "note": "20 back-to-back calls alternating the two sensors' cubes (the rounds-1-3 headline; Infinity-Cache-assisted)"}}
         fused_mean = fft_obj(fft_time(fft_chain_loader_means), FFT_MEANS_BYTES_PER_SF,
                              "hupr_k_doppler_range + hupr_k_angle<loader + elevation mean> (FFT chain, Normalize, HuPRNet's elevation mean)",
                              fft_time_cold(fft_chain_loader_means), "fused_mean")
@@ -442,6 +445,45 @@ def main():
         del trash
         fft_roof = dict(fused_mean if fused_step else loader)
         fft_roof["loader_variant" if fused_step else "fused_mean_variant"] = loader if fused_step else fused_mean
+    attn_roof = None
+    if rank == 0 and args.dtype == "bf16" and fft_roof is not None:
+        # MSCSA level-1 attention (C = 64, N = 4096: 88 % of the attention flops) at this batch, kernels alone through the C ABI:
+        # forward 4 N^2 C flops per sample, backward (prep + dQ + dK/dV) 10 N^2 C algorithmic; HIP events on the launch stream
+        L_, rt_ = F_.rt.lib(), F_.rt
+        Na, Ca = 4096, 64
+        ga = torch.Generator(device=dev).manual_seed(11)
+        ka, qa, va = (torch.randn(B, Na, Ca, device=dev, generator=ga) * s_ for s_ in (0.5, 0.5, 1.0))
+        kb_, qb_, vb_ = ka.bfloat16(), qa.bfloat16(), va.bfloat16()
+        g32 = torch.randn(B, Na, Ca, device=dev, generator=ga)
+        gb_ = g32.bfloat16()
+        oa, la = torch.empty(B, Na, Ca, device=dev), torch.empty(B, Na, device=dev)
+        dka, dqa, dva, sca = (torch.empty(B, Na, Ca, device=dev) for _ in range(3)) + (torch.empty(B, Na, device=dev),)
+        a_fwd = lambda: rt_.check(L_.hupr_attn_fwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(la), B, Na, Ca, rt_.stream()))      # noqa: E731
+        a_bwd = lambda: rt_.check(L_.hupr_attn_bwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(gb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(g32), rt_.ptr(la),      # noqa: E731
+                                                          rt_.ptr(dka), rt_.ptr(dqa), rt_.ptr(dva), rt_.ptr(sca), B, Na, Ca, 1, rt_.stream()))
+
+        def a_time(fn, n=10):
+            for _ in range(3):
+                fn()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for _ in range(n):
+                fn()
+            ev[1].record()
+            torch.cuda.synchronize()
+            return ev[0].elapsed_time(ev[1]) * 1e-3 / n
+        tf, tb = a_time(a_fwd), a_time(a_bwd)
+        ffl, bfl = 4.0 * Na * Na * Ca * B, 10.0 * Na * Na * Ca * B
+        attn_roof = {"bound": "mfma", "kernel": "hupr_k_attn_fwd_pp64 / hupr_k_attn_bwd_dq + hupr_k_attn_bwd_dkv (MSCSA level 1: C = 64, N = 4096, B = %d)" % B,
+                     "forward": {"us": round(tf * 1e6, 1), "achieved": round(ffl / tf / 1e12, 1), "frac": round(ffl / tf / 1e12 / peak, 4)},
+                     "backward": {"us": round(tb * 1e6, 1), "achieved": round(bfl / tb / 1e12, 1), "frac": round(bfl / tb / 1e12 / peak, 4),
+                                  "note": "algorithmic 10 N^2 C; the two kernels execute 14 N^2 C (S and dP recomputed in each)"},
+                     "achieved": round((ffl + bfl) / (tf + tb) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round((ffl + bfl) / (tf + tb) / 1e12 / peak, 4),
+                     "limiter": "non-MFMA instruction issue beside a power-paced matrix pipe: the forward's phases (MFMA 65 us, fragment reads 38, "
+                                "soft-max VALU 65-70, stores / DMA / barrier 28) add up instead of overlapping (profiles/r04_attn_ablation.txt, "
+                                "profiles/r04_valu_issue_probe.txt)"}
+        del ka, qa, va, kb_, qb_, vb_, g32, gb_, oa, la, dka, dqa, dva, sca
     if dist.is_initialized():
         dist.all_reduce(torch.zeros(1))
 
@@ -516,6 +558,8 @@ def main():
             "roofline": conv_roofline(probe_events, B, args.dtype, peak),
             "fft_roofline": fft_roof,
         }
+        if attn_roof is not None:
+            out["attention_roofline"] = attn_roof
         if parity is not None:
             out["parity_path"] = parity
         if c2 is not None:

@@ -216,14 +216,20 @@ __global__ __launch_bounds__(256) void hupr_k_range_doppler(const int16_t* __res
 // ------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// The swizzled operand is SRC0.  Round 4 (scripts/probes/pk_victim.hip, profiles/r04_pk_victim_race.txt): a two-source VOP3P
+// instruction whose SRC1 low lane reads the high half (op_sel:[0,1]: v_pk_add_f32, v_pk_mul_f32) returns changed results in 11 %
+// of the threads that share the chip with hupr_k_conv_halo_bf16<64, 64> on another stream — and never alone; the same swizzle on
+// SRC0 (op_sel:[1,0]), op_sel_hi forms, and the three-source v_pk_fma_f32 forms below are clean in 1.6e8 thread-evaluations each.
+// Rounds 1-3 wrote these two as (a, b op_sel:[0,1]): the loader chain then differed from its launch alone in 443 of 600 launches
+// beside that convolution (scripts/fft_race.py).  Addition commutes: same bits.
 __device__ __forceinline__ v2f pk_add_mi(v2f a, v2f b) {          // a - i b = (a.x + b.y, a.y - b.x)
     v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 __device__ __forceinline__ v2f pk_add_pi(v2f a, v2f b) {          // a + i b = (a.x - b.y, a.y + b.x)
     v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 // a * w:  t = (a.x w.x, a.x w.y);  d = (t.x - a.y w.y, t.y + a.y w.x).   _s: w uniform (SGPR pair), _v: w per lane.
@@ -693,7 +699,11 @@ extern "C" size_t hupr_fft_chain_ws_bytes(int n_sf) {
     return (size_t)n_sf * kDop * kRange * kVant * sizeof(float2);
 }
 
-static int g_fft_variant = 0;          // A/B aid: bit 0 = non-temporal ADC loads, bit 1 = antenna groups ordered per XCD
+// A/B aid.  bit 0 = TEMPORAL ADC loads (rounds 1-3), default non-temporal: the cube is read exactly once, and with the nt hint the
+// cold pass — how the training step sees it, 25 GB of other traffic since the last call — runs as fast as the Infinity-Cache-warm
+// one: 106.4 -> 68.6 us per 256 sensor-frames, 2.52 -> 3.91 TB/s on SURVEY's bytes (profiles/r04_fft_variants.txt).
+// bit 1 = the three antennas of a receiver back to back on one XCD (measured neutral, off).
+static int g_fft_variant = 0;
 extern "C" void hupr_debug_fft_variant(int v) { g_fft_variant = v; }
 static int g_fft_range_first = 0;      // A/B aid: 1 = the round-1/2 range-first kernel
 extern "C" void hupr_debug_fft_range_first(int on) { g_fft_range_first = on; }
@@ -730,8 +740,8 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
         const int n_groups = n_sf * 4;
         const dim3 g1(grouped ? ((n_groups + 7) / 8) * 24 : n_items), b1(256);
 #define HUPR_DR(W_, H_)                                                                                                      \
-        if (g_fft_variant & 1) hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 2>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped); \
-        else hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 0>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped)
+        if (g_fft_variant & 1) hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 0>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped); \
+        else hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 2>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped)
         switch ((flags & 3) | (loader ? 4 : 0)) {
             case 0: HUPR_DR(0, false); break;
             case 1: HUPR_DR(1, false); break;

@@ -56,10 +56,20 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // Activation storage helpers: 4 consecutive channels as fp32 (16 B) or bf16 (8 B), always computed on as fp32.
 typedef __bf16 hupr_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float hupr_f32x4 __attribute__((ext_vector_type(4)));
+// HUPR_NT_ACT_LOADS (A/B build): the element-wise / statistics kernels read their activations with the non-temporal hint
+#ifdef HUPR_NT_ACT_LOADS
+#define HUPR_ACT_LD(TYPE_, PTR_) __builtin_nontemporal_load(reinterpret_cast<const TYPE_*>(PTR_))
+#else
+#define HUPR_ACT_LD(TYPE_, PTR_) (*reinterpret_cast<const TYPE_*>(PTR_))
+#endif
 template <typename T> __device__ __forceinline__ float4 ld_act4(const T* p);
-template <> __device__ __forceinline__ float4 ld_act4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld_act4<float>(const float* p) {
+    const hupr_f32x4 t = HUPR_ACT_LD(hupr_f32x4, p);
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
 template <> __device__ __forceinline__ float4 ld_act4<__bf16>(const __bf16* p) {
-    const hupr_bf16x4 v = *reinterpret_cast<const hupr_bf16x4*>(p);
+    const hupr_bf16x4 v = HUPR_ACT_LD(hupr_bf16x4, p);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 __device__ __forceinline__ void st_act4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -73,8 +83,8 @@ template <typename T> struct ActVec;
 template <> struct ActVec<float> {
     static constexpr int V = 4;
     static __device__ __forceinline__ void load(const float* p, float* v) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        const hupr_f32x4 t = HUPR_ACT_LD(hupr_f32x4, p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
     }
     static __device__ __forceinline__ void store(float* p, const float* v) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -84,7 +94,7 @@ template <> struct ActVec<__bf16> {
     static constexpr int V = 8;
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     static __device__ __forceinline__ void load(const __bf16* p, float* v) {
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+        const bf16x8 t = HUPR_ACT_LD(bf16x8, p);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (float)t[k];
     }

@@ -36,7 +36,8 @@ HANN_RANGE, HANN_DOPPLER, MAGNITUDE, ZERO_DOPPLER_EXACT, RANGE_FIRST = 1, 2, 4, 
 #                 so an unmodified reference Normalize / a reference-trained checkpoint sees what it was trained on;
 #   "exact"       exactly zero (round 3's chain; the loader emits zeros in slot f = 4);
 #   "range_first" the rounds-1/2 kernel order, whose own fp32 rounding residue fills the bin (slower).
-# HUPR_FFT_ZERO_DOPPLER selects the process default; tools.Runner records the mode in its checkpoints ("fft_zero_doppler").
+# HUPR_FFT_ZERO_DOPPLER selects the process default; tools.Runner records the mode in `preprocess.json` next to its checkpoints and
+# warns when weights trained under one convention are loaded under another.
 ZERO_DOPPLER_MODES = {"dither": 0, "exact": ZERO_DOPPLER_EXACT, "range_first": RANGE_FIRST}
 ZERO_DOPPLER = os.environ.get("HUPR_FFT_ZERO_DOPPLER", "dither")
 if ZERO_DOPPLER not in ZERO_DOPPLER_MODES:

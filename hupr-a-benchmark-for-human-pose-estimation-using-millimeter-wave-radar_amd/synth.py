@@ -254,12 +254,21 @@ def pose_joints(u):
     return np.clip(np.floor(j), 40, 215).astype(np.int64)
 
 
-def pose_scenes(batch, seed):
-    """Deterministic held-out scenes: (hori, vert, joints) numpy, regenerable anywhere from the seed."""
+def pose_scenes(batch, seed, zero_doppler=None):
+    """Deterministic held-out scenes: (hori, vert, joints) numpy, regenerable anywhere from the seed.
+    zero_doppler: what Doppler slot f = 4 of both inputs holds — None: noise + the reflectors of its Doppler half (rounds 2-3);
+    "noise": unit noise and no reflector, like the real chain, whose clutter-nulled zero-Doppler bin carries no target energy
+    (reference Normalize of the rounding residue / this chain's dither); "zero": zeros (round 3's exact clutter removal)."""
     key = 7919 + 104729 * int(seed)
     joints = pose_joints(uniform01(batch * 31, "pose", key).reshape(batch, 31))
     nh, nv = model_inputs(batch, key)
     h, v = pose_scene_inputs(pose_scene_blobs(joints), nh, nv)
+    if zero_doppler == "noise":
+        h[:, :, 4], v[:, :, 4] = nh[:, :, 4], nv[:, :, 4]
+    elif zero_doppler == "zero":
+        h[:, :, 4], v[:, :, 4] = 0.0, 0.0
+    elif zero_doppler is not None:
+        raise ValueError(zero_doppler)
     return h, v, joints
 
 

@@ -91,6 +91,11 @@ class BaseRunner():
             torch.save(group, os.path.join(self.dir, "model_best.pth"))
         print("==========>Save the latest model...")
         torch.save(group, os.path.join(self.dir, "checkpoint.pth"))
+        # Which zero-Doppler convention the on-GPU FFT loader fed these weights (preprocessing.ZERO_DOPPLER).  A sidecar,
+        # not a checkpoint key: the checkpoint dict keeps exactly the reference's four keys (tools/base.py:76-81).
+        from ..preprocessing import process_iwr1843 as _pre
+        with open(os.path.join(self.dir, "preprocess.json"), "w") as fp:
+            json.dump({"fft_zero_doppler": _pre.ZERO_DOPPLER}, fp)
         if epoch % 5 == 0:
             torch.save(group, os.path.join(self.dir, "checkpoint_%d.pth" % epoch))
 
@@ -105,6 +110,13 @@ class BaseRunner():
             return
         ck = torch.load(path, map_location=self.device)
         self.model.load_state_dict(ck["model_state_dict"])
+        side = os.path.join(self.dir, "preprocess.json")
+        if os.path.exists(side):
+            from ..preprocessing import process_iwr1843 as _pre
+            with open(side) as fp:
+                trained = json.load(fp).get("fft_zero_doppler")
+            if trained and trained != _pre.ZERO_DOPPLER:
+                print("==========>WARNING: these weights were trained with HUPR_FFT_ZERO_DOPPLER=%s, this process runs %s" % (trained, _pre.ZERO_DOPPLER))
         if not self.args.eval and not getattr(self.args, "pretrained", False):
             print("==========>Load the previous optimizer")
             self.optimizer.load_state_dict(ck["optimizer_state_dict"])      # torch.optim.Adam layout either way

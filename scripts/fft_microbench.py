@@ -74,7 +74,7 @@ if len(sys.argv) > 2 and sys.argv[2] in ("cold", "detail"):
             torch.cuda.synchronize()
             ts.append(s.elapsed_time(e) * 1e3)
         med = sorted(ts[2:])[len(ts[2:]) // 2]
-        print("variant %d (bit 0 nt loads, bit 1 per-XCD antenna groups) %s, %d sensor-frames per call: per-call us %s  median %.1f us = %.0f GB/s (%.3f of 8 TB/s)" %
+        print("variant %d (bit 0 temporal ADC loads as in rounds 1-3, bit 1 per-XCD antenna groups) %s, %d sensor-frames per call: per-call us %s  median %.1f us = %.0f GB/s (%.3f of 8 TB/s)" %
               (variant, "cold (4 GB fill between calls)" if cold else "warm (back to back)", half, " ".join("%.0f" % t for t in ts), med,
                half * b_m / n_sf / med / 1e3, half * b_m / n_sf / med / 1e3 / 8000))
     rt.lib().hupr_debug_fft_variant(0)

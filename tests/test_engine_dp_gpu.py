@@ -234,6 +234,8 @@ def test_bench_line_single_gpu_carries_every_object():
     assert out["config"]["parallelism"] == "dp1" and out["config"]["launch"] == "eager"
     assert out["roofline"]["launches"] == 3 * 12 and 0 < out["roofline"]["frac"] < 1
     assert out["fft_roofline"]["bound"] == "hbm" and 0 < out["fft_roofline"]["frac"] < 1 and "loader_variant" in out["fft_roofline"]
+    assert 0 < out["fft_roofline"]["warm"]["frac"] < 1                  # `frac` itself is the cold figure since round 4
+    assert out["attention_roofline"]["bound"] == "mfma" and 0 < out["attention_roofline"]["frac"] < 1
     assert out["parity_path"]["dtype"] == "f32" and out["parity_path"]["roofline"]["peak"] == 157.3
     assert "arg-max" in out["config"]["workload"]
     # SURVEY 8(d)'s algorithmic bytes, not the implementation's traffic
