@@ -457,7 +457,8 @@ def main():
         g32 = torch.randn(B, Na, Ca, device=dev, generator=ga)
         gb_ = g32.bfloat16()
         oa, la = torch.empty(B, Na, Ca, device=dev), torch.empty(B, Na, device=dev)
-        dka, dqa, dva, sca = (torch.empty(B, Na, Ca, device=dev) for _ in range(3)) + (torch.empty(B, Na, device=dev),)
+        dka, dqa, dva = (torch.empty(B, Na, Ca, device=dev) for _ in range(3))
+        sca = torch.empty(B, Na, device=dev)
         a_fwd = lambda: rt_.check(L_.hupr_attn_fwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(la), B, Na, Ca, rt_.stream()))      # noqa: E731
         a_bwd = lambda: rt_.check(L_.hupr_attn_bwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(gb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(g32), rt_.ptr(la),      # noqa: E731
                                                           rt_.ptr(dka), rt_.ptr(dqa), rt_.ptr(dva), rt_.ptr(sca), B, Na, Ca, 1, rt_.stream()))

@@ -263,6 +263,20 @@ __device__ __forceinline__ void store_ct_add16(float* dst_row, const f32x16* acc
     }
 }
 
+// (token block bx, sample by) of this workgroup in an (nx, Bn) grid.  xcd_map (Bn % 8 == 0): workgroup id -> XCD is id % 8 and every
+// XCD has its own L2, so the nx workgroups of a sample — each of which streams ALL of the sample's K / V (Q / dO) — are given ids
+// that are congruent mod 8: one L2 fetches the sample's operands once instead of up to eight (round 4; the ping-pong forward does
+// the same with its 1-D grid).
+__device__ __forceinline__ void xcd_block(int& bx, int& by, int xcd_map) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    if (xcd_map) {
+        const int nx = gridDim.x, L = blockIdx.y * nx + blockIdx.x, idx = L >> 3;
+        bx = idx % nx;
+        by = (L & 7) + 8 * (idx / nx);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
@@ -470,17 +484,19 @@ template <int D, typename TI>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
-                                                          float* __restrict__ dQ, int N, int ldk, int ldq, int lddq, int lddo) {
+                                                          float* __restrict__ dQ, int N, int ldk, int ldq, int lddq, int lddo, int xcd_map) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
-    const long base = (long)blockIdx.y * N * D;
-    const int q = blockIdx.x * 128 + wave * 32 + lr;
-    K += (long)blockIdx.y * N * ldk;
+    int bx, by;
+    xcd_block(bx, by, xcd_map);
+    const long base = (long)by * N * D;
+    const int q = bx * 128 + wave * 32 + lr;
+    K += (long)by * N * ldk;
     bf16x8 qf[D / 16], gf[D / 16];
-    load_frags<D, TI>(qf, Q + ((long)blockIdx.y * N + q) * ldq, lh);
-    load_frags<D, TI>(gf, dO + ((long)blockIdx.y * N + q) * lddo, lh);
-    const float nlse_q = -lse[(long)blockIdx.y * N + q] * kLog2e, d_q = Dq[(long)blockIdx.y * N + q];
+    load_frags<D, TI>(qf, Q + ((long)by * N + q) * ldq, lh);
+    load_frags<D, TI>(gf, dO + ((long)by * N + q) * lddo, lh);
+    const float nlse_q = -lse[(long)by * N + q] * kLog2e, d_q = Dq[(long)by * N + q];
     f32x16 dq[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -515,7 +531,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
             for (int r = 0; r < 16; ++r) st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], kLog2e, nlse_q)) * (dp[t][r] - d_q);   // dS^T
         mma_tr_x_tile<D>(dq, Ks, st, lane);                   // dQ^T += K^T dS^T
     }
-    store_ct<D>(dQ + ((long)blockIdx.y * N + q) * lddq, dq, 1.f, nullptr, lh);
+    store_ct<D>(dQ + ((long)by * N + q) * lddq, dq, 1.f, nullptr, lh);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -527,18 +543,20 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
                                                            const float* dVadd,
                                                            const float* __restrict__ lse, const float* __restrict__ Dq,
                                                            float* __restrict__ dK, float* dV, int N, int ldk,
-                                                           int ldq, int lddk, int lddo, const __bf16* dVadd16, int ldadd16) {
+                                                           int ldq, int lddk, int lddo, const __bf16* dVadd16, int ldadd16, int xcd_map) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[64 * D];
     __shared__ float s_lse[64], s_d[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
-    const long base = (long)blockIdx.y * N * D;
-    const int key = blockIdx.x * 128 + wave * 32 + lr;        // this lane's key
+    int bx, by;
+    xcd_block(bx, by, xcd_map);
+    const long base = (long)by * N * D;
+    const int key = bx * 128 + wave * 32 + lr;                // this lane's key
     bf16x8 kf[D / 16], vf[D / 16];
-    load_frags<D, TI>(kf, K + ((long)blockIdx.y * N + key) * ldk, lh);
+    load_frags<D, TI>(kf, K + ((long)by * N + key) * ldk, lh);
     load_frags<D, TI>(vf, V + base + (long)key * D, lh);
-    Q += (long)blockIdx.y * N * ldq;
-    dO += (long)blockIdx.y * N * lddo;
+    Q += (long)by * N * ldq;
+    dO += (long)by * N * lddo;
     // NH = 2 (D = 256): blockIdx.z picks the half of the OUTPUT channels this launch slice accumulates (S, dS are
     // recomputed per half — the full set of dK, dV accumulators would not fit the register file)
     constexpr int DV = D / NH;
@@ -562,8 +580,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         if (PFG) gr.store(Gs, tid);
         else stage_rows<D, 64, TI>(Gs, dO + (long)q0 * lddo, lddo, tid);
         if (tid < 64) {
-            s_lse[tid] = -lse[(long)blockIdx.y * N + q0 + tid] * kLog2e;      // pre-scaled for the exp2 form
-            s_d[tid] = Dq[(long)blockIdx.y * N + q0 + tid];
+            s_lse[tid] = -lse[(long)by * N + q0 + tid] * kLog2e;              // pre-scaled for the exp2 form
+            s_d[tid] = Dq[(long)by * N + q0 + tid];
         }
         __syncthreads();
         if (q0 + 64 < N) {
@@ -585,8 +603,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
         mma_tr_x_tile<D, DV / 32>(dv, Gs, s, lane, c0 / 32);  // dV^T += dO^T P
         mma_tr_x_tile<D, DV / 32>(dk, Qs, dp, lane, c0 / 32); // dK^T += Q^T dS
     }
-    store_ct<DV>(dK + ((long)blockIdx.y * N + key) * lddk + c0, dk, 1.f, nullptr, lh);
-    if (dVadd16) store_ct_add16<DV>(dV + base + (long)key * D + c0, dv, dVadd16 + ((long)blockIdx.y * N + key) * ldadd16 + c0, lh);
+    store_ct<DV>(dK + ((long)by * N + key) * lddk + c0, dk, 1.f, nullptr, lh);
+    if (dVadd16) store_ct_add16<DV>(dV + base + (long)key * D + c0, dv, dVadd16 + ((long)by * N + key) * ldadd16 + c0, lh);
     else store_ct<DV>(dV + base + (long)key * D + c0, dv, 1.f, dVadd ? dVadd + base + (long)key * D + c0 : nullptr, lh);
 }
 
@@ -924,6 +942,8 @@ extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C =
 // widens it to every grid below 128 workgroups, -1 switches it off.
 static int g_attn_split = 0;
 extern "C" void hupr_debug_attn_split(int mode) { g_attn_split = mode; }
+static int g_attn_xcd = 1;     // A/B aid: 0 = the backward kernels keep the plain (token block, sample) -> workgroup id order
+extern "C" void hupr_debug_attn_xcd(int on) { g_attn_xcd = on; }
 static int g_attn_pp = 1;      // A/B aid: 0 = the rounds-1-3 kernels for the D = 64 shapes too; bits 4.. = phase ablations of the ping-pong kernels (timing only)
 extern "C" void hupr_debug_attn_pingpong(int on) { g_attn_pp = on; }
 static unsigned long long* g_attn_trace = nullptr;      // profiling: device buffer of 3 x 2 x 4096 s_memtime stamps (fwd, dQ, dK/dV) or null
@@ -1096,12 +1116,13 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     const float* add32 = residual ? dout32 : (accumulate ? dV : nullptr);
     const __bf16* add16 = (residual && !dout32) ? reinterpret_cast<const __bf16*>(dO) : nullptr;
     const dim3 pgrid((unsigned)((rows + 15) / 16));
+    const int xmap = (g_attn_xcd && Bn % 8 == 0) ? 1 : 0;
 #define HUPR_ATTN_BWD(D_, NH_)                                                                                             \
     if (dout32) hipLaunchKernelGGL((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
     else hipLaunchKernelGGL((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
-    hipLaunchKernelGGL((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo);  \
+    hipLaunchKernelGGL((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo, xmap);  \
     hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<D_, TI, NH_>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
-                       dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo);
+                       dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);
     if (C == 64) { HUPR_ATTN_BWD(64, 1) } else if (C == 128) { HUPR_ATTN_BWD(128, 1) } else { HUPR_ATTN_BWD(256, 2) }
 #undef HUPR_ATTN_BWD
     HUPR_LAUNCH_OK("hupr_k_attn_bwd");

@@ -63,3 +63,10 @@ for rnd in range(2):
         print("round %d %-10s fwd %.1f us (%.0f TF/s)%s" % (rnd, "ping-pong" if pp else "rounds-1-3", t[0], 4.0 * N * N * C * B / t[0] / 1e6,
               ", bwd (prep + dQ + dK/dV) %.1f us (%.0f TF/s algorithmic)" % (t[1], 10.0 * N * N * C * B / t[1] / 1e6) if what == "all" else ""))
 L.hupr_debug_attn_pingpong(1)
+if what == "all":      # backward kernels: a sample's workgroups on one XCD (round 4) vs plain grid order
+    for rnd in range(2):
+        for x in (0, 1):
+            L.hupr_debug_attn_xcd(x)
+            t = timeit(new["bwd"])
+            print("round %d backward, workgroups of a sample %s: %.1f us (%.0f TF/s algorithmic)" % (rnd, "on one XCD" if x else "in grid order", t, 10.0 * N * N * C * B / t / 1e6))
+    L.hupr_debug_attn_xcd(1)

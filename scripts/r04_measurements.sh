@@ -13,6 +13,7 @@ bash scripts/prof_bench.sh r04_bench --steps 3 --warmup 2 --no-parity-path --no-
 bash scripts/pmc_run.sh r04_conv scripts/pmc_conv1.py
 bash scripts/pmc_run.sh r04_fft scripts/pmc_fft.py
 bash scripts/pmc_run.sh r04_attn scripts/pmc_attn.py
+bash scripts/pmc_run.sh r04_attn_old scripts/pmc_attn.py 0
 python scripts/attn_pp_ablate.py > gpurun_out/r04_attn_ablation.txt 2>&1
 python scripts/attn_pp_trace.py > gpurun_out/r04_attn_trace.txt 2>&1
 python scripts/halo_ablation.py --bf16act > gpurun_out/r04_halo_ablation.txt 2>&1
@@ -21,4 +22,4 @@ python scripts/fft_microbench.py 512 cold > gpurun_out/r04_fft_microbench.txt 2>
 python scripts/gemm_path_calls.py > gpurun_out/r04_gemm_path_calls.txt 2>&1
 python scripts/attn_pp_ab.py all > gpurun_out/r04_attn_fwd_ab.txt 2>&1
 for f in gpurun_out/r04_b_*.json; do tail -1 $f | cut -c1-160; done
-tail -3 gpurun_out/r04_conv_pmc.txt gpurun_out/r04_attn_pmc.txt
+tail -n 3 gpurun_out/r04_conv_pmc.txt gpurun_out/r04_attn_pmc.txt

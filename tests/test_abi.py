@@ -52,3 +52,25 @@ def test_no_cpu_fallback(built):
     from hupr_amd import preprocessing
     with pytest.raises(built.HuprError):
         preprocessing.fft_chain(torch.zeros((1, 4, 192, 256, 2), dtype=torch.int16))
+
+
+def test_no_two_source_packed_instruction_swizzles_src1():
+    """Round 4: v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[x,1] — a two-source packed instruction whose SRC1 low
+    lane reads the high half — returns changed results when its wave shares the chip with hupr_k_conv_halo_bf16<64, 64> on another
+    stream (scripts/probes/pk_victim.hip: 11 % of the threads, never alone, never with the swizzle on SRC0).  The build keeps the
+    device assembly of every source (csrc/Makefile, --save-temps=obj) and refuses to link such an instruction; this test reads the
+    same listings."""
+    import glob
+    import re
+    lst = glob.glob(os.path.join(ROOT, "hupr-a-benchmark-for-human-pose-estimation-using-millimeter-wave-radar_amd", "build", "*-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    if not lst:
+        pytest.skip("no device listings (library not built in this tree)")
+    assert len(lst) >= 15
+    bad = re.compile(r"v_pk_[a-z0-9_]+ v\[?[0-9:]+\]?, [^,]+, [^,]+ .*op_sel:\[[01],1\]")
+    n_packed = 0
+    for f in lst:
+        for line in open(f):
+            if "v_pk_" in line:
+                n_packed += 1
+                assert not bad.search(line), (os.path.basename(f), line.strip())
+    assert n_packed > 5000          # the listings are the real ones (the FFT butterflies alone hold ~6 000 packed instructions)
