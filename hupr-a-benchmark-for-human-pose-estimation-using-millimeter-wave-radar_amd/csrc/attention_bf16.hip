@@ -617,13 +617,14 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
 // 1 800 cycles per tile instead of hiding in the first one's stalls — the two waves of a SIMD run the same phases in step
 // (matrix beside matrix, soft-max beside soft-max), and a kernel without MFMAs and exponentials still takes 153 of 206 us:
 // register-staged K / V tiles (global -> VGPR -> ds_write, two barriers per tile) and fragment reads in front of their MFMAs.
-// Here a 512-thread workgroup owns 256 queries (32 per wave) and its two wave groups (waves 0-3 / 4-7 = the two waves of every
-// SIMD) are held in ANTI-PHASE by where they take the ONE barrier of a key tile: every wave alternates a soft-max segment (VALU;
-// it also reads its next fragments from LDS) and a matrix segment (S^T of the next key tile and O^T += V^T P^T of the current
-// one: 16 back-to-back MFMAs whose operands are already in registers); group 0 meets the barrier after its matrix segment,
-// group 1 between its two segments, so that one wave of a SIMD multiplies while its partner exponentiates.  (Two barriers per
-// tile — strict alternation — was the first build: the soft-max segments, 1 300-1 650 cycles against 600 for the MFMAs, then
-// run one after the other and the matrix pipe idles two thirds of the time; stamps in profiles/r04_attn_pp_trace.txt.)
+// Here a 512-thread workgroup owns 256 queries (32 per wave; two waves per SIMD) and every wave software-pipelines a key tile
+// INSIDE itself: the soft-max of tile j is interleaved, instruction group by instruction group, with the MFMAs of its
+// neighbours that do not depend on it (O^T += V^T P^T of tile j - 1 under the row maxima, S^T of tile j + 1 under the
+// exponentials), with ONE barrier per key tile.  Two earlier builds held the two wave groups (waves 0-3 / 4-7) in anti-phase
+// instead — first with two barriers per tile (strict alternation), then with one barrier taken at different points — so that
+// one wave of a SIMD multiplies while its partner exponentiates: the soft-max segments (1 300-1 650 cycles against 600 for the
+// MFMAs) then run one after the other; all three builds are within 3 % (stamps in profiles/r04_attn_trace.txt, ablations
+// in profiles/r04_attn_ablation.txt; DESIGN.md section 7 has the clock finding that explains why the phases add).
 //   * K / V tiles travel global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, the swizzle applied on the source side) through
 //     a ring of eight 16 KB slots, four tiles ahead: no staging registers, no ds_write, no barrier of their own (each wave
 //     covers its own pieces with a counted vmcnt before the tile barrier; a slot is rewritten five tiles after its last read);

@@ -734,7 +734,7 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
             case 2: hipLaunchKernelGGL(hupr_k_range_doppler<2>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
             default: hipLaunchKernelGGL(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
         }
-    } else {
+    } else if (!(g_fft_variant & 4)) {
         // grouped order: (sensor-frame, receiver) groups x 3 antennas, one group per XCD slot; the grid is padded to a multiple of 24
         const int n_items = n_sf * kVant, grouped = (g_fft_variant & 2) ? 1 : 0;
         const int n_groups = n_sf * 4;
@@ -755,6 +755,7 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
 #undef HUPR_DR
     }
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
+    if (g_fft_variant & 8) return HUPR_OK;              // measurement only (bit 2 = no first kernel, bit 3 = no angle kernel)
     if (loader && means)
         hipLaunchKernelGGL(hupr_k_angle<3>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
     else if (loader)

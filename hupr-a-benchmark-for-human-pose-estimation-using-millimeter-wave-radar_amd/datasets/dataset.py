@@ -242,7 +242,8 @@ class SequenceGroupedSampler(data.Sampler):
     sequences (``rank::world``), and the windows of ``group`` sequences at a time are shuffled together: with
     ``group <= cache_sequences`` every sequence is read and transformed exactly once per epoch and a batch still mixes
     windows of ``group`` recordings.  Memory bound of the cache: ``cache_sequences`` x 2 sensors x duration x 2.1 MB
-    (4 x 2.5 GB = 10 GB at the default).  All ranks yield the same number of indices (shortest rank's count).
+    (4 x 2.5 GB = 10 GB at the default).  All ranks yield the same number of indices in EVERY epoch (the smallest share any
+    shuffle can produce).
     With ``-sr > 1`` and the reference's random index multiplier (datasets/dataset.py:121-124) a sampled index may land
     in an earlier sequence than the one it is grouped with: still correct, occasionally a miss."""
 
@@ -255,6 +256,11 @@ class SequenceGroupedSampler(data.Sampler):
             self.by_seq.setdefault(dataset.items[min(i * sr, len(dataset.items) - 1)]["seq"], []).append(i)
         if len(self.by_seq) < world:
             raise ValueError("%d sequences cannot be sharded over %d ranks" % (len(self.by_seq), world))
+        # The length must not depend on the epoch (tools/run.py fixes the LR warm-up step count and the logger from
+        # epoch 0): every epoch yields the count of the SMALLEST share any shuffle can produce — the per-rank number of sequences
+        # times the shortest sequence.  HuPR's sequences all hold `duration` windows, so nothing is dropped there.
+        per_rank = len(self.by_seq) // world
+        self._n = sum(sorted(len(v) for v in self.by_seq.values())[:per_rank])
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -265,10 +271,10 @@ class SequenceGroupedSampler(data.Sampler):
         rng.shuffle(seqs)
         per_rank = len(seqs) // self.world
         shares = [seqs[r::self.world][:per_rank] for r in range(self.world)]
-        return shares, min(sum(len(self.by_seq[s]) for s in sh) for sh in shares)
+        return shares, self._n
 
     def __len__(self):
-        return self._plan()[1]
+        return self._n
 
     def __iter__(self):
         shares, n = self._plan()

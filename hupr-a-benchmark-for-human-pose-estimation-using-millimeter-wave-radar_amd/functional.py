@@ -80,17 +80,19 @@ def _math_scoped(cls):
     fwd, bwd = cls.forward, cls.backward
 
     def forward(ctx, *a):
-        ctx._hupr_math = (MATH, _ACT_F32_HERE)
+        ctx._hupr_math = (MATH, _ACT_F32_HERE, _REGION_SWITCHED)
         return fwd(ctx, *a)
 
     def backward(ctx, *g):
-        global MATH, _ACT_F32_HERE
-        prev = (MATH, _ACT_F32_HERE)
-        MATH, _ACT_F32_HERE = ctx._hupr_math
+        # (the precision state is PROCESS-wide: one model per process at a time, forward and backward on the autograd engine's
+        # single device thread of that process — ADVICE r3; every piece of it is saved and restored here)
+        global MATH, _ACT_F32_HERE, _REGION_SWITCHED
+        prev = (MATH, _ACT_F32_HERE, _REGION_SWITCHED)
+        MATH, _ACT_F32_HERE, _REGION_SWITCHED = ctx._hupr_math
         try:
             return bwd(ctx, *g)
         finally:
-            MATH, _ACT_F32_HERE = prev
+            MATH, _ACT_F32_HERE, _REGION_SWITCHED = prev
     cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
     return cls
 

@@ -300,3 +300,14 @@ def test_sequence_grouped_sampler_keeps_the_raw_capture_cache_hot():
     ia, ib = list(a), list(b)
     sa, sb = {items[i]["seq"] for i in ia}, {items[i]["seq"] for i in ib}
     assert len(ia) == len(ib) == len(a) == 5 * dur and not (sa & sb) and len(sa | sb) == 10
+    # sequences of UNEQUAL length — the length may not change from epoch to epoch (the LR warm-up step count and the
+    # logger are fixed from epoch 0), and every rank yields exactly that many indices in every epoch
+    ds2 = DS()
+    ds2.items = [{"seq": s, "frame": f} for k, s in enumerate(seqs) for f in range(dur + 3 * k)]
+    smps = [SequenceGroupedSampler(ds2, group=4, seed=1, rank=r, world=2) for r in (0, 1)]
+    n0 = len(smps[0])
+    assert n0 == sum(dur + 3 * k for k in range(5))                      # the five shortest sequences: the smallest possible share
+    for epoch in range(6):
+        for sm in smps:
+            sm.set_epoch(epoch)
+            assert len(sm) == n0 and len(list(sm)) == n0
