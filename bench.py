@@ -403,18 +403,24 @@ def main():
         trash = torch.empty(1 << 28, dtype=torch.float32, device=dev)      # 1 GiB: four Infinity Caches
 
         def fft_time_cold(fn):
-            """One call per sensor with 1 GiB of unrelated traffic in front of it, as inside the step (~25 GB between two
-            calls): inputs never in the 256 MB Infinity Cache.  HIP events around each call, median of 6."""
-            ts = []
-            for i in range(6):
+            """The two sensors' calls back to back with 1 GiB of unrelated traffic in front of the pair, as inside the step (~25 GB
+            between two pairs): inputs never in the 256 MB Infinity Cache.  HIP events around the pair, median of 6, per call = half
+            (events around ONE call also count ~8 us of launch floor — an empty-bodied kernel measures 13 us that way — which the
+            step's back-to-back launches do not pay; that figure is kept as `single_call`)."""
+            pair, single = [], []
+            for i in range(12):
                 trash.fill_(float(i))
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 ev[0].record()
-                fn(adc_h if i % 2 == 0 else adc_v)
+                if i % 2 == 0:
+                    fn(adc_h)
+                    fn(adc_v)
+                else:
+                    fn(adc_h if i % 4 == 1 else adc_v)
                 ev[1].record()
                 torch.cuda.synchronize()
-                ts.append(ev[0].elapsed_time(ev[1]) * 1e-3)
-            return sorted(ts)[len(ts) // 2] / (B * G)
+                (pair if i % 2 == 0 else single).append(ev[0].elapsed_time(ev[1]) * 1e-3 / (2 if i % 2 == 0 else 1))
+            return sorted(pair)[len(pair) // 2] / (B * G), sorted(single)[len(single) // 2] / (B * G)
 
         try:      # HBM bytes per sensor-frame of the same kernels, measured offline with rocprofv3 --pmc (profiles/)
             fft_pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_fft.json")))
@@ -425,14 +431,18 @@ def main():
             # `achieved` / `frac` = the COLD figure: one call per sensor behind 1 GiB of unrelated traffic, which
             # is how the training step sees the chain; the back-to-back figure of rounds 1-3 (part of the int16 cube still in the
             # 256 MB Infinity Cache) is kept as the `warm` sub-object.
+            per_sf_cold, per_sf_single = per_sf_cold
             gbs, cold = nbytes / per_sf / 1e9, nbytes / per_sf_cold / 1e9
             return {"bound": "hbm", "kernel": kernel, "achieved": round(cold, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(cold / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_sensor_frame": nbytes,
                     "traffic": fft_pmc.get(pmc_key, {}).get("traffic_bytes_per_sensor_frame"),
                     "traffic_note": "HBM bytes per sensor-frame, 2 x FETCH_SIZE + WRITE_SIZE of both kernels (profiles/pmc_fft.json)",
                     "sensor_frames_per_s": round(1.0 / per_sf_cold, 1), "share_of_step_ms": round(per_sf_cold * 2 * B * G * 1e3, 3),
-                    "measured": "cold: per call with 1 GiB of unrelated traffic in front (how the step sees it: no Infinity-Cache hits "
-                                "on the int16 cubes), median of 6 calls, HIP events; share_of_step_ms uses this figure",
+                    "measured": "cold: the two sensors' calls back to back with 1 GiB of unrelated traffic in front of the pair (how the "
+                                "step sees them: no Infinity-Cache hits on the int16 cubes), HIP events around the pair, median of 6, per "
+                                "call = half; share_of_step_ms uses this figure",
+                    "single_call": {"achieved": round(nbytes / per_sf_single / 1e9, 1), "frac": round(nbytes / per_sf_single / 1e9 / PEAK_HBM_GBS, 4),
+                                    "note": "events around ONE cold call (the round-4 interim figure): includes ~8 us of launch floor"},
                     "warm": {"achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4),
                              "sensor_frames_per_s": round(1.0 / per_sf, 1),
                              "note": "20 back-to-back calls alternating the two sensors' cubes (the rounds-1-3 headline; Infinity-Cache-assisted)"}}

@@ -491,12 +491,15 @@ __device__ __forceinline__ AngleOut angle_cell(const v2f* __restrict__ cell, con
 //   sum_a' Re(X)^2  = (sum |X|^2 + Re sum X^2) / 2,  sum_a' Im(X)^2 = (sum |X|^2 - Re sum X^2) / 2
 // and  sum_a |p + w q|^2 = sum (|p|^2 + |q|^2) + 2 Re(w sum conj(p) q):  five real sums over the 64 x 12 inputs of the
 // workgroup give the mean and the unbiased variance of all sixteen planes.
+// 8 workgroups per CU (<= 64 registers per lane): the loader grids — 8 planes x 256 sensor-frames = 2 048 workgroups — are then ONE
+// round of the 256 CUs instead of 1.14 (70 registers: 7 per CU, a second round of 256 workgroups at one per CU)
 template <int MODE>
 __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ rd, void* __restrict__ out_) {
     constexpr bool LOADER = MODE == 1 || MODE == 3;
     __shared__ v2f cells[kRange * kVant];      // RD for this (sf, i): 64 range bins x 12 antennas
     __shared__ v2f tw64[64];
     __shared__ v2f s_mean[8], s_rstd[8];       // (re, im) pairs per OUTPUT elevation bin
+    __shared__ double s_red[8];                // the seven sums behind the statistics, one or two per wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kPlanes = LOADER ? 8 : 16;
@@ -512,24 +515,46 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
     __syncthreads();
 
     if (LOADER) {
-        if (wave == 0) {                        // lane = range bin
-            const v2f* c = cells + lane * kVant;
-            double sa = 0.0, scx = 0.0, scy = 0.0, t4 = 0.0;
+        {                                       // lane = range bin; wave w reduces its share of the seven sums (same per-lane
+            const v2f* c = cells + lane * kVant;    // expressions and the same butterfly order as when one wave did all seven)
+            double ra = 0.0, rb = 0.0;
+            if (wave == 0) {                    // sa
 #pragma unroll
-            for (int a = 2; a < 6; ++a) {
-                const double px = c[a].x, py = c[a].y, qx = c[8 + a - 2].x, qy = c[8 + a - 2].y;
-                sa += px * px + py * py + qx * qx + qy * qy;
-                scx += px * qx + py * qy;                     // conj(p) q
-                scy += px * qy - py * qx;
+                for (int a = 2; a < 6; ++a) {
+                    const double px = c[a].x, py = c[a].y, qx = c[8 + a - 2].x, qy = c[8 + a - 2].y;
+                    ra += px * px + py * py + qx * qx + qy * qy;
+                }
+            } else if (wave == 1) {             // conj(p) q
+#pragma unroll
+                for (int a = 2; a < 6; ++a) {
+                    const double px = c[a].x, py = c[a].y, qx = c[8 + a - 2].x, qy = c[8 + a - 2].y;
+                    ra += px * qx + py * qy;
+                    rb += px * qy - py * qx;
+                }
+            } else if (wave == 2) {             // the e' = 0 extras
+                const double t4 = (double)c[1].x * c[1].x + (double)c[1].y * c[1].y + (double)c[6].x * c[6].x + (double)c[6].y * c[6].y +
+                                  (double)c[7].x * c[7].x + (double)c[7].y * c[7].y;
+                const double z0x = c[0].x, z0y = c[0].y;
+                ra = t4 + z0x * z0x + z0y * z0y;
+                rb = z0x * z0x - z0y * z0y;
+            } else {
+                ra = c[0].x;
+                rb = c[0].y;
             }
-            t4 = (double)c[1].x * c[1].x + (double)c[1].y * c[1].y + (double)c[6].x * c[6].x + (double)c[6].y * c[6].y +
-                 (double)c[7].x * c[7].x + (double)c[7].y * c[7].y;
-            const double z0x = c[0].x, z0y = c[0].y;
-            double red[8] = {sa, scx, scy, t4 + z0x * z0x + z0y * z0y, z0x, z0y, z0x * z0x - z0y * z0y, 0.0};
 #pragma unroll
-            for (int k = 0; k < 7; ++k)
+            for (int o = 32; o > 0; o >>= 1) ra += __shfl_xor(ra, o, 64);
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) red[k] += __shfl_xor(red[k], o, 64);
+            for (int o = 32; o > 0; o >>= 1) rb += __shfl_xor(rb, o, 64);
+            if (lane == 0) {
+                s_red[wave == 0 ? 0 : wave == 1 ? 1 : wave == 2 ? 3 : 4] = ra;      // red[0..6] = sa, scx, scy, t4 + |z0|^2, z0x, z0y, Re z0^2
+                s_red[wave == 0 ? 7 : wave == 1 ? 2 : wave == 2 ? 6 : 5] = rb;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double red[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[k] = s_red[k];
             if (lane < 8) {                     // lane = OUTPUT elevation bin e <- e' = (3 - e) mod 8
                 const int ep = (3 - lane) & 7;
                 constexpr double hh = 0.70710678118654752440;
@@ -559,9 +584,21 @@ __global__ __launch_bounds__(256) void hupr_k_angle(const float2* __restrict__ r
     const int a_out = (31 - lane) & 63;
 
     if (LOADER) {
-        v2f rstd[8], nmr[8];                    // x * rstd - mean * rstd, one fused multiply-add per (re, im) pair
+        // x * rstd - mean * rstd, one fused multiply-add per (re, im) pair.  The sixteen 1/std are the same in every lane: held in
+        // scalar registers (the multiply-add takes one scalar operand) they leave the kernel at <= 64 vector registers = 8
+        // workgroups per CU, so that the 2 048 workgroups of a 256-sensor-frame loader call are ONE round of the chip, not 1.14
+        v2f rstd[8], nmr[8];
 #pragma unroll
-        for (int e = 0; e < kEl; ++e) { rstd[e] = s_rstd[e]; nmr[e] = -(s_mean[e] * rstd[e]); }
+        for (int e = 0; e < kEl; ++e) {
+            // (written as asm: through __builtin_amdgcn_readfirstlane hipcc read only the .x components and broadcast them into
+            // both halves of the packed operand — op_sel_hi:[1,0] on an s[n:n+1] whose upper half was never written;
+            // tests/test_fft_gpu.py::test_fused_loader_vs_oracle caught it)
+            const v2f r = s_rstd[e];
+            float rx, ry;
+            asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(rx), "=s"(ry) : "v"(r.x), "v"(r.y));
+            rstd[e] = (v2f){rx, ry};
+            nmr[e] = -(s_mean[e] * rstd[e]);
+        }
         float* out = reinterpret_cast<float*>(out_);
         if constexpr (MODE == 3) {
             // means[sf][j = 2 pl + c][r][a] = mean over the 8 elevation bins of the normalised plane, summed exactly like
