@@ -17,9 +17,19 @@ namespace hupr {
 
 // ABL: compile-time phase ablation for scripts/halo_ablation.py (wrong results, timing only): 1 = no weight staging
 // (stages read whatever Bs holds), 2 = no per-stage barrier, 4 = fragments of K-step 0 only (no re-reads inside a stage)
+//      16 = the rounds-1-4 stage protocol (barrier behind a stage's last K-step, fragment pipeline restarted after it), A/B aid
 template <bool ABF, int ABL = 0>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
+    // PL (bf16 activations, no ablation): the stage barrier sits IN FRONT of a stage's last K-step instead of behind it, and the
+    // fragment pipeline runs across stage boundaries.  What the SQ counters said about the old protocol
+    // (profiles/r04_conv_sq_pmc.txt): matrix pipe busy 58 % of the cycles, the waves parked at a wait or the barrier 36 % of
+    // theirs — behind every barrier all eight waves asked for the same 56 KB of first fragments at once and the pipe idled until
+    // they arrived.  Now a wave reaches the barrier holding the fragments of the stage's last K-step (all its reads of the
+    // stage's weight buffer have returned, so the barrier also frees that buffer: the LDS-DMA of stage s + 2 is issued right
+    // behind it), leaves it with six MFMAs ready, and reads the first fragments of stage s + 1 — whose weights every wave waited
+    // for before the barrier — under them.  Same two buffers, same MFMA order, same bits.
+    constexpr bool PL = ABF && ABL == 0;
     constexpr int TD = 4, TH = 8, TW = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2;
     constexpr int NVOX = HD * HH * HW;                         // 600 halo voxels
     constexpr int T = 27, NSTAGE = 9;                          // stage = (kz, kx), its three taps = ky 0..2
@@ -183,8 +193,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     // all but the youngest N_ vector-memory operations of this wave have completed (vmcnt is 6 bits: [3:0] and [15:14])
 #define HUPR_VMCNT(N_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N_) & 15) | (((N_) >> 4) << 14))
 
-    // prologue: first item's halo, weight stage 0 -> Bs[0], weight stage 1 in flight
+    // prologue: first item's halo, weight stage 0 -> Bs[0] (PL: and stage 1 -> Bs[1])
     HUPR_W_DMA(cur.cot, cur.ch, 0, 0)
+    if constexpr (PL) { HUPR_W_DMA(cur.cot, cur.ch, 1, 1) }
     HUPR_HALO_ISSUE(0, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
     HUPR_HALO_COMMIT(0)
     if constexpr (!ABF) {
@@ -194,6 +205,28 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     HUPR_VMCNT(0);
     __syncthreads();
 
+    // fragments of stage ST_, K-step KS_: activations from the halo, weights from buffer BUF_
+    bf16x8 af[2][4], bq[2][TS];                                   // two fragment sets: K-step ks + 1 is read while ks multiplies
+#define HUPR_FRAGS_A(SET_, ST_, KS_)                                                                                \
+    {                                                                                                               \
+        const int toff_ = (((ST_) / 3) * HH * HW + ((ST_) % 3)) * LDK;                                              \
+        const int xkey_ = ((wx + ((ST_) % 3)) >> 1) & 3;                                                            \
+        const int cw_ = (KS_) * 2 + lh;                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                               \
+            af[SET_][r] = *reinterpret_cast<const bf16x8*>(                                                         \
+                &Hs[abase + toff_ + r * (HW * LDK) + ((cw_ ^ (xkey_ | (ekey ^ ((r >> 1) << 2)))) << 3)]);           \
+    }
+#define HUPR_FRAGS_B(SET_, KS_, BUF_)                                                                               \
+    {                                                                                                               \
+        const int cw_ = (KS_) * 2 + lh;                                                                             \
+        _Pragma("unroll") for (int t = 0; t < TS; ++t)                                                              \
+            bq[SET_][t] = *reinterpret_cast<const bf16x8*>(                                                         \
+                &Bs[BUF_][t][(wn * 32 + lr) * LDK + ((cw_ ^ bkey) << 3)]);                                          \
+    }
+    if constexpr (PL) {
+        HUPR_FRAGS_A(0, 0, 0)
+        HUPR_FRAGS_B(0, 0, 0)
+    }
     int g = 0;                                                    // global stage counter: stage g reads Bs[g & 1]
     for (int q = 0; q < n_items; ++q) {
         const int b = cur.b, d0 = cur.tdi * TD, h0 = cur.thi * TH, w0 = cur.twi * TW, n0 = cur.cot * BN;
@@ -225,7 +258,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             const int par = (g + st_) & 1;
             // weights of the next stage -> the idle half of Bs (everyone left it at the previous barrier).  (A ring of three
             // with the DMA two stages ahead measured no faster: the wait below is not where the staging cost sits.)
-            if constexpr (!(ABL & 1)) {
+            if constexpr (!(ABL & 1) && !PL) {
                 if (st_ + 1 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 1, par ^ 1) }
                 else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, 0, par ^ 1) }
             }
@@ -233,12 +266,56 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                 HUPR_HALO_ISSUE(0, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
             }
             if (st_ == 0) { HUPR_STAMP() }                        // 1: stage-0 issue work done
-            {
+            if constexpr (PL) {
+#pragma unroll
+                for (int ks = 0; ks < KC / 16; ++ks) {
+                    if (ks == KC / 16 - 1) {
+                        // the stage's barrier: this wave's reads of Bs[par] have all returned (lgkmcnt 0) and its pieces of stage
+                        // s + 1 have landed in Bs[par ^ 1] (issued behind the previous barrier; younger operations — in stage 0
+                        // the next halo's NH register loads and three stores of the parked tile — stay in flight)
+                        if (st_ == 0 && has_next) {
+                            if (pend) { __builtin_amdgcn_s_waitcnt(0x0070 | ((NH + 3) & 15) | (((NH + 3) >> 4) << 14)); }
+                            else { __builtin_amdgcn_s_waitcnt(0x0070 | (NH & 15) | ((NH >> 4) << 14)); }
+                        } else {
+                            __builtin_amdgcn_s_waitcnt(0x0070);
+                        }
+                        __syncthreads();
+                        // Bs[par] is free: weights of stage s + 2
+                        if (st_ + 2 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 2, par) }
+                        else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, st_ + 2 - NSTAGE, par) }
+                    }
+                    // the next K-step's fragments: of this stage, or K-step 0 of the next one (across an item boundary only its
+                    // weights — the halo changes first)
+                    if (ks + 1 < KC / 16) {
+                        if (ks & 1) { HUPR_FRAGS_A(0, st_, ks + 1) HUPR_FRAGS_B(0, ks + 1, par) }
+                        else { HUPR_FRAGS_A(1, st_, ks + 1) HUPR_FRAGS_B(1, ks + 1, par) }
+                    } else if (st_ + 1 < NSTAGE) {
+                        HUPR_FRAGS_A(0, (st_ + 1) % NSTAGE, 0)
+                        HUPR_FRAGS_B(0, 0, par ^ 1)
+                    } else if (has_next) {
+                        HUPR_FRAGS_B(0, 0, par ^ 1)
+                    }
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) {                // ky;  D'[channel][voxel]
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t + 1], acc[1], 0, 0, 0);
+                    }
+                    if (st_ == 0 && pend) {                       // piece ks of the previous tile's epilogue rides under these MFMAs
+                        halo_store_packed_part(p, accP[ks >> 1], mP + (ks >> 1) * p.W, chP, (ks & 1) * 2);
+                    }
+#pragma unroll
+                    for (int i_ = 0; i_ < 6; ++i_) {              // one fragment read in front of every MFMA (see below)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
                 const int kz = st_ / 3, kx = st_ % 3;
                 const int toff = (kz * HH * HW + kx) * LDK;
                 const int xkey = ((wx + kx) >> 1) & 3;
                 const __bf16* Bt = &Bs[par][0][0];
-                bf16x8 af[2][4], bq[2][TS];                       // two fragment sets: K-step ks + 1 is read while ks multiplies
 #define HUPR_FRAGS(SET_, KS_)                                                                                       \
                 {                                                                                                   \
                     const int cw_ = (KS_) * 2 + lh;                                                                 \
@@ -290,8 +367,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             // this wave's pieces of the next stage have landed (in stage 0 the next halo's NH younger register loads stay in
             // flight); after the barrier Bs[par ^ 1] is complete and all waves are done with Bs[par] (and, after stage 8, Hs)
             // (the parked tile's four stores of stage 0 are younger still; guarded fp32 loads have no fixed count)
-            if (ABF && st_ == 0 && has_next) { if (pend) { HUPR_VMCNT(NH + 4); } else { HUPR_VMCNT(NH); } } else { HUPR_VMCNT(0); }
-            if constexpr (!(ABL & 2)) __syncthreads();
+            if constexpr (!PL) {
+                if (ABF && st_ == 0 && has_next) { if (pend) { HUPR_VMCNT(NH + 4); } else { HUPR_VMCNT(NH); } } else { HUPR_VMCNT(0); }
+                if constexpr (!(ABL & 2)) __syncthreads();
+            }
             if (st_ == 0) { pend = false; HUPR_STAMP() }          // 2: first stage computed (and the parked tile stored)
         }
         g += NSTAGE;
@@ -343,6 +422,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                 HUPR_HALO_COMMIT(NH)
             }
             __syncthreads();
+            if constexpr (PL) { HUPR_FRAGS_A(0, 0, 0) }           // its weight fragments were read under the last MFMAs above
         }
         HUPR_STAMP()                                              // 5: next halo in LDS
         cur = nxt;
@@ -363,6 +443,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             p.stats[(long)blockIdx.x * 2 * p.Co + k * p.Co + ch] = t;
         }
     }
+#undef HUPR_FRAGS_A
+#undef HUPR_FRAGS_B
 #undef HUPR_W_DMA
 #undef HUPR_VMCNT
 #undef HUPR_STAMP
@@ -399,6 +481,7 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
             case 4: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 4>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
             case 5: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 5>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
             case 8: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 8>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 16>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
             default: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 7>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
         }
         return true;

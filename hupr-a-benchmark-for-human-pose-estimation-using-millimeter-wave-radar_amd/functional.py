@@ -1437,6 +1437,15 @@ class MSCSALevelFn(torch.autograd.Function):
 GCN_MATH = None if os.environ.get("HUPR_GCN_BF16", "0") == "1" else "f32"
 
 
+GCN_PRODUCTS = os.environ.get("HUPR_NO_GCN_PRODUCTS", "0") != "1"      # A/B aid: the generic fp32 engine instead of csrc/gcn_products.hip
+
+
+def _gcn_products_ok(x, weight):
+    """The dedicated PRGCN product kernels apply: fp32 pipe (the default of the head in every mode), 16-wide key-point slots."""
+    return (GCN_PRODUCTS and (GCN_MATH == "f32" or MATH == "f32") and x.dtype == torch.float32 and x.shape[2] == 16
+            and x.shape[1] % 64 == 0 and tuple(weight.shape) == (x.shape[1], x.shape[1]))
+
+
 @_math_scoped
 class GCNLayerFn(torch.autograd.Function):
     """y = act( (W x) A + bias ) == W (x A) + bias  (models/gcn_networks.py:23-29); x, y: (B, F, ld=16)."""
@@ -1452,6 +1461,10 @@ class GCNLayerFn(torch.autograd.Function):
             # eight K slices side by side as a batched GEMM; the adjacency kernel sums them
             S = 8
             t = gemm(0, 0, weight, x, F, ld, F // S, F, ld, S, F // S, (F // S) * ld, math=GCN_MATH)
+        elif _gcn_products_ok(x, weight):
+            S = 1
+            t = torch.empty_like(x)
+            rt.check(L.hupr_gcn_wx_f32(rt.ptr(_c(weight)), rt.ptr(x), rt.ptr(t), B, F, ld, 0, rt.stream()))
         else:
             S = 1
             t = gemm(0, 0, weight, x, F, ld, F, F, ld, B, 0, F * ld, math=GCN_MATH)
@@ -1477,6 +1490,13 @@ class GCNLayerFn(torch.autograd.Function):
         dbias = torch.empty((F, K), dtype=torch.float32, device=x.device)
         rt.check(L.hupr_gcn_adj_bwd_f32(rt.ptr(_c(dy)), rt.ptr(y), rt.ptr(adj), rt.ptr(dt), rt.ptr(gm), rt.ptr(dbias), B, F, K,
                                         ld, 1 if ctx.relu else 0, rt.stream()))
+        if _gcn_products_ok(x, weight) and B > 1:
+            # the batch folded into the matrix pipe's column axis (dx) / reduction axis (dW) in place: csrc/gcn_products.hip
+            dx = torch.empty_like(x)
+            rt.check(L.hupr_gcn_wx_f32(rt.ptr(_c(weight)), rt.ptr(dt), rt.ptr(dx), B, F, ld, 1, rt.stream()))
+            dw = torch.empty((F, F), dtype=torch.float32, device=x.device)
+            rt.check(L.hupr_gcn_dw_f32(rt.ptr(dt), rt.ptr(x), rt.ptr(dw), B, F, ld, rt.stream()))
+            return dx, dw, dbias, None, None
         dx = gemm(1, 0, weight, dt, F, ld, F, F, ld, B, 0, F * ld, math=GCN_MATH)              # W^T dt
         # dW[f][g] = sum_{b,k} dt[b][f][k] x[b][g][k]: fold the batch into the reduction axis
         dt2 = dt.permute(1, 0, 2).reshape(F, B * ld)

@@ -116,6 +116,8 @@ SIGNATURES = {
     "hupr_gcn_adj_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "hupr_gcn_adj_fwd_sliced_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "hupr_gcn_adj_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
+    "hupr_gcn_wx_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "hupr_gcn_dw_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "hupr_sigmoid_to_nchw_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "hupr_sigmoid_to_nchw_bwd_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
     "hupr_bce_ws_bytes": (c_size_t, []),

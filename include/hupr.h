@@ -363,6 +363,13 @@ int hupr_gcn_adj_fwd_sliced_f32(const float* t, int slices, const float* adj, co
                                 int K, int ld, int relu, hupr_stream_t stream);
 int hupr_gcn_adj_bwd_f32(const float* dy, const float* y, const float* adj, float* dt, float* gmasked,
                          float* dbias, int Bn, int F, int K, int ld, int relu, hupr_stream_t stream);
+/* The feature products of a PRGCN layer on the fp32 matrix pipe, batch folded into the MFMA column axis in place (x, t, dt: (Bn, F, 16),
+ * W: (F, F) as nn.Parameter of gcn_networks.py:18 stores it; ld must be 16, F a multiple of 64):
+ *   hupr_gcn_wx_f32, trans_w = 0:  t[b][f][n]  = sum_g W[f][g] x[b][g][n]       support = W . x          (gcn_networks.py:25)
+ *   hupr_gcn_wx_f32, trans_w = 1:  t[b][g][n]  = sum_f W[f][g] x[b][f][n]       its input gradient W^T . dt
+ *   hupr_gcn_dw_f32:               dW[f][g]    = sum_{b,n} dt[b][f][n] x[b][g][n]                     its weight gradient */
+int hupr_gcn_wx_f32(const float* W, const float* x, float* t, int Bn, int F, int ld, int trans_w, hupr_stream_t stream);
+int hupr_gcn_dw_f32(const float* dt, const float* x, float* dW, int Bn, int F, int ld, hupr_stream_t stream);
 
 /* (a8) sigmoid heads: channels-last logits (B,HW,ld) -> NCHW probabilities (B,K,HW)  (networks.py:40, gcn_networks.py:64) */
 int hupr_sigmoid_to_nchw_f32(const float* x, float* y, int Bn, int HW, int K, int ld, hupr_stream_t stream);

@@ -401,10 +401,14 @@ def test_attention_large_logits_stable():
     close(out, ref, 1e-4, "attention big logits")
 
 
-def test_gcn_layer():
+@pytest.mark.parametrize("B,products", [(2, True), (3, True), (32, True), (2, False)])
+def test_gcn_layer(B, products, monkeypatch):
+    """PRGCN layer forward / backward vs fp64 torch; products: the dedicated kernels of csrc/gcn_products.hip (even, odd and the
+    bench's batch) or the generic fp32 engine they replace."""
     from hupr_amd import functional as F_
     from oracle.model import adjacency
-    B, Fdim, K = 2, 1024, 14
+    monkeypatch.setattr(F_, "GCN_PRODUCTS", products)
+    Fdim, K = 1024, 14
     x = torch.zeros(B, Fdim, 16)
     x[..., :K] = rnd(B, Fdim, K, seed=29)
     w, b = rnd(Fdim, Fdim, seed=30, scale=1 / 32), rnd(Fdim, K, seed=31, scale=1 / 32)
@@ -669,6 +673,29 @@ def test_conv_halo256_persistent_kernel_matches_128_voxel_kernel(bf16_math):
     close(y256, y128, 1e-6, "halo256 vs halo128")
     ref = F.conv3d(_bf16_round(ncdhw(x.cpu()))[:1], _bf16_round(w.cpu()), bias.cpu().double(), 1, 1)
     close(ncdhw(y256.cpu())[:1] - ncdhw(res.cpu())[:1].double(), ref, 2e-5, "halo256 vs fp64")
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 64, 8, 64, 64), (9, 128, 128, 4, 32, 32), (3, 64, 128, 8, 32, 64)])
+def test_conv_halo256_stage_protocols_agree_bitwise(shape, bf16_math):
+    """The 256-voxel kernel's stage protocol of this round (barrier in front of a stage's last K-step, fragment pipeline across stage
+    and item boundaries) against the rounds-1-4 protocol kept as template variant 16: same MFMA order, so the same bits — one and
+    two channel chunks, one and two output-channel tiles, a tile count that does not divide evenly over the 256 workgroups."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    B, Ci, Co, D, H, W = shape
+    x = rnd(B, D, H, W, Ci, seed=54).cuda().bfloat16()
+    w = rnd(Co, Ci, 3, 3, 3, seed=55, scale=(Ci * 27) ** -0.5).cuda()
+    try:
+        L.hupr_debug_halo_ablate(16 << 4)
+        y_old = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        L.hupr_debug_halo_ablate(0)
+        y_new = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        y_new2 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+    finally:
+        L.hupr_debug_halo_ablate(0)
+    assert y_new.dtype == torch.bfloat16 and torch.equal(y_new, y_old) and torch.equal(y_new, y_new2)
+    ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
+    close(ncdhw(y_new.float().cpu())[:1], ref, 1e-2, "halo256 (bf16 store) vs fp64")
 
 
 # ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
