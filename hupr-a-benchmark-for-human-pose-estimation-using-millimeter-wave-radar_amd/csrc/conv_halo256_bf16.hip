@@ -91,15 +91,15 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     // (the secondary path) keep guarded flat loads
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.x), 0, ABF ? (int)((long)p.Bn * p.D * p.H * p.W * p.in_ld * 2) : 0, 0x00020000);
-#define HUPR_HALO_ISSUE(U0, B_, D0_, H0_, W0_, C0_)                                                                \
-    _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
-        const int it = tid + (u + (U0)) * 512;                                                                      \
+#define HUPR_HALO_ISSUE_ITEM(u, U0, COND_, B_, D0_, H0_, W0_, C0_)                                                 \
+    {                                                                                                               \
+        const int it = tid + ((u) + (U0)) * 512;                                                                    \
         const int vox = it >> 3, c8 = it & 7;                                                                       \
         const int hx = vox % HW;                                                                                    \
         const int t_ = vox / HW;                                                                                    \
         const int hy = t_ % HH, hz = t_ / HH;                                                                       \
         const int d = (D0_) + hz - 1, h = (H0_) + hy - 1, w = (W0_) + hx - 1;                                       \
-        const bool ok = it < NVOX * C8 && !(p.ablate & 1) && (unsigned)d < (unsigned)p.D &&                         \
+        const bool ok = (COND_) && it < NVOX * C8 && !(p.ablate & 1) && (unsigned)d < (unsigned)p.D &&              \
                         (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;                                 \
         if constexpr (ABF) {                                                                                        \
             const int off = (((((B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8) * 2;              \
@@ -116,6 +116,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
             }                                                                                                       \
         }                                                                                                           \
     }
+#define HUPR_HALO_ISSUE(U0, B_, D0_, H0_, W0_, C0_)                                                                \
+    _Pragma("unroll") for (int u = 0; u < NH; ++u) HUPR_HALO_ISSUE_ITEM(u, U0, true, B_, D0_, H0_, W0_, C0_)
     // COMMIT: registers -> LDS (zeros outside the tensor)
 #define HUPR_HALO_COMMIT(U0)                                                                                       \
     _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                 if (st_ + 1 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 1, par ^ 1) }
                 else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, 0, par ^ 1) }
             }
-            if (st_ == 0 && has_next) {                           // next item's halo rides under the remaining stages
+            if (!PL && st_ == 0 && has_next) {                    // next item's halo rides under the remaining stages
                 HUPR_HALO_ISSUE(0, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
             }
             if (st_ == 0) { HUPR_STAMP() }                        // 1: stage-0 issue work done
@@ -273,9 +275,16 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                         // the stage's barrier: this wave's reads of Bs[par] have all returned (lgkmcnt 0) and its pieces of stage
                         // s + 1 have landed in Bs[par ^ 1] (issued behind the previous barrier; younger operations — in stage 0
                         // the next halo's NH register loads and three stores of the parked tile — stay in flight)
-                        if (st_ == 0 && has_next) {
-                            if (pend) { __builtin_amdgcn_s_waitcnt(0x0070 | ((NH + 3) & 15) | (((NH + 3) >> 4) << 14)); }
-                            else { __builtin_amdgcn_s_waitcnt(0x0070 | (NH & 15) | ((NH >> 4) << 14)); }
+                        // (younger than those pieces and left in flight: the next halo's register loads issued since — one
+                        // per K-step from the item's first one on, see below — and in stage 0 three stores of the parked tile)
+                        // halo items of K-steps 4 s - 1 .. 4 s + 2: three, four, three for s = 0, 1, 2 (NH = 10 items in all)
+                        static_assert(NH == 10, "the counted waits below assume ten halo items per thread");
+                        if (st_ == 0) {
+                            if (pend) { __builtin_amdgcn_s_waitcnt(0x0070 | 6); } else { __builtin_amdgcn_s_waitcnt(0x0070 | 3); }
+                        } else if (st_ == 1) {
+                            __builtin_amdgcn_s_waitcnt(0x0070 | 4);
+                        } else if (st_ == 2) {
+                            __builtin_amdgcn_s_waitcnt(0x0070 | 3);
                         } else {
                             __builtin_amdgcn_s_waitcnt(0x0070);
                         }
@@ -283,6 +292,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                         // Bs[par] is free: weights of stage s + 2
                         if (st_ + 2 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 2, par) }
                         else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, st_ + 2 - NSTAGE, par) }
+                        // behind the LAST stage's barrier nobody reads this item's halo any more: the next one (all of its register
+                        // loads returned by the fourth barrier) goes to LDS under the six MFMAs still to come
+                        if (st_ == NSTAGE - 1 && has_next) { HUPR_HALO_COMMIT(0) }
                     }
                     // the next K-step's fragments: of this stage, or K-step 0 of the next one (across an item boundary only its
                     // weights — the halo changes first)
@@ -302,6 +314,14 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                     }
                     if (st_ == 0 && pend) {                       // piece ks of the previous tile's epilogue rides under these MFMAs
                         halo_store_packed_part(p, accP[ks >> 1], mP + (ks >> 1) * p.W, chP, (ks & 1) * 2);
+                    }
+                    // the next item's halo, global -> registers: ONE item (address arithmetic + a 16-byte load) per K-step, under
+                    // its MFMAs, from the item's first K-step on (as one block in front of stage 0 it cost 1 850 cycles per tile
+                    // during which the wave issued no MFMA: scripts/halo_trace.py, profiles/r04_halo_trace.txt)
+                    // (branch-free: past the last item the load is issued with an out-of-range offset — no memory access — so that
+                    // the counted waits hold and the scheduler may mix the arithmetic with the MFMAs)
+                    if (4 * st_ + ks < NH) {
+                        HUPR_HALO_ISSUE_ITEM(4 * st_ + ks, 0, has_next, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
                     }
 #pragma unroll
                     for (int i_ = 0; i_ < 6; ++i_) {              // one fragment read in front of every MFMA (see below)
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         }
         HUPR_STAMP()                                              // 4: tile stored
         if (has_next) {
-            HUPR_HALO_COMMIT(0)
+            if constexpr (!PL) { HUPR_HALO_COMMIT(0) }
             if constexpr (!ABF) {                                 // fp32 sources: second half of the halo, not prefetched
                 HUPR_HALO_ISSUE(NH, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
                 HUPR_HALO_COMMIT(NH)
@@ -449,6 +469,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #undef HUPR_VMCNT
 #undef HUPR_STAMP
 #undef HUPR_HALO_ISSUE
+#undef HUPR_HALO_ISSUE_ITEM
 #undef HUPR_HALO_COMMIT
 }
 

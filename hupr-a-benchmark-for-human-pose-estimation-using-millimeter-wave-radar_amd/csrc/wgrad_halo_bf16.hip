@@ -292,8 +292,6 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const long x_bytes = (long)p.Bn * p.D * p.H * p.W * p.in_ld * 2, dy_bytes = (long)p.Bn * p.D * p.H * p.W * p.dy_ld * 2;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)dy_bytes, 0x00020000);
     constexpr int kOOB = 0x7ffffff0;                 // beyond num_records: the DMA deposits zeros
 
     // LDS-DMA pieces of this wave: piece pc = 8 u + wave moves 64 items (8 rows x 128 B) to image offset pc KiB.  What
@@ -326,31 +324,69 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
             msk[u] = (co0 + c8 * 8 >= p.Co) ? 64 : 0;
         }
     }
-    // The fill is UNCONDITIONAL (past the last tile it re-fetches the last one): hipcc can only count how many younger
-    // memory operations are guaranteed to be in flight, and a conditional fill would turn every wait in front of an LDS
-    // read that may alias an older DMA into vmcnt(0).
-#define HUPR_WG_FILL(ST_, BUF_)                                                                                     \
+    // The fill travels by LDS-DMA issued from inline asm (M0 = LDS address of the wave's 1 KiB piece, saved / restored around it):
+    // hipcc then neither counts it nor guards LDS reads with vmcnt waits of its own — the tile protocol below does its own counted
+    // waits (rounds 1-4 used the builtin and three LDS objects with static roles so that hipcc's bookkeeping came out right; that
+    // form could not carry a fill that is spread over the MFMA groups).  The fill is UNCONDITIONAL (past the last tile it
+    // re-fetches the last one), so every wave always has the same number of pieces in flight.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const u32x4 rxs = {(unsigned)(unsigned long)p.x, (unsigned)((unsigned long)p.x >> 32) & 0xffffu, (unsigned)x_bytes, 0x00020000u};
+    const u32x4 rdys = {(unsigned)(unsigned long)p.dy, (unsigned)((unsigned long)p.dy >> 32) & 0xffffu, (unsigned)dy_bytes, 0x00020000u};
+    // tile coordinates of the fill advance by carries (p.groups in mixed radix), not by divisions
+    const int last_tile = group + ((p.n_spatial - 1 - group) / p.groups) * p.groups;      // last tile of this workgroup
+    int gw_, gh_, gd_, gb_;
+    {
+        int t_ = p.groups;
+        gw_ = t_ % p.nw; t_ /= p.nw;
+        gh_ = t_ % p.nh; t_ /= p.nh;
+        gd_ = t_ % p.nd;
+        gb_ = t_ / p.nd;
+    }
+    int f_t = group, f_twi, f_thi, f_tdi, f_b;
+    {
+        int q_ = group;
+        f_twi = q_ % p.nw; q_ /= p.nw;
+        f_thi = q_ % p.nh; q_ /= p.nh;
+        f_tdi = q_ % p.nd;
+        f_b = q_ / p.nd;
+    }
+    int fl_bx = 0, fl_bdy = 0, fl_flags = 0;
+    // coordinates of the tile the NEXT fill carries (then advance to the one after)
+#define HUPR_WG_FILL_OPEN()                                                                                         \
     {                                                                                                               \
-        int q_ = min((ST_), last_tile);                                                                             \
-        const int twi_ = q_ % p.nw; q_ /= p.nw;                                                                     \
-        const int thi_ = q_ % p.nh; q_ /= p.nh;                                                                     \
-        const int tdi_ = q_ % p.nd;                                                                                 \
-        const int b_ = q_ / p.nd;                                                                                   \
-        const int d0_ = tdi_ * TD, h0_ = thi_ * 8, w0_ = twi_ * TW;                                                 \
-        const int org_ = ((b_ * p.D + d0_) * p.H + h0_) * p.W + w0_;                                                \
-        const int bx_ = org_ * p.in_ld * 2, bdy_ = org_ * p.dy_ld * 2;                                              \
-        const int flags_ = 64 | (d0_ == 0 ? 1 : 0) | (d0_ + TD == p.D ? 2 : 0) | (h0_ == 0 ? 4 : 0) |               \
-                           (h0_ + 8 == p.H ? 8 : 0) | (w0_ == 0 ? 16 : 0) | (w0_ + TW == p.W ? 32 : 0);             \
-        _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                            \
-            const int pc_ = u * 8 + wave;                        /* wave-uniform */                                 \
-            if (u < NP - 1 || wave < NLAST) {                                                                       \
-                const bool isx_ = pc_ < PX;                                                                         \
-                const int voff_ = (msk[u] & flags_) ? kOOB : (isx_ ? bx_ : bdy_) + rel[u];                          \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(isx_ ? rx : rdy,                                           \
-                                                         (__attribute__((address_space(3))) void*)((BUF_) + pc_ * 1024), \
-                                                         16, voff_, 0, 0, 0);                                       \
-            }                                                                                                       \
+        const int d0_ = f_tdi * TD, h0_ = f_thi * 8, w0_ = f_twi * TW;                                              \
+        const int org_ = ((f_b * p.D + d0_) * p.H + h0_) * p.W + w0_;                                               \
+        fl_bx = org_ * p.in_ld * 2;                                                                                 \
+        fl_bdy = org_ * p.dy_ld * 2;                                                                                \
+        fl_flags = 64 | (d0_ == 0 ? 1 : 0) | (d0_ + TD == p.D ? 2 : 0) | (h0_ == 0 ? 4 : 0) |                       \
+                   (h0_ + 8 == p.H ? 8 : 0) | (w0_ == 0 ? 16 : 0) | (w0_ + TW == p.W ? 32 : 0);                     \
+        if (f_t + p.groups <= last_tile) {                                                                          \
+            f_t += p.groups;                                                                                        \
+            f_twi += gw_;                                                                                           \
+            int c_ = f_twi >= p.nw ? 1 : 0;                                                                         \
+            f_twi -= c_ ? p.nw : 0;                                                                                 \
+            f_thi += gh_ + c_;                                                                                      \
+            c_ = f_thi >= p.nh ? 1 : 0;                                                                             \
+            f_thi -= c_ ? p.nh : 0;                                                                                 \
+            f_tdi += gd_ + c_;                                                                                      \
+            c_ = f_tdi >= p.nd ? 1 : 0;                                                                             \
+            f_tdi -= c_ ? p.nd : 0;                                                                                 \
+            f_b += gb_ + c_;                                                                                        \
         }                                                                                                           \
+    }
+    // piece U_ (compile-time) of the open fill -> image BUF_
+#define HUPR_WG_PIECE(U_, BUF_)                                                                                     \
+    if ((U_) < NP - 1 || wave_u < NLAST) {                                                                          \
+        const int pc_ = (U_) * 8 + wave_u;                       /* wave-uniform */                                 \
+        const bool isx_ = pc_ < PX;                                                                                 \
+        const int voff_ = (msk[U_] & fl_flags) ? kOOB : (isx_ ? fl_bx : fl_bdy) + rel[U_];                          \
+        const unsigned dst_ = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)(BUF_) + pc_ * 1024; \
+        unsigned keep_;                                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
+                     "s_mov_b32 m0, %0"                                                                             \
+                     : "=&s"(keep_)                                                                                 \
+                     : "s"(dst_), "v"(voff_), "s"(isx_ ? rxs : rdys)                                                \
+                     : "memory");                                                                                   \
     }
 
     bf16x8 a[2], xq[2][3];
@@ -364,68 +400,96 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
             xq[SET_][kx] = tr_pair((IMG_) + rows_ * kRowB, xb[kx][par_][0], xb[kx][par_][1]);                       \
         if (ky_ == 0) a[ks_ & 1] = tr_pair((IMG_) + ks_ * 16 * kRowB, dyb[0], dyb[1]);                              \
     }
-#define HUPR_WG2_STEP(IMG_, KS0_, J_, NJ_)                                                                          \
+    // group J_ of NJ_: its three MFMAs; under them the next group's fragments — of this tile (J_ + 1 < NJ_) or group 0 of the
+    // tile in NXT_ — and, in the first groups, one piece each of the open fill -> FREE_
+#define HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, J_, NJ_)                                                             \
     {                                                                                                               \
         if ((J_) + 1 < (NJ_)) { HUPR_WG2_LOAD(IMG_, ((J_) + 1) & 1, KS0_, ((J_) + 1 < (NJ_) ? (J_) + 1 : 0)) }      \
-        if (g_sched_burst_) __builtin_amdgcn_sched_barrier(0);                                                      \
+        else { HUPR_WG2_LOAD(NXT_, 0, KS0_, 0) }                                                                    \
+        if ((J_) + 1 < (NJ_)) {                                                                                     \
+            _Pragma("unroll") for (int u_ = 0; u_ < NP; ++u_)                                                       \
+                if (u_ % ((NJ_) - 1) == (J_)) { HUPR_WG_PIECE(u_, FREE_) }                                          \
+        }                                                                                                           \
         _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
             acc[((J_) % 3) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[((KS0_) + (J_) / 3) & 1], xq[(J_) & 1][kx], \
                                                                                acc[((J_) % 3) * 3 + kx], 0, 0, 0);  \
-        if (!g_sched_burst_) {            /* the next group's fragment reads spread between this group's MFMAs */   \
-            _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                      \
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                  \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                  \
-            }                                                                                                       \
+        /* the next group's fragment reads spread between this group's MFMAs */                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                          \
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
         }                                                                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
-#define HUPR_WG2_HALF(IMG_, KS0_, NJ_)                                                                              \
-    HUPR_WG2_LOAD(IMG_, 0, KS0_, 0)                                                                                 \
-    HUPR_WG2_STEP(IMG_, KS0_, 0, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 1, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 2, NJ_)           \
-    HUPR_WG2_STEP(IMG_, KS0_, 3, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 4, NJ_) HUPR_WG2_STEP(IMG_, KS0_, 5, NJ_)
-#define HUPR_WG2_TILE(IMG_, KS0_)                                                                                   \
-    HUPR_WG2_HALF(IMG_, KS0_, 12)                                                                                   \
-    HUPR_WG2_STEP(IMG_, KS0_, 6, 12) HUPR_WG2_STEP(IMG_, KS0_, 7, 12) HUPR_WG2_STEP(IMG_, KS0_, 8, 12)              \
-    HUPR_WG2_STEP(IMG_, KS0_, 9, 12) HUPR_WG2_STEP(IMG_, KS0_, 10, 12) HUPR_WG2_STEP(IMG_, KS0_, 11, 12)
+    // all groups but the last of a half tile (6 groups) / tile (12 groups)
+#define HUPR_WG2_HEAD6(IMG_, NXT_, FREE_, KS0_)                                                                     \
+    HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 0, 6) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 1, 6) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 2, 6) \
+    HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 3, 6) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 4, 6)
+#define HUPR_WG2_HEAD12(IMG_, NXT_, FREE_, KS0_)                                                                    \
+    HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 0, 12) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 1, 12) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 2, 12) \
+    HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 3, 12) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 4, 12) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 5, 12) \
+    HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 6, 12) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 7, 12) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 8, 12) \
+    HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 9, 12) HUPR_WG2_STEP(IMG_, NXT_, FREE_, KS0_, 10, 12)
 
-    // The DMA runs two tiles ahead.  Per tile: wait until this wave's pieces of tile st have landed while leaving its
-    // pieces of tile st + 1 in flight (counted vmcnt — the builtin, so that hipcc's own bookkeeping sees it), barrier,
-    // issue tile st + 2 into the image everyone has just left, multiply tile st.  The loop starts two (virtual) tiles early
-    // with the multiply switched off, so every LDS-DMA of the kernel is issued from the three in-loop sites.
-    const int last_tile = group + ((p.n_spatial - 1 - group) / p.groups) * p.groups;      // last tile of this workgroup
-#define HUPR_WG_ITER(CUR_, FILL_)                                                                                   \
+    // Tile protocol (round 5; the SQ counters of the old one — barrier, whole fill, first fragments, then the MFMAs — showed the
+    // matrix pipe busy 53 % of the cycles: profiles/r04_wgrad_sq_pmc.txt).  Three images in a ring: CUR (tile st), NXT (tile
+    // st + 1, landing or landed), FREE (tile st - 1's, released by the previous barrier).  A wave multiplies all groups of tile st
+    // but the last, issuing one piece of the fill of tile st + 2 -> FREE under each of the first groups; then it waits until its
+    // own pieces of tile st + 1 have landed (all but the youngest NP or NP - 1 operations: those of tile st + 2) and its reads of
+    // CUR have returned, and takes the tile's ONE barrier holding the last group's fragments: it leaves the barrier with three
+    // MFMAs ready and reads the first fragments of tile st + 1 under them.  The loop starts two (virtual) tiles early with the
+    // multiply switched off.
+#define HUPR_WG_ITER(CUR_, NXT_, FREE_)                                                                             \
     {                                                                                                               \
         if (st >= p.n_spatial) break;                                                                               \
-        if (wave < NLAST) __builtin_amdgcn_s_waitcnt(0x0F70 | NP);                                                  \
-        else __builtin_amdgcn_s_waitcnt(0x0F70 | (NP - 1));                                                         \
-        __builtin_amdgcn_s_barrier();                                                                               \
-        asm volatile("" ::: "memory");                                                                              \
-        HUPR_WG_FILL(st + 2 * p.groups, FILL_)                                                                      \
+        HUPR_WG_FILL_OPEN()                                                                                         \
         if (st >= 0) {                                                                                              \
             if (CI32) {                                                                                             \
-                if (kq == 0) { if (wbit == 0) { HUPR_WG2_HALF(CUR_, 0, 6) } else { HUPR_WG2_HALF(CUR_, 2, 6) } }    \
-                else { if (wbit == 0) { HUPR_WG2_HALF(CUR_, 4, 6) } else { HUPR_WG2_HALF(CUR_, 6, 6) } }            \
+                if (kq == 0) { if (wbit == 0) { HUPR_WG2_HEAD6(CUR_, NXT_, FREE_, 0) } else { HUPR_WG2_HEAD6(CUR_, NXT_, FREE_, 2) } } \
+                else { if (wbit == 0) { HUPR_WG2_HEAD6(CUR_, NXT_, FREE_, 4) } else { HUPR_WG2_HEAD6(CUR_, NXT_, FREE_, 6) } } \
             } else {                                                                                                \
-                if (kq == 0) { HUPR_WG2_TILE(CUR_, 0) } else { HUPR_WG2_TILE(CUR_, 4) }                             \
+                if (kq == 0) { HUPR_WG2_HEAD12(CUR_, NXT_, FREE_, 0) } else { HUPR_WG2_HEAD12(CUR_, NXT_, FREE_, 4) } \
+            }                                                                                                       \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int u_ = 0; u_ < NP; ++u_) { HUPR_WG_PIECE(u_, FREE_) }                          \
+        }                                                                                                           \
+        if (wave_u < NLAST) __builtin_amdgcn_s_waitcnt(0x0070 | NP);                                                \
+        else __builtin_amdgcn_s_waitcnt(0x0070 | (NP - 1));                                                         \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("" ::: "memory");                                                                              \
+        if (st >= 0) {                                                                                              \
+            if (CI32) {                                                                                             \
+                if (kq == 0) { if (wbit == 0) { HUPR_WG2_STEP(CUR_, NXT_, FREE_, 0, 5, 6) } else { HUPR_WG2_STEP(CUR_, NXT_, FREE_, 2, 5, 6) } } \
+                else { if (wbit == 0) { HUPR_WG2_STEP(CUR_, NXT_, FREE_, 4, 5, 6) } else { HUPR_WG2_STEP(CUR_, NXT_, FREE_, 6, 5, 6) } } \
+            } else {                                                                                                \
+                if (kq == 0) { HUPR_WG2_STEP(CUR_, NXT_, FREE_, 0, 11, 12) } else { HUPR_WG2_STEP(CUR_, NXT_, FREE_, 4, 11, 12) } \
+            }                                                                                                       \
+        } else if (st + p.groups >= 0) {                        /* the first real tile's first fragments */         \
+            if (CI32) {                                                                                             \
+                if (kq == 0) { if (wbit == 0) { HUPR_WG2_LOAD(NXT_, 0, 0, 0) } else { HUPR_WG2_LOAD(NXT_, 0, 2, 0) } } \
+                else { if (wbit == 0) { HUPR_WG2_LOAD(NXT_, 0, 4, 0) } else { HUPR_WG2_LOAD(NXT_, 0, 6, 0) } }      \
+            } else {                                                                                                \
+                if (kq == 0) { HUPR_WG2_LOAD(NXT_, 0, 0, 0) } else { HUPR_WG2_LOAD(NXT_, 0, 4, 0) }                 \
             }                                                                                                       \
         }                                                                                                           \
         st += p.groups;                                                                                             \
     }
+    static_assert(NP < 16 && NP <= 11, "piece count exceeds the counted wait / the groups of a tile");
     if (group >= p.n_spatial) return;
     int st = group - 2 * p.groups;
     for (;;) {
-        HUPR_WG_ITER(bufB, bufA)
-        HUPR_WG_ITER(bufC, bufB)
-        HUPR_WG_ITER(bufA, bufC)
+        HUPR_WG_ITER(bufB, bufC, bufA)
+        HUPR_WG_ITER(bufC, bufA, bufB)
+        HUPR_WG_ITER(bufA, bufB, bufC)
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);              // the two re-fetches past the last tile must land before the LDS is released
 #undef HUPR_WG_ITER
-#undef HUPR_WG_FILL
+#undef HUPR_WG_FILL_OPEN
+#undef HUPR_WG_PIECE
 #undef HUPR_WG2_LOAD
 #undef HUPR_WG2_STEP
-#undef HUPR_WG2_TILE
-#undef HUPR_WG2_HALF
+#undef HUPR_WG2_HEAD6
+#undef HUPR_WG2_HEAD12
 
     // Merge the two K halves through the (now dead) images: the kq = 1 waves park their accumulators, six taps and then
     // three, the kq = 0 waves add them — one partial tensor per workgroup instead of two halves what the workgroups
