@@ -1140,7 +1140,10 @@ class AttentionFn(torch.autograd.Function):
 
 # BASELINE.json config 5: fp8 (e4m3) MFMA operands in the MSCSA attention — opt-in, forward only, the C = 64 level.  Measured
 # against the bf16 flash kernel (scripts/attn_fp8_ab.py -> profiles/r02_attn_fp8_ab.txt) it is not the default: see DESIGN.md.
-ATTN_FP8 = os.environ.get("HUPR_ATTN_FP8", "0") == "1"
+# "mx" (HUPR_ATTN_FP8=mx): the block-scaled form (csrc/attention_mx8.hip: v_mfma_scale_f32_32x32x64_f8f6f4, one E8M0 scale per 32
+# elements, probabilities as 2^8 p) — also in the TRAINING forward of a fused MSCSA level (the backward stays on the bf16 kernels,
+# which read the bf16 projections the forward quantised from); True (HUPR_ATTN_FP8=1): the round-2 per-tensor kernel, no_grad only.
+ATTN_FP8 = {"1": True, "mx": "mx"}.get(os.environ.get("HUPR_ATTN_FP8", "0"), False)
 
 
 def attention_fp8(k, q, v, residual):
@@ -1157,7 +1160,32 @@ def attention_fp8(k, q, v, residual):
 
 
 def attn_fp8_ok(v):
-    return ATTN_FP8 and MATH == "bf16" and not torch.is_grad_enabled() and v.shape[-1] == 64 and v.shape[1] % 128 == 0
+    return ATTN_FP8 is True and MATH == "bf16" and not torch.is_grad_enabled() and v.shape[-1] == 64 and v.shape[1] % 128 == 0
+
+
+def attn_mx8_ok(N, C):
+    return ATTN_FP8 == "mx" and C == 64 and N % 128 == 0
+
+
+def attention_mx8(k, q, v, residual):
+    """One MSCSA attention on the block-scaled fp8 kernels; k, q, v: fp32 or bf16 (B, N, 64) token-major -> (out fp32 (B, N, 64),
+    lse (B, N)).  (The level node quantises a level's eight projections and two value maps in one step; this wrapper packs k and q
+    into projection slots 0 and 1 of one map for tests and measurements.)"""
+    B, N, C = v.shape
+    assert C == 64 and N % 128 == 0
+    L = rt.lib()
+    y = torch.zeros((B, N, 4 * C), dtype=torch.bfloat16, device=v.device)
+    y[..., :C] = k
+    y[..., C:2 * C] = q
+    vb = _c(v.to(torch.bfloat16))
+    v32 = _c(v.float())
+    out = torch.empty((B, N, C), dtype=torch.float32, device=v.device)
+    lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
+    ws = workspace(L.hupr_attn_mx8_ws_bytes(B, N, C), v.device)
+    rt.check(L.hupr_attn_mx8_quant_level(rt.ptr(y), rt.ptr(y), rt.ptr(vb), rt.ptr(vb), B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
+    rt.check(L.hupr_attn_mx8_fwd(rt.ptr(ws), 0, 0, 0, 1, 0, rt.ptr(v32) if residual else None, rt.ptr(out), rt.ptr(lse), None, 0,
+                                 B, N, C, ws.numel(), rt.stream()))
+    return out, lse
 
 
 LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
@@ -1169,8 +1197,8 @@ def mscsa_level_fused_ok(ra):
     """One MSCSA level can run as MSCSALevelFn (bf16 math; any (N, C) — shapes without a fused attention kernel keep the
     GEMM / row-softmax attention core inside the node)."""
     B, _, H, W, C = ra.shape
-    if ATTN_FP8 and C == 64 and not torch.is_grad_enabled():
-        return False                      # config 5: this level runs as separate projections + fp8 attentions
+    if ATTN_FP8 is True and C == 64 and not torch.is_grad_enabled():
+        return False                      # config 5, per-tensor form: this level runs as separate projections + fp8 attentions
     return LEVEL_FUSION and MATH == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
 
 
@@ -1310,8 +1338,14 @@ class MSCSALevelFn(torch.autograd.Function):
         else:
             vb = maps
             aux = [torch.empty((B, N, N), dtype=torch.float32, device=dev) for _ in range(4)]       # P[query][key]
+        # config 5, block-scaled form: the level's eight projections and two value maps -> e4m3 + E8M0 scales in one step
+        mx8 = flash and attn_mx8_ok(N, C)
+        if mx8:
+            ws8 = workspace(L.hupr_attn_mx8_ws_bytes(B, N, C), dev)
+            rt.check(L.hupr_attn_mx8_quant_level(rt.ptr(Y[0]), rt.ptr(Y[1]), rt.ptr(vb[0]), rt.ptr(vb[1]), B, N, C, rt.ptr(ws8),
+                                                 ws8.numel(), rt.stream()))
         # single-sample inference (config C2): the four attentions of the level as ONE split launch + ONE merge launch instead of eight
-        split_bytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C) if (infer and flash and ATTN_BATCH) else 0
+        split_bytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C) if (infer and flash and ATTN_BATCH and not mx8) else 0
         if split_bytes:
             items = (rt.AttnItem * 4)()
             for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
@@ -1325,7 +1359,11 @@ class MSCSALevelFn(torch.autograd.Function):
             if split_bytes:
                 break
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
-            if flash:
+            if mx8:
+                rt.check(L.hupr_attn_mx8_fwd(rt.ptr(ws8), ks, kslot, qs, qslot, vs, rt.ptr(maps[vs]) if residual else None, rt.ptr(out),
+                                             rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None, 4 * C, B, N, C, ws8.numel(),
+                                             rt.stream()))
+            elif flash:
                 ws = _attn_ws(B, N, C, dev)
                 rt.check(L.hupr_attn_fwd_bf16in_ld_ws(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
                                                       rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,

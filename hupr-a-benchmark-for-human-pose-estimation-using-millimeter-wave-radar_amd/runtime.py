@@ -162,6 +162,9 @@ SIGNATURES = {
     "hupr_attn_quant_fp8": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
     "hupr_attn_fwd_fp8_quantized": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_size_t, c_void_p]),
     "hupr_attn_fwd_fp8": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_attn_mx8_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "hupr_attn_mx8_quant_level": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_attn_mx8_fwd": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int] * 4 + [c_size_t, c_void_p]),
     # (e) RCCL exchange step
     "hupr_comm_load": (c_int, [c_char_p]),
     "hupr_comm_unique_id": (c_int, [c_void_p]),

@@ -492,6 +492,19 @@ int hupr_attn_fwd_fp8_quantized(const void* ws, const float* Vres, float* out, f
                                 hupr_stream_t stream);
 int hupr_attn_fwd_fp8(const float* K, const float* Q, const float* V, int residual, float* out, float* lse, int Bn, int N, int C,
                       void* ws, size_t ws_bytes, hupr_stream_t stream);
+/* The same attention on the block-scaled fp8 matrix instruction of gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4: one E8M0 power-of-two
+ *      scale per 32 elements of the reduction axis, applied in the matrix pipe): the operands of ONE MSCSA level (layers.py:150-163)
+ *      are quantised in one step — Ya / Ye: bf16 (Bn, N, 4 C), the four 1x1 projections of map 0 / map 1 side by side; va / ve:
+ *      bf16 (Bn, N, C) value maps (written transposed, keys in the accumulator order of a probability tile pair) — and each of the
+ *      level's attentions then names its operands: keys = projection kslot (0..3) of map kmap (0 / 1), queries likewise, values =
+ *      map vmap.  Vres: fp32 value map added to the output (cross attention :146,148) or null; out fp32 (Bn, N, C); lse (Bn, N);
+ *      out16 (optional): bf16 copy of out, ld16 elements between tokens.  C = 64, N % 128 == 0.  functional.ATTN_FP8 = "mx"
+ *      (HUPR_ATTN_FP8=mx): inference and the training forward (the backward stays on the bf16 kernels). */
+size_t hupr_attn_mx8_ws_bytes(int Bn, int N, int C);
+int hupr_attn_mx8_quant_level(const void* Ya, const void* Ye, const void* va, const void* ve, int Bn, int N, int C, void* ws,
+                              size_t ws_bytes, hupr_stream_t stream);
+int hupr_attn_mx8_fwd(const void* ws, int kmap, int kslot, int qmap, int qslot, int vmap, const float* Vres, float* out, float* lse,
+                      void* out16, int ld16, int Bn, int N, int C, size_t ws_bytes, hupr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * (e) Data-parallel exchange over RCCL / xGMI.  Nothing in the reference to mirror: it trains on one

@@ -103,6 +103,11 @@ def main(scenes=128):
         rows.append(("fp8 kernel (csrc/attention_fp8.hip, per tensor)", ev("bf16")))
     finally:
         F_.ATTN_FP8 = False
+    F_.ATTN_FP8 = "mx"
+    try:
+        rows.append(("fp8 kernel (csrc/attention_mx8.hip, MX blocks)", ev("bf16")))
+    finally:
+        F_.ATTN_FP8 = False
     n = scenes * 14
     ap_ref = pose_fit.decode_ap(ref[1], joints)
     print("%d held-out scenes (%d joints per head); fp32 path OKS AP %.4f" % (scenes, n, ap_ref))

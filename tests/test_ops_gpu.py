@@ -1092,6 +1092,109 @@ def test_model_eval_with_fp8_attention_stays_inside_the_bf16_envelope():
         F_.set_math("f32")
 
 
+def _mx_e4m3(x, dim):
+    """OCP MX restated with torch casts: blocks of 32 along ``dim`` share the power-of-two scale 2^ceil(log2(amax / 448)); values
+    rounded to e4m3 (round to nearest even, nothing saturates) and scaled back, fp64."""
+    x = x.double().movedim(dim, -1)
+    sh = x.shape
+    b = x.reshape(sh[:-1] + (sh[-1] // 32, 32))
+    amax = b.abs().amax(-1, keepdim=True)
+    sc = torch.exp2(torch.ceil(torch.log2(amax.clamp_min(1e-300) / 448.0)))
+    sc = torch.where(amax > 0, sc, torch.ones_like(sc))
+    return ((b / sc).float().to(torch.float8_e4m3fn).double() * sc).reshape(sh).movedim(-1, dim)
+
+
+@pytest.mark.parametrize("residual", [True, False])
+def test_attention_mx8_forward_vs_restatement_and_fp64(residual):
+    """BASELINE.json config 5, block-scaled form (csrc/attention_mx8.hip): v_mfma_scale_f32_32x32x64_f8f6f4 with one E8M0 scale per
+    (token, 32 channels) of K and Q and per (channel, 32 consecutive keys) of V, probabilities as e4m3(2^8 p).
+    Against (a) a torch restatement of exactly that quantisation evaluated in fp64 — pins the operand layout of the instruction, the
+    scale bytes and the key permutation of the transposed values — and (b) the fp64 statement of models/layers.py:126-133."""
+    from hupr_amd import functional as F_
+    torch.manual_seed(5)
+    B, N, C = 2, 1024, 64
+    k = (torch.randn(B, N, C, device="cuda") * 0.6 * torch.rand(B, N, 1, device="cuda")).bfloat16().float()
+    q = (torch.randn(B, N, C, device="cuda") * 0.6).bfloat16().float()
+    v = (torch.randn(B, N, C, device="cuda") * (0.2 + torch.rand(1, 1, C, device="cuda"))).bfloat16().float()
+    out, lse = F_.attention_mx8(k, q, v, residual)
+    # (a) the restatement: K, Q blocks of 32 channels; V blocks of 32 consecutive keys per channel
+    kq, qq, vq = _mx_e4m3(k, 2), _mx_e4m3(q, 2), _mx_e4m3(v, 1)
+    S = torch.einsum("bjc,bqc->bjq", kq, qq)
+    P = torch.softmax(S, dim=1)
+    m = S.amax(1, keepdim=True)
+    p8 = (256.0 * torch.exp(S - m)).float().to(torch.float8_e4m3fn).double()      # relative to the FINAL maximum (the kernel: the running one)
+    att_q = torch.einsum("bjq,bjc->bqc", p8, vq) / (256.0 * torch.exp(S - m)).sum(1).unsqueeze(-1)
+    S0 = torch.einsum("bjc,bqc->bjq", k.double(), q.double())
+    att = torch.einsum("bjq,bjc->bqc", torch.softmax(S0, dim=1), v.double())
+    add = v.double() if residual else 0
+    rel_q = ((out.double() - (att_q + add)).norm() / att.norm()).item()
+    rel = ((out.double() - (att + add)).norm() / att.norm()).item()
+    lse_q = (lse.double() - torch.logsumexp(S, dim=1)).abs().max().item()
+    lse_0 = (lse.double() - torch.logsumexp(S0, dim=1)).abs().max().item()
+    print("mx8 attention (residual=%s): rel-L2 of the attention term vs the restatement %.3e, vs fp64 %.3e; lse max-abs %.3e / %.3e" %
+          (residual, rel_q, rel, lse_q, lse_0))
+    assert rel_q <= 2e-2 and lse_q <= 1e-3          # the same quantised operands: only the running-maximum rounding of P differs
+    assert rel <= 1.2e-1 and lse_0 <= 0.5
+    L = F_.rt.lib()
+    assert L.hupr_attn_mx8_fwd(None, 0, 0, 0, 1, 0, None, F_.rt.ptr(out), F_.rt.ptr(lse), None, 0, B, 1000, C, 1 << 30, None) == -1
+
+
+def test_mscsa_level_with_mx8_forward_trains_on_the_bf16_backward(bf16_math):
+    """A fused MSCSA level with config 5's block-scaled forward (functional.ATTN_FP8 = "mx") against the bf16 level on the same
+    inputs: outputs within the fp8 envelope, and the backward — the bf16 kernels on the bf16 projections, with the forward's fp8
+    log-sum-exp — gives gradients close to the bf16 level's."""
+    from hupr_amd import functional as F_
+    torch.manual_seed(6)
+    B, H, W, C = 2, 32, 32, 64
+    ra = torch.randn(B, 1, H, W, C, device="cuda") * 0.5
+    re = torch.randn(B, 1, H, W, C, device="cuda") * 0.5
+    ws = [(torch.randn(C, C, 1, 1, device="cuda") * C ** -0.5) for _ in range(8)]
+    g = torch.randn(B, 1, H, W, 4 * C, device="cuda").bfloat16()
+    saved = F_.ATTN_FP8
+    res = {}
+    try:
+        for mode in (False, "mx"):
+            F_.ATTN_FP8 = mode
+            a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
+            w = [t.clone().requires_grad_(True) for t in ws]
+            (cat,) = F_.MSCSALevelFn.apply(a, e, 1, *w)
+            cat.backward(g)
+            res[mode] = (cat.float().detach(), a.grad.clone(), e.grad.clone(), w[0].grad.clone(), w[5].grad.clone())
+    finally:
+        F_.ATTN_FP8 = saved
+    names = ("outputs", "d ra", "d re", "d w[0]", "d w[5]")
+    for nme, x, y in zip(names, res["mx"], res[False]):
+        rel = ((x - y).norm() / y.norm()).item()
+        print("mx8 level vs bf16 level, %s: rel-L2 %.3e" % (nme, rel))
+        assert torch.isfinite(x).all() and rel <= (5e-2 if nme == "outputs" else 1.5e-1), nme
+    assert not torch.equal(res["mx"][0], res[False][0])
+
+
+def test_model_eval_with_mx8_attention_stays_inside_the_bf16_envelope():
+    """HuPRNet eval forward with config 5's block-scaled form switched on: finite, close to the bf16 run."""
+    import numpy as np
+    from hupr_amd import functional as F_, synth
+    from hupr_amd.config_tree import load_config
+    from hupr_amd.models import HuPRNet
+    saved = F_.ATTN_FP8
+    try:
+        F_.set_math("bf16")
+        net = HuPRNet(load_config()).cuda().eval()
+        net.load_state_dict({k_: torch.from_numpy(np.array(v_)) for k_, v_ in synth.hupr_state(1, gain=1.4).items()})
+        h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(2, 5))
+        with torch.no_grad():
+            F_.ATTN_FP8 = False
+            a1, a2 = net(h, v)
+            F_.ATTN_FP8 = "mx"
+            b1, b2 = net(h, v)
+        d1, d2 = (a1 - b1).abs().max().item(), (a2 - b2).abs().max().item()
+        print("mx8 vs bf16 attention inside the model: heat-map max-abs %.3e / %.3e" % (d1, d2))
+        assert torch.isfinite(b1).all() and torch.isfinite(b2).all() and 0 < d1 <= 2e-2 and d2 <= 2e-2
+    finally:
+        F_.ATTN_FP8 = saved
+        F_.set_math("f32")
+
+
 def test_conv_halo512_first_layer_shape_matches_the_128_voxel_kernel(bf16_math):
     """The 512-voxel register-blocked kernel (Ci = 32: the encoder's first layer at the bench batch) against the 128-voxel
     kernel on the same bf16 operands — same products, another fp32 summation order (K chunks of 32, kz-major taps): equal up to
