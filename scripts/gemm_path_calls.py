@@ -36,6 +36,8 @@ wrap("hupr_tmerge_dgrad_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d" % (a[4], a[5],
 wrap("hupr_tmerge_fwd_stream_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d" % (a[3], a[4], a[5], a[6], a[7]))
 wrap("hupr_tmerge_dgrad_stream_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d" % (a[3], a[4], a[5], a[6], a[7]))
 wrap("hupr_tmerge_wgrad_stream_bf16", lambda a: "B%d G%d HW%d Ci%d Co%d (incl. the partial reduce)" % (a[3], a[4], a[5], a[6], a[7]))
+wrap("hupr_gcn_wx_f32", lambda a: "PRGCN product Bn%d F%d trans%d (dedicated kernel, was hupr_gemm_f32 M1024 N16 K1024 batch32)" % (a[3], a[4], a[6]))
+wrap("hupr_gcn_dw_f32", lambda a: "PRGCN weight gradient Bn%d F%d (dedicated kernel, was hupr_gemm_f32 M1024 N1024 K512)" % (a[3], a[4]))
 eng.train_step_from_adc(adc_h, adc_v, joints, decode="device")
 torch.cuda.synchronize()
 agg = collections.OrderedDict()

