@@ -525,10 +525,19 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
         f32x16 st[2], dp[2];
         mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T
         mma_rows_x_frags<D>(dp, Vs, gf, lr, lh);              // dP^T = V dO^T
+        {      // dS^T on accumulator pairs (packed fma / add / mul: same roundings, half the VALU instructions)
+            typedef float f32x2a __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[t][r] = __builtin_amdgcn_exp2f(fmaf(st[t][r], kLog2e, nlse_q)) * (dp[t][r] - d_q);   // dS^T
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2a arg = __builtin_elementwise_fma((f32x2a){st[t][r], st[t][r + 1]}, (f32x2a){kLog2e, kLog2e}, (f32x2a){nlse_q, nlse_q});
+                    const f32x2a pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                    const f32x2a ds = pv * ((f32x2a){dp[t][r], dp[t][r + 1]} - (f32x2a){d_q, d_q});
+                    st[t][r] = ds[0];
+                    st[t][r + 1] = ds[1];
+                }
+        }
         mma_tr_x_tile<D>(dq, Ks, st, lane);                   // dQ^T += K^T dS^T
     }
     store_ct<D>(dQ + ((long)by * N + q) * lddq, dq, 1.f, nullptr, lh);
@@ -608,6 +617,93 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
     else store_ct<DV>(dV + base + (long)key * D + c0, dv, 1.f, dVadd ? dVadd + base + (long)key * D + c0 : nullptr, lh);
 }
 
+
+// dK / dV at the level-1 shape (D = 64, bf16 operands): 512 threads own 256 keys (32 per wave) and stream the 64-query tiles through
+// DOUBLE-buffered images with ONE barrier per tile, both tiles (Q and dO) prefetched into registers one tile ahead.  What the SQ
+// counters said about the 256-thread kernel above at this shape (profiles/r04b_attn_sq_pmc.txt): the waves parked 38 % of their
+// cycles — it sits at the register limit of two waves per SIMD, so only the query rows were prefetched and every tile waited for the
+// global loads of its dO rows between two barriers.  With eight waves sharing a tile a thread stages 16 bytes of each image instead
+// of 32 of one, and both prefetches fit in the registers one used.  Same arithmetic per (key, query tile), same tile order: the
+// same bits as the kernel above.
+__global__ __launch_bounds__(512) void hupr_k_attn_bwd_dkv512(const __bf16* __restrict__ K, const __bf16* __restrict__ Q,
+                                                              const __bf16* __restrict__ V, const __bf16* __restrict__ dO,
+                                                              const float* dVadd, const float* __restrict__ lse,
+                                                              const float* __restrict__ Dq, float* __restrict__ dK, float* dV, int N,
+                                                              int ldk, int ldq, int lddk, int lddo, const __bf16* dVadd16,
+                                                              int ldadd16, int xcd_map) {
+    constexpr int D = 64;
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[2][64 * D];
+    __shared__ __attribute__((aligned(16))) __bf16 Gs[2][64 * D];
+    __shared__ float s_lse[2][64], s_d[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    int bx, by;
+    xcd_block(bx, by, xcd_map);
+    const long base = (long)by * N * D;
+    const int key = bx * 256 + wave * 32 + lr;                // this lane's key
+    bf16x8 kf[D / 16], vf[D / 16];
+    load_frags<D, __bf16>(kf, K + ((long)by * N + key) * ldk, lh);
+    load_frags<D, __bf16>(vf, V + base + (long)key * D, lh);
+    Q += (long)by * N * ldq;
+    dO += (long)by * N * lddo;
+    f32x16 dk[D / 32], dv[D / 32];
+#pragma unroll
+    for (int ct = 0; ct < D / 32; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.f; dv[ct][r] = 0.f; }
+    // staging: thread t moves chunk t & 7 (16 bytes) of row t >> 3 of both images; threads 0..63 / 64..127 the row statistics
+    const int srow = tid >> 3, sch = tid & 7;
+    const __bf16* qp = Q + (long)srow * ldq + sch * 8;
+    const __bf16* gp = dO + (long)srow * lddo + sch * 8;
+    const float* sp = tid < 64 ? lse + (long)by * N + tid : Dq + (long)by * N + (tid & 63);
+    u32x4a qreg = *reinterpret_cast<const u32x4a*>(qp), greg = *reinterpret_cast<const u32x4a*>(gp);
+    float sreg = tid < 128 ? *sp : 0.f;
+    *reinterpret_cast<u32x4a*>(&Qs[0][Img<D>::off(srow, sch)]) = qreg;
+    *reinterpret_cast<u32x4a*>(&Gs[0][Img<D>::off(srow, sch)]) = greg;
+    if (tid < 64) s_lse[0][tid] = -sreg * kLog2e;             // pre-scaled for the exp2 form
+    else if (tid < 128) s_d[0][tid - 64] = sreg;
+    __syncthreads();
+    for (int q0 = 0; q0 < N; q0 += 64) {
+        const int cb = (q0 >> 6) & 1;
+        if (q0 + 64 < N) {                                     // the next tile travels while this one is multiplied
+            qreg = *reinterpret_cast<const u32x4a*>(qp + (long)(q0 + 64) * ldq);
+            greg = *reinterpret_cast<const u32x4a*>(gp + (long)(q0 + 64) * lddo);
+            if (tid < 128) sreg = sp[q0 + 64];
+        }
+        f32x16 s[2], dp[2];
+        mma_rows_x_frags<D>(s, Qs[cb], kf, lr, lh);            // S tile: rows = queries, this lane's column = its key
+        mma_rows_x_frags<D>(dp, Gs[cb], vf, lr, lh);           // dP = dO V^T
+        // P and dS on accumulator PAIRS (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: the same roundings in half the VALU
+        // instructions — 160 VALU per tile beside 32 MFMAs were as many issue cycles as the matrix pipe's own)
+        typedef float f32x2a __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int qi = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const f32x2a lv = *reinterpret_cast<const f32x2a*>(&s_lse[cb][qi]);
+                const f32x2a dd = *reinterpret_cast<const f32x2a*>(&s_d[cb][qi]);
+                const f32x2a arg = __builtin_elementwise_fma((f32x2a){s[t][r], s[t][r + 1]}, (f32x2a){kLog2e, kLog2e}, lv);
+                const f32x2a pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                const f32x2a ds = pv * ((f32x2a){dp[t][r], dp[t][r + 1]} - dd);
+                dp[t][r] = ds[0];                               // dS
+                dp[t][r + 1] = ds[1];
+                s[t][r] = pv[0];                                // P
+                s[t][r + 1] = pv[1];
+            }
+        mma_tr_x_tile<D, D / 32>(dv, Gs[cb], s, lane, 0);      // dV^T += dO^T P
+        mma_tr_x_tile<D, D / 32>(dk, Qs[cb], dp, lane, 0);     // dK^T += Q^T dS
+        if (q0 + 64 < N) {                                     // the other buffers were last read one tile ago, behind a barrier
+            *reinterpret_cast<u32x4a*>(&Qs[cb ^ 1][Img<D>::off(srow, sch)]) = qreg;
+            *reinterpret_cast<u32x4a*>(&Gs[cb ^ 1][Img<D>::off(srow, sch)]) = greg;
+            if (tid < 64) s_lse[cb ^ 1][tid] = -sreg * kLog2e;
+            else if (tid < 128) s_d[cb ^ 1][tid - 64] = sreg;
+        }
+        __syncthreads();
+    }
+    store_ct<D>(dK + ((long)by * N + key) * lddk, dk, 1.f, nullptr, lh);
+    if (dVadd16) store_ct_add16<D>(dV + base + (long)key * D, dv, dVadd16 + ((long)by * N + key) * ldadd16, lh);
+    else store_ct<D>(dV + base + (long)key * D, dv, 1.f, dVadd ? dVadd + base + (long)key * D : nullptr, lh);
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Ping-pong kernels (round 4; D = 64, bf16 operands) — the MSCSA level-1 shape (N = 4096), 88 % of the attention flops
@@ -945,6 +1041,8 @@ static int g_attn_split = 0;
 extern "C" void hupr_debug_attn_split(int mode) { g_attn_split = mode; }
 static int g_attn_xcd = 1;     // A/B aid: 0 = the backward kernels keep the plain (token block, sample) -> workgroup id order
 extern "C" void hupr_debug_attn_xcd(int on) { g_attn_xcd = on; }
+static int g_attn_dkv512 = 1;      // A/B aid: 0 = the 256-thread dK / dV kernel at the level-1 shape too
+extern "C" void hupr_debug_attn_dkv512(int on) { g_attn_dkv512 = on; }
 static int g_attn_pp = 1;      // A/B aid: 0 = the rounds-1-3 kernels for the D = 64 shapes too; bits 4.. = phase ablations of the ping-pong kernels (timing only)
 extern "C" void hupr_debug_attn_pingpong(int on) { g_attn_pp = on; }
 static unsigned long long* g_attn_trace = nullptr;      // profiling: device buffer of 3 x 2 x 4096 s_memtime stamps (fwd, dQ, dK/dV) or null
@@ -1122,8 +1220,13 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     if (dout32) hipLaunchKernelGGL((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
     else hipLaunchKernelGGL((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
     hipLaunchKernelGGL((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo, xmap);  \
-    hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<D_, TI, NH_>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
-                       dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);
+    if (D_ == 64 && sizeof(TI) == 2 && g_attn_dkv512 && N % 256 == 0)                                                       \
+        hipLaunchKernelGGL(hupr_k_attn_bwd_dkv512, dim3(N / 256, Bn), dim3(512), 0, s, reinterpret_cast<const __bf16*>(K),       \
+                           reinterpret_cast<const __bf16*>(Q), reinterpret_cast<const __bf16*>(V), reinterpret_cast<const __bf16*>(dO), \
+                           add32, lse, Dq, dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);                                 \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<D_, TI, NH_>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
+                           dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);
     if (C == 64) { HUPR_ATTN_BWD(64, 1) } else if (C == 128) { HUPR_ATTN_BWD(128, 1) } else { HUPR_ATTN_BWD(256, 2) }
 #undef HUPR_ATTN_BWD
     HUPR_LAUNCH_OK("hupr_k_attn_bwd");

@@ -59,6 +59,7 @@ SIGNATURES = {
     "hupr_debug_attn_pingpong": (None, [c_int]),
     "hupr_debug_attn_trace": (None, [c_void_p]),
     "hupr_debug_attn_xcd": (None, [c_int]),
+    "hupr_debug_attn_dkv512": (None, [c_int]),
     "hupr_debug_halo_ablate": (None, [c_int]),
     "hupr_debug_halo_variant": (None, [c_int]),
     "hupr_debug_halo_small_tiles": (None, [c_int]),

@@ -205,6 +205,7 @@ int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, i
 int hupr_pack_conv_weights_table(const void* descs_dev, const void* blocks_dev, int n_blocks, hupr_stream_t stream);
 void hupr_debug_attn_pingpong(int on);    /* A/B aid: 0 = the rounds-1-3 attention kernels for the C = 64 shapes too (default 1: ping-pong kernels) */
 void hupr_debug_attn_xcd(int on);         /* A/B aid: 0 = attention backward workgroups in plain grid order (default 1: a sample's workgroups share an XCD) */
+void hupr_debug_attn_dkv512(int on);      /* A/B aid: 0 = the 256-thread dK / dV kernel at C = 64 too (default 1: 512 threads, one barrier per query tile) */
 void hupr_debug_attn_trace(void* dev_buf); /* profiling aid: device buffer of 3 x 2 x 4096 uint64 s_memtime stamps written by workgroup 0 of the ping-pong attention kernels, or null */
 void hupr_debug_fft_variant(int bits);     /* A/B aid: bit 0 = temporal ADC loads (rounds 1-3; default: non-temporal), bit 1 = the three antennas of a receiver back to back on one XCD */
 void hupr_debug_fft_range_first(int on);  /* A/B aid: 1 = the range-first K1 of rounds 1-2 instead of the Doppler-first kernel */
