@@ -293,7 +293,7 @@ def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(bf1
     assert bad == 0, "%d of 600 launches differ from the launch alone" % bad
 
 
-@pytest.mark.parametrize("victim", ["fft_chain", "halo_conv_epilogue", "attention_forward"])
+@pytest.mark.parametrize("victim", ["fft_chain", "halo_conv_epilogue", "attention_forward", "attention_backward"])
 def test_packed_fp32_kernels_are_unaffected_by_co_resident_kernels(victim, bf16_math):
     """VERDICT r3 item 7.  Round 3's corruption needed one compiler-formed packed-fp32 sequence and one
     co-resident kernel, and its mechanism inside the chip was never established.  The library still carries HAND-WRITTEN packed
@@ -318,6 +318,21 @@ def test_packed_fp32_kernels_are_unaffected_by_co_resident_kernels(victim, bf16_
         def run():
             with torch.no_grad():
                 return F_.conv(xa, wa, None, None, (1, 1, 1))
+    elif victim == "attention_backward":
+        # the dS arithmetic of hupr_k_attn_bwd_dq / hupr_k_attn_bwd_dkv512 on accumulator pairs (compiler-formed v_pk_fma_f32,
+        # v_pk_add_f32 with neg modifiers, v_pk_mul_f32 from two-element vectors: round 4, second half)
+        k, q, v = (torch.randn(2, 1024, 64, device=dev, generator=gen) for _ in range(3))
+        kb, qb, vb = (k * 0.5).bfloat16(), (q * 0.5).bfloat16(), v.bfloat16()
+        g32 = torch.randn(2, 1024, 64, device=dev, generator=gen)
+        gb = g32.bfloat16()
+        o0, l0 = torch.empty(2, 1024, 64, device=dev), torch.empty(2, 1024, device=dev)
+        rt.check(L.hupr_attn_fwd_bf16in(rt.ptr(kb), rt.ptr(qb), rt.ptr(vb), rt.ptr(v), rt.ptr(o0), rt.ptr(l0), 2, 1024, 64, rt.stream()))
+        def run():
+            d = torch.empty(3, 2, 1024, 64, device=dev)
+            scr = torch.empty(2, 1024, device=dev)
+            rt.check(L.hupr_attn_bwd_bf16in(rt.ptr(kb), rt.ptr(qb), rt.ptr(vb), rt.ptr(gb), rt.ptr(v), rt.ptr(o0), rt.ptr(g32), rt.ptr(l0),
+                                            rt.ptr(d[0]), rt.ptr(d[1]), rt.ptr(d[2]), rt.ptr(scr), 2, 1024, 64, 1, rt.stream()))
+            return d
     else:
         k, q, v = (torch.randn(2, 1024, 64, device=dev, generator=gen) for _ in range(3))
         kb, qb, vb = (k * 0.5).bfloat16(), (q * 0.5).bfloat16(), v.bfloat16()
