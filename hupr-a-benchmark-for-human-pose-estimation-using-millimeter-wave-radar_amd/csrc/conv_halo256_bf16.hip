@@ -29,7 +29,15 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
     // stage's weight buffer have returned, so the barrier also frees that buffer: the LDS-DMA of stage s + 2 is issued right
     // behind it), leaves it with six MFMAs ready, and reads the first fragments of stage s + 1 — whose weights every wave waited
     // for before the barrier — under them.  Same two buffers, same MFMA order, same bits.
-    constexpr bool PL = ABF && ABL == 0;
+    constexpr bool PL = ABF && (ABL == 0 || ABL == 32);
+    // ABL 32 (timing only, wrong results): every 32x32x16 MFMA of the tap loop replaced by two v_mfma_f32_16x16x32_bf16 on the same
+    // fragment registers and eight 16 x 16 accumulators — same bytes, same flops, the other instruction shape (DESIGN.md section 4,
+    // "Which matrix-instruction shape does the most work per joule"): what a conversion of this kernel would buy
+    constexpr bool M16 = ABL == 32;
+    typedef float f32x4t __attribute__((ext_vector_type(4)));
+    f32x4t acc16[M16 ? 8 : 1];
+#pragma unroll
+    for (int i = 0; i < (M16 ? 8 : 1); ++i) acc16[i] = (f32x4t){0.f, 0.f, 0.f, 0.f};
     constexpr int TD = 4, TH = 8, TW = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2;
     constexpr int NVOX = HD * HH * HW;                         // 600 halo voxels
     constexpr int T = 27, NSTAGE = 9;                          // stage = (kz, kx), its three taps = ky 0..2
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         }
         const bool has_next = q + 1 < n_items;
         HUPR_STAMP()                                              // 0: item start
-        if (first_chunk) {
+        if (first_chunk && !M16) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -309,8 +317,15 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
                     }
 #pragma unroll
                     for (int t = 0; t < TS; ++t) {                // ky;  D'[channel][voxel]
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t + 1], acc[1], 0, 0, 0);
+                        if constexpr (M16) {
+                            acc16[(4 * t) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks & 1][t], af[ks & 1][t], acc16[(4 * t) & 7], 0, 0, 0);
+                            acc16[(4 * t + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[ks & 1][t], af[ks & 1][t + 1], acc16[(4 * t + 1) & 7], 0, 0, 0);
+                            acc16[(4 * t + 2) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks & 1][t], bq[ks & 1][t], acc16[(4 * t + 2) & 7], 0, 0, 0);
+                            acc16[(4 * t + 3) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks & 1][t + 1], bq[ks & 1][t], acc16[(4 * t + 3) & 7], 0, 0, 0);
+                        } else {
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t], acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[ks & 1][t], af[ks & 1][t + 1], acc[1], 0, 0, 0);
+                        }
                     }
                     if (st_ == 0 && pend) {                       // piece ks of the previous tile's epilogue rides under these MFMAs
                         halo_store_packed_part(p, accP[ks >> 1], mP + (ks >> 1) * p.W, chP, (ks & 1) * 2);
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #pragma unroll
                     for (int i_ = 0; i_ < 6; ++i_) {              // one fragment read in front of every MFMA (see below)
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, M16 ? 2 : 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -395,6 +410,12 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
         }
         g += NSTAGE;
         HUPR_STAMP()                                              // 3: all stages done
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i & 1][4 * (i >> 1) + j] = acc16[i][j];       // (the large accumulators are dead during the loop)
+        }
         if (last_chunk && !(p.ablate & 4)) {
             const long m0 = (((long)b * p.D + d0 + wm) * p.H + h0 + hy0) * p.W + w0 + wx;
             if (defer && has_next) {                              // park: stored during the next item's stage 0
@@ -503,6 +524,7 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
             case 5: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 5>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
             case 8: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 8>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
             case 16: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 16>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 32>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
             default: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 7>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
         }
         return true;

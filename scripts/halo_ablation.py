@@ -13,7 +13,7 @@ for name, (Ci, Co, D, H, W, k, pad) in shapes.items():
     flop = 2.0 * 32 * D * H * W * Co * Ci * k[0] * 9
     res = {}
     for rnd in range(3):
-        for variant, bits, label in ((1, 0, "v128 full"), (2, 0, "v256 full"), (2, 256, "v256 old-stage-protocol full"), (2, 256 + 5, "old-protocol skeleton"), (2, 2, "v256 immediate-epilogue"), (2, 8, "v256 no-xcd-map"), (2, 1, "v256 no-fill"), (2, 4, "v256 no-store"), (2, 5, "v256 skeleton"), (2, 5 + 16, "skel no-wstage"), (2, 5 + 64, "skel frags-once"), (2, 5 + 112, "skel mfma-only")):
+        for variant, bits, label in ((1, 0, "v128 full"), (2, 0, "v256 full"), (2, 256, "v256 old-stage-protocol full"), (2, 512, "v256 with 16x16x32 MFMAs (timing only)"), (2, 512 + 5, "16x16x32 skeleton"), (2, 256 + 5, "old-protocol skeleton"), (2, 2, "v256 immediate-epilogue"), (2, 8, "v256 no-xcd-map"), (2, 1, "v256 no-fill"), (2, 4, "v256 no-store"), (2, 5, "v256 skeleton"), (2, 5 + 16, "skel no-wstage"), (2, 5 + 64, "skel frags-once"), (2, 5 + 112, "skel mfma-only")):
             L.hupr_debug_halo_variant(variant); L.hupr_debug_halo_ablate(bits)
             for _ in range(2): F_._conv_raw(x, w, 0, None, None, Co, k, pad, (D, H, W))
             torch.cuda.synchronize()
