@@ -187,7 +187,7 @@ def conv_roofline(events, B, dtype, peak):
         pass
     avg = float(np.mean(ms)) * 1e-3
     ach = kflop / avg / 1e12
-    kname = "hupr_k_conv_halo256_bf16<bf16 activations>" if dtype == "bf16" else "hupr_k_gemm_f32<128,64,2,2,A_CONV,B_NK>"
+    kname = "hupr_k_conv_halo256m_bf16 (256-voxel halo convolution on v_mfma_f32_16x16x32_bf16, bf16 activations)" if dtype == "bf16" else "hupr_k_gemm_f32<128,64,2,2,A_CONV,B_NK>"
     # what limits the kernel: bf16 — the tap loop is issue/LDS-bound underneath the matrix pipe, graded
     # against the bf16 MFMA peak because the work is GEMM-shaped; f32 — the fp32 matrix pipe itself
     return {"bound": "mfma", "kernel": kname + " (Encoder3D.layer1 64->64 3x3x3, fwd+dgrad launches)",

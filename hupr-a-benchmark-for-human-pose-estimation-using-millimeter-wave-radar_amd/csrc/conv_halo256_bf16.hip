@@ -494,6 +494,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 #undef HUPR_HALO_COMMIT
 }
 
+static int g_halo_m16 = 1;      // 1 (default): bf16-activation launches go to the 16 x 16 x 32 kernel (conv_halo256m_bf16.hip): -6 % / -7 % on the layer-1 / layer-2 shapes
+void set_halo_m16(int on) { g_halo_m16 = on; }
+
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
     if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
     const long tiles = (long)Bn * (a.D / 4) * (a.H / 8) * (a.W / 8) * (a.Co / 64);
@@ -529,7 +532,8 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
         }
         return true;
     }
-    if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(kHalo256Grid), dim3(512), 0, s, a);
+    if (abf && g_halo_m16 && a.ablate == 0 && a.trace == nullptr) launch_conv_halo256m(a, s);      // v_mfma_f32_16x16x32_bf16 form
+    else if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(kHalo256Grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<false>, dim3(kHalo256Grid), dim3(512), 0, s, a);
     return true;
 }

@@ -1,0 +1,340 @@
+// The 256-voxel persistent halo convolution (conv_halo256_bf16.hip, bf16 activations) on v_mfma_f32_16x16x32_bf16.
+//
+// Why another instruction shape: with the chip at its power limit the 16 x 16 x 32 form does 15-17 % more work per joule than
+// the 32 x 32 x 16 form (register-fed; 5-7 % fed from LDS at this kernel's rate: scripts/probes/mfma_shapes_probe.hip), and the
+// timing-only variant 32 of the old kernel measured -5 % / -7 % on the layer-1 / layer-2 shapes (profiles/r04b_halo_ablation_m16.txt).
+// Same tile (4 x 8 x 8 voxels x 64 output channels per 512-thread workgroup), same LDS images, same LDS-DMA weight stages and the
+// same stage protocol (barrier in front of a stage's last tap, fragment pipeline across stages, next halo's register loads one
+// item per tap, its LDS commit behind the last stage's barrier) as hupr_k_conv_halo256_bf16<true, 0>; what changes is who owns what:
+//   wave = depth slice wm (4) x 32-channel half wn (2), as before; lane = (idx = lane & 15, kq = lane >> 4);
+//   the wave's 64 voxels are four groups vg of 16 (rows 2 vg, 2 vg + 1; idx = 8 yy + wx), its 32 channels two groups cg of 16;
+//   D'[channel][voxel] = W X^T: lane holds voxel idx of every group and channels 16 cg + 4 kq .. + 3: c[vg][cg] (eight f32x4);
+//   a K-step is 32 input channels (lane kq reads the 16-byte chunk 4 kk + kq of a row); per tap ky: 2 weight fragments (cg) and the
+//   4 activation fragments of halo rows rho = 2 vg + ky feed 8 MFMAs; rho = 2, 4, 6 serve ky = 0 and ky = 2 (9 activation reads per
+//   K-step for 12 (vg, ky) pairs); two register banks of four activation fragments rotate (the even-rho bank of K-step kk + 1 is
+//   loaded into the odd-rho bank of kk while ky = 2 multiplies): 13 fragments live, 52 registers (the old kernel: 56).
+// The fp32 sums differ from the 32 x 32 x 16 kernel's in the order inside a 32-channel group only (checked against it and fp64).
+#include "conv_halo.h"
+
+namespace hupr {
+
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
+    constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
+    constexpr int TD = 4, TH = 8, TW = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2;
+    constexpr int NVOX = HD * HH * HW;                         // 600 halo voxels
+    constexpr int T = 27, NSTAGE = 9, NTAP = 6;                // stage = (kz, kx); its taps: K-step kk (2) x ky (3)
+    constexpr int NH = (NVOX * C8 + 511) / 512;                // 10 halo items (8 channels of a voxel) per thread
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];
+    // fused BatchNorm statistics: per lane the running sums of its eight channels over its voxels (bf16-ROUNDED outputs):
+    // [wave][lane][cg * 4 + r sums, 8 + cg * 4 + r sums of squares]; reduced over the sixteen voxel lanes and the four depth-slice
+    // waves once, after the tile loop, in double
+    __shared__ __attribute__((aligned(16))) float St[8][64][16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int idx = lane & 15, kq = lane >> 4, yy = idx >> 3, wx = idx & 7;
+    const int n_tiles = p.Bn * p.nd * p.nh * p.nw * p.n_co_tiles;
+
+    // ---- weight stages by LDS-DMA (as in the 32 x 32 x 16 kernel) ------------------------------------------------------
+    const int wrow_ = 8 * wave + (lane >> 3);
+    const int wsrc_lane = (wrow_ * T * p.Ci + (((lane & 7) ^ (wrow_ >> 1)) & 7) * 8) * 2;      // bytes; < 2^31
+    const u32x4 wrs = {(unsigned)(unsigned long)p.wp, (unsigned)((unsigned long)p.wp >> 32) & 0xffffu,
+                       (unsigned)((long)p.Co * T * p.Ci * 2), 0x00020000u};
+    const unsigned bs_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
+    const unsigned wdst_wave = __builtin_amdgcn_readfirstlane(bs_lds + wave * 1024);
+#define HUPR_W_DMA(COT_, CH_, S_, PAR_)                                                                             \
+    {                                                                                                               \
+        const int wbase_ = (((COT_) * BN * T + ((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + (CH_) * KC) * 2 + wsrc_lane;   \
+        _Pragma("unroll") for (int j = 0; j < TS; ++j) {                                                            \
+            unsigned keep_;                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
+                         "s_mov_b32 m0, %0"                                                                         \
+                         : "=&s"(keep_)                                                                             \
+                         : "s"(wdst_wave + ((PAR_) * TS + j) * (BN * LDK * 2)), "v"(wbase_ + j * (3 * p.Ci * 2)), "s"(wrs) \
+                         : "memory");                                                                               \
+        }                                                                                                           \
+    }
+
+    // ---- halo: global -> registers -> LDS ------------------------------------------------------------------------------
+    u32x4 vb[NH];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.x), 0, (int)((long)p.Bn * p.D * p.H * p.W * p.in_ld * 2), 0x00020000);
+#define HUPR_HALO_ISSUE_ITEM(u, COND_, B_, D0_, H0_, W0_, C0_)                                                     \
+    {                                                                                                               \
+        const int it = tid + (u) * 512;                                                                             \
+        const int vox = it >> 3, c8 = it & 7;                                                                       \
+        const int hx = vox % HW;                                                                                    \
+        const int t_ = vox / HW;                                                                                    \
+        const int hy = t_ % HH, hz = t_ / HH;                                                                       \
+        const int d = (D0_) + hz - 1, h = (H0_) + hy - 1, w = (W0_) + hx - 1;                                       \
+        const bool ok = (COND_) && it < NVOX * C8 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&  \
+                        (unsigned)w < (unsigned)p.W;                                                                \
+        const int off = (((((B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8) * 2;                  \
+        const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : 0x7ffffff0, 0, 0);                  \
+        vb[u] = (u32x4){ld_[0], ld_[1], ld_[2], ld_[3]};                                                            \
+    }
+#define HUPR_HALO_COMMIT()                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
+        const int it = tid + u * 512;                                                                               \
+        if (it < NVOX * C8) {                                                                                       \
+            const int vox = it >> 3, c8 = it & 7;                                                                   \
+            const int hx = vox % HW;                                                                                \
+            *reinterpret_cast<u32x4*>(&Hs[vox * LDK + ((c8 ^ (((hx >> 1) & 3) << 1)) << 3)]) = vb[u];              \
+        }                                                                                                           \
+    }
+
+    struct Pos { int cot, twi, thi, tdi, b, ch; };
+    const int n_chunks = p.Ci / KC;
+    const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int wg_rank = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // an eighth of the tile sequence per XCD
+    const int t_begin = wg_rank * per_wg, t_end = min(n_tiles, t_begin + per_wg);
+    if (p.stats) {
+        for (int i = tid; i < 8 * 64 * 16; i += 512) (&St[0][0][0])[i] = 0.f;      // published by the prologue barrier
+        if (t_begin >= t_end) {
+            for (int c = tid; c < 2 * p.Co; c += 512) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
+        }
+    }
+    if (t_begin >= t_end) return;
+    Pos cur;
+    {
+        cur.cot = t_begin % p.n_co_tiles;
+        int st = t_begin / p.n_co_tiles;
+        cur.twi = st % p.nw; st /= p.nw;
+        cur.thi = st % p.nh; st /= p.nh;
+        cur.tdi = st % p.nd;
+        cur.b = st / p.nd;
+        cur.ch = 0;
+    }
+    const int n_items = (t_end - t_begin) * n_chunks;
+
+    // ---- fragment addresses ----------------------------------------------------------------------------------------
+    // weights: row n = 32 wn + 16 cg + idx of a tap's [64][64] image, chunk 4 kk + kq at position chunk ^ ((n >> 1) & 7)
+    int woff[2][2];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int n = 32 * wn + 16 * cg + idx;
+            woff[cg][kk] = n * LDK + (((4 * kk + kq) ^ ((n >> 1) & 7)) << 3);
+        }
+    // activations: halo voxel (wm + kz, rho + yy, wx + kx).  Halo row swizzle of THIS kernel: 16-byte chunk c of voxel (hy, hx) lives at
+    // chunk c ^ (((hx >> 1) & 3) << 1).  A 16-lane ds_read_b128 group holds eight lanes of chunk parity 0 and eight of parity 1 such
+    // that the two rows yy of a column differ in that parity; voxel pitch 128 B puts the column parity into bank bit 5; the key separates
+    // the four columns of one parity in chunk bits 1-2: all 64 banks, every tap (the 32 x 32 x 16 kernel's key gave 32 % conflict cycles
+    // with this lane map: SQ_LDS_BANK_CONFLICT)
+    const int xlane = ((wm * HH + yy) * HW + wx) * LDK;
+#define HUPR_XF(ST_, RHO_, KK_)                                                                                     \
+    (*reinterpret_cast<const bf16x8*>(&Hs[xlane + ((((ST_) / 3) * HH + (RHO_)) * HW + ((ST_) % 3)) * LDK +          \
+        (((4 * (KK_) + kq) ^ ((((wx + ((ST_) % 3)) >> 1) & 3) << 1)) << 3)]))
+#define HUPR_WF(BUF_, KY_, CG_, KK_) (*reinterpret_cast<const bf16x8*>(&Bs[BUF_][KY_][woff[CG_][KK_]]))
+
+    f32x4c c[4][2];
+    unsigned accP[4][2][2];                                      // parked tile: bf16 pairs of c[vg][cg]
+    __bf16* pP = nullptr;                                        // parked tile: this lane's 16-byte run of voxel group 0
+    bool pend = false;
+    const bool defer = !p.bias && !p.res && (p.Co & 7) == 0 && (p.out_ld & 7) == 0;
+    bf16x8 xq[2][4], x8, wq[2][2];
+    // fragments of tap TAU_ (= 3 kk + ky) of stage ST_ from weight buffer BUF_ (WX_: 1 weights only, 2 activations only, 3 both)
+#define HUPR_LOAD_TAP(ST_, TAU_, BUF_, WX_)                                                                         \
+    {                                                                                                               \
+        constexpr int kk_ = (TAU_) / 3, ky_ = (TAU_) % 3;                                                           \
+        if ((WX_) & 1) {                                                                                            \
+            wq[(TAU_) & 1][0] = HUPR_WF(BUF_, ky_, 0, kk_);                                                         \
+            wq[(TAU_) & 1][1] = HUPR_WF(BUF_, ky_, 1, kk_);                                                         \
+        }                                                                                                           \
+        if ((WX_) & 2) {                                                                                            \
+            if (ky_ == 0) { _Pragma("unroll") for (int vg = 0; vg < 4; ++vg) xq[kk_ & 1][vg] = HUPR_XF(ST_, 2 * vg, kk_); } \
+            else if (ky_ == 1) { _Pragma("unroll") for (int vg = 0; vg < 4; ++vg) xq[(kk_ & 1) ^ 1][vg] = HUPR_XF(ST_, 2 * vg + 1, kk_); } \
+            else { x8 = HUPR_XF(ST_, 8, kk_); }                                                                     \
+        }                                                                                                           \
+    }
+#define HUPR_VMCNT_LGKM0(N_) __builtin_amdgcn_s_waitcnt(0x0070 | ((N_) & 15) | (((N_) >> 4) << 14))
+
+    // prologue: first item's halo, weight stages 0 and 1
+    HUPR_W_DMA(cur.cot, cur.ch, 0, 0)
+    HUPR_W_DMA(cur.cot, cur.ch, 1, 1)
+#pragma unroll
+    for (int u = 0; u < NH; ++u) HUPR_HALO_ISSUE_ITEM(u, true, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
+    HUPR_HALO_COMMIT()
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    HUPR_LOAD_TAP(0, 0, 0, 3)
+
+    int g = 0;                                                    // global stage counter: stage g reads Bs[g & 1]
+    for (int q = 0; q < n_items; ++q) {
+        const int b = cur.b, d0 = cur.tdi * TD, h0 = cur.thi * TH, w0 = cur.twi * TW, n0 = cur.cot * BN;
+        const bool first_chunk = cur.ch == 0, last_chunk = cur.ch == n_chunks - 1;
+        Pos nxt = cur;
+        if (++nxt.ch == n_chunks) {
+            nxt.ch = 0;
+            if (++nxt.cot == p.n_co_tiles) {
+                nxt.cot = 0;
+                if (++nxt.twi == p.nw) {
+                    nxt.twi = 0;
+                    if (++nxt.thi == p.nh) {
+                        nxt.thi = 0;
+                        if (++nxt.tdi == p.nd) { nxt.tdi = 0; ++nxt.b; }
+                    }
+                }
+            }
+        }
+        const bool has_next = q + 1 < n_items;
+        if (first_chunk) {
+#pragma unroll
+            for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) c[vg][cg] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int st_ = 0; st_ < NSTAGE; ++st_) {
+            const int par = (g + st_) & 1;
+#pragma unroll
+            for (int tau = 0; tau < NTAP; ++tau) {
+                const int kk = tau / 3, ky = tau % 3;
+                if (tau == NTAP - 1) {
+                    // the stage's barrier: this wave's reads of Bs[par] have all returned and its pieces of stage s + 1 have landed in
+                    // Bs[par ^ 1]; younger operations stay in flight: the next halo's register loads issued since (one per tap: five
+                    // in front of the first two barriers of an item) and in stage 0 the four stores of the parked tile
+                    if (st_ == 0) { if (pend) { HUPR_VMCNT_LGKM0(9); } else { HUPR_VMCNT_LGKM0(5); } }
+                    else if (st_ == 1) { HUPR_VMCNT_LGKM0(5); }
+                    else { HUPR_VMCNT_LGKM0(0); }
+                    __syncthreads();
+                    if (st_ + 2 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 2, par) }
+                    else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, st_ + 2 - NSTAGE, par) }
+                    if (st_ == NSTAGE - 1 && has_next) { HUPR_HALO_COMMIT() }
+                }
+                // the next tap's fragments: of this stage, or tap 0 of the next one (across an item boundary only its weights)
+                if (tau == 0) { HUPR_LOAD_TAP(st_, 1, par, 3) }
+                else if (tau == 1) { HUPR_LOAD_TAP(st_, 2, par, 3) }
+                else if (tau == 2) { HUPR_LOAD_TAP(st_, 3, par, 3) }
+                else if (tau == 3) { HUPR_LOAD_TAP(st_, 4, par, 3) }
+                else if (tau == 4) { HUPR_LOAD_TAP(st_, 5, par, 3) }
+                else if (st_ + 1 < NSTAGE) { HUPR_LOAD_TAP((st_ + 1) % NSTAGE, 0, par ^ 1, 3) }
+                else if (has_next) { HUPR_LOAD_TAP(0, 0, par ^ 1, 1) }
+                // eight MFMAs: activation rows rho = 2 vg + ky
+#pragma unroll
+                for (int vg = 0; vg < 4; ++vg) {
+                    const bf16x8 xf = ky == 0 ? xq[kk & 1][vg] : (ky == 1 ? xq[(kk & 1) ^ 1][vg] : (vg < 3 ? xq[kk & 1][vg + 1] : x8));
+                    c[vg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[tau & 1][0], xf, c[vg][0], 0, 0, 0);
+                    c[vg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[tau & 1][1], xf, c[vg][1], 0, 0, 0);
+                }
+                if (st_ == 0 && pend && tau < 4) {
+                    // one voxel group of the parked tile per tap.  v_permlane16_swap trades the odd 16-lane rows of the cg = 0 dwords for the
+                    // even rows of the cg = 1 dwords: a kq-even lane then holds channels 4 kq .. 4 kq + 7 of group 0, a kq-odd lane
+                    // channels 4 (kq - 1) .. + 7 of group 1 — ONE 16-byte store per lane and voxel instead of two 8-byte ones
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(accP[tau][0][0], accP[tau][1][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(accP[tau][0][1], accP[tau][1][1], false, false);
+                    *reinterpret_cast<u32x4*>(pP + (long)(2 * tau * p.W) * p.out_ld) = (u32x4){r0[0], r1[0], r0[1], r1[1]};
+                }
+                // the next item's halo: one item per tap under its MFMAs (branch-free: an out-of-range offset past the last item)
+                if (NTAP * st_ + tau < NH) {
+                    HUPR_HALO_ISSUE_ITEM(NTAP * st_ + tau, has_next, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
+                }
+                // a fragment read in front of the MFMAs, one at a time (six reads at most, eight MFMAs)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+                for (int i_ = 0; i_ < 4; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (st_ == 0) pend = false;
+        }
+        g += NSTAGE;
+        if (last_chunk) {
+            // lane's voxel of group vg: (dz = wm, row 2 vg + yy, column wx); its channels: n0 + 32 wn + 16 cg + 4 kq .. + 3
+            const long m0 = (((long)b * p.D + d0 + wm) * p.H + h0 + yy) * p.W + w0 + wx;
+            const int ch0 = n0 + 32 * wn + 4 * kq;
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            if (defer && has_next) {                              // park: stored during the next item's stage 0
+#pragma unroll
+                for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg) {
+                        const bf16x2 lo = {(__bf16)c[vg][cg][0], (__bf16)c[vg][cg][1]}, hi = {(__bf16)c[vg][cg][2], (__bf16)c[vg][cg][3]};
+                        accP[vg][cg][0] = __builtin_bit_cast(unsigned, lo);
+                        accP[vg][cg][1] = __builtin_bit_cast(unsigned, hi);
+                    }
+                pP = static_cast<__bf16*>(p.y) + m0 * p.out_ld + n0 + 32 * wn + ((kq & 1) ? 16 + 4 * (kq - 1) : 4 * kq);
+                pend = true;
+            } else {
+#pragma unroll
+                for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg) {
+                        const long m = m0 + 2 * vg * p.W;
+                        const int ch = ch0 + 16 * cg;
+                        if (ch < p.Co) {
+                            f32x4n v = {c[vg][cg][0], c[vg][cg][1], c[vg][cg][2], c[vg][cg][3]};
+                            if (p.bias) v += (f32x4n){p.bias[ch], p.bias[ch + 1], p.bias[ch + 2], p.bias[ch + 3]};
+                            if (p.res) {
+                                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.res) + m * p.res_ld + ch);
+                                v += (f32x4n){(float)rv[0], (float)rv[1], (float)rv[2], (float)rv[3]};
+                            }
+                            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                            *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(p.y) + m * p.out_ld + ch) = o;
+                        }
+                    }
+            }
+            if (p.stats) {
+                // this lane's eight channels over its four voxels of the tile, rounded exactly as they are stored
+                f32x4n* slot = reinterpret_cast<f32x4n*>(&St[wave][lane][0]);
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    f32x4n sv = {0.f, 0.f, 0.f, 0.f}, qv = sv;
+#pragma unroll
+                    for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = (float)(__bf16)c[vg][cg][r];
+                            sv[r] += a;
+                            qv[r] = fmaf(a, a, qv[r]);
+                        }
+                    slot[cg] += sv;
+                    slot[2 + cg] += qv;
+                }
+            }
+        }
+        if (has_next) {
+            __syncthreads();                                      // the halo committed behind the last stage's barrier is complete
+            HUPR_LOAD_TAP(0, 0, g & 1, 2)                         // its weight fragments were read under the last MFMAs above
+        }
+        cur = nxt;
+    }
+    if (p.stats) {
+        // channel ch = 32 wn + 16 cg + 4 kq + r collects, in a fixed order and as doubles, the sixteen voxel lanes of its (kq) row
+        // group in each of the four depth-slice waves
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int k = tid >> 6, ch = tid & 63;
+            const int wn_ = ch >> 5, cg = (ch >> 4) & 1, kq_ = (ch >> 2) & 3, r = ch & 3;
+            double t = 0.0;
+#pragma unroll
+            for (int wm_ = 0; wm_ < 4; ++wm_)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += (double)St[2 * wm_ + wn_][16 * kq_ + i][8 * k + 4 * cg + r];
+            p.stats[(long)blockIdx.x * 2 * p.Co + k * p.Co + ch] = t;
+        }
+    }
+#undef HUPR_W_DMA
+#undef HUPR_HALO_ISSUE_ITEM
+#undef HUPR_HALO_COMMIT
+#undef HUPR_XF
+#undef HUPR_WF
+#undef HUPR_LOAD_TAP
+#undef HUPR_VMCNT_LGKM0
+}
+
+void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(hupr_k_conv_halo256m_bf16, dim3(kHalo256Grid), dim3(512), 0, s, a);
+}
+
+}  // namespace hupr

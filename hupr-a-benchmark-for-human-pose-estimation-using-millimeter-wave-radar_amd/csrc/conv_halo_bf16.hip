@@ -394,6 +394,7 @@ static unsigned long long* g_halo_trace = nullptr;
 extern "C" void hupr_debug_halo_trace(void* buf) { g_halo_trace = reinterpret_cast<unsigned long long*>(buf); }
 extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
 extern "C" void hupr_debug_halo_variant(int v) { g_halo_variant = v; }
+extern "C" void hupr_debug_halo_m16(int on) { set_halo_m16(on); }      // 256-voxel kernel: 1 = the v_mfma_f32_16x16x32_bf16 form
 static int g_halo_split_k = 1;      // A/B aid: 0 = never slice the reduction of small grids
 extern "C" void hupr_debug_halo_split_k(int on) { g_halo_split_k = on; }
 static int g_halo_small_tiles = 1;  // A/B aid: 0 keeps 64-wide channel tiles on small grids

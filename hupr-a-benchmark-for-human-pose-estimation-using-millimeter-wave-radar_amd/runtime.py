@@ -62,6 +62,7 @@ SIGNATURES = {
     "hupr_debug_attn_dkv512": (None, [c_int]),
     "hupr_debug_halo_ablate": (None, [c_int]),
     "hupr_debug_halo_variant": (None, [c_int]),
+    "hupr_debug_halo_m16": (None, [c_int]),
     "hupr_debug_halo_small_tiles": (None, [c_int]),
     "hupr_debug_halo_trace": (None, [c_void_p]),
     "hupr_debug_wgrad_groups": (None, [c_int]),
@@ -199,6 +200,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("HUPR_HALO_M16") in ("0", "1") and hasattr(L, "hupr_debug_halo_m16"):
+            L.hupr_debug_halo_m16(int(os.environ["HUPR_HALO_M16"]))      # A/B aid: the 256-voxel convolution's MFMA shape
         _lib = L
     return _lib
 

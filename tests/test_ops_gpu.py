@@ -701,16 +701,27 @@ def test_conv_halo256_stage_protocols_agree_bitwise(shape, bf16_math):
     x = rnd(B, D, H, W, Ci, seed=54).cuda().bfloat16()
     w = rnd(Co, Ci, 3, 3, 3, seed=55, scale=(Ci * 27) ** -0.5).cuda()
     try:
+        L.hupr_debug_halo_m16(0)
         L.hupr_debug_halo_ablate(16 << 4)
         y_old = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
         L.hupr_debug_halo_ablate(0)
         y_new = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
         y_new2 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        L.hupr_debug_halo_m16(1)
+        y_m16 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        y_m16b = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
     finally:
         L.hupr_debug_halo_ablate(0)
+        L.hupr_debug_halo_m16(1)
     assert y_new.dtype == torch.bfloat16 and torch.equal(y_new, y_old) and torch.equal(y_new, y_new2)
     ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
     close(ncdhw(y_new.float().cpu())[:1], ref, 1e-2, "halo256 (bf16 store) vs fp64")
+    # the default kernel (v_mfma_f32_16x16x32_bf16: another fp32 order inside a 32-channel group): deterministic, the same products,
+    # a handful of outputs one bf16 step away from the 32 x 32 x 16 kernel's
+    assert torch.equal(y_m16, y_m16b)
+    d = (y_m16.float() - y_new.float()).abs()
+    assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(y_new.float().abs(), y_m16.float().abs()) * 2 ** -7 + 1e-5).all()
+    close(ncdhw(y_m16.float().cpu())[:1], ref, 1e-2, "halo256m (bf16 store) vs fp64")
 
 
 # ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
@@ -741,7 +752,18 @@ def test_conv_halo_bf16_activations(case, bf16_math):
     y32 = F_._conv_raw(x, w, 0, bias, res, Co, k, pad, (D, H, W))
     y16 = F_._conv_raw(x.bfloat16(), w, 0, bias, res.bfloat16() if has_res else None, Co, k, pad, (D, H, W))
     assert y16.dtype == torch.bfloat16
-    assert torch.equal(y16.float(), _q(y32)), (y16.float() - _q(y32)).abs().max().item()
+    d16 = (y16.float() - _q(y32)).abs()
+    if not torch.equal(y16.float(), _q(y32)):
+        # only where the 256-voxel kernel engages: its bf16-activation form multiplies on v_mfma_f32_16x16x32_bf16 (another fp32 order
+        # inside a 32-channel group than the fp32-activation form's 32 x 32 x 16): a few outputs land one bf16 step away
+        assert (d16 > 0).float().mean().item() < 2e-3 and (d16 <= torch.maximum(_q(y32).abs(), y16.float().abs()) * 2 ** -7 + 1e-5).all(), d16.max().item()      # (+ the fp32 order noise where residual and sum cancel)
+        L_ = F_.rt.lib()
+        try:
+            L_.hupr_debug_halo_m16(0)
+            y16b = F_._conv_raw(x.bfloat16(), w, 0, bias, res.bfloat16() if has_res else None, Co, k, pad, (D, H, W))
+        finally:
+            L_.hupr_debug_halo_m16(1)
+        assert torch.equal(y16b.float(), _q(y32))              # the 32 x 32 x 16 form: store rounding only
     # weight gradient: fp32 output, identical products; only the fp32 summation order over voxel slices differs
     # (LDS-DMA kernel: two K halves per workgroup, other slice count)
     if Ci % 32 == 0 and Co % 8 == 0:
