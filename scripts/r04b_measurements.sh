@@ -17,4 +17,4 @@ python scripts/gemm_path_calls.py > gpurun_out/r04b_gemm_path_calls.txt 2>&1
 python scripts/wgrad_microbench.py > gpurun_out/r04b_wgrad_microbench.txt 2>&1
 for f in gpurun_out/r04b_b_*.json; do tail -1 $f | cut -c1-160; done
 tail -n 3 gpurun_out/r04b_conv_pmc.txt
-grep -E "conv_halo256.*(BUSY_CYCLES|WAIT_ANY|WAIT_INST_ANY|ACTIVE_INST_ANY|INSTS_MFMA|WAVE_CYCLES)" gpurun_out/r04b_conv_sq_pmc.txt
+grep -E "conv_halo256.*(LDS_BANK_CONFLICT|BUSY_CYCLES|WAIT_ANY|WAIT_INST_ANY|ACTIVE_INST_ANY|INSTS_MFMA|WAVE_CYCLES)" gpurun_out/r04b_conv_sq_pmc.txt
