@@ -495,7 +495,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 }
 
 static int g_halo_m16 = 1;      // 1 (default): bf16-activation launches go to the 16 x 16 x 32 kernel (conv_halo256m_bf16.hip): -6 % / -7 % on the layer-1 / layer-2 shapes
-void set_halo_m16(int on) { g_halo_m16 = on; }
+static int g_halo_m16_td2 = 1;  // the 2 x 8 x 16 tile of that kernel for D % 4 != 0 (2 = on via hupr_debug_halo_m16(1), 0 via hupr_debug_halo_m16(2): 4 x 8 x 8 only)
+void set_halo_m16(int on) { g_halo_m16 = on != 0; g_halo_m16_td2 = on != 2; }
 
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
     if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
@@ -507,6 +508,21 @@ bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
 
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     // measured (scripts/halo_ablation.py): faster on the 3-D encoder layers, neutral to slower on the 2-D decoder maps
+    if (abf && g_halo_m16 && g_halo_m16_td2 && a.kd == 3 && a.D % 4 != 0 && a.D % 2 == 0 && a.H % 8 == 0 && a.W % 16 == 0 && a.Ci % 64 == 0 &&
+        a.Co % 64 == 0 && a.ablate == 0 && a.trace == nullptr && !a.stats) {
+        // depth not a multiple of four (encoder level 3: D = 2): the 2 x 8 x 16 tile of the 16 x 16 x 32 kernel
+        a.TD = 2;
+        a.log2TW = 4;
+        a.nd = a.D / 2;
+        a.nh = a.H / 8;
+        a.nw = a.W / 16;
+        a.n_co_tiles = a.Co / 64;
+        const long tiles2 = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
+        if (tiles2 >= 256 && tiles2 < (1L << 31) && (long)Bn * a.D * a.H * a.W * a.in_ld * 2 < 0x7ffffff0L) {
+            launch_conv_halo256m(a, s);
+            return true;
+        }
+    }
     if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
     a.TD = 4;
     a.log2TW = 3;

@@ -20,22 +20,32 @@ namespace hupr {
 
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 
+// Tile 4 x 8 x 8 (TD = 4, TW = 8: the encoder levels with D % 4 == 0) or 2 x 8 x 16 (TD = 2, TW = 16: level 3, D = 2 — before this
+// variant those layers ran on the 128-voxel kernel at 935 TF/s); a wave owns depth slice wm (TD = 4) or (depth slice wm >> 1, column
+// half wm & 1) (TD = 2): 8 x 8 voxels either way.  The statistics slots exist for the 4 x 8 x 8 tile only (level 1, Co = 64).
+template <int TD, int TW>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
-    constexpr int TD = 4, TH = 8, TW = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2;
-    constexpr int NVOX = HD * HH * HW;                         // 600 halo voxels
+    constexpr int TH = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2;
+    static_assert(TD * TW == 32, "256 voxels per tile");
+    constexpr int NVOX = HD * HH * HW;                         // 600 (4 x 8 x 8) / 720 (2 x 8 x 16) halo voxels
     constexpr int T = 27, NSTAGE = 9, NTAP = 6;                // stage = (kz, kx); its taps: K-step kk (2) x ky (3)
-    constexpr int NH = (NVOX * C8 + 511) / 512;                // 10 halo items (8 channels of a voxel) per thread
+    constexpr int NH = (NVOX * C8 + 511) / 512;                // 10 / 12 halo items (8 channels of a voxel) per thread
+    // items are issued one per tap from the item's first tap on; in front of the barriers of stages 0, 1, 2 (each in front of the stage's
+    // sixth tap) the items of taps 6 s - 1 .. 6 s + 4 are younger than the weight pieces the barrier waits for
+    constexpr int Y0 = NH < 5 ? NH : 5, Y1 = NH - 5 < 0 ? 0 : (NH - 5 > 6 ? 6 : NH - 5), Y2 = NH - 11 < 0 ? 0 : (NH - 11 > 6 ? 6 : NH - 11);
+    static_assert(NH <= 17, "halo items must all be issued within the first three stages");
     __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];
     // fused BatchNorm statistics: per lane the running sums of its eight channels over its voxels (bf16-ROUNDED outputs):
     // [wave][lane][cg * 4 + r sums, 8 + cg * 4 + r sums of squares]; reduced over the sixteen voxel lanes and the four depth-slice
     // waves once, after the tile loop, in double
-    __shared__ __attribute__((aligned(16))) float St[8][64][16];
+    __shared__ __attribute__((aligned(16))) float St[TD == 4 ? 8 : 1][64][16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int wm = wave >> 1, wn = wave & 1;
+    const int dzw = TD == 4 ? wm : wm >> 1, xw0 = TD == 4 ? 0 : 8 * (wm & 1);      // the wave's depth slice and first column
     const int idx = lane & 15, kq = lane >> 4, yy = idx >> 3, wx = idx & 7;
     const int n_tiles = p.Bn * p.nd * p.nh * p.nw * p.n_co_tiles;
 
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
     const int wg_rank = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // an eighth of the tile sequence per XCD
     const int t_begin = wg_rank * per_wg, t_end = min(n_tiles, t_begin + per_wg);
-    if (p.stats) {
+    if (TD == 4 && p.stats) {
         for (int i = tid; i < 8 * 64 * 16; i += 512) (&St[0][0][0])[i] = 0.f;      // published by the prologue barrier
         if (t_begin >= t_end) {
             for (int c = tid; c < 2 * p.Co; c += 512) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
@@ -126,10 +136,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     // that the two rows yy of a column differ in that parity; voxel pitch 128 B puts the column parity into bank bit 5; the key separates
     // the four columns of one parity in chunk bits 1-2: all 64 banks, every tap (the 32 x 32 x 16 kernel's key gave 32 % conflict cycles
     // with this lane map: SQ_LDS_BANK_CONFLICT)
-    const int xlane = ((wm * HH + yy) * HW + wx) * LDK;
+    const int xlane = ((dzw * HH + yy) * HW + xw0 + wx) * LDK;
 #define HUPR_XF(ST_, RHO_, KK_)                                                                                     \
     (*reinterpret_cast<const bf16x8*>(&Hs[xlane + ((((ST_) / 3) * HH + (RHO_)) * HW + ((ST_) % 3)) * LDK +          \
-        (((4 * (KK_) + kq) ^ ((((wx + ((ST_) % 3)) >> 1) & 3) << 1)) << 3)]))
+        (((4 * (KK_) + kq) ^ ((((xw0 + wx + ((ST_) % 3)) >> 1) & 3) << 1)) << 3)]))
 #define HUPR_WF(BUF_, KY_, CG_, KK_) (*reinterpret_cast<const bf16x8*>(&Bs[BUF_][KY_][woff[CG_][KK_]]))
 
     f32x4c c[4][2];
@@ -199,8 +209,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                     // the stage's barrier: this wave's reads of Bs[par] have all returned and its pieces of stage s + 1 have landed in
                     // Bs[par ^ 1]; younger operations stay in flight: the next halo's register loads issued since (one per tap: five
                     // in front of the first two barriers of an item) and in stage 0 the four stores of the parked tile
-                    if (st_ == 0) { if (pend) { HUPR_VMCNT_LGKM0(9); } else { HUPR_VMCNT_LGKM0(5); } }
-                    else if (st_ == 1) { HUPR_VMCNT_LGKM0(5); }
+                    if (st_ == 0) { if (pend) { HUPR_VMCNT_LGKM0(Y0 + 4); } else { HUPR_VMCNT_LGKM0(Y0); } }
+                    else if (st_ == 1) { HUPR_VMCNT_LGKM0(Y1); }
+                    else if (st_ == 2) { HUPR_VMCNT_LGKM0(Y2); }
                     else { HUPR_VMCNT_LGKM0(0); }
                     __syncthreads();
                     if (st_ + 2 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 2, par) }
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         g += NSTAGE;
         if (last_chunk) {
             // lane's voxel of group vg: (dz = wm, row 2 vg + yy, column wx); its channels: n0 + 32 wn + 16 cg + 4 kq .. + 3
-            const long m0 = (((long)b * p.D + d0 + wm) * p.H + h0 + yy) * p.W + w0 + wx;
+            const long m0 = (((long)b * p.D + d0 + dzw) * p.H + h0 + yy) * p.W + w0 + xw0 + wx;
             const int ch0 = n0 + 32 * wn + 4 * kq;
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             if (defer && has_next) {                              // park: stored during the next item's stage 0
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                         }
                     }
             }
-            if (p.stats) {
+            if (TD == 4 && p.stats) {
                 // this lane's eight channels over its four voxels of the tile, rounded exactly as they are stored
                 f32x4n* slot = reinterpret_cast<f32x4n*>(&St[wave][lane][0]);
 #pragma unroll
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         }
         cur = nxt;
     }
-    if (p.stats) {
+    if (TD == 4 && p.stats) {
         // channel ch = 32 wn + 16 cg + 4 kq + r collects, in a fixed order and as doubles, the sixteen voxel lanes of its (kq) row
         // group in each of the four depth-slice waves
         __syncthreads();
@@ -334,7 +345,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 }
 
 void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(hupr_k_conv_halo256m_bf16, dim3(kHalo256Grid), dim3(512), 0, s, a);
+    if (a.TD == 4) hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<4, 8>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<2, 16>), dim3(kHalo256Grid), dim3(512), 0, s, a);
 }
 
 }  // namespace hupr

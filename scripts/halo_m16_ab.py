@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hupr_amd import functional as F_
 F_.set_math("bf16")
 L = F_.rt.lib()
-shapes = {"l1 64>64 @8x64x64 B32": (32, 64, 64, 8, 64, 64), "l2 128>128 @4x32x32 B32": (32, 128, 128, 4, 32, 32), "64>128 @8x32x64 B3": (3, 64, 128, 8, 32, 64)}
+shapes = {"l1 64>64 @8x64x64 B32": (32, 64, 64, 8, 64, 64), "l2 128>128 @4x32x32 B32": (32, 128, 128, 4, 32, 32), "64>128 @8x32x64 B3": (3, 64, 128, 8, 32, 64),
+          "l3 256>256 @2x16x16 B32 (2 x 8 x 16 tile; before: the 128-voxel kernel)": (32, 256, 256, 2, 16, 16), "l3 256>256 @2x16x32 B17": (17, 256, 256, 2, 16, 32)}
 for name, (B, Ci, Co, D, H, W) in shapes.items():
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(B, D, H, W, Ci, device="cuda", generator=g).relu().bfloat16()

@@ -724,6 +724,32 @@ def test_conv_halo256_stage_protocols_agree_bitwise(shape, bf16_math):
     close(ncdhw(y_m16.float().cpu())[:1], ref, 1e-2, "halo256m (bf16 store) vs fp64")
 
 
+@pytest.mark.parametrize("shape", [(32, 64, 256, 2, 16, 16), (17, 128, 128, 2, 16, 32)])
+def test_conv_halo256m_two_slice_tile_matches_the_128_voxel_kernel(shape, bf16_math):
+    """Depth 2 (encoder level 3): the 16 x 16 x 32 kernel's 2 x 8 x 16 tile against the 128-voxel kernel these layers ran on before
+    (hupr_debug_halo_m16(2)) — same products, another fp32 order: a few outputs one bf16 step apart — and against fp64; with and
+    without the residual epilogue; even and uneven tile counts over the 256 workgroups."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    B, Ci, Co, D, H, W = shape
+    x = rnd(B, D, H, W, Ci, seed=56).cuda().bfloat16()
+    w = rnd(Co, Ci, 3, 3, 3, seed=57, scale=(Ci * 27) ** -0.5).cuda()
+    res = rnd(B, D, H, W, Co, seed=58).cuda().bfloat16()
+    out = {}
+    try:
+        for mode in (2, 1):
+            L.hupr_debug_halo_m16(mode)
+            out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W)),
+                         F_._conv_raw(x, w, 0, None, res, Co, (3, 3, 3), (1, 1, 1), (D, H, W)))
+    finally:
+        L.hupr_debug_halo_m16(1)
+    for a, b in zip(out[1], out[2]):
+        d = (a.float() - b.float()).abs()
+        assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + 1e-5).all()
+    ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
+    close(ncdhw(out[1][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 (bf16 store) vs fp64")
+
+
 # ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
 # The fp32-activation kernels round x to bf16 while staging, so on bf16-representable inputs both variants perform the
 # SAME arithmetic; the bf16act result must equal the fp32 result rounded once to bf16 (store rounding only).
