@@ -260,7 +260,19 @@ def test_single_sample_attentions_of_a_level_in_one_launch(H, C, cat, bf16_math)
         close(a.float(), b.float(), 1e-2 if cat else 2e-5, "split + batched vs one-pass attention")
 
 
-def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(bf16_math):
+@pytest.fixture(params=["hupr_k_conv_halo_bf16<64, 64>", "hupr_k_conv_halo256m_bf16<2, 16>"])
+def level3_aggressor(request):
+    """The level-3 convolution at B = 32 that shares the chip with a victim: round 3's aggressor (the 128-voxel kernel, which these
+    layers ran on until the end of round 4 and smaller batches still do: hupr_debug_halo_m16(2) keeps depth-2 layers on it) and the
+    kernel they run on now (the 16 x 16 x 32 kernel's 2 x 8 x 16 tile)."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    L.hupr_debug_halo_m16(2 if request.param.startswith("hupr_k_conv_halo_bf16") else 1)
+    yield request.param
+    L.hupr_debug_halo_m16(1)
+
+
+def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(level3_aggressor, bf16_math):
     """Round 3 regression (scripts/interp_race.py): the build of hupr_k_interp_fwd that hipcc's SLP vectoriser
     produced returned wrong sums in >90 % of the launches that shared the chip with the level-3 convolution kernel
     (hupr_k_conv_halo_bf16<64, 64>, B = 32) running on another stream — and in none alone.  The library's kernel (scalar FMAs,
@@ -294,7 +306,7 @@ def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(bf1
 
 
 @pytest.mark.parametrize("victim", ["fft_chain", "halo_conv_epilogue", "attention_forward", "attention_backward"])
-def test_packed_fp32_kernels_are_unaffected_by_co_resident_kernels(victim, bf16_math):
+def test_packed_fp32_kernels_are_unaffected_by_co_resident_kernels(victim, level3_aggressor, bf16_math):
     """VERDICT r3 item 7.  Round 3's corruption needed one compiler-formed packed-fp32 sequence and one
     co-resident kernel, and its mechanism inside the chip was never established.  The library still carries HAND-WRITTEN packed
     fp32 arithmetic — the FFT butterflies (hupr_k_doppler_range / hupr_k_angle: 6 000 v_pk_*_f32), the 4-vector adds of the halo
