@@ -523,6 +523,21 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
             return true;
         }
     }
+    if (abf && g_halo_m16 && g_halo_m16_td2 && a.kd == 1 && a.D == 1 && a.H % 16 == 0 && a.W % 16 == 0 && a.Ci % 64 == 0 && a.Co % 64 == 0 &&
+        a.ablate == 0 && a.trace == nullptr && !a.stats) {
+        // 1 x 3 x 3 convolutions of the decoder: the 1 x 16 x 16 tile of the 16 x 16 x 32 kernel
+        a.TD = 1;
+        a.log2TW = 4;
+        a.nd = 1;
+        a.nh = a.H / 16;
+        a.nw = a.W / 16;
+        a.n_co_tiles = a.Co / 64;
+        const long tiles1 = (long)Bn * a.nh * a.nw * a.n_co_tiles;
+        if (tiles1 >= 256 && tiles1 < (1L << 31) && (long)Bn * a.H * a.W * a.in_ld * 2 < 0x7ffffff0L) {
+            launch_conv_halo256m(a, s);
+            return true;
+        }
+    }
     if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
     a.TD = 4;
     a.log2TW = 3;

@@ -23,29 +23,33 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // Tile 4 x 8 x 8 (TD = 4, TW = 8: the encoder levels with D % 4 == 0) or 2 x 8 x 16 (TD = 2, TW = 16: level 3, D = 2 — before this
 // variant those layers ran on the 128-voxel kernel at 935 TF/s); a wave owns depth slice wm (TD = 4) or (depth slice wm >> 1, column
 // half wm & 1) (TD = 2): 8 x 8 voxels either way.  The statistics slots exist for the 4 x 8 x 8 tile only (level 1, Co = 64).
-template <int TD, int TW>
+// 1 x 16 x 16 with KD = 1 (the decoder's 1 x 3 x 3 convolutions on 64 x 64 and 32 x 32 maps, before on the 128-voxel kernel at
+// 590-940 TF/s): three stages of three taps, a wave owns one 8 x 8 quadrant.
+template <int TD, int TH, int TW, int KD>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
-    constexpr int TH = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2;
-    static_assert(TD * TW == 32, "256 voxels per tile");
+    constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
+    static_assert(TD * TH * TW == 256 && TH % 8 == 0 && TW % 8 == 0 && (KD == 1 || KD == 3), "256 voxels per tile, 8 x 8 per wave");
     constexpr int NVOX = HD * HH * HW;                         // 600 (4 x 8 x 8) / 720 (2 x 8 x 16) halo voxels
-    constexpr int T = 27, NSTAGE = 9, NTAP = 6;                // stage = (kz, kx); its taps: K-step kk (2) x ky (3)
+    constexpr int T = 9 * KD, NSTAGE = 3 * KD, NTAP = 6;       // stage = (kz, kx); its taps: K-step kk (2) x ky (3)
     constexpr int NH = (NVOX * C8 + 511) / 512;                // 10 / 12 halo items (8 channels of a voxel) per thread
     // items are issued one per tap from the item's first tap on; in front of the barriers of stages 0, 1, 2 (each in front of the stage's
     // sixth tap) the items of taps 6 s - 1 .. 6 s + 4 are younger than the weight pieces the barrier waits for
     constexpr int Y0 = NH < 5 ? NH : 5, Y1 = NH - 5 < 0 ? 0 : (NH - 5 > 6 ? 6 : NH - 5), Y2 = NH - 11 < 0 ? 0 : (NH - 11 > 6 ? 6 : NH - 11);
-    static_assert(NH <= 17, "halo items must all be issued within the first three stages");
+    static_assert(NH <= 6 * NSTAGE - 1 && NH <= 17, "halo items must all be issued in front of the item's last barrier (and within three stages)");
     __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];
     // fused BatchNorm statistics: per lane the running sums of its eight channels over its voxels (bf16-ROUNDED outputs):
     // [wave][lane][cg * 4 + r sums, 8 + cg * 4 + r sums of squares]; reduced over the sixteen voxel lanes and the four depth-slice
     // waves once, after the tile loop, in double
-    __shared__ __attribute__((aligned(16))) float St[TD == 4 ? 8 : 1][64][16];
+    constexpr bool STATS = TD == 4 && KD == 3;                 // the statistics slots exist for the 4 x 8 x 8 tile only
+    __shared__ __attribute__((aligned(16))) float St[STATS ? 8 : 1][64][16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int wm = wave >> 1, wn = wave & 1;
-    const int dzw = TD == 4 ? wm : wm >> 1, xw0 = TD == 4 ? 0 : 8 * (wm & 1);      // the wave's depth slice and first column
+    constexpr int NBX = TW / 8, NBY = TH / 8;
+    const int xw0 = 8 * (wm % NBX), yw0 = 8 * ((wm / NBX) % NBY), dzw = wm / (NBX * NBY);      // the wave's 8 x 8 block: first column, first row, depth slice
     const int idx = lane & 15, kq = lane >> 4, yy = idx >> 3, wx = idx & 7;
     const int n_tiles = p.Bn * p.nd * p.nh * p.nw * p.n_co_tiles;
 
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         const int hx = vox % HW;                                                                                    \
         const int t_ = vox / HW;                                                                                    \
         const int hy = t_ % HH, hz = t_ / HH;                                                                       \
-        const int d = (D0_) + hz - 1, h = (H0_) + hy - 1, w = (W0_) + hx - 1;                                       \
+        const int d = (D0_) + hz - KD / 2, h = (H0_) + hy - 1, w = (W0_) + hx - 1;                                  \
         const bool ok = (COND_) && it < NVOX * C8 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&  \
                         (unsigned)w < (unsigned)p.W;                                                                \
         const int off = (((((B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8) * 2;                  \
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
     const int wg_rank = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // an eighth of the tile sequence per XCD
     const int t_begin = wg_rank * per_wg, t_end = min(n_tiles, t_begin + per_wg);
-    if (TD == 4 && p.stats) {
+    if (STATS && p.stats) {
         for (int i = tid; i < 8 * 64 * 16; i += 512) (&St[0][0][0])[i] = 0.f;      // published by the prologue barrier
         if (t_begin >= t_end) {
             for (int c = tid; c < 2 * p.Co; c += 512) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     // that the two rows yy of a column differ in that parity; voxel pitch 128 B puts the column parity into bank bit 5; the key separates
     // the four columns of one parity in chunk bits 1-2: all 64 banks, every tap (the 32 x 32 x 16 kernel's key gave 32 % conflict cycles
     // with this lane map: SQ_LDS_BANK_CONFLICT)
-    const int xlane = ((dzw * HH + yy) * HW + xw0 + wx) * LDK;
+    const int xlane = ((dzw * HH + yw0 + yy) * HW + xw0 + wx) * LDK;
 #define HUPR_XF(ST_, RHO_, KK_)                                                                                     \
     (*reinterpret_cast<const bf16x8*>(&Hs[xlane + ((((ST_) / 3) * HH + (RHO_)) * HW + ((ST_) % 3)) * LDK +          \
         (((4 * (KK_) + kq) ^ ((((xw0 + wx + ((ST_) % 3)) >> 1) & 3) << 1)) << 3)]))
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         g += NSTAGE;
         if (last_chunk) {
             // lane's voxel of group vg: (dz = wm, row 2 vg + yy, column wx); its channels: n0 + 32 wn + 16 cg + 4 kq .. + 3
-            const long m0 = (((long)b * p.D + d0 + dzw) * p.H + h0 + yy) * p.W + w0 + xw0 + wx;
+            const long m0 = (((long)b * p.D + d0 + dzw) * p.H + h0 + yw0 + yy) * p.W + w0 + xw0 + wx;
             const int ch0 = n0 + 32 * wn + 4 * kq;
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             if (defer && has_next) {                              // park: stored during the next item's stage 0
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                         }
                     }
             }
-            if (TD == 4 && p.stats) {
+            if (STATS && p.stats) {
                 // this lane's eight channels over its four voxels of the tile, rounded exactly as they are stored
                 f32x4n* slot = reinterpret_cast<f32x4n*>(&St[wave][lane][0]);
 #pragma unroll
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         }
         cur = nxt;
     }
-    if (TD == 4 && p.stats) {
+    if (STATS && p.stats) {
         // channel ch = 32 wn + 16 cg + 4 kq + r collects, in a fixed order and as doubles, the sixteen voxel lanes of its (kq) row
         // group in each of the four depth-slice waves
         __syncthreads();
@@ -345,8 +349,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 }
 
 void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
-    if (a.TD == 4) hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<4, 8>), dim3(kHalo256Grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<2, 16>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    if (a.kd == 1) hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else if (a.TD == 4) hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<4, 8, 8, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<2, 8, 16, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
 }
 
 }  // namespace hupr

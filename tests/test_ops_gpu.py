@@ -736,30 +736,31 @@ def test_conv_halo256_stage_protocols_agree_bitwise(shape, bf16_math):
     close(ncdhw(y_m16.float().cpu())[:1], ref, 1e-2, "halo256m (bf16 store) vs fp64")
 
 
-@pytest.mark.parametrize("shape", [(32, 64, 256, 2, 16, 16), (17, 128, 128, 2, 16, 32)])
+@pytest.mark.parametrize("shape", [(32, 64, 256, 2, 16, 16), (17, 128, 128, 2, 16, 32), (8, 320, 64, 1, 64, 64), (9, 64, 192, 1, 32, 48)])
 def test_conv_halo256m_two_slice_tile_matches_the_128_voxel_kernel(shape, bf16_math):
-    """Depth 2 (encoder level 3): the 16 x 16 x 32 kernel's 2 x 8 x 16 tile against the 128-voxel kernel these layers ran on before
+    """Depth 2 (encoder level 3) and depth 1 with 1 x 3 x 3 taps (decoder): the 16 x 16 x 32 kernel's 2 x 8 x 16 / 1 x 16 x 16 tiles against the 128-voxel kernel these layers ran on before
     (hupr_debug_halo_m16(2)) — same products, another fp32 order: a few outputs one bf16 step apart — and against fp64; with and
     without the residual epilogue; even and uneven tile counts over the 256 workgroups."""
     from hupr_amd import functional as F_
     L = F_.rt.lib()
     B, Ci, Co, D, H, W = shape
+    k3, pad = ((3, 3, 3), (1, 1, 1)) if D > 1 else ((1, 3, 3), (0, 1, 1))      # D = 1: the decoder's 1 x 3 x 3 taps on the 1 x 16 x 16 tile
     x = rnd(B, D, H, W, Ci, seed=56).cuda().bfloat16()
-    w = rnd(Co, Ci, 3, 3, 3, seed=57, scale=(Ci * 27) ** -0.5).cuda()
+    w = rnd(Co, Ci, *k3, seed=57, scale=(Ci * 9 * k3[0]) ** -0.5).cuda()
     res = rnd(B, D, H, W, Co, seed=58).cuda().bfloat16()
     out = {}
     try:
         for mode in (2, 1):
             L.hupr_debug_halo_m16(mode)
-            out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W)),
-                         F_._conv_raw(x, w, 0, None, res, Co, (3, 3, 3), (1, 1, 1), (D, H, W)))
+            out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, k3, pad, (D, H, W)),
+                         F_._conv_raw(x, w, 0, None, res, Co, k3, pad, (D, H, W)))
     finally:
         L.hupr_debug_halo_m16(1)
     for a, b in zip(out[1], out[2]):
         d = (a.float() - b.float()).abs()
         assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + 1e-5).all()
-    ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
-    close(ncdhw(out[1][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 (bf16 store) vs fp64")
+    ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, pad)
+    close(ncdhw(out[1][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 / 1x16x16 (bf16 store) vs fp64")
 
 
 # ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
