@@ -495,8 +495,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 }
 
 static int g_halo_m16 = 1;      // 1 (default): bf16-activation launches go to the 16 x 16 x 32 kernel (conv_halo256m_bf16.hip): -6 % / -7 % on the layer-1 / layer-2 shapes
-static int g_halo_m16_td2 = 1;  // the 2 x 8 x 16 tile of that kernel for D % 4 != 0 (2 = on via hupr_debug_halo_m16(1), 0 via hupr_debug_halo_m16(2): 4 x 8 x 8 only)
-void set_halo_m16(int on) { g_halo_m16 = on != 0; g_halo_m16_td2 = on != 2; }
+static int g_halo_m16_td2 = 1;  // its 2 x 8 x 16 tile for D % 4 != 0 (off with hupr_debug_halo_m16(2): 4 x 8 x 8 only)
+static int g_halo_m16_2d = 0;   // its 1 x 16 x 16 tile for 1 x 3 x 3 taps: opt-in (hupr_debug_halo_m16(3)), see DESIGN.md section 4
+void set_halo_m16(int on) { g_halo_m16 = on != 0; g_halo_m16_td2 = on != 2; g_halo_m16_2d = on == 3; }
 
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
     if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
@@ -523,7 +524,7 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
             return true;
         }
     }
-    if (abf && g_halo_m16 && g_halo_m16_td2 && a.kd == 1 && a.D == 1 && a.H % 16 == 0 && a.W % 16 == 0 && a.Ci % 64 == 0 && a.Co % 64 == 0 &&
+    if (abf && g_halo_m16 && g_halo_m16_2d && a.kd == 1 && a.D == 1 && a.H % 16 == 0 && a.W % 16 == 0 && a.Ci % 64 == 0 && a.Co % 64 == 0 &&
         a.ablate == 0 && a.trace == nullptr && !a.stats) {
         // 1 x 3 x 3 convolutions of the decoder: the 1 x 16 x 16 tile of the 16 x 16 x 32 kernel
         a.TD = 1;

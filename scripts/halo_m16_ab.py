@@ -19,7 +19,7 @@ for name, (B, Ci, Co, D, H, W) in shapes.items():
     res = torch.randn(B, D, H, W, Co, device="cuda", generator=g).bfloat16()
     out = {}
     for m16 in (0, 1):
-        L.hupr_debug_halo_m16(m16)
+        L.hupr_debug_halo_m16(3 * m16)      # 3: every tile of the 16 x 16 x 32 kernel, the opt-in 1 x 16 x 16 one included
         y = F_._conv_raw(x, w, 0, None, None, Co, K3, PAD, (D, H, W))
         yr = F_._conv_raw(x, w, 0, None, res, Co, K3, PAD, (D, H, W))
         out[m16] = (y.float(), yr.float())
@@ -31,7 +31,7 @@ for name, (B, Ci, Co, D, H, W) in shapes.items():
     t = {0: [], 1: []}
     for rnd in range(3):
         for m16 in (0, 1):
-            L.hupr_debug_halo_m16(m16)
+            L.hupr_debug_halo_m16(3 * m16)
             for _ in range(2): F_._conv_raw(x, w, 0, None, None, Co, K3, PAD, (D, H, W))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -40,4 +40,4 @@ for name, (B, Ci, Co, D, H, W) in shapes.items():
             t[m16].append(s.elapsed_time(e) * 100)
     fl = 2.0 * B * D * H * W * Co * Ci * 9 * K3[0]
     print("    time: 32x32x16 %.1f us (%.0f TF/s)   16x16x32 %.1f us (%.0f TF/s)" % (min(t[0]), fl / min(t[0]) / 1e6, min(t[1]), fl / min(t[1]) / 1e6))
-L.hupr_debug_halo_m16(0)
+L.hupr_debug_halo_m16(1)
