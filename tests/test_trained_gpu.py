@@ -214,14 +214,20 @@ def _agree(b, r, tie=1e-3):
     return same.sum().item(), (same | (gap <= tie)).sum().item(), near.sum().item()
 
 
-def _gate_512(p, pf, label):
-    """bf16 vs fp32 path on 512 held-out scenes of the fit ``p`` -> per-head (strict, tie-aware, near) rates, AP of both paths."""
+_EVAL_BATCHES = 64     # x 32 scenes = 2 048 held-out scenes, 28 672 joints per head
+
+
+def _gate_scenes(p, pf, label):
+    """bf16 vs fp32 path on 2 048 held-out scenes of the fit ``p`` -> per-head (strict, tie-aware, near) rates, AP of both paths.
+    Rounds 3-4 evaluated 512 scenes (the first sixteen batches of the same seeded stream; their AP difference is still printed):
+    there every change of a summation order anywhere in the step moved the AP difference by 0.1-0.25 points through single
+    key points crossing an OKS threshold — the size of north_star's +-0.2-point budget itself.  Four times the scenes halve that."""
     rng = np.random.default_rng(777)
     gen = torch.Generator(device="cuda").manual_seed(888)
     dec = {"f32": [], "bf16": []}
     cnt = np.zeros((2, 3), dtype=np.int64)
     tot, joints = 0, []
-    for _ in range(16):
+    for _ in range(_EVAL_BATCHES):
         h, v, j = pf.scene_batch(32, rng, gen, torch.device("cuda"), p.get("zero_doppler"))
         joints.append(j.numpy())
         out = {math: pf.evaluate(p["sd"], p["cfg"], h, v, math) for math in ("f32", "bf16")}
@@ -234,16 +240,19 @@ def _gate_512(p, pf, label):
         tot += 32 * 14
     joints = np.concatenate(joints)
     ap = {m: pf.decode_ap_from_indices(torch.cat(dec[m]).numpy(), joints) for m in dec}
+    ap512 = {m: pf.decode_ap_from_indices(torch.cat(dec[m][:16]).numpy(), joints[:512]) for m in dec}
     rates = cnt / tot
-    print("%s, 512 held-out scenes (7 168 joints per head): first head identical %.4f (%.4f counting ties of the fp32 map), decoded head "
-          "identical %.4f (%.4f counting ties, %.4f within one pixel); OKS AP fp32 path %.4f, bf16 path %.4f (%.2f AP points)" %
-          (label, rates[0, 0], rates[0, 1], rates[1, 0], rates[1, 1], rates[1, 2], ap["f32"], ap["bf16"], 100 * abs(ap["f32"] - ap["bf16"])))
+    print("%s, %d held-out scenes (%d joints per head): first head identical %.4f (%.4f counting ties of the fp32 map), decoded head "
+          "identical %.4f (%.4f counting ties, %.4f within one pixel); OKS AP fp32 path %.4f, bf16 path %.4f (%.2f AP points; on the "
+          "first 512 scenes alone %.4f / %.4f = %.2f points)" %
+          (label, 32 * _EVAL_BATCHES, tot, rates[0, 0], rates[0, 1], rates[1, 0], rates[1, 1], rates[1, 2], ap["f32"], ap["bf16"],
+           100 * abs(ap["f32"] - ap["bf16"]), ap512["f32"], ap512["bf16"], 100 * abs(ap512["f32"] - ap512["bf16"])))
     return rates, ap
 
 
-def test_bf16_path_meets_the_argmax_and_ap_gates_on_512_scenes():
-    """The gates on a sample large enough to mean something: 512 held-out scenes (noise drawn on the device from a fixed seed,
-    joints from the seeded generator), 7 168 joints per head.  SURVEY 8(d): arg-max identical on >= 99 % of the joints —
+def test_bf16_path_meets_the_argmax_and_ap_gates_on_2048_scenes():
+    """The gates on a sample large enough to mean something: 2 048 held-out scenes (noise drawn on the device from a fixed seed,
+    joints from the seeded generator), 28 672 joints per head.  SURVEY 8(d): arg-max identical on >= 99 % of the joints —
     asserted for BOTH heads, a flip counting as agreement only where it is a proven tie of the fp32 map
     (``_agree``: the fp32 map's own value at the bf16 arg-max within 1e-3 of its maximum; the decoded head's map is a 2x
     align_corners up-sampling of a 32 x 32 map, so its two best pixels are interpolations of the same two nodes and lie within
@@ -253,9 +262,9 @@ def test_bf16_path_meets_the_argmax_and_ap_gates_on_512_scenes():
     tie-aware rates of 99.6-100 %).  And the AP-level check north_star
     asks for (COCO OKS AP within +-0.2 points of the reference path): both paths' decoded key-points are scored against the
     scenes' joints with misc/oks_eval.py (== the reference's COCOeval to 1e-12, tests/golden/oks_eval.json); one image crossing
-    one of the ten OKS thresholds moves AP by 0.0002 here — on a 32-scene set the same event is 0.003."""
+    one of the ten OKS thresholds moves AP by 0.00005 here — on a 32-scene set the same event is 0.003."""
     p = _pose_trained()
-    rates, ap = _gate_512(p, p["fit"], "main fit")
+    rates, ap = _gate_scenes(p, p["fit"], "main fit")
     assert rates[0, 1] >= 0.99 and rates[1, 1] >= 0.99
     assert rates[0, 0] >= 0.98
     assert rates[1, 0] >= 0.975 and rates[1, 2] >= 0.995
@@ -278,7 +287,7 @@ def test_bf16_gates_on_further_independent_fits(which):
     sd, cfg, log = pose_fit.fit(steps=4000, lr=2e-4, verbose=False, **kw)
     print("further fit (%s): loss %.4f -> %.4f (gcn %.4f)" % (which, log[0][1], log[-1][1], log[-1][2]))
     assert min(l[1] for l in log[-3:]) < 0.05 * log[0][1]
-    rates, ap = _gate_512(dict(sd=sd, cfg=cfg, zero_doppler=kw["zero_doppler"]), pose_fit, "fit: " + which)
+    rates, ap = _gate_scenes(dict(sd=sd, cfg=cfg, zero_doppler=kw["zero_doppler"]), pose_fit, "fit: " + which)
     assert rates[0, 1] >= 0.99 and rates[1, 1] >= 0.99
     assert rates[0, 0] >= 0.98
     assert ap["f32"] >= 0.3 and ap["bf16"] >= ap["f32"] - 0.002 and abs(ap["bf16"] - ap["f32"]) <= 0.005
@@ -326,7 +335,7 @@ def _reference_convention_fit():
 
 
 def test_zero_doppler_conventions_on_a_reference_convention_fit():
-    """A network trained the reference's way (unit noise in the clutter-nulled slot) is evaluated on 512 held-out scenes with
+    """A network trained the reference's way (unit noise in the clutter-nulled slot) is evaluated on 2 048 held-out scenes with
       "noise"    the same convention,
       "renoise"  ANOTHER realisation of that noise in otherwise identical scenes — what separates the reference's own rounding
                  residue from the chain's frame-keyed dither (two pseudo-random planes of the same statistics),
@@ -339,21 +348,23 @@ def test_zero_doppler_conventions_on_a_reference_convention_fit():
     pf = p["fit"]
     assert min(l[1] for l in p["log"][-3:]) < 0.05 * p["log"][0][1]
     dev = torch.device("cuda")
-    ap = {}
+    ap, ap512 = {}, {}
     for conv in ("noise", "renoise", "zero"):
         rng = np.random.default_rng(777)
         gen = torch.Generator(device="cuda").manual_seed(888)
         gen4 = torch.Generator(device="cuda").manual_seed(999) if conv == "renoise" else None
         idx, joints = [], []
-        for _ in range(16):
+        for _ in range(_EVAL_BATCHES):
             h, v, j = pf.scene_batch(32, rng, gen, dev, "noise" if conv == "renoise" else conv, gen4)
             _, b2 = pf.evaluate(p["sd"], p["cfg"], h, v, "bf16")
             idx.append(b2.reshape(32, 14, -1).argmax(-1).cpu())
             joints.append(j.numpy())
         ap[conv] = pf.decode_ap_from_indices(torch.cat(idx).numpy(), np.concatenate(joints))
-    print("reference-convention fit, 512 held-out scenes: OKS AP %.4f; another noise realisation %.4f (%.2f AP points); exactly-zero "
-          "plane %.4f (%.2f AP points)" %
-          (ap["noise"], ap["renoise"], 100 * abs(ap["noise"] - ap["renoise"]), ap["zero"], 100 * abs(ap["noise"] - ap["zero"])))
+        ap512[conv] = pf.decode_ap_from_indices(torch.cat(idx[:16]).numpy(), np.concatenate(joints[:16]))
+    print("reference-convention fit, 2 048 held-out scenes: OKS AP %.4f; another noise realisation %.4f (%.2f AP points); exactly-zero "
+          "plane %.4f (%.2f AP points); on the first 512 scenes alone %.2f / %.2f points" %
+          (ap["noise"], ap["renoise"], 100 * abs(ap["noise"] - ap["renoise"]), ap["zero"], 100 * abs(ap["noise"] - ap["zero"]),
+           100 * abs(ap512["noise"] - ap512["renoise"]), 100 * abs(ap512["noise"] - ap512["zero"])))
     assert ap["noise"] >= 0.3
     assert abs(ap["noise"] - ap["renoise"]) <= 0.002
 
@@ -384,14 +395,14 @@ def test_bf16_training_mode_forward_meets_the_same_gates():
     _bf16_gates(outs["bf16"][0], outs["bf16"][1], outs["f32"][0], outs["f32"][1])
     ap32, ap16 = p["fit"].decode_ap(outs["f32"][1], p["joints"]), p["fit"].decode_ap(outs["bf16"][1], p["joints"])
     print("  OKS AP of the decoded key-points: fp32 path %.4f, bf16 path %.4f (32 images: one image crossing one OKS threshold "
-          "moves AP by 0.003; the AP gate proper is the 512-scene test)" % (ap32, ap16))
+          "moves AP by 0.003; the AP gate proper is the 2 048-scene test)" % (ap32, ap16))
     assert ap32 >= 0.3 and abs(ap16 - ap32) <= 0.01
 
 
 def _bf16_gates(b1, b2, r1, r2):
     """Reduced-precision spot check on a SMALL set of a trained network's uni-modal maps (n = 224 or 448 joints).  SURVEY 8(d)'s gate —
-    arg-max identical on >= 99 % of the joints, AP within 0.2 points — is asserted where a percentage means something: on 7 168 joints
-    in test_bf16_path_meets_the_argmax_and_ap_gates_on_512_scenes.  A rate of 99 % observed on n joints has a standard deviation of
+    arg-max identical on >= 99 % of the joints, AP within 0.2 points — is asserted where a percentage means something: on 28 672 joints
+    in test_bf16_path_meets_the_argmax_and_ap_gates_on_2048_scenes.  A rate of 99 % observed on n joints has a standard deviation of
     sqrt(0.99 * 0.01 / n) — 0.66 % at n = 224, 0.47 % at n = 448, one joint being 0.45 % / 0.22 % — and which joints fall into a small
     set changes with every fit (the fit is chaotic: any kernel whose summation order changes moves it; round 3 saw 98.2-100 % on these
     sets for 512-scene rates of 99.2-99.8 %).  The small sets therefore assert the THREE-SIGMA lower bound of the gated rate:
