@@ -74,3 +74,39 @@ def test_no_two_source_packed_instruction_swizzles_src1():
                 n_packed += 1
                 assert not bad.search(line), (os.path.basename(f), line.strip())
     assert n_packed > 5000          # the listings are the real ones (the FFT butterflies alone hold ~6 000 packed instructions)
+
+
+def test_hot_kernels_keep_their_register_and_lds_budgets():
+    """The kernels that hold most of the step must not start spilling vector registers to scratch or lose their occupancy through a
+    source change that still compiles and still passes the numerics tests (the 256-voxel convolution is built
+    around two waves per SIMD = at most 256 unified registers per wave and 155 KB of LDS; the ring-of-3 variant of round 4 was abandoned
+    at 256 VGPRs + 23 spills).  Read from the code-object metadata in the listings the build keeps."""
+    import glob
+    lst = glob.glob(os.path.join(ROOT, "hupr-a-benchmark-for-human-pose-estimation-using-millimeter-wave-radar_amd", "build", "*-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    if not lst:
+        pytest.skip("no device listings (library not built in this tree)")
+    meta = {}
+    for f in lst:
+        txt = open(f).read()
+        for blk in re.findall(r"- \.agpr_count:.*?(?=\n  - \.agpr_count:|\namdhsa\.target)", txt, flags=re.S):
+            get = lambda key: re.search(r"\.%s:\s+(\S+)" % key, blk).group(1)
+            meta[get("name")] = dict(vgpr=int(get("vgpr_count")), spill=int(get("vgpr_spill_count")),
+                                     scratch=int(get("private_segment_fixed_size")), lds=int(get("group_segment_fixed_size")))
+    assert len(meta) >= 200
+    # (substring of the mangled name, max unified VGPRs as the code object states them, max static LDS bytes).  512-thread kernels
+    # with one workgroup per CU run two waves per SIMD: 256 registers each; the FFT kernels are sized for >= 3-4 waves per SIMD
+    budgets = [("hupr_k_conv_halo256m_bf16ILi4ELi8ELi8ELi3E", 256, 160 * 1024),
+               ("hupr_k_conv_halo256m_bf16ILi2ELi8ELi16ELi3E", 256, 160 * 1024),
+               ("hupr_k_conv_halo256m_bf16ILi1ELi16ELi16ELi1E", 256, 160 * 1024),
+               ("hupr_k_wgrad_halo_gldsILb1ELb0E", 256, 160 * 1024),
+               ("hupr_k_attn_fwd_pp64ILi0E", 256, 160 * 1024),
+               ("hupr_k_attn_bwd_dkv512", 256, 64 * 1024),
+               ("hupr_k_attn_bwd_dqILi64EDF16bE", 256, 64 * 1024),
+               ("hupr_k_gcn_wxILb0E", 168, 64 * 1024), ("hupr_k_gcn_wxILb1E", 168, 64 * 1024), ("hupr_k_gcn_dw", 168, 64 * 1024),
+               ("hupr_k_doppler_rangeILi0ELb1E", 128, 40 * 1024), ("hupr_k_angle", 64, 16 * 1024)]
+    for pat, max_vgpr, max_lds in budgets:
+        hits = {n: m for n, m in meta.items() if pat in n}
+        assert hits, "no kernel matches %s" % pat
+        for n, m in hits.items():
+            assert m["spill"] == 0 and m["scratch"] == 0, (n, m)
+            assert m["vgpr"] <= max_vgpr and m["lds"] <= max_lds, (n, m)
