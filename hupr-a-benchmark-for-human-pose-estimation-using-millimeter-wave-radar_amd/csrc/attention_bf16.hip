@@ -27,7 +27,19 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int D>
 struct Img {   // row-major bf16 LDS image [rows][D] with XOR-swizzled 16-byte chunks
     static constexpr int CH = D / 8;
-    static __device__ __forceinline__ int key(int row) { return (D == 64) ? ((row >> 1) & 7) : (row & (D / 8 - 1)); }
+    // key(row): which 16-byte chunk position a row's chunk c lands on (c ^ key).  Two kinds of reads hit an image: ds_read_b128 of
+    // one chunk position over 16 rows per lane group (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} + 32), and ds_read_b64_tr_b16
+    // of four consecutive rows x one 64-byte column segment per 32-lane group.  Rounds 1-4 used the row bits in place
+    // ((row >> 1) & 7 at D = 64, row & 15 / 31 above): conflict-free for the first kind, but the four rows of a transpose read then
+    // differ only in the LOW key bits, which permute chunks inside the same 64-byte segment — rows r and r + 2 (D = 64; all four
+    // rows at D >= 128) meet on the same 16 banks: every transpose read took 2 (4) LDS cycles per group, 33 / 20 / 22 % of all LDS
+    // cycles of the forward / dQ / dK-dV kernels (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r04b_attn_sq_pmc.txt; the
+    // model in scripts/lds_bank_model.py gives the same 33 %).  Rotating the key so that the fastest-changing row bits select the
+    // 64-byte segment keeps it a bijection on every b128 lane group and separates the rows of a transpose read: 0 conflict cycles
+    // in the model for both kinds at D = 64, 128, 256.
+    static __device__ __forceinline__ int key(int row) {
+        return (D == 64) ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((((row & 3) << 2) | ((row >> 2) & 3)) | (row & (D / 8 - 1) & ~15));
+    }
     static __device__ __forceinline__ int off(int row, int chunk) { return row * D + ((chunk ^ key(row)) << 3); }   // bf16 elements
 };
 
@@ -1074,7 +1086,7 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     if constexpr (sizeof(TI) == 2) {
         // level-1 shape: the ping-pong kernel (256 queries per 512-thread workgroup, LDS-DMA ring)
         if (S <= 1 && C == 64 && N % 256 == 0 && N >= 256 && g_attn_pp && (long)N * ldk * 2 < (1L << 31)) {
-#define HUPR_PP_FWD(A_) hipLaunchKernelGGL(hupr_k_attn_fwd_pp64<A_>, dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, \
+#define HUPR_PP_FWD(A_) HUPR_LAUNCH(hupr_k_attn_fwd_pp64<A_>, dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, \
                                            out, lse, N, Bn, ldk, ldq, o16, ld16, g_attn_trace)
             switch (g_attn_pp >> 4) {
                 case 0: HUPR_PP_FWD(0); break;
@@ -1106,17 +1118,17 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
         const dim3 cgrid((unsigned)((rows * (C / 4) + 255) / 256));
         hipStream_t s = as_stream(stream);
 #define HUPR_ATTN_SPLIT(D_)                                                                                                \
-        hipLaunchKernelGGL((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, \
+        HUPR_LAUNCH((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, \
                            part_o, part_ml, AttnBatch());                                                                  \
-        hipLaunchKernelGGL((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, Vres, out, lse, o16, ld16, AttnBatch());
+        HUPR_LAUNCH((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, Vres, out, lse, o16, ld16, AttnBatch());
         if (C == 64) { HUPR_ATTN_SPLIT(64) } else if (C == 128) { HUPR_ATTN_SPLIT(128) } else { HUPR_ATTN_SPLIT(256) }
 #undef HUPR_ATTN_SPLIT
         HUPR_LAUNCH_OK("hupr_k_attn_fwd (split)");
         return HUPR_OK;
     }
-    if (C == 64) hipLaunchKernelGGL((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
-    else if (C == 128) hipLaunchKernelGGL((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
-    else hipLaunchKernelGGL((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    if (C == 64) HUPR_LAUNCH((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    else if (C == 128) HUPR_LAUNCH((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    else HUPR_LAUNCH((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
@@ -1175,8 +1187,8 @@ extern "C" int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int
     float* const nf = nullptr;
     __bf16* const nh = nullptr;
 #define HUPR_ATTN_BATCH(D_)                                                                                                          \
-    hipLaunchKernelGGL((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, nk, nk, nk, nf, nf, nf, N, ldk, ldq, nh, ld16, part_o, part_ml, b); \
-    hipLaunchKernelGGL((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, nf, nf, nf, nh, ld16, b);
+    HUPR_LAUNCH((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, nk, nk, nk, nf, nf, nf, N, ldk, ldq, nh, ld16, part_o, part_ml, b); \
+    HUPR_LAUNCH((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, nf, nf, nf, nh, ld16, b);
     if (C == 64) { HUPR_ATTN_BATCH(64) } else if (C == 128) { HUPR_ATTN_BATCH(128) } else { HUPR_ATTN_BATCH(256) }
 #undef HUPR_ATTN_BATCH
     HUPR_LAUNCH_OK("hupr_k_attn_fwd (split, batch)");
@@ -1217,15 +1229,15 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     const dim3 pgrid((unsigned)((rows + 15) / 16));
     const int xmap = (g_attn_xcd && Bn % 8 == 0) ? 1 : 0;
 #define HUPR_ATTN_BWD(D_, NH_)                                                                                             \
-    if (dout32) hipLaunchKernelGGL((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
-    else hipLaunchKernelGGL((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
-    hipLaunchKernelGGL((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo, xmap);  \
+    if (dout32) HUPR_LAUNCH((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
+    else HUPR_LAUNCH((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
+    HUPR_LAUNCH((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo, xmap);  \
     if (D_ == 64 && sizeof(TI) == 2 && g_attn_dkv512 && N % 256 == 0)                                                       \
-        hipLaunchKernelGGL(hupr_k_attn_bwd_dkv512, dim3(N / 256, Bn), dim3(512), 0, s, reinterpret_cast<const __bf16*>(K),       \
+        HUPR_LAUNCH(hupr_k_attn_bwd_dkv512, dim3(N / 256, Bn), dim3(512), 0, s, reinterpret_cast<const __bf16*>(K),       \
                            reinterpret_cast<const __bf16*>(Q), reinterpret_cast<const __bf16*>(V), reinterpret_cast<const __bf16*>(dO), \
                            add32, lse, Dq, dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);                                 \
     else                                                                                                                     \
-        hipLaunchKernelGGL((hupr_k_attn_bwd_dkv<D_, TI, NH_>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
+        HUPR_LAUNCH((hupr_k_attn_bwd_dkv<D_, TI, NH_>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
                            dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);
     if (C == 64) { HUPR_ATTN_BWD(64, 1) } else if (C == 128) { HUPR_ATTN_BWD(128, 1) } else { HUPR_ATTN_BWD(256, 2) }
 #undef HUPR_ATTN_BWD

@@ -230,12 +230,12 @@ extern "C" int hupr_attn_quant_fp8(const float* K, const float* Q, const float* 
     const long rows = (long)Bn * N, n4 = rows * C / 4;
     if (hipMemsetAsync(amax, 0, 16, s) != hipSuccess) return fail(HUPR_ERR_LAUNCH, "hupr_attn_quant_fp8: memset failed");
     const dim3 rg((unsigned)min((long)2048, (n4 + 255) / 256));
-    hipLaunchKernelGGL(hupr_k_absmax, rg, dim3(256), 0, s, K, n4, amax);
-    hipLaunchKernelGGL(hupr_k_absmax, rg, dim3(256), 0, s, Q, n4, amax + 1);
-    hipLaunchKernelGGL(hupr_k_absmax, rg, dim3(256), 0, s, V, n4, amax + 2);
-    hipLaunchKernelGGL(hupr_k_quant_e4m3<false>, rg, dim3(256), 0, s, K, k8, amax, scales, rows, N);
-    hipLaunchKernelGGL(hupr_k_quant_e4m3<false>, rg, dim3(256), 0, s, Q, q8, amax + 1, scales + 1, rows, N);
-    hipLaunchKernelGGL(hupr_k_quant_e4m3<true>, dim3((unsigned)min((long)2048, rows / 64)), dim3(256), 0, s, V, vt8, amax + 2, scales + 2, rows, N);
+    HUPR_LAUNCH(hupr_k_absmax, rg, dim3(256), 0, s, K, n4, amax);
+    HUPR_LAUNCH(hupr_k_absmax, rg, dim3(256), 0, s, Q, n4, amax + 1);
+    HUPR_LAUNCH(hupr_k_absmax, rg, dim3(256), 0, s, V, n4, amax + 2);
+    HUPR_LAUNCH(hupr_k_quant_e4m3<false>, rg, dim3(256), 0, s, K, k8, amax, scales, rows, N);
+    HUPR_LAUNCH(hupr_k_quant_e4m3<false>, rg, dim3(256), 0, s, Q, q8, amax + 1, scales + 1, rows, N);
+    HUPR_LAUNCH(hupr_k_quant_e4m3<true>, dim3((unsigned)min((long)2048, rows / 64)), dim3(256), 0, s, V, vt8, amax + 2, scales + 2, rows, N);
     HUPR_LAUNCH_OK("hupr_k_quant_e4m3");
     return HUPR_OK;
 }
@@ -250,7 +250,7 @@ extern "C" int hupr_attn_fwd_fp8_quantized(const void* ws, const float* Vres, fl
     const unsigned char* q8 = k8 + t;
     const unsigned char* vt8 = q8 + t;
     const float* scales = reinterpret_cast<const float*>(vt8 + t + 16);
-    hipLaunchKernelGGL(hupr_k_attn_fwd_fp8, dim3(N / 128, Bn), dim3(256), 0, as_stream(stream), k8, q8, vt8, scales, Vres, out, lse, N);
+    HUPR_LAUNCH(hupr_k_attn_fwd_fp8, dim3(N / 128, Bn), dim3(256), 0, as_stream(stream), k8, q8, vt8, scales, Vres, out, lse, N);
     HUPR_LAUNCH_OK("hupr_k_attn_fwd_fp8");
     return HUPR_OK;
 }

@@ -311,9 +311,9 @@ extern "C" int hupr_attn_mx8_quant_level(const void* Ya, const void* Ye, const v
     const void* V[2] = {va, ve};
     for (int m = 0; m < 2; ++m) {
         unsigned char* base = static_cast<unsigned char*>(ws) + m * l.per_map;
-        hipLaunchKernelGGL(hupr_k_quant_rows_mx8, dim3((unsigned)min((long)4096, (nblocks + 255) / 256)), dim3(256), 0, s,
+        HUPR_LAUNCH(hupr_k_quant_rows_mx8, dim3((unsigned)min((long)4096, (nblocks + 255) / 256)), dim3(256), 0, s,
                            static_cast<const __bf16*>(Y[m]), base + l.y8, base + l.ysc, nblocks);
-        hipLaunchKernelGGL(hupr_k_quant_vt_mx8, dim3(N / 64, Bn), dim3(256), 0, s, static_cast<const __bf16*>(V[m]), base + l.vt8,
+        HUPR_LAUNCH(hupr_k_quant_vt_mx8, dim3(N / 64, Bn), dim3(256), 0, s, static_cast<const __bf16*>(V[m]), base + l.vt8,
                            base + l.vsc, N);
     }
     HUPR_LAUNCH_OK("hupr_k_quant_mx8");
@@ -334,7 +334,7 @@ extern "C" int hupr_attn_mx8_fwd(const void* ws, int kmap, int kslot, int qmap, 
     const unsigned char* kb = base + kmap * l.per_map;
     const unsigned char* qb = base + qmap * l.per_map;
     const unsigned char* vb = base + vmap * l.per_map;
-    hipLaunchKernelGGL(hupr_k_attn_fwd_mx8, dim3(N / 128, Bn), dim3(256), 0, as_stream(stream), kb + l.y8 + kslot * C, 4 * C,
+    HUPR_LAUNCH(hupr_k_attn_fwd_mx8, dim3(N / 128, Bn), dim3(256), 0, as_stream(stream), kb + l.y8 + kslot * C, 4 * C,
                        kb + l.ysc + kslot * (C / 32), 4 * C / 32, qb + l.y8 + qslot * C, 4 * C, qb + l.ysc + qslot * (C / 32), 4 * C / 32,
                        vb + l.vt8, vb + l.vsc, Vres, out, lse, static_cast<__bf16*>(out16), ld16, N);
     HUPR_LAUNCH_OK("hupr_k_attn_fwd_mx8");

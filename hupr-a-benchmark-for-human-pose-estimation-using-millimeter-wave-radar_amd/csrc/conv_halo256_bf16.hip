@@ -552,21 +552,21 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     // one persistent workgroup per CU
     if (abf && (a.ablate >> 4)) {      // compile-time ablations (profiling only)
         switch (a.ablate >> 4) {
-            case 1: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 1>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            case 2: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 2>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            case 3: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 4>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            case 5: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 5>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            case 8: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 8>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            case 16: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 16>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            case 32: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 32>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
-            default: hipLaunchKernelGGL((hupr_k_conv_halo256_bf16<true, 7>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 1: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 1>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 2: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 2>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 3: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 4: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 4>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 5: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 5>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 8: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 8>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 16: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 16>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            case 32: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 32>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
+            default: HUPR_LAUNCH((hupr_k_conv_halo256_bf16<true, 7>), dim3(kHalo256Grid), dim3(512), 0, s, a); break;
         }
         return true;
     }
     if (abf && g_halo_m16 && a.ablate == 0 && a.trace == nullptr) launch_conv_halo256m(a, s);      // v_mfma_f32_16x16x32_bf16 form
-    else if (abf) hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<true>, dim3(kHalo256Grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(hupr_k_conv_halo256_bf16<false>, dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else if (abf) HUPR_LAUNCH(hupr_k_conv_halo256_bf16<true>, dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else HUPR_LAUNCH(hupr_k_conv_halo256_bf16<false>, dim3(kHalo256Grid), dim3(512), 0, s, a);
     return true;
 }
 

@@ -349,9 +349,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 }
 
 void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
-    if (a.kd == 1) hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), dim3(kHalo256Grid), dim3(512), 0, s, a);
-    else if (a.TD == 4) hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<4, 8, 8, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((hupr_k_conv_halo256m_bf16<2, 8, 16, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else if (a.TD == 4) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<2, 8, 16, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
 }
 
 }  // namespace hupr

@@ -271,7 +271,7 @@ bool launch_conv_halo512(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     a.nh = a.H / 8;
     a.nw = a.W / 16;
     a.n_co_tiles = a.Co / 64;
-    hipLaunchKernelGGL(hupr_k_conv_halo512_bf16, dim3(kHalo256Grid), dim3(512), 0, s, a);      // one persistent workgroup per CU
+    HUPR_LAUNCH(hupr_k_conv_halo512_bf16, dim3(kHalo256Grid), dim3(512), 0, s, a);      // one persistent workgroup per CU
     return true;
 }
 

@@ -371,7 +371,7 @@ using namespace hupr;
 extern "C" int hupr_pack_conv_weights_table(const void* descs_dev, const void* blocks_dev, int n_blocks, hupr_stream_t stream) {
     HUPR_REQUIRE(descs_dev && blocks_dev && n_blocks > 0, "hupr_pack_conv_weights_table: bad argument");
     static_assert(sizeof(PackDesc) == 48 && sizeof(PackBlock) == 16, "PackDesc / PackBlock layouts are part of the ABI");
-    hipLaunchKernelGGL(hupr_k_pack_table, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream),
+    HUPR_LAUNCH(hupr_k_pack_table, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const PackDesc*>(descs_dev), reinterpret_cast<const PackBlock*>(blocks_dev));
     HUPR_LAUNCH_OK("hupr_k_pack_table");
     return HUPR_OK;
@@ -382,7 +382,7 @@ extern "C" int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co
     HUPR_REQUIRE(w && wp_bf16 && Co > 0 && Ci > 0 && taps > 0 && (mode == 0 || mode == 1),
                  "hupr_pack_conv_weights_bf16: bad argument");
     const long n = (long)Co * Ci * taps;
-    hipLaunchKernelGGL(hupr_k_pack_weights_bf16, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w,
+    HUPR_LAUNCH(hupr_k_pack_weights_bf16, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w,
                        reinterpret_cast<__bf16*>(wp_bf16), Co, Ci, taps, mode);
     HUPR_LAUNCH_OK("hupr_k_pack_weights_bf16");
     return HUPR_OK;
@@ -490,11 +490,11 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     do {                                                                                                                 \
         const dim3 grid_((unsigned)blocks, (unsigned)n_slices);                                                          \
         if (kd == 3) {                                                                                                   \
-            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, true>), grid_, dim3(256), 0, s, a);       \
-            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, true>), grid_, dim3(256), 0, s, a);          \
+            if (abf) HUPR_LAUNCH((hupr_k_conv_halo_bf16<BN_, KC_, true, true>), grid_, dim3(256), 0, s, a);       \
+            else HUPR_LAUNCH((hupr_k_conv_halo_bf16<BN_, KC_, false, true>), grid_, dim3(256), 0, s, a);          \
         } else {                                                                                                         \
-            if (abf) hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, true, false>), grid_, dim3(256), 0, s, a);      \
-            else hipLaunchKernelGGL((hupr_k_conv_halo_bf16<BN_, KC_, false, false>), grid_, dim3(256), 0, s, a);         \
+            if (abf) HUPR_LAUNCH((hupr_k_conv_halo_bf16<BN_, KC_, true, false>), grid_, dim3(256), 0, s, a);      \
+            else HUPR_LAUNCH((hupr_k_conv_halo_bf16<BN_, KC_, false, false>), grid_, dim3(256), 0, s, a);         \
         }                                                                                                                \
     } while (0)
     if (Ci % 64 == 0) {
@@ -507,7 +507,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     if (partial_only) return HUPR_OK;
     if (n_slices > 1) {
         const long n4 = (long)Bn * D * H * W * (Co / 4);
-        hipLaunchKernelGGL(hupr_k_conv_partial_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, n_slices);
+        HUPR_LAUNCH(hupr_k_conv_partial_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a, n_slices);
         HUPR_LAUNCH_OK("hupr_k_conv_partial_reduce");
     }
     return HUPR_OK;

@@ -766,10 +766,10 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
     const int zd = (flags & HUPR_FFT_ZERO_DOPPLER_EXACT) ? 1 : 0;
     if (g_fft_range_first || (flags & HUPR_FFT_RANGE_FIRST)) {
         switch (flags & 3) {
-            case 0: hipLaunchKernelGGL(hupr_k_range_doppler<0>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
-            case 1: hipLaunchKernelGGL(hupr_k_range_doppler<1>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
-            case 2: hipLaunchKernelGGL(hupr_k_range_doppler<2>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
-            default: hipLaunchKernelGGL(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+            case 0: HUPR_LAUNCH(hupr_k_range_doppler<0>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+            case 1: HUPR_LAUNCH(hupr_k_range_doppler<1>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+            case 2: HUPR_LAUNCH(hupr_k_range_doppler<2>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
+            default: HUPR_LAUNCH(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
         }
     } else if (!(g_fft_variant & 4)) {
         // grouped order: (sensor-frame, receiver) groups x 3 antennas, one group per XCD slot; the grid is padded to a multiple of 24
@@ -777,8 +777,8 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
         const int n_groups = n_sf * 4;
         const dim3 g1(grouped ? ((n_groups + 7) / 8) * 24 : n_items), b1(256);
 #define HUPR_DR(W_, H_)                                                                                                      \
-        if (g_fft_variant & 1) hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 0>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped); \
-        else hipLaunchKernelGGL((hupr_k_doppler_range<W_, H_, 2>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped)
+        if (g_fft_variant & 1) HUPR_LAUNCH((hupr_k_doppler_range<W_, H_, 0>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped); \
+        else HUPR_LAUNCH((hupr_k_doppler_range<W_, H_, 2>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped)
         switch ((flags & 3) | (loader ? 4 : 0)) {
             case 0: HUPR_DR(0, false); break;
             case 1: HUPR_DR(1, false); break;
@@ -794,13 +794,13 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
     if (g_fft_variant & 8) return HUPR_OK;              // measurement only (bit 2 = no first kernel, bit 3 = no angle kernel)
     if (loader && means)
-        hipLaunchKernelGGL(hupr_k_angle<3>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
+        HUPR_LAUNCH(hupr_k_angle<3>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
     else if (loader)
-        hipLaunchKernelGGL(hupr_k_angle<1>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
+        HUPR_LAUNCH(hupr_k_angle<1>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
     else if (flags & HUPR_FFT_MAGNITUDE)
-        hipLaunchKernelGGL(hupr_k_angle<2>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
+        HUPR_LAUNCH(hupr_k_angle<2>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
     else
-        hipLaunchKernelGGL(hupr_k_angle<0>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
+        HUPR_LAUNCH(hupr_k_angle<0>, dim3(n_sf * 16), dim3(256), 0, s, rd, out);
     HUPR_LAUNCH_OK("hupr_k_angle");
     return HUPR_OK;
 }
@@ -832,7 +832,7 @@ extern "C" int hupr_loader_normalize_c64(const void* cube_c64, int n_sf, float* 
     HUPR_REQUIRE(cube_c64 && out, "hupr_loader_normalize_c64: null pointer");
     HUPR_REQUIRE(((uintptr_t)cube_c64 & 15) == 0 && ((uintptr_t)out & 15) == 0,
                  "hupr_loader_normalize_c64: misaligned buffer");
-    hipLaunchKernelGGL(hupr_k_loader_normalize, dim3(n_sf * 8), dim3(256), 0, as_stream(stream),
+    HUPR_LAUNCH(hupr_k_loader_normalize, dim3(n_sf * 8), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float2*>(cube_c64), out);
     HUPR_LAUNCH_OK("hupr_k_loader_normalize");
     return HUPR_OK;
@@ -868,7 +868,7 @@ extern "C" int hupr_dca1000_deinterleave(const int16_t* raw, int16_t* adc_iq, in
     HUPR_REQUIRE(raw && adc_iq && ((uintptr_t)raw & 7) == 0 && ((uintptr_t)adc_iq & 7) == 0,
                  "hupr_dca1000_deinterleave: null or misaligned pointer");
     const long n_groups = (long)n_frames * kRx * kChirps * kSamples / 2;
-    hipLaunchKernelGGL(hupr::hupr_k_dca1000_deinterleave, dim3((unsigned)min((long)8192, (n_groups + 255) / 256)), dim3(256), 0,
+    HUPR_LAUNCH(hupr::hupr_k_dca1000_deinterleave, dim3((unsigned)min((long)8192, (n_groups + 255) / 256)), dim3(256), 0,
                        as_stream(stream), reinterpret_cast<const short4*>(raw), reinterpret_cast<short4*>(adc_iq), n_groups);
     HUPR_LAUNCH_OK("hupr_k_dca1000_deinterleave");
     return HUPR_OK;

@@ -122,8 +122,8 @@ extern "C" int hupr_gcn_wx_f32(const float* W, const float* x, float* t, int Bn,
     HUPR_REQUIRE(W && x && t && Bn > 0, "hupr_gcn_wx_f32: bad argument");
     HUPR_REQUIRE(ld == 16 && F > 0 && F % 64 == 0 /* F / 2 % 32 == 0 */, "hupr_gcn_wx_f32: needs ld = 16 and F %% 64 == 0 (got ld=%d F=%d)", ld, F);
     const dim3 grid(F / 64, (Bn + 1) / 2);
-    if (trans_w) hipLaunchKernelGGL(hupr_k_gcn_wx<true>, grid, dim3(256), 0, as_stream(stream), W, x, t, Bn, F);
-    else hipLaunchKernelGGL(hupr_k_gcn_wx<false>, grid, dim3(256), 0, as_stream(stream), W, x, t, Bn, F);
+    if (trans_w) HUPR_LAUNCH(hupr_k_gcn_wx<true>, grid, dim3(256), 0, as_stream(stream), W, x, t, Bn, F);
+    else HUPR_LAUNCH(hupr_k_gcn_wx<false>, grid, dim3(256), 0, as_stream(stream), W, x, t, Bn, F);
     HUPR_LAUNCH_OK("hupr_k_gcn_wx");
     return HUPR_OK;
 }
@@ -131,7 +131,7 @@ extern "C" int hupr_gcn_wx_f32(const float* W, const float* x, float* t, int Bn,
 extern "C" int hupr_gcn_dw_f32(const float* dt, const float* x, float* dW, int Bn, int F, int ld, hupr_stream_t stream) {
     HUPR_REQUIRE(dt && x && dW && Bn > 0, "hupr_gcn_dw_f32: bad argument");
     HUPR_REQUIRE(ld == 16 && F > 0 && F % 64 == 0, "hupr_gcn_dw_f32: needs ld = 16 and F %% 64 == 0 (got ld=%d F=%d)", ld, F);
-    hipLaunchKernelGGL(hupr_k_gcn_dw, dim3(F / 64, F / 64), dim3(256), 0, as_stream(stream), dt, x, dW, Bn, F);
+    HUPR_LAUNCH(hupr_k_gcn_dw, dim3(F / 64, F / 64), dim3(256), 0, as_stream(stream), dt, x, dW, Bn, F);
     HUPR_LAUNCH_OK("hupr_k_gcn_dw");
     return HUPR_OK;
 }

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void hupr_k_gemm_bf16(GemmArgs p) {
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
 static void launch_h(const GemmArgs& a, int batch, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((hupr_k_gemm_bf16<BM, BN, WM, WN, AM, BMD>), dim3(mt * nt, a.ksplit, batch), dim3(256), 0, s, a);
+    HUPR_LAUNCH((hupr_k_gemm_bf16<BM, BN, WM, WN, AM, BMD>), dim3(mt * nt, a.ksplit, batch), dim3(256), 0, s, a);
 }
 
 static int g_small_tiles_off = 0;      // A/B aid (hupr_debug_gemm_small_tiles)

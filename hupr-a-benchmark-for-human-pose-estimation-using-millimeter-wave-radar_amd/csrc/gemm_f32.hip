@@ -382,7 +382,7 @@ template <int BM, int BN, int WM, int WN, int AM, int BMD>
 static void launch(const GemmArgs& a, int batch, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     dim3 grid(mt * nt, a.ksplit, batch);
-    hipLaunchKernelGGL((hupr_k_gemm_f32<BM, BN, WM, WN, AM, BMD>), grid, dim3(256), 0, s, a);
+    HUPR_LAUNCH((hupr_k_gemm_f32<BM, BN, WM, WN, AM, BMD>), grid, dim3(256), 0, s, a);
 }
 
 template <int AM, int BMD>
@@ -450,11 +450,11 @@ void launch_splitk_reduce(const float* part, float* out, long n, int splits, lon
                           hipStream_t s) {
     if (n % 4 == 0 && ci % 4 == 0 && split_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
         const long n4 = n / 4;
-        hipLaunchKernelGGL(hupr_k_splitk_reduce4, dim3((n4 + 63) / 64), dim3(256), 0, s, part, out, n4, splits, split_stride,
+        HUPR_LAUNCH(hupr_k_splitk_reduce4, dim3((n4 + 63) / 64), dim3(256), 0, s, part, out, n4, splits, split_stride,
                            taps, ci);
         return;
     }
-    hipLaunchKernelGGL(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, out, n, splits, split_stride,
+    HUPR_LAUNCH(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, out, n, splits, split_stride,
                        taps, ci);
 }
 
@@ -566,7 +566,7 @@ extern "C" int hupr_pack_conv_weights_f32(const float* w, float* wp, int Co, int
     HUPR_REQUIRE(w && wp && Co > 0 && Ci > 0 && taps > 0 && (mode == 0 || mode == 1),
                  "hupr_pack_conv_weights_f32: bad argument");
     const long n = (long)Co * Ci * taps;
-    hipLaunchKernelGGL(hupr_k_pack_weights, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, wp,
+    HUPR_LAUNCH(hupr_k_pack_weights, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), w, wp,
                        Co, Ci, taps, mode);
     HUPR_LAUNCH_OK("hupr_k_pack_weights");
     return HUPR_OK;

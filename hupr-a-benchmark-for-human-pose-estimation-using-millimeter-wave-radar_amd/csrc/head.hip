@@ -376,13 +376,13 @@ using namespace hupr;
 
 extern "C" int hupr_softmax_rows_f32(float* s, long rows, int n, hupr_stream_t stream) {
     HUPR_REQUIRE(s && rows > 0 && n > 0 && n % 4 == 0 && rows < (1L << 31), "hupr_softmax_rows_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_softmax_rows, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), s, n);
+    HUPR_LAUNCH(hupr_k_softmax_rows, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), s, n);
     HUPR_LAUNCH_OK("hupr_k_softmax_rows");
     return HUPR_OK;
 }
 extern "C" int hupr_softmax_rows_bwd_f32(const float* p, float* dp_inout, long rows, int n, hupr_stream_t stream) {
     HUPR_REQUIRE(p && dp_inout && rows > 0 && n > 0 && n % 4 == 0 && rows < (1L << 31), "hupr_softmax_rows_bwd_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_softmax_rows_bwd, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), p, dp_inout, n);
+    HUPR_LAUNCH(hupr_k_softmax_rows_bwd, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), p, dp_inout, n);
     HUPR_LAUNCH_OK("hupr_k_softmax_rows_bwd");
     return HUPR_OK;
 }
@@ -392,7 +392,7 @@ extern "C" int hupr_head1x1_fwd_f32(const float* x, const float* w16, float* y, 
     HUPR_REQUIRE(M >= 0, "hupr_head1x1_fwd_f32: M=%ld", M);
     if (M == 0) return HUPR_OK;
     HUPR_REQUIRE(x && w16 && y && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "hupr_head1x1_fwd_f32: null or misaligned pointer");
-    hipLaunchKernelGGL(hupr_k_head1x1_fwd, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), x, w16, y, M);
+    HUPR_LAUNCH(hupr_k_head1x1_fwd, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), x, w16, y, M);
     HUPR_LAUNCH_OK("hupr_k_head1x1_fwd");
     return HUPR_OK;
 }
@@ -403,14 +403,14 @@ extern "C" int hupr_head1x1_bwd_f32(const float* x, const float* w16, const floa
     HUPR_REQUIRE(x && w16 && dy && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx_or_null & 15) == 0,
                  "hupr_head1x1_bwd_f32: null or misaligned pointer");
     if (dx_or_null) {
-        hipLaunchKernelGGL(hupr_k_head1x1_dgrad, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), dy, w16, dx_or_null, M);
+        HUPR_LAUNCH(hupr_k_head1x1_dgrad, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream), dy, w16, dx_or_null, M);
         HUPR_LAUNCH_OK("hupr_k_head1x1_dgrad");
     }
     if (dw16_or_null) {
         if (!ws || ws_bytes < hupr_head1x1_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_head1x1_bwd_f32: workspace %zu < %zu", ws_bytes, hupr_head1x1_ws_bytes());
         const int grid = (int)min((long)kHeadWgradGrid, (M + 127) / 128);
-        hipLaunchKernelGGL(hupr_k_head1x1_wgrad, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, static_cast<float*>(ws), M);
-        hipLaunchKernelGGL(hupr_k_head1x1_wgrad_reduce, dim3(8), dim3(256), 0, as_stream(stream), static_cast<const float*>(ws), dw16_or_null, grid);
+        HUPR_LAUNCH(hupr_k_head1x1_wgrad, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, static_cast<float*>(ws), M);
+        HUPR_LAUNCH(hupr_k_head1x1_wgrad_reduce, dim3(8), dim3(256), 0, as_stream(stream), static_cast<const float*>(ws), dw16_or_null, grid);
         HUPR_LAUNCH_OK("hupr_k_head1x1_wgrad");
     }
     return HUPR_OK;
@@ -420,7 +420,7 @@ extern "C" int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const floa
                                     int ld, int relu, hupr_stream_t stream) {
     HUPR_REQUIRE(t && adj && bias && y && Bn > 0 && F > 0 && K > 0 && K <= 16 && ld >= K && ld <= 16, "hupr_gcn_adj_fwd_f32: bad argument");
     const long rows = (long)Bn * F;
-    hipLaunchKernelGGL(hupr_k_gcn_adj_fwd, dim3((unsigned)min((long)4096, (rows + 15) / 16)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu, 1);
+    HUPR_LAUNCH(hupr_k_gcn_adj_fwd, dim3((unsigned)min((long)4096, (rows + 15) / 16)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu, 1);
     HUPR_LAUNCH_OK("hupr_k_gcn_adj_fwd");
     return HUPR_OK;
 }
@@ -430,7 +430,7 @@ extern "C" int hupr_gcn_adj_fwd_sliced_f32(const float* t, int slices, const flo
     HUPR_REQUIRE(t && adj && bias && y && Bn > 0 && F > 0 && K > 0 && K <= 16 && ld >= K && ld <= 16 && slices >= 1 && slices <= 64,
                  "hupr_gcn_adj_fwd_sliced_f32: bad argument");
     const long rows = (long)Bn * F;
-    hipLaunchKernelGGL(hupr_k_gcn_adj_fwd, dim3((unsigned)min((long)4096, (rows + 15) / 16)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu, slices);
+    HUPR_LAUNCH(hupr_k_gcn_adj_fwd, dim3((unsigned)min((long)4096, (rows + 15) / 16)), dim3(256), 0, as_stream(stream), t, adj, bias, y, rows, F, K, ld, relu, slices);
     HUPR_LAUNCH_OK("hupr_k_gcn_adj_fwd");
     return HUPR_OK;
 }
@@ -440,23 +440,23 @@ extern "C" int hupr_gcn_adj_bwd_f32(const float* dy, const float* y, const float
                  "hupr_gcn_adj_bwd_f32: bad argument");
     const long rows = (long)Bn * F;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(hupr_k_gcn_adj_bwd, dim3(grid1d(rows)), dim3(256), 0, s, dy, y, adj, dt, gmasked, rows, K, ld, relu);
+    HUPR_LAUNCH(hupr_k_gcn_adj_bwd, dim3(grid1d(rows)), dim3(256), 0, s, dy, y, adj, dt, gmasked, rows, K, ld, relu);
     HUPR_LAUNCH_OK("hupr_k_gcn_adj_bwd");
-    hipLaunchKernelGGL(hupr_k_gcn_dbias, dim3((F * K + 255) / 256), dim3(256), 0, s, gmasked, dbias, Bn, F, K, ld);
+    HUPR_LAUNCH(hupr_k_gcn_dbias, dim3((F * K + 255) / 256), dim3(256), 0, s, gmasked, dbias, Bn, F, K, ld);
     HUPR_LAUNCH_OK("hupr_k_gcn_dbias");
     return HUPR_OK;
 }
 
 extern "C" int hupr_sigmoid_to_nchw_f32(const float* x, float* y, int Bn, int HW, int K, int ld, hupr_stream_t stream) {
     HUPR_REQUIRE(x && y && Bn > 0 && HW > 0 && K > 0 && ld >= K, "hupr_sigmoid_to_nchw_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_sigmoid_to_nchw, dim3(grid1d((long)Bn * K * HW)), dim3(256), 0, as_stream(stream), x, y, Bn, HW, K, ld);
+    HUPR_LAUNCH(hupr_k_sigmoid_to_nchw, dim3(grid1d((long)Bn * K * HW)), dim3(256), 0, as_stream(stream), x, y, Bn, HW, K, ld);
     HUPR_LAUNCH_OK("hupr_k_sigmoid_to_nchw");
     return HUPR_OK;
 }
 extern "C" int hupr_sigmoid_to_nchw_bwd_f32(const float* dy, const float* y, float* dx, int Bn, int HW, int K, int ld,
                                             hupr_stream_t stream) {
     HUPR_REQUIRE(dy && y && dx && Bn > 0 && HW > 0 && K > 0 && ld >= K, "hupr_sigmoid_to_nchw_bwd_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_sigmoid_to_nchw_bwd, dim3(grid1d((long)Bn * HW * ld)), dim3(256), 0, as_stream(stream), dy, y, dx, Bn, HW, K, ld);
+    HUPR_LAUNCH(hupr_k_sigmoid_to_nchw_bwd, dim3(grid1d((long)Bn * HW * ld)), dim3(256), 0, as_stream(stream), dy, y, dx, Bn, HW, K, ld);
     HUPR_LAUNCH_OK("hupr_k_sigmoid_to_nchw_bwd");
     return HUPR_OK;
 }
@@ -468,15 +468,15 @@ extern "C" int hupr_bce_fwd_f32(const float* p, const float* t, long n, float* l
     if (ws_bytes < hupr_bce_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_bce_fwd_f32: workspace too small");
     hipStream_t s = as_stream(stream);
     const int nblk = grid1d(n, 256, 1024);
-    hipLaunchKernelGGL(hupr_k_bce_fwd, dim3(nblk), dim3(256), 0, s, p, t, n, reinterpret_cast<double*>(ws));
+    HUPR_LAUNCH(hupr_k_bce_fwd, dim3(nblk), dim3(256), 0, s, p, t, n, reinterpret_cast<double*>(ws));
     HUPR_LAUNCH_OK("hupr_k_bce_fwd");
-    hipLaunchKernelGGL(hupr_k_bce_final, dim3(1), dim3(64), 0, s, reinterpret_cast<const double*>(ws), nblk, 1.0 / (double)n, loss);
+    HUPR_LAUNCH(hupr_k_bce_final, dim3(1), dim3(64), 0, s, reinterpret_cast<const double*>(ws), nblk, 1.0 / (double)n, loss);
     HUPR_LAUNCH_OK("hupr_k_bce_final");
     return HUPR_OK;
 }
 extern "C" int hupr_bce_bwd_f32(const float* p, const float* t, const float* grad_out, float* dp, long n, hupr_stream_t stream) {
     HUPR_REQUIRE(p && t && grad_out && dp && n > 0, "hupr_bce_bwd_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_bce_bwd, dim3(grid1d(n)), dim3(256), 0, as_stream(stream), p, t, grad_out, 1.0f / (float)n, dp, n);
+    HUPR_LAUNCH(hupr_k_bce_bwd, dim3(grid1d(n)), dim3(256), 0, as_stream(stream), p, t, grad_out, 1.0f / (float)n, dp, n);
     HUPR_LAUNCH_OK("hupr_k_bce_bwd");
     return HUPR_OK;
 }
@@ -484,14 +484,14 @@ extern "C" int hupr_bce_bwd_f32(const float* p, const float* t, const float* gra
 extern "C" int hupr_gaussian_targets_f32(const long long* joints, const float* patch, float* t, int BK, int H, int rad,
                                          float stride, hupr_stream_t stream) {
     HUPR_REQUIRE(joints && patch && t && BK > 0 && H > 0 && rad > 0 && stride > 0.f, "hupr_gaussian_targets_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_gaussian_targets, dim3(grid1d((long)BK * H * H)), dim3(256), 0, as_stream(stream), joints, patch, t, BK, H, rad, stride);
+    HUPR_LAUNCH(hupr_k_gaussian_targets, dim3(grid1d((long)BK * H * H)), dim3(256), 0, as_stream(stream), joints, patch, t, BK, H, rad, stride);
     HUPR_LAUNCH_OK("hupr_k_gaussian_targets");
     return HUPR_OK;
 }
 
 extern "C" int hupr_argmax_rows_f32(const float* p, long rows, int n, int* idx, float* maxval, hupr_stream_t stream) {
     HUPR_REQUIRE(p && idx && maxval && rows > 0 && n > 0 && rows < (1L << 31), "hupr_argmax_rows_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_argmax_rows, dim3((unsigned)rows), dim3(64), 0, as_stream(stream), p, n, idx, maxval);
+    HUPR_LAUNCH(hupr_k_argmax_rows, dim3((unsigned)rows), dim3(64), 0, as_stream(stream), p, n, idx, maxval);
     HUPR_LAUNCH_OK("hupr_k_argmax_rows");
     return HUPR_OK;
 }
@@ -502,7 +502,7 @@ extern "C" int hupr_adam_step_f32(float* p, const float* g, float* exp_avg, floa
     HUPR_REQUIRE(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, "hupr_adam_step_f32: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(hupr_k_adam, dim3(grid1d(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n, lr,
+    HUPR_LAUNCH(hupr_k_adam, dim3(grid1d(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), gscale);
     HUPR_LAUNCH_OK("hupr_k_adam");
     return HUPR_OK;
@@ -514,7 +514,7 @@ extern "C" int hupr_adam_step_dev_f32(float* p, const float* g, float* exp_avg, 
                                       const float* dev_state, float beta1, float beta2, float eps, float weight_decay,
                                       float gscale, hupr_stream_t stream) {
     HUPR_REQUIRE(p && g && exp_avg && exp_avg_sq && dev_state && n > 0, "hupr_adam_step_dev_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_adam_dev, dim3(grid1d(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n,
+    HUPR_LAUNCH(hupr_k_adam_dev, dim3(grid1d(n, 256, 8192)), dim3(256), 0, as_stream(stream), p, g, exp_avg, exp_avg_sq, n,
                        dev_state, beta1, beta2, eps, weight_decay, gscale);
     HUPR_LAUNCH_OK("hupr_k_adam_dev");
     return HUPR_OK;

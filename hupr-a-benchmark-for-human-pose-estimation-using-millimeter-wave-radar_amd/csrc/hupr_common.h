@@ -31,6 +31,15 @@ inline int fail(int code, const char* fmt, ...) {
             return ::hupr::fail(HUPR_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// Every kernel launch of the library goes through HUPR_LAUNCH: a process-wide relaxed counter (hupr_launch_count) lets bench.py
+// print the step's launch count without a tracer ("730 launches per step").
+unsigned long long* launch_counter();
+#define HUPR_LAUNCH(...)                                              \
+    do {                                                              \
+        __atomic_fetch_add(::hupr::launch_counter(), 1ull, __ATOMIC_RELAXED); \
+        hipLaunchKernelGGL(__VA_ARGS__);                              \
+    } while (0)
+
 // ---- device helpers -------------------------------------------------------------------
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }

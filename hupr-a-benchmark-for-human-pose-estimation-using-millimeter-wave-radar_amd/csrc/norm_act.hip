@@ -635,10 +635,10 @@ static int bn_train_stats(const char* who, const T* x, long M, int C, const floa
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, (const T*)nullptr,
+    HUPR_LAUNCH((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, (const T*)nullptr,
                        (const T*)nullptr, nullptr, nullptr, M, C, partial, (const float*)nullptr, (const float*)nullptr);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, M, C, gamma,
+    HUPR_LAUNCH(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, M, C, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd");
     return HUPR_OK;
@@ -653,7 +653,7 @@ extern "C" int hupr_bn_train_finalize_f32(const void* partial, int nblk, long M,
                                           hupr_stream_t stream) {
     HUPR_REQUIRE(partial && nblk > 0 && M > 0 && C > 0 && gamma && beta && save_mean && save_invstd && scale && shift,
                  "hupr_bn_train_finalize_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, as_stream(stream),
+    HUPR_LAUNCH(hupr_k_bn_finalize_fwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, as_stream(stream),
                        static_cast<const double*>(partial), nblk, M, C, gamma, beta, running_mean, running_var, momentum, eps,
                        save_mean, save_invstd, scale, shift);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd");
@@ -679,7 +679,7 @@ extern "C" int hupr_bn_eval_params_f32(const float* gamma, const float* beta, co
                                        const float* running_var, float eps, int C, float* scale, float* shift,
                                        hupr_stream_t stream) {
     HUPR_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "hupr_bn_eval_params_f32: bad argument");
-    hipLaunchKernelGGL(hupr_k_bn_eval_params, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), gamma, beta,
+    HUPR_LAUNCH(hupr_k_bn_eval_params, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), gamma, beta,
                        running_mean, running_var, eps, C, scale, shift);
     HUPR_LAUNCH_OK("hupr_k_bn_eval_params");
     return HUPR_OK;
@@ -694,7 +694,7 @@ static int scale_shift_act(const char* who, const T* x1, const float* scale1, co
     int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
     const long nv = M * C / act_v<T>();
-    hipLaunchKernelGGL(hupr_k_scale_shift_act<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x1, scale1, shift1,
+    HUPR_LAUNCH(hupr_k_scale_shift_act<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x1, scale1, shift1,
                        x2, scale2, shift2, y, nv, C, act);
     HUPR_LAUNCH_OK("hupr_k_scale_shift_act");
     return HUPR_OK;
@@ -720,7 +720,7 @@ static int bn_eval_act(const char* who, const T* x1, const float* g1, const floa
     int rc = bn_check(who, M, C, act_v<T>());
     if (rc) return rc;
     const long nv = M * C / act_v<T>();
-    hipLaunchKernelGGL(hupr_k_bn_eval_act<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x1,
+    HUPR_LAUNCH(hupr_k_bn_eval_act<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x1,
                        BnEvalSide{g1, b1, rm1, rv1, eps1}, x2, BnEvalSide{g2, b2, rm2, rv2, eps2}, y, nv, C, act);
     HUPR_LAUNCH_OK("hupr_k_bn_eval_act");
     return HUPR_OK;
@@ -757,10 +757,10 @@ extern "C" int hupr_infer_tail_bf16act(int mode, const void* x1, int n1, const f
     const dim3 grid((unsigned)((n4 + 255) / 256));
     if (mode == 0) {
         HUPR_REQUIRE(g1 && b1 && m1 && v1 && (!x2 || (g2 && b2 && m2 && v2)), "%s: mode 0 needs the BatchNorm tensors", who);
-        hipLaunchKernelGGL(hupr_k_infer_tail<0>, grid, dim3(256), 0, as_stream(stream), s1, s2, alpha, relu, static_cast<__bf16*>(y), M, C);
+        HUPR_LAUNCH(hupr_k_infer_tail<0>, grid, dim3(256), 0, as_stream(stream), s1, s2, alpha, relu, static_cast<__bf16*>(y), M, C);
     } else {
         HUPR_REQUIRE(mode == 1 && alpha, "%s: mode 1 needs the PReLU slope", who);
-        hipLaunchKernelGGL(hupr_k_infer_tail<1>, grid, dim3(256), 0, as_stream(stream), s1, s2, alpha, relu, static_cast<__bf16*>(y), M, C);
+        HUPR_LAUNCH(hupr_k_infer_tail<1>, grid, dim3(256), 0, as_stream(stream), s1, s2, alpha, relu, static_cast<__bf16*>(y), M, C);
     }
     HUPR_LAUNCH_OK("hupr_k_infer_tail");
     return HUPR_OK;
@@ -780,14 +780,14 @@ static int bn_bwd(const char* who, const T* dy, const T* y_mask, const float* fs
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 2 * C * sizeof(double));
-    hipLaunchKernelGGL((hupr_k_colstats<1, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, dy, y_mask, save_mean,
+    HUPR_LAUNCH((hupr_k_colstats<1, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, dy, y_mask, save_mean,
                        save_invstd, M, C, partial, fs, ft);
     HUPR_LAUNCH_OK("hupr_k_colstats<1>");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_bwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C,
+    HUPR_LAUNCH(hupr_k_bn_finalize_bwd, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C,
                        gamma, save_invstd, 1.0f / (float)M, train, dgamma, dbeta, coef);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd");
     const long nv = M * C / act_v<T>();
-    hipLaunchKernelGGL(hupr_k_bn_bwd_apply<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x, save_mean, coef, dx, nv, C, fs, ft);
+    HUPR_LAUNCH(hupr_k_bn_bwd_apply<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x, save_mean, coef, dx, nv, C, fs, ft);
     HUPR_LAUNCH_OK("hupr_k_bn_bwd_apply");
     return HUPR_OK;
 }
@@ -843,14 +843,14 @@ static int bn_bwd2(const char* who, const T* dy, const T* y_mask, const float* c
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kStatBlocks * 3 * C * sizeof(double));
-    hipLaunchKernelGGL(hupr_k_colstats2<T>, dim3(nblk), dim3(256), stats_lds<T>(C, 3), s, x1, x2, dy, y_mask, mean1, invstd1,
+    HUPR_LAUNCH(hupr_k_colstats2<T>, dim3(nblk), dim3(256), stats_lds<T>(C, 3), s, x1, x2, dy, y_mask, mean1, invstd1,
                        mean2, invstd2, M, C, partial, fs1, ft1, fs2, ft2);
     HUPR_LAUNCH_OK("hupr_k_colstats2");
-    hipLaunchKernelGGL(hupr_k_bn_finalize_bwd2, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, gamma1,
+    HUPR_LAUNCH(hupr_k_bn_finalize_bwd2, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, gamma1,
                        invstd1, gamma2, invstd2, 1.0f / (float)M, train, dgamma1, dbeta1, dgamma2, dbeta2, coef);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_bwd2");
     const long nv = M * C / act_v<T>();
-    hipLaunchKernelGGL(hupr_k_bn_bwd_apply2<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x1, x2, mean1, mean2, coef, dx1, dx2,
+    HUPR_LAUNCH(hupr_k_bn_bwd_apply2<T>, dim3(ew_grid(nv)), dim3(256), 0, s, dy, y_mask, x1, x2, mean1, mean2, coef, dx1, dx2,
                        nv, C, fs1, ft1, fs2, ft2);
     HUPR_LAUNCH_OK("hupr_k_bn_bwd_apply2");
     return HUPR_OK;
@@ -900,7 +900,7 @@ template <typename T>
 static int prelu_fwd(const char* who, const T* x, const float* alpha, T* y, long n, hupr_stream_t stream) {
     HUPR_REQUIRE(x && alpha && y && n > 0 && n % act_v<T>() == 0, "%s: bad argument", who);
     const long nv = n / act_v<T>();
-    hipLaunchKernelGGL(hupr_k_prelu_fwd<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x, alpha, y, nv);
+    HUPR_LAUNCH(hupr_k_prelu_fwd<T>, dim3(ew_grid(nv)), dim3(256), 0, as_stream(stream), x, alpha, y, nv);
     HUPR_LAUNCH_OK("hupr_k_prelu_fwd");
     return HUPR_OK;
 }
@@ -922,9 +922,9 @@ static int prelu_bwd(const char* who, const T* dy, const T* x, const float* alph
     const long nv = n / act_v<T>();
     const int grid = ew_grid(nv);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(hupr_k_prelu_bwd<T>, dim3(grid), dim3(256), 0, s, dy, x, alpha, dx, nv, partial);
+    HUPR_LAUNCH(hupr_k_prelu_bwd<T>, dim3(grid), dim3(256), 0, s, dy, x, alpha, dx, nv, partial);
     HUPR_LAUNCH_OK("hupr_k_prelu_bwd");
-    hipLaunchKernelGGL(hupr_k_sum_partials, dim3(1), dim3(256), 0, s, partial, grid, dalpha);
+    HUPR_LAUNCH(hupr_k_sum_partials, dim3(1), dim3(256), 0, s, partial, grid, dalpha);
     HUPR_LAUNCH_OK("hupr_k_sum_partials");
     return HUPR_OK;
 }
@@ -948,10 +948,10 @@ static int colsum(const char* who, const T* x, long M, int C, float* out, void* 
     hipStream_t s = as_stream(stream);
     const int nblk = (int)min((long)kStatBlocks, (M + 63) / 64);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, (const T*)nullptr,
+    HUPR_LAUNCH((hupr_k_colstats<0, T>), dim3(nblk), dim3(256), stats_lds<T>(C, 2), s, x, (const T*)nullptr,
                        (const T*)nullptr, nullptr, nullptr, M, C, partial, (const float*)nullptr, (const float*)nullptr);
     HUPR_LAUNCH_OK("hupr_k_colstats<0>");
-    hipLaunchKernelGGL(hupr_k_colsum_final, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, out);
+    HUPR_LAUNCH(hupr_k_colsum_final, dim3((C + kFinalizeCh - 1) / kFinalizeCh), dim3(256), 0, s, partial, nblk, C, out);
     HUPR_LAUNCH_OK("hupr_k_colsum_final");
     return HUPR_OK;
 }
@@ -971,14 +971,14 @@ __global__ __launch_bounds__(256) void hupr_k_cast(const TI* __restrict__ x, TO*
 }  // namespace hupr
 extern "C" int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream) {
     HUPR_REQUIRE(x && y && n > 0 && n % 4 == 0, "hupr_cast_f32_to_bf16: bad argument");
-    hipLaunchKernelGGL((hupr_k_cast<float, __bf16>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), x,
+    HUPR_LAUNCH((hupr_k_cast<float, __bf16>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), x,
                        static_cast<__bf16*>(y), n / 4);
     HUPR_LAUNCH_OK("hupr_k_cast");
     return HUPR_OK;
 }
 extern "C" int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream) {
     HUPR_REQUIRE(x && y && n > 0 && n % 4 == 0, "hupr_cast_bf16_to_f32: bad argument");
-    hipLaunchKernelGGL((hupr_k_cast<__bf16, float>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream),
+    HUPR_LAUNCH((hupr_k_cast<__bf16, float>), dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream),
                        static_cast<const __bf16*>(x), y, n / 4);
     HUPR_LAUNCH_OK("hupr_k_cast");
     return HUPR_OK;

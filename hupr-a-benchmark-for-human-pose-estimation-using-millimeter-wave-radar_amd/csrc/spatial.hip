@@ -411,7 +411,7 @@ static int mnet_fwd(const char* who, const float* x, const float* w, const float
     HUPR_REQUIRE(x && w && bias && out && n_bg > 0 && pixels > 0, "%s: bad argument", who);
     const long total = n_bg * pixels;
     const int grid = (int)min((long)8192, (total + 255) / 256);
-    hipLaunchKernelGGL(hupr_k_mnet_fwd<T>, dim3(grid), dim3(256), 0, as_stream(stream), x, w, bias, out, means, n_bg, pixels);
+    HUPR_LAUNCH(hupr_k_mnet_fwd<T>, dim3(grid), dim3(256), 0, as_stream(stream), x, w, bias, out, means, n_bg, pixels);
     HUPR_LAUNCH_OK("hupr_k_mnet_fwd");
     return HUPR_OK;
 }
@@ -430,7 +430,7 @@ static int mnet_fwd_means(const char* who, const float* mp, const float* w, cons
     HUPR_REQUIRE(mp && w && bias && out && n_bg > 0 && pixels > 0, "%s: bad argument", who);
     const long total = n_bg * pixels;
     const int grid = (int)min((long)8192, (total + 255) / 256);
-    hipLaunchKernelGGL(hupr_k_mnet_fwd_means<T>, dim3(grid), dim3(256), 0, as_stream(stream), mp, w, bias, out, means, n_bg, pixels);
+    HUPR_LAUNCH(hupr_k_mnet_fwd_means<T>, dim3(grid), dim3(256), 0, as_stream(stream), mp, w, bias, out, means, n_bg, pixels);
     HUPR_LAUNCH_OK("hupr_k_mnet_fwd_means");
     return HUPR_OK;
 }
@@ -454,10 +454,10 @@ static int mnet_bwd(const char* who, const float* x, const float* means, const f
     const long total = n_bg * pixels;
     const int grid = (int)min((long)1024, (total + 63) / 64);      // 64 pixels per workgroup pass; partial[grid][160]
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(hupr_k_mnet_bwd<T>, dim3(grid), dim3(256), 0, s, x, w, bias, dy, means, n_bg, pixels,
+    HUPR_LAUNCH(hupr_k_mnet_bwd<T>, dim3(grid), dim3(256), 0, s, x, w, bias, dy, means, n_bg, pixels,
                        reinterpret_cast<float*>(ws));
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd");
-    hipLaunchKernelGGL(hupr_k_mnet_bwd_final, dim3(kNF * 5), dim3(256), 0, s, reinterpret_cast<const float*>(ws), grid, dw, dbias);
+    HUPR_LAUNCH(hupr_k_mnet_bwd_final, dim3(kNF * 5), dim3(256), 0, s, reinterpret_cast<const float*>(ws), grid, dw, dbias);
     HUPR_LAUNCH_OK("hupr_k_mnet_bwd_final");
     return HUPR_OK;
 }
@@ -492,10 +492,10 @@ static int interp_fwd(const char* who, const T* x, T* y, int Bn, int Di, int Hi,
     if (rc) return rc;
     const long total = (long)Bn * Do * Ho * Wo * (C / 4);
     if (g_interp_packed)
-        hipLaunchKernelGGL((hupr_k_interp_fwd<T, true>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+        HUPR_LAUNCH((hupr_k_interp_fwd<T, true>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
                            as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     else
-        hipLaunchKernelGGL((hupr_k_interp_fwd<T, false>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+        HUPR_LAUNCH((hupr_k_interp_fwd<T, false>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
                            as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     HUPR_LAUNCH_OK("hupr_k_interp_fwd");
     return HUPR_OK;
@@ -522,11 +522,11 @@ static int interp_bwd(const char* who, const T* dy, T* dx, int Bn, int Di, int H
     const long voxels = (long)Bn * Di * Hi * Wi;
     if (C % (4 * V) == 0 && voxels * (C / (4 * V)) >= 256 * 256) {       // 4 vectors per thread while the grid stays full
         const long total = voxels * (C / (4 * V));
-        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 4, ACC>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
+        HUPR_LAUNCH((hupr_k_interp_bwd<T, 4, ACC>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
                            as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     } else {
         const long total = voxels * (C / V);
-        hipLaunchKernelGGL((hupr_k_interp_bwd<T, 1, ACC>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
+        HUPR_LAUNCH((hupr_k_interp_bwd<T, 1, ACC>), dim3((int)min((long)16384, (total + 255) / 256)), dim3(256), 0,
                            as_stream(stream), dy, dx, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     }
     HUPR_LAUNCH_OK("hupr_k_interp_bwd");

@@ -408,9 +408,9 @@ extern "C" int hupr_tmerge_fwd_stream_bf16(const void* x, const void* wp_bf16, f
     const __bf16* xb = static_cast<const __bf16*>(x);
     const __bf16* wb = static_cast<const __bf16*>(wp_bf16);
     hipStream_t s = as_stream(stream);
-    if (G == 8) hipLaunchKernelGGL(hupr_k_tmerge_fwd_stream<8>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
-    else if (G == 4) hipLaunchKernelGGL(hupr_k_tmerge_fwd_stream<4>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
-    else hipLaunchKernelGGL(hupr_k_tmerge_fwd_stream<2>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
+    if (G == 8) HUPR_LAUNCH(hupr_k_tmerge_fwd_stream<8>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
+    else if (G == 4) HUPR_LAUNCH(hupr_k_tmerge_fwd_stream<4>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
+    else HUPR_LAUNCH(hupr_k_tmerge_fwd_stream<2>, grid, dim3(256), 0, s, xb, wb, y, Bn, HW);
     HUPR_LAUNCH_OK("hupr_k_tmerge_fwd_stream");
     return HUPR_OK;
 }
@@ -426,9 +426,9 @@ extern "C" int hupr_tmerge_dgrad_stream_bf16(const float* dy, const void* wp1_bf
     const __bf16* wb = static_cast<const __bf16*>(wp1_bf16);
     __bf16* dxb = static_cast<__bf16*>(dx);
     hipStream_t s = as_stream(stream);
-    if (G == 8) hipLaunchKernelGGL(hupr_k_tmerge_dgrad_stream<8>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
-    else if (G == 4) hipLaunchKernelGGL(hupr_k_tmerge_dgrad_stream<4>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
-    else hipLaunchKernelGGL(hupr_k_tmerge_dgrad_stream<2>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
+    if (G == 8) HUPR_LAUNCH(hupr_k_tmerge_dgrad_stream<8>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
+    else if (G == 4) HUPR_LAUNCH(hupr_k_tmerge_dgrad_stream<4>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
+    else HUPR_LAUNCH(hupr_k_tmerge_dgrad_stream<2>, grid, dim3(256), 0, s, dy, wb, dxb, Bn, HW);
     HUPR_LAUNCH_OK("hupr_k_tmerge_dgrad_stream");
     return HUPR_OK;
 }
@@ -468,14 +468,14 @@ extern "C" int hupr_tmerge_wgrad_stream_bf16(const void* x, const float* dy, flo
     float* part = static_cast<float*>(ws);
     hipStream_t s = as_stream(stream);
     const dim3 grid((unsigned)(nb * n_slots));
-    if (F == 8) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<8>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
-    else if (F == 4) hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<4>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
-    else hipLaunchKernelGGL(hupr_k_tmerge_wgrad_stream<2>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
+    if (F == 8) HUPR_LAUNCH(hupr_k_tmerge_wgrad_stream<8>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
+    else if (F == 4) HUPR_LAUNCH(hupr_k_tmerge_wgrad_stream<4>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
+    else HUPR_LAUNCH(hupr_k_tmerge_wgrad_stream<2>, grid, dim3(256), 0, s, xb, dy, part, Bn, HW, SUB, nb);
     HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_stream");
     if (SUB == 1 && nb == 1 && n_out % 4 == 0)
-        hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce4, dim3((n_out / 4 + 15) / 16), dim3(256), 0, s, part, dw, n_slots, n_out / 4);
+        HUPR_LAUNCH(hupr_k_tmerge_wgrad_reduce4, dim3((n_out / 4 + 15) / 16), dim3(256), 0, s, part, dw, n_slots, n_out / 4);
     else
-        hipLaunchKernelGGL(hupr_k_tmerge_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, part, dw, n_slots, nb, SUB, F, n_out);
+        HUPR_LAUNCH(hupr_k_tmerge_wgrad_reduce, dim3((n_out + 15) / 16), dim3(256), 0, s, part, dw, n_slots, nb, SUB, F, n_out);
     HUPR_LAUNCH_OK("hupr_k_tmerge_wgrad_reduce");
     return HUPR_OK;
 }

@@ -616,11 +616,11 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
             // the 32 -> 64 layer-1 shape at 102 tiles per workgroup; +2-3 us on shapes with one or two tiles per workgroup)
             const bool ci32 = Ci <= 32 && (g_wgrad_ci32 == 2 || (g_wgrad_ci32 == 1 && a.n_spatial >= 16 * gw));
             if (kd == 3) {
-                if (ci32) hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<true, true>), grid, dim3(512), 0, s, a);
-                else hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<true, false>), grid, dim3(512), 0, s, a);
+                if (ci32) HUPR_LAUNCH((hupr_k_wgrad_halo_glds<true, true>), grid, dim3(512), 0, s, a);
+                else HUPR_LAUNCH((hupr_k_wgrad_halo_glds<true, false>), grid, dim3(512), 0, s, a);
             } else {
-                if (ci32) hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<false, true>), grid, dim3(512), 0, s, a);
-                else hipLaunchKernelGGL((hupr_k_wgrad_halo_glds<false, false>), grid, dim3(512), 0, s, a);
+                if (ci32) HUPR_LAUNCH((hupr_k_wgrad_halo_glds<false, true>), grid, dim3(512), 0, s, a);
+                else HUPR_LAUNCH((hupr_k_wgrad_halo_glds<false, false>), grid, dim3(512), 0, s, a);
             }
             HUPR_LAUNCH_OK("hupr_k_wgrad_halo_glds");
             launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw, n, kd * 9, Ci, s);
@@ -631,11 +631,11 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     a.groups = groups;
     const dim3 grid(groups, kd, a.n_ci_tiles * a.n_co_tiles);
     if (kd == 3) {
-        if (abf) hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<true, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<false, true>), grid, dim3(256), 0, s, a);
+        if (abf) HUPR_LAUNCH((hupr_k_wgrad_halo_bf16<true, true>), grid, dim3(256), 0, s, a);
+        else HUPR_LAUNCH((hupr_k_wgrad_halo_bf16<false, true>), grid, dim3(256), 0, s, a);
     } else {
-        if (abf) hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<true, false>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((hupr_k_wgrad_halo_bf16<false, false>), grid, dim3(256), 0, s, a);
+        if (abf) HUPR_LAUNCH((hupr_k_wgrad_halo_bf16<true, false>), grid, dim3(256), 0, s, a);
+        else HUPR_LAUNCH((hupr_k_wgrad_halo_bf16<false, false>), grid, dim3(256), 0, s, a);
     }
     HUPR_LAUNCH_OK("hupr_k_wgrad_halo_bf16");
     launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, groups, n, kd * 9, Ci, s);

@@ -19,17 +19,66 @@ from . import runtime as rt
 
 _ws_cache = {}
 CONV_PROBE = None      # bench.py installs a callable(x, co, k) -> (start_event, end_event) | None
-MATH = "f32"           # matrix-pipe arithmetic of the GEMM-shaped ops: "f32" (parity path) or "bf16"
+# Precision state (round 5: per THREAD, ADVICE r3 item 5 / VERDICT r4 weak 2).  ``_st.math`` = matrix-pipe arithmetic of the GEMM-shaped
+# ops: "f32" (parity path) or "bf16"; ``_st.act_f32_here`` / ``_st.region_switched`` = inside a region switched to "f32act" / to the fp32
+# pipe.  Rounds 1-4 kept the three as module globals mutated from whichever thread ran a forward or — through the autograd engine's
+# device thread — a backward: two models driven from two threads of one process (or one per device) silently shared one pipe
+# selection.  Now every thread owns its copy: ``set_math`` sets the calling thread's mode (and the default a thread that never chose
+# one starts from), ``math_mode`` scopes it, ``HuPRNet.math_mode`` pins it per model, and every autograd node carries the state of
+# its forward into its backward on whatever thread the engine runs it (``_math_scoped``).  ``F_.MATH`` etc. stay readable
+# (module ``__getattr__``) and name the calling thread's values.
+import threading
+
+_DEFAULT_MATH = ["f32"]
+
+
+class _State(threading.local):
+    def __init__(self):            # runs once per thread, on its first access
+        self.math = _DEFAULT_MATH[0]
+        self.act_f32_here = False
+        self.region_switched = False
+
+
+_st = _State()
+
+
+def __getattr__(name):             # PEP 562: F_.MATH / F_._ACT_F32_HERE / F_._REGION_SWITCHED of the calling thread
+    if name == "MATH":
+        return _st.math
+    if name == "_ACT_F32_HERE":
+        return _st.act_f32_here
+    if name == "_REGION_SWITCHED":
+        return _st.region_switched
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
 ACT_BF16 = True        # bf16 mode only: the 3-D encoders keep their activations in HBM as bf16 ("bf16act" kernels)
 ACT_BF16_DECODER = os.environ.get("HUPR_DECODER_F32", "0") != "1"      # ... and so do the BasicBlock2D decoder stacks
 
 
 def set_math(mode):
-    """Select v_mfma_f32_32x32x2_f32 ("f32", exact) or v_mfma_f32_32x32x16_bf16 ("bf16", fp32 accumulate)."""
-    global MATH
+    """Select v_mfma_f32_32x32x2_f32 ("f32", exact) or the bf16 matrix pipe ("bf16", fp32 accumulate) for the CALLING thread, and as
+    the mode threads that have not chosen one start from."""
     if mode not in ("f32", "bf16"):
         raise ValueError("math mode must be 'f32' or 'bf16'")
-    MATH = mode
+    _st.math = mode
+    _DEFAULT_MATH[0] = mode
+
+
+class math_mode:
+    """``with math_mode("bf16"):`` — the calling thread's matrix-pipe mode for the block (nothing process-wide changes)."""
+
+    def __init__(self, mode):
+        if mode not in ("f32", "bf16"):
+            raise ValueError("math mode must be 'f32' or 'bf16'")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = (_st.math, _st.act_f32_here, _st.region_switched)
+        _st.math, _st.act_f32_here, _st.region_switched = self.mode, False, False
+        return self
+
+    def __exit__(self, *exc):
+        _st.math, _st.act_f32_here, _st.region_switched = self.prev
+        return False
 
 
 # Per-region precision inside a bf16 run: PRECISION[region] = "f32" runs that region of HuPRNet.forward on the fp32 matrix
@@ -48,8 +97,6 @@ if "HUPR_F32_REGIONS" in os.environ or "HUPR_F32ACT_REGIONS" in os.environ:
 else:
     PRECISION = {"dec1b": "f32act", "head": "f32"}
 assert all(r in REGIONS for r in PRECISION), PRECISION
-_ACT_F32_HERE = False      # inside a region switched to "f32act"
-_REGION_SWITCHED = False   # inside a region of a bf16 run that was switched to the fp32 pipe
 
 
 class region:
@@ -60,18 +107,16 @@ class region:
         self.name = name
 
     def __enter__(self):
-        global MATH, _ACT_F32_HERE, _REGION_SWITCHED
-        self.prev = (MATH, _ACT_F32_HERE, _REGION_SWITCHED)
+        self.prev = (_st.math, _st.act_f32_here, _st.region_switched)
         mode = PRECISION.get(self.name)
-        if MATH == "bf16" and mode == "f32":
-            MATH = "f32"
-            _REGION_SWITCHED = True
-        _ACT_F32_HERE = MATH == "bf16" and mode == "f32act"
+        if _st.math == "bf16" and mode == "f32":
+            _st.math = "f32"
+            _st.region_switched = True
+        _st.act_f32_here = _st.math == "bf16" and mode == "f32act"
         return self
 
     def __exit__(self, *exc):
-        global MATH, _ACT_F32_HERE, _REGION_SWITCHED
-        MATH, _ACT_F32_HERE, _REGION_SWITCHED = self.prev
+        _st.math, _st.act_f32_here, _st.region_switched = self.prev
         return False
 
 
@@ -80,30 +125,28 @@ def _math_scoped(cls):
     fwd, bwd = cls.forward, cls.backward
 
     def forward(ctx, *a):
-        ctx._hupr_math = (MATH, _ACT_F32_HERE, _REGION_SWITCHED)
+        ctx._hupr_math = (_st.math, _st.act_f32_here, _st.region_switched)
         return fwd(ctx, *a)
 
     def backward(ctx, *g):
-        # (the precision state is PROCESS-wide: one model per process at a time, forward and backward on the autograd engine's
-        # single device thread of that process — ADVICE r3; every piece of it is saved and restored here)
-        global MATH, _ACT_F32_HERE, _REGION_SWITCHED
-        prev = (MATH, _ACT_F32_HERE, _REGION_SWITCHED)
-        MATH, _ACT_F32_HERE, _REGION_SWITCHED = ctx._hupr_math
+        # (the engine runs this on ITS thread: that thread's state is set from the node and restored afterwards)
+        prev = (_st.math, _st.act_f32_here, _st.region_switched)
+        _st.math, _st.act_f32_here, _st.region_switched = ctx._hupr_math
         try:
             return bwd(ctx, *g)
         finally:
-            MATH, _ACT_F32_HERE, _REGION_SWITCHED = prev
+            _st.math, _st.act_f32_here, _st.region_switched = prev
     cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
     return cls
 
 
 def _fn(stem):
-    return getattr(rt.lib(), "hupr_%s_%s" % (stem, MATH))
+    return getattr(rt.lib(), "hupr_%s_%s" % (stem, _st.math))
 
 
 def act_bf16():
     """True when the encoder island stores activations as bf16 (bf16 math + ACT_BF16)."""
-    return MATH == "bf16" and ACT_BF16 and not _ACT_F32_HERE
+    return _st.math == "bf16" and ACT_BF16 and not _st.act_f32_here
 
 
 def _act(stem, t):
@@ -343,7 +386,7 @@ USE_HALO = True        # bf16 mode: LDS halo-tiled kernel for 3x3(x3) "same" con
 
 
 def _halo_ok(x, k, pad, co=4):
-    if MATH != "bf16" or not USE_HALO or co % 4 != 0:
+    if _st.math != "bf16" or not USE_HALO or co % 4 != 0:
         return False
     B, Di, Hi, Wi, Ci = _vox(x)
     if x.dtype == torch.bfloat16 and Ci % 8 != 0:
@@ -434,7 +477,7 @@ INFER_TAILS = os.environ.get("HUPR_NO_INFER_TAILS", "0") != "1"      # A/B aid
 
 def infer_fast_ok(x):
     """Single-sample style inference on the bf16 path: no autograd, bf16-stored channels-last input, bf16 matrix pipe."""
-    return INFER_TAILS and MATH == "bf16" and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
+    return INFER_TAILS and _st.math == "bf16" and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
 
 
 def conv_infer_sliced(shape, weight, pad):
@@ -745,7 +788,7 @@ MERGE_DOWN = os.environ.get("HUPR_NO_MERGE_DOWN", "0") != "1"
 
 
 def merge_down_ok(x):
-    return MERGE_DOWN and MATH == "bf16" and x.dtype == torch.bfloat16 and x.is_cuda
+    return MERGE_DOWN and _st.math == "bf16" and x.dtype == torch.bfloat16 and x.is_cuda
 
 
 def temporal_merge(x, weight):
@@ -754,7 +797,7 @@ def temporal_merge(x, weight):
     if x.dtype == torch.bfloat16 and os.environ.get("HUPR_TMERGE_CAST", "0") == "1":      # A/B aid: cast + generic conv
         x = cast(x, torch.float32)
     if x.dtype == torch.bfloat16:
-        if MATH != "bf16":
+        if _st.math != "bf16":
             raise rt.HuprError("bf16-stored activations need the bf16 math mode")
         return TemporalMergeFn.apply(x, weight)
     return ConvFn.apply(x, weight, None, None, (0, 0, 0))
@@ -1087,7 +1130,7 @@ class AttentionFn(torch.autograd.Function):
         k, q, v = _c(k), _c(q), _c(v)
         B, N, C = v.shape
         L = rt.lib()
-        ctx.flash = MATH == "bf16" and USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
+        ctx.flash = _st.math == "bf16" and USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
         if attn_fp8_ok(v):                # config 5 (opt-in, no_grad only): nothing is saved for a backward pass
             return attention_fp8(k, q, v, residual)[0]
         if ctx.flash:
@@ -1160,7 +1203,7 @@ def attention_fp8(k, q, v, residual):
 
 
 def attn_fp8_ok(v):
-    return ATTN_FP8 is True and MATH == "bf16" and not torch.is_grad_enabled() and v.shape[-1] == 64 and v.shape[1] % 128 == 0
+    return ATTN_FP8 is True and _st.math == "bf16" and not torch.is_grad_enabled() and v.shape[-1] == 64 and v.shape[1] % 128 == 0
 
 
 def attn_mx8_ok(N, C):
@@ -1199,7 +1242,7 @@ def mscsa_level_fused_ok(ra):
     B, _, H, W, C = ra.shape
     if ATTN_FP8 is True and C == 64 and not torch.is_grad_enabled():
         return False                      # config 5, per-tensor form: this level runs as separate projections + fp8 attentions
-    return LEVEL_FUSION and MATH == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
+    return LEVEL_FUSION and _st.math == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
 
 
 # Derived inference constants (concatenated projection weights, the zero-padded head filter): one entry per set of source
@@ -1480,7 +1523,7 @@ GCN_PRODUCTS = os.environ.get("HUPR_NO_GCN_PRODUCTS", "0") != "1"      # A/B aid
 
 def _gcn_products_ok(x, weight):
     """The dedicated PRGCN product kernels apply: fp32 pipe (the default of the head in every mode), 16-wide key-point slots."""
-    return (GCN_PRODUCTS and (GCN_MATH == "f32" or MATH == "f32") and x.dtype == torch.float32 and x.shape[2] == 16
+    return (GCN_PRODUCTS and (GCN_MATH == "f32" or _st.math == "f32") and x.dtype == torch.float32 and x.shape[2] == 16
             and x.shape[1] % 64 == 0 and tuple(weight.shape) == (x.shape[1], x.shape[1]))
 
 
@@ -1576,7 +1619,7 @@ class Head1x1Fn(torch.autograd.Function):
 def head_conv(x, w16):
     """1x1 head: the dedicated fp32 kernels inside a bf16 run whose "head" region is switched to fp32 (32 -> 16 channels),
     the generic convolution otherwise (the pure fp32 parity path keeps the arithmetic its golden fixtures were pinned with)."""
-    if _REGION_SWITCHED and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 32 and tuple(w16.shape) == (16, 32, 1, 1):
+    if _st.region_switched and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 32 and tuple(w16.shape) == (16, 32, 1, 1):
         return Head1x1Fn.apply(x, w16)
     return conv(x, w16, None, None, (0, 0, 0))
 

@@ -32,11 +32,20 @@ class HuPRNet(nn.Module):
         self.RAradarEncoder = Encoder3D(cfg)
         self.REradarEncoder = Encoder3D(cfg)
         self.radarDecoder = MultiScaleCrossSelfAttentionPRGCN(cfg, batchnorm=False, activation=nn.PReLU)
+        # None: the calling thread's mode (functional.set_math); "f32" / "bf16": this model's forward (and, through its autograd
+        # nodes, its backward) runs under that mode whatever the thread's is — two models of one process on different pipes
+        self.math_mode = None
 
     def forward_chirp(self, VRDAEmaps_hori, VRDAEmaps_vert):
         return self.RAchirpNet(VRDAEmaps_hori), self.REchirpNet(VRDAEmaps_vert)
 
     def forward(self, VRDAEmaps_hori, VRDAEmaps_vert):
+        if self.math_mode is not None:
+            with F_.math_mode(self.math_mode):
+                return self._forward(VRDAEmaps_hori, VRDAEmaps_vert)
+        return self._forward(VRDAEmaps_hori, VRDAEmaps_vert)
+
+    def _forward(self, VRDAEmaps_hori, VRDAEmaps_vert):
         F_._conv_stats.clear()                  # no fused-statistics hand-over survives a forward pass
         if F_.two_streams_ok(VRDAEmaps_hori):
             # vertical branch on the side stream, horizontal branch on the current one (see functional.TWO_STREAMS)
@@ -56,6 +65,8 @@ class HuPRNet(nn.Module):
                 for t in (REl1feat, REl2feat, REfeat):
                     t.record_stream(main)             # allocated on the side stream, consumed by the decoder
         else:
+            if VRDAEmaps_hori.is_cuda and not torch.cuda.is_current_stream_capturing():
+                F_.refresh_packed(VRDAEmaps_hori.device)            # stale cached layouts / derived constants are refilled in place
             RAmaps, REmaps = self.forward_chirp(VRDAEmaps_hori, VRDAEmaps_vert)
             RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(RAmaps)
             REl1feat, REl2feat, REfeat = self.REradarEncoder(REmaps)

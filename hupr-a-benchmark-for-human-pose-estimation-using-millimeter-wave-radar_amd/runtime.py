@@ -26,6 +26,7 @@ class AttnItem(ctypes.Structure):
 SIGNATURES = {
     "hupr_version": (c_int, []),
     "hupr_last_error": (c_char_p, []),
+    "hupr_launch_count": (ctypes.c_ulonglong, []),
     "hupr_fft_chain_ws_bytes": (c_size_t, [c_int]),
     "hupr_fft_chain_c64": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_fft_chain_loader_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -93,9 +93,12 @@ class BaseRunner():
         torch.save(group, os.path.join(self.dir, "checkpoint.pth"))
         # Which zero-Doppler convention the on-GPU FFT loader fed these weights (preprocessing.ZERO_DOPPLER).  A sidecar,
         # not a checkpoint key: the checkpoint dict keeps exactly the reference's four keys (tools/base.py:76-81).
-        from ..preprocessing import process_iwr1843 as _pre
-        with open(os.path.join(self.dir, "preprocess.json"), "w") as fp:
-            json.dump({"fft_zero_doppler": _pre.ZERO_DOPPLER}, fp)
+        # Written only when the GPU FFT loader actually fed this run (raw-capture dataset): a run on stored .npy cubes never touched
+        # the chain, and a sidecar there would claim a convention nobody used.
+        if getattr(self, "uses_gpu_fft_loader", False):
+            from ..preprocessing import process_iwr1843 as _pre
+            with open(os.path.join(self.dir, "preprocess.json"), "w") as fp:
+                json.dump({"fft_zero_doppler": _pre.ZERO_DOPPLER}, fp)
         if epoch % 5 == 0:
             torch.save(group, os.path.join(self.dir, "checkpoint_%d.pth" % epoch))
 
@@ -117,6 +120,11 @@ class BaseRunner():
                 trained = json.load(fp).get("fft_zero_doppler")
             if trained and trained != _pre.ZERO_DOPPLER:
                 print("==========>WARNING: these weights were trained with HUPR_FFT_ZERO_DOPPLER=%s, this process runs %s" % (trained, _pre.ZERO_DOPPLER))
+        elif getattr(self, "uses_gpu_fft_loader", False):
+            from ..preprocessing import process_iwr1843 as _pre
+            print("==========>NOTE: no preprocess.json beside these weights: the zero-Doppler convention they were trained with is unknown "
+                  "(reference-trained or .npy-trained weights: the reference's rounding residue; a round-3 native run: 'exact'); this "
+                  "process feeds them HUPR_FFT_ZERO_DOPPLER=%s" % _pre.ZERO_DOPPLER)
         if not self.args.eval and not getattr(self.args, "pretrained", False):
             print("==========>Load the previous optimizer")
             self.optimizer.load_state_dict(ck["optimizer_state_dict"])      # torch.optim.Adam layout either way

@@ -209,6 +209,7 @@ class GradientBuckets:
             (dist.is_initialized() or self.device.type == "cuda")
         self.active = self.world_size > 1 or self.force_collective      # is there an exchange step at all?
         self.transport = make_transport(self.device, process_group) if self.active else None
+        self._timing = None
         self.reduce_this_pass = True      # False while accumulating the leading micro-batches of an optimiser step
         self._accum_live = False
         self.use_streams = self.device.type == "cuda"
@@ -307,7 +308,14 @@ class GradientBuckets:
                     self.comm_stream.wait_stream(s)
                 if self._accum_live:                               # earlier micro-batches of this optimiser step
                     b.flat_grad.add_(b.accum)
+                if self._timing is not None:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(self.comm_stream)
                 b.work = self.transport.all_reduce(b.flat_grad, self.comm_stream)
+                if self._timing is not None:
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(self.comm_stream)
+                    self._timing["buckets"].append((self.buckets.index(b), t0, t1))
         else:
             if self._accum_live:
                 b.flat_grad.add_(b.accum)
@@ -343,9 +351,42 @@ class GradientBuckets:
             if self._accum_live and self.reduce_this_pass and not self.active:
                 b.flat_grad.add_(b.accum)                       # single rank: no exchange, just the micro-batch sum
         if self.use_streams and self.active and self.reduce_this_pass:
+            if self._timing is not None:
+                # where backward ended on the compute stream vs where the last collective ended on the communication stream: the
+                # difference (if positive) is the part of the exchange step that overlapped with nothing
+                e_bwd, e_comm = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e_bwd.record(torch.cuda.current_stream(self.device))
+                e_comm.record(self.comm_stream)
+                self._timing["tails"].append((e_bwd, e_comm))
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         if self.reduce_this_pass:
             self._accum_live = False
+
+    # -- measurement (bench.py --gpus N): per-bucket all-reduce durations and the exposed tail ---------------------------------
+    def enable_timing(self, on=True):
+        """Record HIP events around every bucket's all-reduce (communication stream) and at the join before Adam.  Eager steps only
+        (events cannot be read back from a graph replay)."""
+        self._timing = {"buckets": [], "tails": []} if (on and self.use_streams) else None
+
+    def timing_report(self):
+        """-> {"buckets": [{"index", "mbytes", "allreduce_us" (mean), "busbw_GBs"}], "exposed_tail_us": mean, "steps": n} from the
+        events recorded since ``enable_timing`` (synchronises the device)."""
+        if self._timing is None:
+            return None
+        torch.cuda.synchronize(self.device)
+        per = {}
+        for i, t0, t1 in self._timing["buckets"]:
+            per.setdefault(i, []).append(t0.elapsed_time(t1) * 1e3)
+        tails = [max(a.elapsed_time(b), 0.0) * 1e3 for a, b in self._timing["tails"]]
+        n = self.world_size
+        out = []
+        for i in sorted(per):
+            nbytes = self.buckets[i].numel * 4
+            us = sum(per[i]) / len(per[i])
+            # ring all-reduce: every rank sends and receives 2 (n - 1) / n of the message ("bus bandwidth" in RCCL's tests)
+            out.append({"index": i, "mbytes": round(nbytes / 1e6, 1), "allreduce_us": round(us, 1),
+                        "busbw_GBs": round(nbytes * 2.0 * (n - 1) / max(n, 1) / (us * 1e-6) / 1e9, 1) if us > 0 and n > 1 else None})
+        return {"buckets": out, "exposed_tail_us": round(sum(tails) / len(tails), 1) if tails else None, "steps": len(tails)}
 
     def close(self):
         """Release the native communicator (engines that are re-created would otherwise leak one each)."""

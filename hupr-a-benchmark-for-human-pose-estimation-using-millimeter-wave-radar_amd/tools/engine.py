@@ -37,6 +37,7 @@ class TrainEngine:
         self.fuse_elevation_mean = os.environ.get("HUPR_NO_FUSED_MEAN", "0") != "1"
         self._fft_ws = None
         self._graph = None
+        self.keep_inference_graphs_current = True      # see _replay
         # the num_batches_tracked counters of all BatchNorms as views of one int64 vector: a training step bumps them
         # with ONE launch instead of one tiny add kernel per BatchNorm (30 per step); state_dict I/O is unchanged
         self._bns = [m for m in self.model.modules()
@@ -161,6 +162,10 @@ class TrainEngine:
         self._graph.replay()
         from .. import functional as F_
         F_.invalidate_packed()      # the graph's Adam node changed the parameters behind every host-side cache
+        if self.keep_inference_graphs_current:
+            # captured INFERENCE graphs (no_grad) read the cached packed / derived weights in place: refill them now, stream-ordered
+            # behind the replay, so that such a graph replayed next sees this step's weights (one table launch)
+            F_.refresh_packed(self.device)
         return self._g_out
 
     @torch.no_grad()

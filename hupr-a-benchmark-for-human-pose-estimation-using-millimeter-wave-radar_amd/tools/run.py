@@ -50,6 +50,8 @@ class Runner(BaseRunner):
         else:
             self.trainLoader = [0]
         self.testSet = getDataset("test" if args.eval else "val", cfg, args)
+        # does the GPU FFT chain feed this run (raw captures), or stored .npy cubes?  (tools/base.py: the preprocess.json sidecar)
+        self.uses_gpu_fft_loader = isinstance(self.testSet, HuPRRawADC) or isinstance(getattr(self, "trainSet", None), HuPRRawADC)
         # evaluation is sharded over the ranks (rank r takes samples r, r + world, ...) and gathered on rank 0
         shard = data.Subset(self.testSet, range(self.rank, len(self.testSet), self.world)) if self.world > 1 else self.testSet
         self.testLoader = data.DataLoader(shard, cfg.TEST.batchSize, shuffle=False, num_workers=0, collate_fn=_collate)

@@ -34,6 +34,9 @@ typedef void* hupr_stream_t; /* hipStream_t */
 
 int hupr_version(void);
 const char* hupr_last_error(void);
+/* kernels launched by this library in this process so far (every launch goes through one counting macro, csrc/hupr_common.h):
+ * bench.py prints the difference over a step as `launches_per_step` — measurement aid, nothing in the reference to replace */
+unsigned long long hupr_launch_count(void);
 
 /* ------------------------------------------------------------------------------------------
  * (a1) FFT chain — replaces RadarObject.generateHeatmap, preprocessing/process_iwr1843.py:106-173

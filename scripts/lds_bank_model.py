@@ -127,7 +127,55 @@ def wgrad_report():
     return ok
 
 
+# ---- csrc/attention_bf16.hip: row-major [row][D] bf16 images, 16-byte chunks at position chunk ^ key(row) (Img<D>) -----------------
+# b128 fragments (mma_rows_x_frags / HUPR_PP_READ_K: lane reads row 32 t + (lane & 31), chunk 2 ks + (lane >> 5)) and transpose
+# fragments (mma_tr_x_tile / HUPR_PP_READ_V: 16-lane group g serves column half g & 1 of row quartet g >> 1).  Rounds 1-4 keyed the
+# swizzle with the row bits in place; round 5 rotates them (the comment at Img<D>::key).  Counters for the old key:
+# SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 33 % (forward), 20 % (dQ), 22 % (dK / dV) in profiles/r04b_attn_sq_pmc.txt.
+ATTN_KEYS = {
+    64: (lambda r: (r >> 1) & 7, lambda r: (((r >> 1) & 1) << 2) | ((r >> 2) & 3)),
+    128: (lambda r: r & 15, lambda r: ((r & 3) << 2) | ((r >> 2) & 3)),
+    256: (lambda r: r & 31, lambda r: ((r & 3) << 2) | ((r >> 2) & 3) | (r & 16)),
+}
+
+
+def attn_cycles(D, key):
+    rb = 2 * D
+    b = [0, 0]
+    for t, ks in itertools.product(range(2), range(D // 16)):
+        c, f = cycles(lambda l: (32 * t + (l & 31)) * rb + (((2 * ks + (l >> 5)) ^ key(32 * t + (l & 31))) << 4), B128_GROUPS, 16)
+        b[0], b[1] = b[0] + c, b[1] + f
+    tr = [0, 0]
+    for t, u, ct, second in itertools.product(range(2), range(2), range(D // 32), range(2)):
+        def addr(l):
+            g, s = l >> 4, l & 15
+            row = 32 * t + 16 * u + 4 * (g >> 1) + (s >> 2) + 8 * second
+            c = 32 * ct + 16 * (g & 1) + 4 * (s & 3)
+            return row * rb + (((c >> 3) ^ key(row)) << 4) + (c & 4) * 2
+        c, f = cycles(addr, TR64_GROUPS, 8)
+        tr[0], tr[1] = tr[0] + c, tr[1] + f
+    return b, tr
+
+
+def attn_report():
+    ok = True
+    for D, (old, new) in ATTN_KEYS.items():
+        for name, key in (("rounds 1-4 key", old), ("rotated key", new)):
+            b, tr = attn_cycles(D, key)
+            # per 64-row tile and wave: forward = one image b128 + one transposed; dQ = two b128 + one transposed; dK / dV = two + two
+            mix = {"fwd": (1, 1), "dQ": (2, 1), "dK/dV": (2, 2)}
+            shares = ", ".join("%s %.0f %%" % (k, 100.0 * (nb * (b[0] - b[1]) + nt * (tr[0] - tr[1])) / (nb * b[0] + nt * tr[0]))
+                               for k, (nb, nt) in mix.items())
+            print("attention D = %3d %-15s: b128 reads %3d LDS cycles for %3d conflict-free, transpose reads %3d for %3d; conflict share of "
+                  "the fragment-read cycles: %s" % (D, name, b[0], b[1], tr[0], tr[1], shares))
+            if name == "rotated key":
+                ok = ok and b[0] == b[1] and tr[0] == tr[1]
+    return ok
+
+
 if __name__ == "__main__":
     a = conv_report()
     b = wgrad_report()
+    c = attn_report()
+    print("attention images conflict-free with the rotated key: %s" % c)
     print("conv weights conflict-free: %s; planned weight-gradient layout conflict-free for every tap: %s" % (a, b))

@@ -242,6 +242,7 @@ def _gate_scenes(p, pf, label):
     ap = {m: pf.decode_ap_from_indices(torch.cat(dec[m]).numpy(), joints) for m in dec}
     ap512 = {m: pf.decode_ap_from_indices(torch.cat(dec[m][:16]).numpy(), joints[:512]) for m in dec}
     rates = cnt / tot
+    p["gate_bf16_ap"] = (ap["bf16"], ap512["bf16"])            # the same scenes, same path: the zero-Doppler test's "noise" leg
     print("%s, %d held-out scenes (%d joints per head): first head identical %.4f (%.4f counting ties of the fp32 map), decoded head "
           "identical %.4f (%.4f counting ties, %.4f within one pixel); OKS AP fp32 path %.4f, bf16 path %.4f (%.2f AP points; on the "
           "first 512 scenes alone %.4f / %.4f = %.2f points)" %
@@ -350,6 +351,9 @@ def test_zero_doppler_conventions_on_a_reference_convention_fit():
     dev = torch.device("cuda")
     ap, ap512 = {}, {}
     for conv in ("noise", "renoise", "zero"):
+        if conv == "noise" and "gate_bf16_ap" in p:            # evaluated already by the arg-max / AP gate of this fit (same seeds)
+            ap[conv], ap512[conv] = p["gate_bf16_ap"]
+            continue
         rng = np.random.default_rng(777)
         gen = torch.Generator(device="cuda").manual_seed(888)
         gen4 = torch.Generator(device="cuda").manual_seed(999) if conv == "renoise" else None
