@@ -574,9 +574,18 @@ def main():
         oa, la = torch.empty(B, Na, Ca, device=dev), torch.empty(B, Na, device=dev)
         dka, dqa, dva = (torch.empty(B, Na, Ca, device=dev) for _ in range(3))
         sca = torch.empty(B, Na, device=dev)
-        a_fwd = lambda: rt_.check(L_.hupr_attn_fwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(la), B, Na, Ca, rt_.stream()))      # noqa: E731
-        a_bwd = lambda: rt_.check(L_.hupr_attn_bwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(gb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(g32), rt_.ptr(la),      # noqa: E731
-                                                          rt_.ptr(dka), rt_.ptr(dqa), rt_.ptr(dva), rt_.ptr(sca), B, Na, Ca, 1, rt_.stream()))
+        qs_ = F_.QS_ATTN                                      # what the step's fused MSCSA levels run (round 5: query operand pre-scaled by log2 e)
+        if qs_:
+            qb_ = (qa * 1.4426950408889634).bfloat16()
+            a_fwd = lambda: rt_.check(L_.hupr_attn_fwd_bf16in_ld_ws_qs(rt_.ptr(kb_), Ca, rt_.ptr(qb_), Ca, rt_.ptr(vb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(la),      # noqa: E731
+                                                                       None, 0, B, Na, Ca, None, 0, rt_.stream()))
+            a_bwd = lambda: rt_.check(L_.hupr_attn_bwd_bf16in_ld_qs(rt_.ptr(kb_), Ca, rt_.ptr(qb_), Ca, rt_.ptr(vb_), rt_.ptr(gb_), Ca, rt_.ptr(va), rt_.ptr(oa),      # noqa: E731
+                                                                    rt_.ptr(g32), rt_.ptr(la), rt_.ptr(dka), Ca, rt_.ptr(dqa), Ca, rt_.ptr(dva), rt_.ptr(sca),
+                                                                    B, Na, Ca, 1, 0, rt_.stream()))
+        else:
+            a_fwd = lambda: rt_.check(L_.hupr_attn_fwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(la), B, Na, Ca, rt_.stream()))      # noqa: E731
+            a_bwd = lambda: rt_.check(L_.hupr_attn_bwd_bf16in(rt_.ptr(kb_), rt_.ptr(qb_), rt_.ptr(vb_), rt_.ptr(gb_), rt_.ptr(va), rt_.ptr(oa), rt_.ptr(g32), rt_.ptr(la),      # noqa: E731
+                                                              rt_.ptr(dka), rt_.ptr(dqa), rt_.ptr(dva), rt_.ptr(sca), B, Na, Ca, 1, rt_.stream()))
 
         def a_time(fn, n=10):
             for _ in range(3):
@@ -590,7 +599,7 @@ def main():
             return ev[0].elapsed_time(ev[1]) * 1e-3 / n
         tf, tb = a_time(a_fwd), a_time(a_bwd)
         ffl, bfl = 4.0 * Na * Na * Ca * B, 10.0 * Na * Na * Ca * B
-        attn_roof = {"bound": "mfma", "kernel": "hupr_k_attn_fwd_pp64 / hupr_k_attn_bwd_dq + hupr_k_attn_bwd_dkv (MSCSA level 1: C = 64, N = 4096, B = %d)" % B,
+        attn_roof = {"bound": "mfma", "kernel": "hupr_k_attn_fwd_pp64 / hupr_k_attn_bwd_dq + hupr_k_attn_bwd_dkv512%s (MSCSA level 1: C = 64, N = 4096, B = %d)" % (" <QS>" if qs_ else "", B),
                      "forward": {"us": round(tf * 1e6, 1), "achieved": round(ffl / tf / 1e12, 1), "frac": round(ffl / tf / 1e12 / peak, 4)},
                      "backward": {"us": round(tb * 1e6, 1), "achieved": round(bfl / tb / 1e12, 1), "frac": round(bfl / tb / 1e12 / peak, 4),
                                   "note": "algorithmic 10 N^2 C; the two kernels execute 14 N^2 C (S and dP recomputed in each)"},

@@ -20,6 +20,16 @@
 namespace hupr {
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+// QS kernels (round 5, "query pre-scaled"): the caller hands over Q' = log2(e) . Q (the factor folded into the 1x1 query
+// projection before its bf16 rounding, functional.MSCSALevelFn), so that K . Q'^T is the exponent of 2 directly; the MFMA chain
+// of a score tile then STARTS from minus the running maximum (forward) or minus the stored log-sum-exp (backward) as its
+// accumulator input, and the score leaves the matrix pipe as the argument of v_exp_f32 — the per-score fma of rounds 1-4
+// (62 of ~276 VALU instructions per two key tiles of the forward, profiles/r04b_attn_isa_loop_mix.txt) is gone.  The forward
+// keeps the running maximum it started a tile with unless the tile exceeds it by more than kDeferBits binary orders (the rescale
+// branch, which was conditional already): P then lies in (0, 2^kDeferBits] instead of (0, 1] at the same relative bf16
+// precision; row sum and O scale with it — the same soft-max.
+constexpr float kDeferBits = 8.f;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -143,16 +153,19 @@ __device__ __forceinline__ void load_frags(bf16x8* frag, const TI* __restrict__ 
 
 // acc[t] (t = 0,1: image rows 32t..32t+31) = img(64 rows x D) . frags  ->  tile [image row][lane token]
 constexpr int g_attn_sched = 0;      // 1: the round-1 order (all fragment reads of a chunk, then its MFMAs)
-template <int D>
+// ZERO = false: acc arrives initialised (the QS kernels start the chain from -max / -log-sum-exp)
+template <int D, bool ZERO = true>
 __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img, const bf16x8* frag, int lr, int lh) {
     // all A fragments of the 64 x D image rows are read before the first MFMA (hipcc otherwise issues each read right in
     // front of its MFMA and every MFMA waits out the LDS latency)
     // (D = 256: in chunks of four K-steps — sixteen would hold 128 registers of fragments)
     constexpr int KS = D / 16, CHK = KS > 8 ? 4 : KS;
+    if constexpr (ZERO) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        }
     }
 #pragma unroll
     for (int k0 = 0; k0 < KS; k0 += CHK) {
@@ -311,7 +324,7 @@ struct AttnBatch {
     __bf16* out16[4];
 };
 
-template <int D, typename TI, bool SPLIT = false>
+template <int D, typename TI, bool SPLIT = false, bool QS = false>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
                                                        float* __restrict__ out, float* __restrict__ lse, int N, int ldk,
@@ -378,15 +391,15 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other half-wave holds the other 32 keys
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-        const float nm = -m_new * kLog2e;                   // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score
+        const float m_new = fmaxf(m_run, mx);               // (QS: scores, maxima and the share statistics are in binary orders)
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * (QS ? 1.f : kLog2e));
+        const float nm = -m_new * (QS ? 1.f : kLog2e);      // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(st[t][r], kLog2e, nm));
+                const float pv = __builtin_amdgcn_exp2f(QS ? st[t][r] + nm : fmaf(st[t][r], kLog2e, nm));
                 st[t][r] = pv;
                 sum += pv;
             }
@@ -413,12 +426,12 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
     store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     if (out16)
         store_ct16<D>(out16 + ((long)blockIdx.y * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
-    if (lh == 0) lse[(long)blockIdx.y * N + q] = m_run + __logf(l_tot);
+    if (lh == 0) lse[(long)blockIdx.y * N + q] = QS ? (m_run + __log2f(l_tot)) * kLn2 : m_run + __logf(l_tot);
 }
 
 // merge the key shares of the SPLIT forward: out = sum_s w_s O_s / sum_s w_s l_s with w_s = exp(m_s - max_s m_s) (+ V), the bf16
 // copy and the log-sum-exp; one thread per (row, four channels)
-template <int D>
+template <int D, bool QS = false>
 __global__ __launch_bounds__(256) void hupr_k_attn_combine(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                           int S, long rows, const float* __restrict__ Vres,
                                                           float* __restrict__ out, float* __restrict__ lse,
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_combine(const float* __restri
     float L = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < S; ++s) {
-        const float w = __builtin_amdgcn_exp2f((part_ml[2 * (s * rows + row)] - m) * kLog2e);
+        const float w = __builtin_amdgcn_exp2f((part_ml[2 * (s * rows + row)] - m) * (QS ? 1.f : kLog2e));
         L = fmaf(w, part_ml[2 * (s * rows + row) + 1], L);
         const float4 o = *reinterpret_cast<const float4*>(part_o + (s * rows + row) * D + c);
         acc.x = fmaf(w, o.x, acc.x); acc.y = fmaf(w, o.y, acc.y); acc.z = fmaf(w, o.z, acc.z); acc.w = fmaf(w, o.w, acc.w);
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_combine(const float* __restri
         const bf16x4 o4 = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
         *reinterpret_cast<bf16x4*>(out16 + row * ld16 + c) = o4;
     }
-    if (c == 0) lse[row] = m + __logf(L);
+    if (c == 0) lse[row] = QS ? (m + __log2f(L)) * kLn2 : m + __logf(L);
 }
 
 // D[q] = sum_c dO[q,c] * (out[q,c] - (residual ? V[q,c] : 0))
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(256) void hupr_k_attn_prep(const TG* __restrict__ d
 // ------------------------------------------------------------------------------------------------------
 // backward, dQ: same walk as the forward
 // ------------------------------------------------------------------------------------------------------
-template <int D, typename TI>
+template <int D, typename TI, bool QS = false>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
@@ -509,6 +522,9 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
     load_frags<D, TI>(qf, Q + ((long)by * N + q) * ldq, lh);
     load_frags<D, TI>(gf, dO + ((long)by * N + q) * lddo, lh);
     const float nlse_q = -lse[(long)by * N + q] * kLog2e, d_q = Dq[(long)by * N + q];
+    f32x16 nlse16;                                            // (QS) accumulator input of every S^T chain of this lane's query
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nlse16[r] = nlse_q;
     f32x16 dq[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -535,7 +551,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
             vr.load(V + base + (long)(j0 + 64) * D, D, tid);
         }
         f32x16 st[2], dp[2];
-        mma_rows_x_frags<D>(st, Ks, qf, lr, lh);              // S^T
+        if constexpr (QS) {                                   // the chain starts from -log-sum-exp (binary orders): S^T leaves as the exponent
+            st[0] = nlse16;
+            st[1] = nlse16;
+            mma_rows_x_frags<D, false>(st, Ks, qf, lr, lh);
+        } else {
+            mma_rows_x_frags<D>(st, Ks, qf, lr, lh);          // S^T
+        }
         mma_rows_x_frags<D>(dp, Vs, gf, lr, lh);              // dP^T = V dO^T
         {      // dS^T on accumulator pairs (packed fma / add / mul: same roundings, half the VALU instructions)
             typedef float f32x2a __attribute__((ext_vector_type(2)));
@@ -543,7 +565,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const f32x2a arg = __builtin_elementwise_fma((f32x2a){st[t][r], st[t][r + 1]}, (f32x2a){kLog2e, kLog2e}, (f32x2a){nlse_q, nlse_q});
+                    const f32x2a arg = QS ? (f32x2a){st[t][r], st[t][r + 1]}
+                                          : __builtin_elementwise_fma((f32x2a){st[t][r], st[t][r + 1]}, (f32x2a){kLog2e, kLog2e}, (f32x2a){nlse_q, nlse_q});
                     const f32x2a pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
                     const f32x2a ds = pv * ((f32x2a){dp[t][r], dp[t][r + 1]} - (f32x2a){d_q, d_q});
                     st[t][r] = ds[0];
@@ -558,7 +581,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
 // ------------------------------------------------------------------------------------------------------
 // backward, dK / dV: a workgroup owns 128 keys (32 per wave) and streams 64-query tiles
 // ------------------------------------------------------------------------------------------------------
-template <int D, typename TI, int NH>
+template <int D, typename TI, int NH, bool QS = false>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                            const TI* __restrict__ V, const TI* __restrict__ dO,
                                                            const float* dVadd,
@@ -567,7 +590,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
                                                            int ldq, int lddk, int lddo, const __bf16* dVadd16, int ldadd16, int xcd_map) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[64 * D];
-    __shared__ float s_lse[64], s_d[64];
+    __shared__ __attribute__((aligned(16))) float s_lse[64], s_d[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     int bx, by;
     xcd_block(bx, by, xcd_map);
@@ -610,21 +633,32 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
             if (PFG) gr.load(dO + (long)(q0 + 64) * lddo, lddo, tid);
         }
         f32x16 s[2], dp[2];
-        mma_rows_x_frags<D>(s, Qs, kf, lr, lh);               // S tile: rows = queries, this lane's column = its key
+        if constexpr (QS) {                                   // rows = queries: register r of tile t starts from -log-sum-exp of ITS query
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(&s_lse[32 * t + 8 * r4 + 4 * lh]);
+                    s[t][4 * r4] = l4.x; s[t][4 * r4 + 1] = l4.y; s[t][4 * r4 + 2] = l4.z; s[t][4 * r4 + 3] = l4.w;
+                }
+            mma_rows_x_frags<D, false>(s, Qs, kf, lr, lh);
+        } else {
+            mma_rows_x_frags<D>(s, Qs, kf, lr, lh);           // S tile: rows = queries, this lane's column = its key
+        }
         mma_rows_x_frags<D>(dp, Gs, vf, lr, lh);              // dP = dO V^T
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], kLog2e, s_lse[qi]));
+                const float pv = __builtin_amdgcn_exp2f(QS ? s[t][r] : fmaf(s[t][r], kLog2e, s_lse[qi]));
                 dp[t][r] = pv * (dp[t][r] - s_d[qi]);          // dS
                 s[t][r] = pv;                                   // P
             }
         mma_tr_x_tile<D, DV / 32>(dv, Gs, s, lane, c0 / 32);  // dV^T += dO^T P
         mma_tr_x_tile<D, DV / 32>(dk, Qs, dp, lane, c0 / 32); // dK^T += Q^T dS
     }
-    store_ct<DV>(dK + ((long)by * N + key) * lddk + c0, dk, 1.f, nullptr, lh);
+    store_ct<DV>(dK + ((long)by * N + key) * lddk + c0, dk, QS ? kLn2 : 1.f, nullptr, lh);      // (QS: dK^T was summed over Q' = log2e Q)
     if (dVadd16) store_ct_add16<DV>(dV + base + (long)key * D + c0, dv, dVadd16 + ((long)by * N + key) * ldadd16 + c0, lh);
     else store_ct<DV>(dV + base + (long)key * D + c0, dv, 1.f, dVadd ? dVadd + base + (long)key * D + c0 : nullptr, lh);
 }
@@ -637,6 +671,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
 // global loads of its dO rows between two barriers.  With eight waves sharing a tile a thread stages 16 bytes of each image instead
 // of 32 of one, and both prefetches fit in the registers one used.  Same arithmetic per (key, query tile), same tile order: the
 // same bits as the kernel above.
+template <bool QS>
 __global__ __launch_bounds__(512) void hupr_k_attn_bwd_dkv512(const __bf16* __restrict__ K, const __bf16* __restrict__ Q,
                                                               const __bf16* __restrict__ V, const __bf16* __restrict__ dO,
                                                               const float* dVadd, const float* __restrict__ lse,
@@ -646,7 +681,7 @@ __global__ __launch_bounds__(512) void hupr_k_attn_bwd_dkv512(const __bf16* __re
     constexpr int D = 64;
     __shared__ __attribute__((aligned(16))) __bf16 Qs[2][64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[2][64 * D];
-    __shared__ float s_lse[2][64], s_d[2][64];
+    __shared__ __attribute__((aligned(16))) float s_lse[2][64], s_d[2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     int bx, by;
     xcd_block(bx, by, xcd_map);
@@ -682,7 +717,18 @@ __global__ __launch_bounds__(512) void hupr_k_attn_bwd_dkv512(const __bf16* __re
             if (tid < 128) sreg = sp[q0 + 64];
         }
         f32x16 s[2], dp[2];
-        mma_rows_x_frags<D>(s, Qs[cb], kf, lr, lh);            // S tile: rows = queries, this lane's column = its key
+        if constexpr (QS) {                                    // register r of tile t starts from -log-sum-exp of ITS query (binary orders)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(&s_lse[cb][32 * t + 8 * r4 + 4 * lh]);
+                    s[t][4 * r4] = l4.x; s[t][4 * r4 + 1] = l4.y; s[t][4 * r4 + 2] = l4.z; s[t][4 * r4 + 3] = l4.w;
+                }
+            mma_rows_x_frags<D, false>(s, Qs[cb], kf, lr, lh);
+        } else {
+            mma_rows_x_frags<D>(s, Qs[cb], kf, lr, lh);        // S tile: rows = queries, this lane's column = its key
+        }
         mma_rows_x_frags<D>(dp, Gs[cb], vf, lr, lh);           // dP = dO V^T
         // P and dS on accumulator PAIRS (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: the same roundings in half the VALU
         // instructions — 160 VALU per tile beside 32 MFMAs were as many issue cycles as the matrix pipe's own)
@@ -692,9 +738,9 @@ __global__ __launch_bounds__(512) void hupr_k_attn_bwd_dkv512(const __bf16* __re
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int qi = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const f32x2a lv = *reinterpret_cast<const f32x2a*>(&s_lse[cb][qi]);
                 const f32x2a dd = *reinterpret_cast<const f32x2a*>(&s_d[cb][qi]);
-                const f32x2a arg = __builtin_elementwise_fma((f32x2a){s[t][r], s[t][r + 1]}, (f32x2a){kLog2e, kLog2e}, lv);
+                f32x2a arg = {s[t][r], s[t][r + 1]};
+                if constexpr (!QS) arg = __builtin_elementwise_fma(arg, (f32x2a){kLog2e, kLog2e}, *reinterpret_cast<const f32x2a*>(&s_lse[cb][qi]));
                 const f32x2a pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
                 const f32x2a ds = pv * ((f32x2a){dp[t][r], dp[t][r + 1]} - dd);
                 dp[t][r] = ds[0];                               // dS
@@ -712,7 +758,7 @@ __global__ __launch_bounds__(512) void hupr_k_attn_bwd_dkv512(const __bf16* __re
         }
         __syncthreads();
     }
-    store_ct<D>(dK + ((long)by * N + key) * lddk, dk, 1.f, nullptr, lh);
+    store_ct<D>(dK + ((long)by * N + key) * lddk, dk, QS ? kLn2 : 1.f, nullptr, lh);      // (QS: dK^T was summed over Q' = log2e Q)
     if (dVadd16) store_ct_add16<D>(dV + base + (long)key * D, dv, dVadd16 + ((long)by * N + key) * ldadd16, lh);
     else store_ct<D>(dV + base + (long)key * D, dv, 1.f, dVadd ? dVadd + base + (long)key * D : nullptr, lh);
 }
@@ -777,7 +823,7 @@ __device__ __forceinline__ void pp_block(int nqb, int Bn, int& b, int& qb) {
     }
 }
 
-template <int abl>
+template <int abl, bool QS = false>
 __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __restrict__ K, const __bf16* __restrict__ Q,
                                                               const __bf16* __restrict__ V, const float* __restrict__ Vres,
                                                               float* __restrict__ out, float* __restrict__ lse, int N, int Bn, int ldk,
@@ -844,7 +890,10 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // QS: m_run is the running maximum in binary orders as DEFERRED (see kDeferBits), starting from 0 — the first tile always takes
+    // the rescale branch — and negm16 (every element -m_run) is the accumulator input of the next tile's S^T chain
+    float m_run = QS ? 0.f : -INFINITY, l_run = 0.f;
+    f32x16 negm16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bf16x8 kf[2][4], vf[2][2][2], pb[2][2][2];                // pb[parity]: P^T of the current tile / of the previous one
 
 #define HUPR_PP_READ_K(SLOT_)                                                                                      \
@@ -913,7 +962,7 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
 #define HUPR_SM(KS_, T_)                                                                                                   \
     if (!(LAST__) && !(abl & 16)) {                                                                                        \
         asm volatile("" : "+v"(kf[T_][KS_]));                                                                              \
-        if ((KS_) == 0) st[NXT__][T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T_][0], qf[0], zero16, 0, 0, 0);        \
+        if ((KS_) == 0) st[NXT__][T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T_][0], qf[0], QS ? negm16 : zero16, 0, 0, 0); \
         else st[NXT__][T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T_][KS_], qf[KS_], st[NXT__][T_], 0, 0, 0);        \
         asm volatile("" : "+v"(kf[T_][KS_]));                                                                              \
     }
@@ -924,7 +973,7 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
         constexpr int t_ = (P_) >> 3, u_ = ((P_) >> 2) & 1, i_ = 2 * ((P_) & 3);                                           \
         v2fa s2_ = {st[CUR__][t_][8 * u_ + i_], st[CUR__][t_][8 * u_ + i_ + 1]};                                           \
         asm volatile("" : "+v"(s2_));                                                                                      \
-        const v2fa e2_ = __builtin_elementwise_fma(s2_, l2e2, nm2);                                                        \
+        const v2fa e2_ = QS ? s2_ : __builtin_elementwise_fma(s2_, l2e2, nm2);                                             \
         const float p0_ = (abl & 4) ? e2_.x : __builtin_amdgcn_exp2f(e2_.x);                                               \
         const float p1_ = (abl & 4) ? e2_.y : __builtin_amdgcn_exp2f(e2_.y);                                               \
         sum2[(P_) & 1] += (v2fa){p0_, p1_};                                                                                \
@@ -963,9 +1012,32 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ua_), "+v"(ub_));                       \
             mx = fmaxf(__builtin_bit_cast(float, ua_), __builtin_bit_cast(float, ub_));                                    \
         }                                                                                                                  \
-        const float m_new = fmaxf(m_run, mx);                                                                              \
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);                                              \
-        const float nm = -m_new * kLog2e;                     /* exp(s - m) = 2^(s log2e - m log2e) */                     \
+        float m_new = fmaxf(m_run, mx);                                                                                    \
+        float alpha = 1.f, nm = 0.f;                                                                                       \
+        if constexpr (QS) {                                                                                                \
+            /* the scores of this tile left the matrix pipe relative to m_run (binary orders); keep it unless the tile      */ \
+            /* exceeds it by more than kDeferBits — then (rare; always in the first tile, whose chain started from 0) move  */ \
+            /* the scores, O (complete: the last MFMA of tile j - 1 was issued above), the row sum and the next chain's     */ \
+            /* accumulator input to the new maximum                                                                        */ \
+            const bool resc_ = FIRST__ || (mx > kDeferBits);                                                               \
+            m_new = m_run;                                                                                                 \
+            if (FIRST__ || __builtin_amdgcn_ballot_w64(resc_)) {                                                           \
+                const float delta_ = resc_ ? mx : 0.f;                                                                     \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                              \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) st[CUR__][t][r] -= delta_;                              \
+                if (!FIRST__) {                                                                                            \
+                    const float a_ = __builtin_amdgcn_exp2f(-delta_);                                                      \
+                    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                       \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) o[ct][r] *= a_;                                     \
+                    l_run *= a_;                                                                                           \
+                }                                                                                                          \
+                m_new = m_run + delta_;                                                                                    \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) negm16[r] = -m_new;                                         \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);                                                      \
+            nm = -m_new * kLog2e;                             /* exp(s - m) = 2^(s log2e - m log2e) */                     \
+        }                                                                                                                  \
         const v2fa nm2 = {nm, nm}, l2e2 = {kLog2e, kLog2e};                                                                \
         v2fa sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};                                                                           \
         HUPR_SB();                                                                                                         \
@@ -987,9 +1059,10 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
         /* ---- tail: the V fragments of tile j for the next iteration, the row sum, the (rare) rescale ---- */            \
         if (!(abl & 2)) { HUPR_PP_READ_V(j & (kPPRing - 1)) }                                                              \
         sum2[0] += sum2[1];                                                                                                \
-        l_run = l_run * alpha + (sum2[0].x + sum2[0].y);                                                                   \
+        if constexpr (QS) l_run += sum2[0].x + sum2[0].y;                                                                  \
+        else l_run = l_run * alpha + (sum2[0].x + sum2[0].y);                                                              \
         m_run = m_new;                                                                                                     \
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {      /* rare after the first tiles; behind the MFMAs of tile j - 1 */ \
+        if (!QS && __builtin_amdgcn_ballot_w64(alpha != 1.f)) { /* rare after the first tiles; behind the MFMAs of tile j - 1 */ \
             _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                               \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;                                          \
         }                                                                                                                  \
@@ -1028,7 +1101,7 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
     if (out16)
         store_ct16<D>(out16 + ((long)b * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     }
-    if (lh == 0) lse[(long)b * N + q] = m_run + __logf(l_tot) + ((abl & 64) ? o[0][0] + o[1][5] : 0.f);
+    if (lh == 0) lse[(long)b * N + q] = (QS ? (m_run + __log2f(l_tot)) * kLn2 : m_run + __logf(l_tot)) + ((abl & 64) ? o[0][0] + o[1][5] : 0.f);
 #undef HUPR_PP_ISSUE
 #undef HUPR_PP_READ_K
 #undef HUPR_PP_READ_V
@@ -1071,7 +1144,7 @@ extern "C" size_t hupr_attn_fwd_split_ws_bytes(int Bn, int N, int C) {
     return S > 1 ? (size_t)S * Bn * N * (C + 2) * sizeof(float) : 0;
 }
 
-template <typename TI>
+template <typename TI, bool QS = false>
 static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const float* Vres, float* out,
                     float* lse, void* out16, int ld16, int Bn, int N, int C, hupr_stream_t stream, void* ws = nullptr,
                     size_t ws_bytes = 0) {
@@ -1088,6 +1161,12 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
         if (S <= 1 && C == 64 && N % 256 == 0 && N >= 256 && g_attn_pp && (long)N * ldk * 2 < (1L << 31)) {
 #define HUPR_PP_FWD(A_) HUPR_LAUNCH(hupr_k_attn_fwd_pp64<A_>, dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, \
                                            out, lse, N, Bn, ldk, ldq, o16, ld16, g_attn_trace)
+            if constexpr (QS) {
+                HUPR_LAUNCH((hupr_k_attn_fwd_pp64<0, true>), dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, out, lse,
+                            N, Bn, ldk, ldq, o16, ld16, g_attn_trace);
+                HUPR_LAUNCH_OK("hupr_k_attn_fwd_pp64 (QS)");
+                return HUPR_OK;
+            }
             switch (g_attn_pp >> 4) {
                 case 0: HUPR_PP_FWD(0); break;
                 case 1: HUPR_PP_FWD(1); break;
@@ -1118,17 +1197,17 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
         const dim3 cgrid((unsigned)((rows * (C / 4) + 255) / 256));
         hipStream_t s = as_stream(stream);
 #define HUPR_ATTN_SPLIT(D_)                                                                                                \
-        HUPR_LAUNCH((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, \
+        HUPR_LAUNCH((hupr_k_attn_fwd<D_, TI, true, QS>), grid, dim3(256), 0, s, K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, \
                            part_o, part_ml, AttnBatch());                                                                  \
-        HUPR_LAUNCH((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, Vres, out, lse, o16, ld16, AttnBatch());
+        HUPR_LAUNCH((hupr_k_attn_combine<D_, QS>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, Vres, out, lse, o16, ld16, AttnBatch());
         if (C == 64) { HUPR_ATTN_SPLIT(64) } else if (C == 128) { HUPR_ATTN_SPLIT(128) } else { HUPR_ATTN_SPLIT(256) }
 #undef HUPR_ATTN_SPLIT
         HUPR_LAUNCH_OK("hupr_k_attn_fwd (split)");
         return HUPR_OK;
     }
-    if (C == 64) HUPR_LAUNCH((hupr_k_attn_fwd<64, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
-    else if (C == 128) HUPR_LAUNCH((hupr_k_attn_fwd<128, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
-    else HUPR_LAUNCH((hupr_k_attn_fwd<256, TI>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    if (C == 64) HUPR_LAUNCH((hupr_k_attn_fwd<64, TI, false, QS>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    else if (C == 128) HUPR_LAUNCH((hupr_k_attn_fwd<128, TI, false, QS>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
+    else HUPR_LAUNCH((hupr_k_attn_fwd<256, TI, false, QS>), grid, dim3(256), 0, as_stream(stream), K, Q, V, Vres, out, lse, N, ldk, ldq, o16, ld16, np, np, AttnBatch());
     HUPR_LAUNCH_OK("hupr_k_attn_fwd");
     return HUPR_OK;
 }
@@ -1156,9 +1235,9 @@ extern "C" int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, in
 // Up to four independent attentions of the same shape and strides in ONE split launch + ONE merge launch (the four attentions of an MSCSA
 // level in single-sample inference: 8 launches -> 2).  Only where the split form applies (hupr_attn_fwd_split_ws_bytes(Bn, N, C) > 0);
 // ws: n_items times that many bytes.  items: host array of hupr_attn_item (bf16 K / Q / V, fp32 Vres or null, fp32 out, lse, bf16 out16 or null).
-extern "C" int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N,
-                                                int C, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    const char* who = "hupr_attn_fwd_bf16in_ld_ws_batch";
+template <bool QS>
+static int attn_fwd_batch(const char* who, const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N,
+                          int C, void* ws, size_t ws_bytes, hupr_stream_t stream) {
     HUPR_REQUIRE(items && n_items >= 1 && n_items <= 4 && Bn > 0 && ws, "%s: bad argument", who);
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
     HUPR_REQUIRE(ldk >= C && ldq >= C && ldk % 8 == 0 && ldq % 8 == 0, "%s: bad row strides %d %d", who, ldk, ldq);
@@ -1187,12 +1266,21 @@ extern "C" int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int
     float* const nf = nullptr;
     __bf16* const nh = nullptr;
 #define HUPR_ATTN_BATCH(D_)                                                                                                          \
-    HUPR_LAUNCH((hupr_k_attn_fwd<D_, TI, true>), grid, dim3(256), 0, s, nk, nk, nk, nf, nf, nf, N, ldk, ldq, nh, ld16, part_o, part_ml, b); \
-    HUPR_LAUNCH((hupr_k_attn_combine<D_>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, nf, nf, nf, nh, ld16, b);
+    HUPR_LAUNCH((hupr_k_attn_fwd<D_, TI, true, QS>), grid, dim3(256), 0, s, nk, nk, nk, nf, nf, nf, N, ldk, ldq, nh, ld16, part_o, part_ml, b); \
+    HUPR_LAUNCH((hupr_k_attn_combine<D_, QS>), cgrid, dim3(256), 0, s, part_o, part_ml, S, rows, nf, nf, nf, nh, ld16, b);
     if (C == 64) { HUPR_ATTN_BATCH(64) } else if (C == 128) { HUPR_ATTN_BATCH(128) } else { HUPR_ATTN_BATCH(256) }
 #undef HUPR_ATTN_BATCH
     HUPR_LAUNCH_OK("hupr_k_attn_fwd (split, batch)");
     return HUPR_OK;
+}
+extern "C" int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N,
+                                                int C, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return attn_fwd_batch<false>("hupr_attn_fwd_bf16in_ld_ws_batch", items, n_items, ldk, ldq, ld16, Bn, N, C, ws, ws_bytes, stream);
+}
+// ... with Q' = log2(e) Q handed over (the QS kernels; see kDeferBits above)
+extern "C" int hupr_attn_fwd_bf16in_ld_ws_batch_qs(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N,
+                                                   int C, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return attn_fwd_batch<true>("hupr_attn_fwd_bf16in_ld_ws_batch_qs", items, n_items, ldk, ldq, ld16, Bn, N, C, ws, ws_bytes, stream);
 }
 
 // the same with a workspace of hupr_attn_fwd_split_ws_bytes(Bn, N, C) bytes (0: the plain kernel already fills the GPU and ws may
@@ -1203,6 +1291,14 @@ extern "C" int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q,
     return attn_fwd("hupr_attn_fwd_bf16in_ld_ws", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
                     static_cast<const __bf16*>(V), Vres, out, lse, out16, ld16, Bn, N, C, stream, ws, ws_bytes);
 }
+// The same attention with the query operand pre-scaled: Q' = log2(e) Q (bf16).  out / lse are those of softmax(K Q^T) — lse in
+// natural units, as always.  The level-1 shape runs the ping-pong kernel with the deferred maximum (kDeferBits).
+extern "C" int hupr_attn_fwd_bf16in_ld_ws_qs(const void* K, int ldk, const void* Qs, int ldq, const void* V, const float* Vres,
+                                             float* out, float* lse, void* out16, int ld16, int Bn, int N, int C, void* ws,
+                                             size_t ws_bytes, hupr_stream_t stream) {
+    return attn_fwd<__bf16, true>("hupr_attn_fwd_bf16in_ld_ws_qs", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Qs), ldq,
+                                  static_cast<const __bf16*>(V), Vres, out, lse, out16, ld16, Bn, N, C, stream, ws, ws_bytes);
+}
 
 // dK, dQ, dV (B,N,C) from dout; Dq: scratch (B,N) floats.  V32 / out / dout32: fp32 tensors of the exact row-sum
 // D = rowsum(dO o (out - V)) and the residual epilogue; K, Q, V, dO: the MFMA operands (fp32 or bf16 copies).
@@ -1210,7 +1306,7 @@ extern "C" int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q,
 // the residual form; may be dV itself to accumulate onto what another attention over the same values left there), or
 // null.  dout32 == null (bf16 dO only): the gradient arrived bf16-stored, so dO itself is the exact gradient — the
 // row-sum and the residual term read it directly.
-template <typename TI>
+template <typename TI, bool QS = false>
 static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq, const TI* V, const TI* dO, int lddo,
                     const float* V32, const float* out, const float* dout32, const float* lse, float* dK, int lddk, float* dQ,
                     int lddq, float* dV, int accumulate, float* Dq, int Bn, int N, int C, int residual, hupr_stream_t stream) {
@@ -1231,13 +1327,13 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
 #define HUPR_ATTN_BWD(D_, NH_)                                                                                             \
     if (dout32) HUPR_LAUNCH((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
     else HUPR_LAUNCH((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
-    HUPR_LAUNCH((hupr_k_attn_bwd_dq<D_, TI>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo, xmap);  \
+    HUPR_LAUNCH((hupr_k_attn_bwd_dq<D_, TI, QS>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo, xmap);  \
     if (D_ == 64 && sizeof(TI) == 2 && g_attn_dkv512 && N % 256 == 0)                                                       \
-        HUPR_LAUNCH(hupr_k_attn_bwd_dkv512, dim3(N / 256, Bn), dim3(512), 0, s, reinterpret_cast<const __bf16*>(K),       \
+        HUPR_LAUNCH(hupr_k_attn_bwd_dkv512<QS>, dim3(N / 256, Bn), dim3(512), 0, s, reinterpret_cast<const __bf16*>(K),       \
                            reinterpret_cast<const __bf16*>(Q), reinterpret_cast<const __bf16*>(V), reinterpret_cast<const __bf16*>(dO), \
                            add32, lse, Dq, dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);                                 \
     else                                                                                                                     \
-        HUPR_LAUNCH((hupr_k_attn_bwd_dkv<D_, TI, NH_>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
+        HUPR_LAUNCH((hupr_k_attn_bwd_dkv<D_, TI, NH_, QS>), dim3(N / 128, Bn, NH_), dim3(256), 0, s, K, Q, V, dO, add32, lse, Dq, \
                            dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);
     if (C == 64) { HUPR_ATTN_BWD(64, 1) } else if (C == 128) { HUPR_ATTN_BWD(128, 1) } else { HUPR_ATTN_BWD(256, 2) }
 #undef HUPR_ATTN_BWD
@@ -1269,4 +1365,14 @@ extern "C" int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, in
     return attn_bwd("hupr_attn_bwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
                     static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), lddo, V32, out, dout32, lse, dK, lddk, dQ,
                     lddq, dV, accumulate, Dq, Bn, N, C, residual, stream);
+}
+// ... with Q' = log2(e) Q as the query operand (what hupr_attn_fwd_bf16in_ld_ws_qs was given): dK, dQ, dV are the gradients with
+// respect to K, the UNSCALED Q and V, as above (the kernels sum dK over Q' and rescale it by ln 2 on the way out)
+extern "C" int hupr_attn_bwd_bf16in_ld_qs(const void* K, int ldk, const void* Qs, int ldq, const void* V, const void* dO, int lddo,
+                                          const float* V32, const float* out, const float* dout32, const float* lse, float* dK,
+                                          int lddk, float* dQ, int lddq, float* dV, float* Dq, int Bn, int N, int C,
+                                          int residual, int accumulate, hupr_stream_t stream) {
+    return attn_bwd<__bf16, true>("hupr_attn_bwd_bf16in_ld_qs", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Qs), ldq,
+                                  static_cast<const __bf16*>(V), static_cast<const __bf16*>(dO), lddo, V32, out, dout32, lse, dK, lddk,
+                                  dQ, lddq, dV, accumulate, Dq, Bn, N, C, residual, stream);
 }

@@ -270,7 +270,7 @@ struct PackDesc {          // mirrors the packed struct built in functional.py (
     void* wp0;             // [Co][tap][Ci]
     void* wp1;             // [Ci][taps-1-tap][Co]
     long first;            // index of this entry's first element in the concatenated element space
-    int co, ci, taps, kind;   // kind 0: fp32 outputs, 1: bf16 outputs
+    int co, ci, taps, kind;   // kind 0: fp32 outputs, 1: bf16 outputs; 2 / 3: projection-concatenation entries (block layout 3)
 };
 // Block kinds (blocks[b] = {entry, layout, start}):
 //   layout 0 / 1: 2048 consecutive DESTINATION elements of that layout of the entry, starting at `start` — the generic
@@ -341,6 +341,21 @@ __global__ __launch_bounds__(256) void hupr_k_pack_table(const PackDesc* __restr
         return;
     }
     const long count = (long)d.co * d.ci * d.taps;
+    if (pb.layout == 3) {
+        // a 1x1 projection weight of an MSCSA level (models/layers.py:150-157) copied into its row block of the level's two
+        // concatenated (4C, C) fp32 matrices: wp0 = the plain one (backward GEMMs), wp1 = the one the forward projection reads,
+        // whose query rows (kind 3) carry the factor log2(e) of the QS attention kernels; kind 2: both plain
+        const float f = d.kind == 3 ? 1.4426950408889634f : 1.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long l = pb.start + tid + 256 * u;
+            if (l >= count) break;
+            const float v = d.w[l];
+            static_cast<float*>(d.wp0)[l] = v;
+            static_cast<float*>(d.wp1)[l] = v * f;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const long l = pb.start + tid + 256 * u;

@@ -326,7 +326,10 @@ def _pack_refresh_all(dev):
             rec[i] = (w.data_ptr(), e.wp[0].data_ptr(), e.wp[1].data_ptr(), first, co, ci, taps, e.kind)
             cnt = co * ci * taps
             first += cnt
-            if e.kind == 1 and co % 32 == 0 and ci % 32 == 0 and taps <= 27:
+            if e.kind >= 2:
+                # a projection weight -> its row block of the level's concatenated matrices (plain, query-scaled): block layout 3
+                blocks.extend((i, 3, st) for st in range(0, cnt, 2048))
+            elif e.kind == 1 and co % 32 == 0 and ci % 32 == 0 and taps <= 27:
                 # 32 x 32 x taps tiles, both layouts per tile through LDS (hupr_k_pack_table, block layout 2)
                 blocks.extend((i, 2, (c0 << 32) | i0) for c0 in range(0, co, 32) for i0 in range(0, ci, 32))
             else:
@@ -379,6 +382,54 @@ def _packed(weight, mode, kind):
             e.wp[1].copy_(pk_into[1])
             e.stamp = (PACK_EPOCH, weight._version)
     return e.wp[mode]
+
+
+# The eight 1x1 projection weights of an MSCSA level as the two (4C, C) matrices its two GEMMs read — [phi_cross | theta_cross |
+# phi_self | theta_self] per map — kept as ENTRIES OF THE PACK TABLE (kinds 2 / 3): the one table-driven launch after an optimiser
+# step refreshes them with everything else, where rounds 1-4 concatenated them with two ATen launches per level and step.  Two
+# copies per map: the plain one (backward GEMMs, GEMM-attention fallback, fp8 forms) and the one whose query (theta) rows carry
+# log2(e) for the QS attention kernels (csrc/attention_bf16.hip, kDeferBits).
+_proj_cache = {}       # (addresses of the four weights) -> (Wc plain, Wc query-scaled, entries)
+QS_ATTN = os.environ.get("HUPR_NO_ATTN_QS", "0") != "1"      # A/B aid: 0 = the rounds-1-4 kernels (plain Q, fma per score)
+
+
+def _proj_cat(ws, C):
+    """-> (Wc, Wc_qs): (4C, C) fp32 concatenations of the four (C, C, 1, 1) projection weights ``ws`` of one map."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    ok = PACK_CACHE and all(w.is_leaf and w.requires_grad and w.is_contiguous() for w in ws)
+    key = tuple(w.data_ptr() for w in ws)
+    ent = _proj_cache.get(key) if ok else None
+    if ent is not None and any(e.wref() is not w for e, w in zip(ent[2], ws)):          # addresses recycled by other tensors
+        ent = None
+    fresh = ent is not None and all(e.stamp == (PACK_EPOCH, w._version) for e, w in zip(ent[2], ws))
+    if not ok or (capturing and (torch.is_grad_enabled() or not fresh)):
+        # not cacheable, or inside a capture that must not create / refresh cache entries (a training graph's own optimiser node
+        # changes the weights between replays): computed in place, in the graph
+        wc = torch.cat([w.detach().reshape(C, C) for w in ws], 0)
+        wq = wc.clone()
+        wq[C:2 * C] *= 1.4426950408889634
+        wq[3 * C:] *= 1.4426950408889634
+        return wc, wq
+    if ent is None:
+        global _pack_table
+        for k in [k for k, v in _proj_cache.items() if any(e.wref() is None for e in v[2])]:
+            del _proj_cache[k]
+        wc = torch.empty((4 * C, C), dtype=torch.float32, device=ws[0].device)
+        wq = torch.empty_like(wc)
+        entries = []
+        for j, w in enumerate(ws):
+            e = _PackEntry()
+            e.wref, e.ptr, e.kind, e.shape = weakref.ref(w), w.data_ptr(), 3 if j in (1, 3) else 2, tuple(w.shape)
+            e.wp = (wc[j * C:(j + 1) * C], wq[j * C:(j + 1) * C])
+            e.stamp = None
+            _pack_entries[(w.data_ptr(), e.kind)] = e
+            entries.append(e)
+        ent = _proj_cache[key] = (wc, wq, entries)
+        _pack_table = None
+        fresh = False
+    if not fresh:
+        _pack_refresh_all(ws[0].device)
+    return ent[0], ent[1]
 
 
 USE_FLASH = True       # bf16 mode: fused attention kernels where supported (C in {64,128}, N % 128 == 0)
@@ -1365,11 +1416,18 @@ class MSCSALevelFn(torch.autograd.Function):
         ydt = torch.bfloat16 if flash else torch.float32
         esz = 2 if flash else 4
         maps = (ra, re)
-        infer = bool(int(cat_bf16) & 2)                  # bit 1 (set by the caller under no_grad: grad mode is always off in here):
-        cat_bf16 = bool(int(cat_bf16) & 1)               # the concatenated weights are constants, keep them
-        Wc = (_cat_weights(weights[:4], C, infer), _cat_weights(weights[4:], C, infer))
+        infer = bool(int(cat_bf16) & 2)                  # bit 1: the caller runs under no_grad (grad mode is always off in here)
+        cat_bf16 = bool(int(cat_bf16) & 1)
+        # config 5, block-scaled form: quantises the plain projections itself
+        mx8 = flash and attn_mx8_ok(N, C)
+        # QS: the query projections leave the GEMM as log2(e) Q (rounded to bf16 once, like every projection), the attention kernels
+        # take the exponent of 2 straight from the matrix pipe (csrc/attention_bf16.hip, kDeferBits)
+        qs = flash and QS_ATTN and not mx8
+        pa, pe = _proj_cat(weights[:4], C), _proj_cat(weights[4:], C)
+        Wc = (pa[0], pe[0])                              # plain: the backward GEMMs
+        Wf = (pa[1], pe[1]) if qs else Wc                # what the forward projections multiply by
         Y = (torch.empty((B, N, 4 * C), dtype=ydt, device=dev), torch.empty((B, N, 4 * C), dtype=ydt, device=dev))
-        for x, wc, y in zip(maps, Wc, Y):          # a 1x1 kernel's packed layout IS the parameter layout (Co, Ci)
+        for x, wc, y in zip(maps, Wf, Y):          # a 1x1 kernel's packed layout IS the parameter layout (Co, Ci)
             rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(y), 1 if flash else 0, B, 1, H, W, C, C,
                                                 1, H, W, 4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.stream()))
         outs = [torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev) for _ in range(4)]
@@ -1382,7 +1440,6 @@ class MSCSALevelFn(torch.autograd.Function):
             vb = maps
             aux = [torch.empty((B, N, N), dtype=torch.float32, device=dev) for _ in range(4)]       # P[query][key]
         # config 5, block-scaled form: the level's eight projections and two value maps -> e4m3 + E8M0 scales in one step
-        mx8 = flash and attn_mx8_ok(N, C)
         if mx8:
             ws8 = workspace(L.hupr_attn_mx8_ws_bytes(B, N, C), dev)
             rt.check(L.hupr_attn_mx8_quant_level(rt.ptr(Y[0]), rt.ptr(Y[1]), rt.ptr(vb[0]), rt.ptr(vb[1]), B, N, C, rt.ptr(ws8),
@@ -1397,7 +1454,8 @@ class MSCSALevelFn(torch.autograd.Function):
                 items[i].out, items[i].lse = rt.ptr(out), rt.ptr(a)
                 items[i].out16 = (cat.data_ptr() + i * C * 2) if cat_bf16 else None
             ws = workspace(4 * split_bytes, dev)
-            rt.check(L.hupr_attn_fwd_bf16in_ld_ws_batch(items, 4, 4 * C, 4 * C, 4 * C, B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
+            fwd_batch = L.hupr_attn_fwd_bf16in_ld_ws_batch_qs if qs else L.hupr_attn_fwd_bf16in_ld_ws_batch
+            rt.check(fwd_batch(items, 4, 4 * C, 4 * C, 4 * C, B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
         for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
             if split_bytes:
                 break
@@ -1408,10 +1466,11 @@ class MSCSALevelFn(torch.autograd.Function):
                                              rt.stream()))
             elif flash:
                 ws = _attn_ws(B, N, C, dev)
-                rt.check(L.hupr_attn_fwd_bf16in_ld_ws(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
-                                                      rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
-                                                      4 * C, B, N, C, rt.ptr(ws) if ws is not None else None,
-                                                      ws.numel() if ws is not None else 0, rt.stream()))
+                fwd = L.hupr_attn_fwd_bf16in_ld_ws_qs if qs else L.hupr_attn_fwd_bf16in_ld_ws
+                rt.check(fwd(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
+                             rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
+                             4 * C, B, N, C, rt.ptr(ws) if ws is not None else None,
+                             ws.numel() if ws is not None else 0, rt.stream()))
             else:
                 # P[q][j] = Q[q] . K[j], softmax over the keys j (row softmax), out = P V (+ V)
                 rt.check(L.hupr_gemm_bf16(0, 1, qp, kp, rt.ptr(a), N, N, C, 4 * C, 4 * C, N, B, N * 4 * C, N * 4 * C, N * N,
@@ -1422,7 +1481,7 @@ class MSCSALevelFn(torch.autograd.Function):
                                           rt.ptr(v) if residual else None, C, N * C if residual else 0, 0, rt.stream()))
         ctx.save_for_backward(ra, re, Wc[0], Wc[1], Y[0], Y[1], vb[0], vb[1], *outs, *aux)
         ctx.weights = weights
-        ctx.flash, ctx.cat_bf16 = flash, cat_bf16
+        ctx.flash, ctx.cat_bf16, ctx.qs = flash, cat_bf16, qs
         if cat_bf16:
             return (cat,)
         return tuple(outs)
@@ -1462,10 +1521,11 @@ class MSCSALevelFn(torch.autograd.Function):
                     dout = _c(dout)
                     gb = _cast(dout, torch.bfloat16)
                     gp, ldg, g32 = rt.ptr(gb), C, rt.ptr(dout)
-                rt.check(L.hupr_attn_bwd_bf16in_ld(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), gp, ldg, rt.ptr(maps[vs]),
-                                                   rt.ptr(out), g32, rt.ptr(a), dkp, 4 * C, dqp, 4 * C, rt.ptr(dV[vs]),
-                                                   rt.ptr(scr), B, N, C, 1 if residual else 0, 0 if residual else 1,
-                                                   rt.stream()))
+                bwd = L.hupr_attn_bwd_bf16in_ld_qs if ctx.qs else L.hupr_attn_bwd_bf16in_ld
+                rt.check(bwd(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), gp, ldg, rt.ptr(maps[vs]),
+                             rt.ptr(out), g32, rt.ptr(a), dkp, 4 * C, dqp, 4 * C, rt.ptr(dV[vs]),
+                             rt.ptr(scr), B, N, C, 1 if residual else 0, 0 if residual else 1,
+                             rt.stream()))
                 continue
             dout = _c(dout)
             v, P, g = maps[vs], a, rt.ptr(dout)

@@ -111,6 +111,11 @@ SIGNATURES = {
                                    + [c_void_p, c_size_t, c_void_p]),
     "hupr_attn_bwd_bf16in_ld": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4
                                 + [c_void_p, c_int, c_void_p, c_int] + [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "hupr_attn_fwd_bf16in_ld_ws_qs": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_void_p, c_int] + [c_int] * 3
+                                      + [c_void_p, c_size_t, c_void_p]),
+    "hupr_attn_fwd_bf16in_ld_ws_batch_qs": (c_int, [ctypes.POINTER(AttnItem)] + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_attn_bwd_bf16in_ld_qs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4
+                                   + [c_void_p, c_int, c_void_p, c_int] + [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "hupr_softmax_rows_f32": (c_int, [c_void_p, c_long, c_int, c_void_p]),
     "hupr_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "hupr_head1x1_ws_bytes": (c_size_t, []),

@@ -352,6 +352,21 @@ int hupr_attn_bwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, cons
                             const float* V32, const float* out, const float* dout32_or_null, const float* lse, float* dK,
                             int lddk, float* dQ, int lddq, float* dV, float* Dq_scratch, int Bn, int N, int C,
                             int residual, int accumulate, hupr_stream_t stream);
+/* The "QS" forms (round 5): the query operand arrives pre-scaled, Qs = log2(e) Q as bf16 (the level's query projections multiply by
+ * log2(e)-scaled weight rows: hupr_pack_conv_weights_table, block layout 3), so that K . Qs^T is the exponent of 2 and the score
+ * leaves the matrix pipe as the argument of v_exp_f32: the MFMA chain of a score tile starts from minus the running maximum
+ * (forward; kept until a tile exceeds it by more than 8 binary orders) or minus the stored log-sum-exp (backward) instead of 0.
+ * Same semantics as the entry points above: out / lse (natural units) of softmax_keys(K Q^T), gradients with respect to K, the
+ * UNSCALED Q and V.  Same reference lines (models/layers.py:126-133). */
+int hupr_attn_fwd_bf16in_ld_ws_qs(const void* K, int ldk, const void* Qs, int ldq, const void* V, const float* Vres, float* out,
+                                  float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, void* ws, size_t ws_bytes,
+                                  hupr_stream_t stream);
+int hupr_attn_fwd_bf16in_ld_ws_batch_qs(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N, int C,
+                                        void* ws, size_t ws_bytes, hupr_stream_t stream);
+int hupr_attn_bwd_bf16in_ld_qs(const void* K, int ldk, const void* Qs, int ldq, const void* V, const void* dO, int lddo,
+                               const float* V32, const float* out, const float* dout32_or_null, const float* lse, float* dK,
+                               int lddk, float* dQ, int lddq, float* dV, float* Dq_scratch, int Bn, int N, int C, int residual,
+                               int accumulate, hupr_stream_t stream);
 
 /* (a7) PRGCN: y = act(t . A + bias) with t = W . x computed by hupr_gemm_f32 (gcn_networks.py:23-29,53-58) */
 /* The 1x1 key-point head nn.Conv2d(32, 14, 1, bias=False) (reference models/layers.py:94) in plain fp32 FMAs: x [M][32],

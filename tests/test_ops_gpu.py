@@ -1017,6 +1017,113 @@ def test_dual_conv_matches_two_convs(act, bf16_math):
     assert torch.equal(f[3], u[3]) and torch.equal(f[4], u[4])
 
 
+def _qs_case(B, N, C, seed, kscale=None, profile=None):
+    """bf16 operands of one attention with the query pre-scaled by log2(e) -> (device tensors, fp64 reference pieces).  The reference
+    uses exactly what the kernels see: bf16 K, V, dO and the bf16 Q' divided by log2(e) in fp64."""
+    import math
+    kscale = C ** -0.25 if kscale is None else kscale
+    k, q, v, g = (rnd(B, N, C, seed=seed + i, scale=(kscale if i < 2 else 1.0)) for i in range(4))
+    if profile is not None:
+        k = k * profile[None, :, None]                      # key norms that vary along the key axis: the running maximum keeps moving
+    kb, vb, gb = k.bfloat16(), v.bfloat16(), g.bfloat16()
+    qsb = (q * math.log2(math.e)).bfloat16()                # Q' as the projection GEMM's epilogue rounds it
+    kr, vr = kb.double().requires_grad_(True), vb.double().requires_grad_(True)
+    qr = (qsb.double() / math.log2(math.e)).requires_grad_(True)
+    return (kb, qsb, vb, gb, v, g), (kr, qr, vr)
+
+
+@pytest.mark.parametrize("B,N,C,residual", [(2, 4096, 64, True), (8, 512, 64, False), (2, 384, 64, True), (2, 256, 128, True),
+                                            (3, 1024, 128, False), (2, 256, 256, True), (1, 384, 256, False)])
+def test_flash_attention_qs_kernels_vs_fp64(B, N, C, residual, bf16_math):
+    """The QS entry points (query operand = log2(e) Q as bf16; accumulator input = minus the deferred running maximum / minus the
+    stored log-sum-exp) through the C ABI against fp64 on the SAME bf16 operands: forward, log-sum-exp in natural units, the bf16
+    output copy, and all three gradients (dQ with respect to the unscaled Q).  (2, 4096, 64) and (8, 512, 64) take the ping-pong
+    forward and the 512-thread dK / dV kernel, (2, 384, 64) the generic D = 64 kernels, the others levels 2 and 3."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    (kb, qsb, vb, gb, v32, g32), (kr, qr, vr) = _qs_case(B, N, C, 300)
+    sref = torch.einsum("bjc,bkc->bjk", kr, qr)
+    outr = torch.einsum("bjc,bjk->bkc", vr, F.softmax(sref, 1))
+    vres = v32.bfloat16().float()                          # the residual term is the fp32 map; use the rounded one on both sides
+    if residual:
+        outr = outr + vres.double()
+    outr.backward(gb.double())
+    dev = lambda t: t.cuda().contiguous()
+    kd, qd, vd, gd, v32d = dev(kb), dev(qsb), dev(vb), dev(gb), dev(vres)
+    out, lse = torch.full((B, N, C), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+    o16 = torch.zeros((B, N, C), dtype=torch.bfloat16, device="cuda")
+    rt.check(L.hupr_attn_fwd_bf16in_ld_ws_qs(rt.ptr(kd), C, rt.ptr(qd), C, rt.ptr(vd), rt.ptr(v32d) if residual else None, rt.ptr(out),
+                                             rt.ptr(lse), rt.ptr(o16), C, B, N, C, None, 0, rt.stream()))
+    close(out, outr, 1e-2, "QS forward")
+    close(lse, torch.logsumexp(sref, 1), 1e-4, "QS log-sum-exp")
+    assert torch.equal(o16, out.bfloat16())
+    dk, dq, dv = (torch.full((B, N, C), float("nan"), device="cuda") for _ in range(3))
+    scr = torch.empty((B, N), device="cuda")
+    # (dout32 = null: the gradient arrived bf16-stored, dO is exact)
+    rt.check(L.hupr_attn_bwd_bf16in_ld_qs(rt.ptr(kd), C, rt.ptr(qd), C, rt.ptr(vd), rt.ptr(gd), C, rt.ptr(v32d), rt.ptr(out), None,
+                                          rt.ptr(lse), rt.ptr(dk), C, rt.ptr(dq), C, rt.ptr(dv), rt.ptr(scr), B, N, C,
+                                          1 if residual else 0, 0, rt.stream()))
+    # (the reference's residual term went through ``vres``, a constant: the kernel's dV also carries dO for it)
+    close(dv, vr.grad + (gb.double() if residual else 0.0), 2e-2, "QS dV")
+    close(dq, qr.grad, 3e-2, "QS dQ")
+    close(dk, kr.grad, 3e-2, "QS dK")
+    # against the plain kernels on the same K, V, dO and the unscaled bf16 Q: two roundings of the same attention
+    qpl = dev((qsb.float() / 1.4426950408889634).bfloat16())
+    out0, lse0 = torch.empty_like(out), torch.empty_like(lse)
+    rt.check(L.hupr_attn_fwd_bf16in_ld_ws(rt.ptr(kd), C, rt.ptr(qpl), C, rt.ptr(vd), rt.ptr(v32d) if residual else None, rt.ptr(out0),
+                                          rt.ptr(lse0), None, 0, B, N, C, None, 0, rt.stream()))
+    close(out, out0, 1.5e-2, "QS vs plain forward")
+
+
+def test_flash_attention_qs_deferred_maximum(bf16_math):
+    """The ping-pong forward keeps the running maximum it entered a key tile with unless the tile exceeds it by more than 8 binary
+    orders.  Keys whose norm grows along the key axis make every regime occur — slow growth (deferred: P up to 2^8), jumps (the
+    rescale branch), and a first tile far below zero — and the largest logits reach a few hundred.  Against fp64 on the same operands,
+    with the backward kernels consuming the log-sum-exp it produced."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    B, N, C = 8, 1024, 64
+    prof = torch.cat([torch.linspace(0.05, 0.3, 256), torch.linspace(0.3, 3.0, 256), torch.full((256,), 6.0), torch.linspace(6.0, 0.1, 256)])
+    (kb, qsb, vb, gb, v32, g32), (kr, qr, vr) = _qs_case(B, N, C, 340, kscale=1.0, profile=prof)
+    sref = torch.einsum("bjc,bkc->bjk", kr, qr)
+    assert sref.abs().max().item() > 100.0
+    outr = torch.einsum("bjc,bjk->bkc", vr, F.softmax(sref, 1))
+    outr.backward(gb.double())
+    kd, qd, vd, gd, v32d = (t.cuda().contiguous() for t in (kb, qsb, vb, gb, vb.float()))
+    out, lse = torch.full((B, N, C), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+    rt.check(L.hupr_attn_fwd_bf16in_ld_ws_qs(rt.ptr(kd), C, rt.ptr(qd), C, rt.ptr(vd), None, rt.ptr(out), rt.ptr(lse), None, 0, B, N, C,
+                                             None, 0, rt.stream()))
+    assert torch.isfinite(out).all() and torch.isfinite(lse).all()
+    close(out, outr, 1e-2, "deferred-maximum forward")
+    close(lse, torch.logsumexp(sref, 1), 1e-4, "deferred-maximum log-sum-exp")
+    dk, dq, dv = (torch.empty((B, N, C), device="cuda") for _ in range(3))
+    scr = torch.empty((B, N), device="cuda")
+    rt.check(L.hupr_attn_bwd_bf16in_ld_qs(rt.ptr(kd), C, rt.ptr(qd), C, rt.ptr(vd), rt.ptr(gd), C, rt.ptr(v32d), rt.ptr(out), None,
+                                          rt.ptr(lse), rt.ptr(dk), C, rt.ptr(dq), C, rt.ptr(dv), rt.ptr(scr), B, N, C, 0, 0, rt.stream()))
+    close(dv, vr.grad, 2e-2, "dV")
+    close(dq, qr.grad, 3e-2, "dQ")
+    close(dk, kr.grad, 3e-2, "dK")
+
+
+@pytest.mark.parametrize("B,N,C", [(1, 4096, 64), (1, 1024, 128), (1, 256, 256)])
+def test_attention_qs_split_keys(B, N, C, bf16_math):
+    """Single-sample inference: the key-split form of the QS forward (shares in binary orders, merged by hupr_k_attn_combine<QS>)."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    (kb, qsb, vb, gb, v32, g32), (kr, qr, vr) = _qs_case(B, N, C, 380)
+    sref = torch.einsum("bjc,bkc->bjk", kr, qr)
+    ref = torch.einsum("bjc,bjk->bkc", vr, F.softmax(sref, 1))
+    nbytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    kd, qd, vd = (t.cuda().contiguous() for t in (kb, qsb, vb))
+    out, lse = torch.full((B, N, C), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda")
+    rt.check(L.hupr_attn_fwd_bf16in_ld_ws_qs(rt.ptr(kd), C, rt.ptr(qd), C, rt.ptr(vd), None, rt.ptr(out), rt.ptr(lse), None, 0, B, N, C,
+                                             rt.ptr(ws), nbytes, rt.stream()))
+    close(out, ref, 1e-2, "QS split forward")
+    close(lse, torch.logsumexp(sref, 1), 1e-4, "QS split log-sum-exp")
+
+
 @pytest.mark.parametrize("C,H", [(64, 16), (128, 16), (64, 32), (256, 16), (32, 8), (96, 16)])      # the last two: no fused attention kernel
 def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
     """MSCSALevelFn (one GEMM per map for its four 1x1 projections with bf16 epilogue, strided attention operands,
@@ -1044,12 +1151,23 @@ def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
         sum((o * g).sum() for o, g in zip(outs, gs)).backward()
         return [o.detach() for o in outs], [a.grad, e.grad] + [t.grad for t in w]
 
-    o1, g1 = run(True)
     o0, g0 = run(False)
-    for i, (x, y) in enumerate(zip(o1, o0)):
-        assert torch.equal(x, y), "attention output %d differs" % i
-    for i, (x, y) in enumerate(zip(g1, g0)):
-        close(x, y, 2e-5, "gradient %d (0,1: maps; 2..9: projection weights)" % i)
+    prev = F_.QS_ATTN
+    try:
+        F_.QS_ATTN = False                      # the rounds-1-4 kernels inside the node: the same products, the same rounding points
+        o1, g1 = run(True)
+        for i, (x, y) in enumerate(zip(o1, o0)):
+            assert torch.equal(x, y), "attention output %d differs" % i
+        for i, (x, y) in enumerate(zip(g1, g0)):
+            close(x, y, 2e-5, "gradient %d (0,1: maps; 2..9: projection weights)" % i)
+        F_.QS_ATTN = True                       # the default (round 5): query projections carry log2(e) before their bf16 rounding and
+        o2, g2 = run(True)                      # the forward keeps a deferred maximum — another rounding of the same attention
+    finally:
+        F_.QS_ATTN = prev
+    for i, (x, y) in enumerate(zip(o2, o0)):
+        close(x, y, 1e-2, "QS attention output %d" % i)
+    for i, (x, y) in enumerate(zip(g2, g0)):
+        close(x, y, 3e-2, "QS gradient %d (0,1: maps; 2..9: projection weights)" % i)
 
 
 @pytest.mark.parametrize("training", [True, False])
