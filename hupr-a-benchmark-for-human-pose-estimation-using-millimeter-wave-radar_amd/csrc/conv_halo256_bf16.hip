@@ -496,8 +496,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256_bf16(HaloArgs p) {
 
 static int g_halo_m16 = 1;      // 1 (default): bf16-activation launches go to the 16 x 16 x 32 kernel (conv_halo256m_bf16.hip): -6 % / -7 % on the layer-1 / layer-2 shapes
 static int g_halo_m16_td2 = 1;  // its 2 x 8 x 16 tile for D % 4 != 0 (off with hupr_debug_halo_m16(2): 4 x 8 x 8 only)
-static int g_halo_m16_2d = 0;   // its 1 x 16 x 16 tile for 1 x 3 x 3 taps: opt-in (hupr_debug_halo_m16(3)), see DESIGN.md section 4
-void set_halo_m16(int on) { g_halo_m16 = on != 0; g_halo_m16_td2 = on != 2; g_halo_m16_2d = on == 3; }
+static int g_halo_m16_2d = 1;   // its 1 x 16 x 16 tile for 1 x 3 x 3 taps (the decoder's convolutions): default since round 5 (built and
+                                // parity-tested in round 4, -16...-25 % per launch; hupr_debug_halo_m16(5) = the round-4 default without it)
+void set_halo_m16(int on) { g_halo_m16 = on != 0; g_halo_m16_td2 = on != 2; g_halo_m16_2d = (on == 1 || on == 3); }
 
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
     if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;

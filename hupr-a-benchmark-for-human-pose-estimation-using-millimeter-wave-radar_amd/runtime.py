@@ -206,7 +206,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if os.environ.get("HUPR_HALO_M16") in ("0", "1", "2", "3") and hasattr(L, "hupr_debug_halo_m16"):
+        if os.environ.get("HUPR_HALO_M16") in ("0", "1", "2", "3", "5") and hasattr(L, "hupr_debug_halo_m16"):
             L.hupr_debug_halo_m16(int(os.environ["HUPR_HALO_M16"]))      # A/B aid: the 256-voxel convolution's MFMA shape
         _lib = L
     return _lib

@@ -214,7 +214,7 @@ void hupr_debug_fft_variant(int bits);     /* A/B aid: bit 0 = temporal ADC load
 void hupr_debug_fft_range_first(int on);  /* A/B aid: 1 = the range-first K1 of rounds 1-2 instead of the Doppler-first kernel */
 void hupr_debug_halo_small_tiles(int on); /* A/B aid: 0 keeps 64-wide channel tiles on grids of <= 256 workgroups (default 1: 32-wide there) */
 void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel, 2 skip the 512-voxel kernel */
-void hupr_debug_halo_m16(int on);         /* 256-voxel halo convolution, bf16 activations: 1 (default) = the v_mfma_f32_16x16x32_bf16 kernel (conv_halo256m_bf16.hip; tiles 4x8x8 and 2x8x16 for D % 4 != 0), 3 = also its 1x16x16 tile for 1x3x3 taps (the decoder's convolutions; opt-in), 2 = that kernel on its 4x8x8 tile only, 0 = the 32x32x16 kernels */
+void hupr_debug_halo_m16(int on);         /* 256-voxel halo convolution, bf16 activations: 1 (default; 3 = the same) = the v_mfma_f32_16x16x32_bf16 kernel (conv_halo256m_bf16.hip) on all three tiles: 4x8x8, 2x8x16 for D % 4 != 0, 1x16x16 for 1x3x3 taps (the decoder's convolutions; default since round 5); 5 = without the 1x16x16 tile (the round-4 default); 2 = its 4x8x8 tile only; 0 = the 32x32x16 kernels */
 void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */
 void hupr_debug_gemm_small_tiles(int off); /* A/B aid: 1 = small bf16 GEMMs keep the 64x128 tile instead of 64x64 */
 void hupr_debug_wgrad_ci32(int on);       /* A/B aid: 0 sends Ci <= 32 weight gradients through the two-quadrant kernel (K halves only), 2 forces the K-quarter mode at any size, 1 = default */
