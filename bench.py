@@ -443,7 +443,7 @@ def main():
     # after the timed region; (iii) the SAME step with the exchange switched off — every rank an independent replica — as the
     # single-rank rate measured in this very invocation, so that efficiency = value / (N x that) needs no second run.
     scaling_check = None
-    if world > 1:
+    if world > 1 or (eng.buckets.active and not args.strong):      # (one rank with HUPR_FORCE_ALLREDUCE=1: the same code path on a 1-GPU box)
         if rccl_ranks is not None and rccl_ranks != world:
             raise SystemExit("bench.py: the native RCCL communicator spans %r ranks, the job has %d" % (rccl_ranks, world))
         if not args.graph:
@@ -452,8 +452,10 @@ def main():
                 one_step()
             rep = eng.buckets.timing_report()
             eng.buckets.enable_timing(False)
-            reps = [None] * world
-            dist.all_gather_object(reps, rep)
+            reps = [rep]
+            if dist.is_initialized():
+                reps = [None] * world
+                dist.all_gather_object(reps, rep)
             # (iii) exchange off: rank-local replicas (weights drift apart from here on — this is the last thing the engine does)
             was_active, eng.buckets.active = eng.buckets.active, False
             for _ in range(3):
@@ -465,7 +467,8 @@ def main():
                 one_step()
             barrier()
             ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            if dist.is_initialized():
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
             eng.buckets.active = was_active
             single = B * micro * n1 / float(ts.item())            # per-rank rate of N concurrent independent replicas
             tails = [r["exposed_tail_us"] for r in reps if r and r.get("exposed_tail_us") is not None]

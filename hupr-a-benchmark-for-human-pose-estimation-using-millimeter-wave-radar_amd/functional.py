@@ -1422,10 +1422,10 @@ class MSCSALevelFn(torch.autograd.Function):
         mx8 = flash and attn_mx8_ok(N, C)
         # QS: the query projections leave the GEMM as log2(e) Q (rounded to bf16 once, like every projection), the attention kernels
         # take the exponent of 2 straight from the matrix pipe (csrc/attention_bf16.hip, kDeferBits)
-        qs = flash and QS_ATTN and not mx8
+        qscaled = flash and QS_ATTN and not mx8      # (not `qs`: the SPEC loops below bind that name to the query source map)
         pa, pe = _proj_cat(weights[:4], C), _proj_cat(weights[4:], C)
         Wc = (pa[0], pe[0])                              # plain: the backward GEMMs
-        Wf = (pa[1], pe[1]) if qs else Wc                # what the forward projections multiply by
+        Wf = (pa[1], pe[1]) if qscaled else Wc                # what the forward projections multiply by
         Y = (torch.empty((B, N, 4 * C), dtype=ydt, device=dev), torch.empty((B, N, 4 * C), dtype=ydt, device=dev))
         for x, wc, y in zip(maps, Wf, Y):          # a 1x1 kernel's packed layout IS the parameter layout (Co, Ci)
             rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(y), 1 if flash else 0, B, 1, H, W, C, C,
@@ -1454,7 +1454,7 @@ class MSCSALevelFn(torch.autograd.Function):
                 items[i].out, items[i].lse = rt.ptr(out), rt.ptr(a)
                 items[i].out16 = (cat.data_ptr() + i * C * 2) if cat_bf16 else None
             ws = workspace(4 * split_bytes, dev)
-            fwd_batch = L.hupr_attn_fwd_bf16in_ld_ws_batch_qs if qs else L.hupr_attn_fwd_bf16in_ld_ws_batch
+            fwd_batch = L.hupr_attn_fwd_bf16in_ld_ws_batch_qs if qscaled else L.hupr_attn_fwd_bf16in_ld_ws_batch
             rt.check(fwd_batch(items, 4, 4 * C, 4 * C, 4 * C, B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
         for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
             if split_bytes:
@@ -1466,7 +1466,7 @@ class MSCSALevelFn(torch.autograd.Function):
                                              rt.stream()))
             elif flash:
                 ws = _attn_ws(B, N, C, dev)
-                fwd = L.hupr_attn_fwd_bf16in_ld_ws_qs if qs else L.hupr_attn_fwd_bf16in_ld_ws
+                fwd = L.hupr_attn_fwd_bf16in_ld_ws_qs if qscaled else L.hupr_attn_fwd_bf16in_ld_ws
                 rt.check(fwd(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
                              rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
                              4 * C, B, N, C, rt.ptr(ws) if ws is not None else None,
@@ -1481,7 +1481,7 @@ class MSCSALevelFn(torch.autograd.Function):
                                           rt.ptr(v) if residual else None, C, N * C if residual else 0, 0, rt.stream()))
         ctx.save_for_backward(ra, re, Wc[0], Wc[1], Y[0], Y[1], vb[0], vb[1], *outs, *aux)
         ctx.weights = weights
-        ctx.flash, ctx.cat_bf16, ctx.qs = flash, cat_bf16, qs
+        ctx.flash, ctx.cat_bf16, ctx.qscaled = flash, cat_bf16, qscaled
         if cat_bf16:
             return (cat,)
         return tuple(outs)
@@ -1521,7 +1521,7 @@ class MSCSALevelFn(torch.autograd.Function):
                     dout = _c(dout)
                     gb = _cast(dout, torch.bfloat16)
                     gp, ldg, g32 = rt.ptr(gb), C, rt.ptr(dout)
-                bwd = L.hupr_attn_bwd_bf16in_ld_qs if ctx.qs else L.hupr_attn_bwd_bf16in_ld
+                bwd = L.hupr_attn_bwd_bf16in_ld_qs if ctx.qscaled else L.hupr_attn_bwd_bf16in_ld
                 rt.check(bwd(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), gp, ldg, rt.ptr(maps[vs]),
                              rt.ptr(out), g32, rt.ptr(a), dkp, 4 * C, dqp, 4 * C, rt.ptr(dV[vs]),
                              rt.ptr(scr), B, N, C, 1 if residual else 0, 0 if residual else 1,

@@ -238,6 +238,11 @@ def test_bench_line_single_gpu_carries_every_object():
     assert out["attention_roofline"]["bound"] == "mfma" and 0 < out["attention_roofline"]["frac"] < 1
     assert out["parity_path"]["dtype"] == "f32" and out["parity_path"]["roofline"]["peak"] == 157.3
     assert "arg-max" in out["config"]["workload"]
+    # round 5: the step's launch count (native counter) and the bounds of the single-sample forward next to its latency
+    assert 100 < out["launches_per_step"] < 1000
+    c2r = out["c2"]["roofline"]
+    assert c2r["bound"] == "launch" and 20 < c2r["launches_per_frame"] < 400 and 0 < c2r["frac"] < 1 and 0 < c2r["frac_of_launch_floor"] <= 1.0
+    assert c2r["bounds_us"]["launch_floor_us"] == round(c2r["launches_per_frame"] * 1.5, 1)
     # SURVEY 8(d)'s algorithmic bytes, not the implementation's traffic
     assert out["fft_roofline"]["algorithmic_bytes_per_sensor_frame"] == 1048576
     assert out["fft_roofline"]["loader_variant"]["algorithmic_bytes_per_sensor_frame"] == 2883584
@@ -255,6 +260,22 @@ def test_bench_under_launcher_uses_rccl_and_graph():
     assert out["n_gpus"] == 1 and out["config"]["collective"].startswith("rccl")
     assert out["config"]["launch"] == "hipGraph replay" and out["roofline"]["launches"] == 3 * 12
     assert out["rccl_ranks"] == 1                                  # as the live communicator reports it (ncclCommCount)
+
+
+def test_bench_line_checks_its_own_exchange_step():
+    """with an exchange step in the job the line carries `scaling_check` — the live communicator's rank count
+    (asserted against the job inside bench.py), per-bucket all-reduce durations from HIP events on the communication stream, the
+    exposed tail at the join, and the same step with the exchange switched off as the single-rank rate of the same invocation.  Here:
+    one rank with a forced (1-rank) RCCL all-reduce — the code path N > 1 takes."""
+    out = _bench(["--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "4", "--no-cpu-baseline", "--no-parity-path", "--no-c2",
+                  "--sustain", "0"], env_extra={"HUPR_FORCE_ALLREDUCE": "1"}, launcher=True)
+    sc = out["scaling_check"]
+    assert sc is not None and sc["rccl_ranks"] == 1 and sc["transport"].startswith("rccl")
+    assert len(sc["buckets_rank0"]) >= 3 and all(b["allreduce_us"] > 0 and b["mbytes"] > 0 for b in sc["buckets_rank0"])
+    assert abs(sum(b["mbytes"] for b in sc["buckets_rank0"]) - 35.54 * 4) < 1.0          # every parameter is in exactly one bucket
+    assert sc["exposed_tail_us_max_over_ranks"] is not None and sc["exposed_tail_us_max_over_ranks"] >= 0.0
+    assert sc["single_rank_frames_per_s"] > 0 and 0.5 < sc["efficiency_vs_single_rank"] < 1.5
+    assert out["launches_per_step"] > 100
 
 
 def test_bench_refuses_more_gpus_than_visible():
