@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad(const float* __restr
     part[(long)blockIdx.x * 512 + k * kHeadCi + c0 + 1] = a1;
 }
 // dw[i] = sum over the partial rows, in a fixed order: 8 workgroups x (64 outputs x 4 row groups), 16 loads in flight per thread
-__global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int rows) {
+__global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int rows, int n_out) {
     __shared__ double red[4][64];
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     double a = 0.0;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void hupr_k_head1x1_wgrad_reduce(const float* 
     for (int r = g; r < rows; r += 4) a += (double)part[(long)r * 512 + i];
     red[g][threadIdx.x & 63] = a;
     __syncthreads();
-    if (g == 0) dw[i] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (g == 0 && i < n_out) dw[i] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 }  // namespace hupr
@@ -396,9 +396,11 @@ extern "C" int hupr_head1x1_fwd_f32(const float* x, const float* w16, float* y, 
     HUPR_LAUNCH_OK("hupr_k_head1x1_fwd");
     return HUPR_OK;
 }
-extern "C" int hupr_head1x1_bwd_f32(const float* x, const float* w16, const float* dy, float* dx_or_null, float* dw16_or_null,
-                                    long M, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(M >= 0, "hupr_head1x1_bwd_f32: M=%ld", M);
+// out_rows: how many of the 16 filter rows of dw are written (16: the padded layout; K = 14: the parameter itself, e.g. its slot in a
+// flat gradient bucket, whose neighbours must not be touched)
+extern "C" int hupr_head1x1_bwd_rows_f32(const float* x, const float* w16, const float* dy, float* dx_or_null, float* dw16_or_null,
+                                         int out_rows, long M, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(M >= 0 && out_rows >= 1 && out_rows <= 16, "hupr_head1x1_bwd_f32: M=%ld out_rows=%d", M, out_rows);
     if (M == 0) return HUPR_OK;
     HUPR_REQUIRE(x && w16 && dy && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx_or_null & 15) == 0,
                  "hupr_head1x1_bwd_f32: null or misaligned pointer");
@@ -410,10 +412,15 @@ extern "C" int hupr_head1x1_bwd_f32(const float* x, const float* w16, const floa
         if (!ws || ws_bytes < hupr_head1x1_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_head1x1_bwd_f32: workspace %zu < %zu", ws_bytes, hupr_head1x1_ws_bytes());
         const int grid = (int)min((long)kHeadWgradGrid, (M + 127) / 128);
         HUPR_LAUNCH(hupr_k_head1x1_wgrad, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, static_cast<float*>(ws), M);
-        HUPR_LAUNCH(hupr_k_head1x1_wgrad_reduce, dim3(8), dim3(256), 0, as_stream(stream), static_cast<const float*>(ws), dw16_or_null, grid);
+        HUPR_LAUNCH(hupr_k_head1x1_wgrad_reduce, dim3(8), dim3(256), 0, as_stream(stream), static_cast<const float*>(ws), dw16_or_null, grid,
+                    out_rows * 32);
         HUPR_LAUNCH_OK("hupr_k_head1x1_wgrad");
     }
     return HUPR_OK;
+}
+extern "C" int hupr_head1x1_bwd_f32(const float* x, const float* w16, const float* dy, float* dx_or_null, float* dw16_or_null,
+                                    long M, void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    return hupr_head1x1_bwd_rows_f32(x, w16, dy, dx_or_null, dw16_or_null, 16, M, ws, ws_bytes, stream);
 }
 
 extern "C" int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,

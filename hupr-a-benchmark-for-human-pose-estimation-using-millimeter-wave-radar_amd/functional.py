@@ -1087,17 +1087,33 @@ class MNetFn(torch.autograd.Function):
         return None, _pret(weight, dw, dw_direct), _pret(bias, db, db_direct), None
 
 
+def _ld_view_ok(t, C):
+    """``t`` (B, D, H, W, C) is a channel slice of a wider contiguous channels-last tensor (row stride = t.stride(3) elements, dense
+    voxel order): kernels with a leading-dimension argument read / write it in place."""
+    B, D, H, W, _ = t.shape
+    ld = t.stride(3)
+    return (t.stride(4) == 1 and ld >= C and t.stride(2) == W * ld and t.stride(1) == H * W * ld
+            and (B == 1 or t.stride(0) == D * H * W * ld) and t.data_ptr() % 16 == 0 and ld % 8 == 0)
+
+
 @_math_scoped
 class InterpFn(torch.autograd.Function):
-    """align_corners=True linear resampling of a channels-last (B,D,H,W,C) tensor to ``size``."""
+    """align_corners=True linear resampling of a channels-last (B,D,H,W,C) tensor to ``size``.  ``out`` (optional): a channel
+    slice of a wider channels-last buffer to write into (the decoder's concatenated input: no concatenation copy); the incoming
+    gradient may be such a slice too and is read in place."""
 
     @staticmethod
     def forward(ctx, x, size):
         x = _c(x)
         B, Di, Hi, Wi, C = _vox(x)
         Do, Ho, Wo = size
-        y = torch.empty((B, Do, Ho, Wo, C), dtype=x.dtype, device=x.device)
-        rt.check(_act("interp_linear_fwd", x)(rt.ptr(x), rt.ptr(y), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C, rt.stream()))
+        out = _interp_out.pop("out", None)           # (a side channel, not an argument: an argument returned as the output would be an
+        if out is None:                               # input alias in autograd's eyes)
+            y, ld = torch.empty((B, Do, Ho, Wo, C), dtype=x.dtype, device=x.device), C
+        else:
+            assert tuple(out.shape) == (B, Do, Ho, Wo, C) and out.dtype == x.dtype and _ld_view_ok(out, C), (out.shape, out.stride())
+            y, ld = out, out.stride(3)
+        rt.check(_act("interp_linear_fwd", x)(rt.ptr(x), rt.ptr(y), B, Di, Hi, Wi, Do, Ho, Wo, C, C, ld, rt.stream()))
         ctx.in_shape = (B, Di, Hi, Wi, C)
         ctx.size = size
         return y
@@ -1106,13 +1122,49 @@ class InterpFn(torch.autograd.Function):
     def backward(ctx, dy):
         B, Di, Hi, Wi, C = ctx.in_shape
         Do, Ho, Wo = ctx.size
-        dy = _c(dy)
+        if dy.is_contiguous() or not _ld_view_ok(dy, C):
+            dy, ld = _c(dy), C
+        else:
+            ld = dy.stride(3)
         dx = torch.empty(ctx.in_shape, dtype=dy.dtype, device=dy.device)
-        rt.check(_act("interp_linear_bwd", dy)(rt.ptr(dy), rt.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, C, C, rt.stream()))
+        rt.check(_act("interp_linear_bwd", dy)(rt.ptr(dy), rt.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, C, ld, rt.stream()))
         return dx, None
 
 
-def interp(x, size):
+class JoinFn(torch.autograd.Function):
+    """The decoder's channel concatenation (reference models/layers.py:166-178) without a copy: the parts were WRITTEN as adjacent
+    channel slices of ``wide`` by their producers (InterpFn / MSCSALevelFn with an output placement), so the forward just hands
+    ``wide`` on, and the backward hands each producer its slice of the gradient (views; the producers' backward kernels read them in
+    place).  Rounds 1-4 paid a concatenation kernel per decoder stage and two ``contiguous`` copies of gradient slices per step."""
+
+    @staticmethod
+    def forward(ctx, wide, *parts):
+        off = 0
+        for t in parts:
+            assert t.data_ptr() == wide.data_ptr() + off * wide.element_size() and t.stride(3) == wide.shape[-1], "parts must be slices of wide"
+            off += t.shape[-1]
+        assert off == wide.shape[-1]
+        ctx.widths = [t.shape[-1] for t in parts]
+        return wide.view(wide.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(g[..., off:off + w])
+            off += w
+        return (None,) + tuple(outs)
+
+
+_interp_out = {}
+
+
+def interp(x, size, out=None):
+    """out: optional output placement (see InterpFn)."""
+    _interp_out.clear()
+    if out is not None:
+        _interp_out["out"] = out
     return InterpFn.apply(x, tuple(size))
 
 
@@ -1282,6 +1334,7 @@ def attention_mx8(k, q, v, residual):
     return out, lse
 
 
+_level_cat_out = {}      # {"out": view}: where the NEXT fused level writes its concatenated bf16 output (models/layers.py sets it)
 LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
 FLASH256 = os.environ.get("HUPR_NO_FLASH256", "0") != "1"      # A/B aid: level-0 (C = 256) attention on the fused kernels
 CAT_FUSION = os.environ.get("HUPR_NO_CAT_FUSION", "0") != "1"      # fused levels return their maps concatenated as bf16
@@ -1294,6 +1347,16 @@ def mscsa_level_fused_ok(ra):
     if ATTN_FP8 is True and C == 64 and not torch.is_grad_enabled():
         return False                      # config 5, per-tensor form: this level runs as separate projections + fp8 attentions
     return LEVEL_FUSION and _st.math == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
+
+
+CAT_INPLACE = os.environ.get("HUPR_NO_CAT_INPLACE", "0") != "1"      # A/B aid: 0 = concatenation copies per decoder stage (rounds 1-4)
+
+
+def level_cat_placement_ok(ra):
+    """The fused level node of map ``ra`` returns ONE concatenated bf16 tensor and can write it into a slice of a wider buffer."""
+    B, _, H, W, C = ra.shape
+    return (CAT_INPLACE and mscsa_level_fused_ok(ra) and USE_FLASH and CAT_FUSION and bool(rt.lib().hupr_attn_flash_supported(H * W, C))
+            and (C != 256 or FLASH256))
 
 
 # Derived inference constants (concatenated projection weights, the zero-padded head filter): one entry per set of source
@@ -1432,7 +1495,15 @@ class MSCSALevelFn(torch.autograd.Function):
                                                 1, H, W, 4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.stream()))
         outs = [torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev) for _ in range(4)]
         cat_bf16 = bool(cat_bf16) and flash
-        cat = torch.empty((B, 1, H, W, 4 * C), dtype=torch.bfloat16, device=dev) if cat_bf16 else None
+        cat, ld16 = None, 4 * C
+        if cat_bf16:
+            cat = _level_cat_out.pop("out", None)      # output placement: a channel slice of the decoder stage's input buffer
+            if cat is not None:
+                assert tuple(cat.shape) == (B, 1, H, W, 4 * C) and cat.dtype == torch.bfloat16 and _ld_view_ok(cat, 4 * C)
+                ld16 = cat.stride(3)
+            else:
+                cat = torch.empty((B, 1, H, W, 4 * C), dtype=torch.bfloat16, device=dev)
+        _level_cat_out.clear()
         if flash:
             vb = (_cast(ra, torch.bfloat16), _cast(re, torch.bfloat16))
             aux = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(4)]          # log-sum-exp per query
@@ -1455,21 +1526,21 @@ class MSCSALevelFn(torch.autograd.Function):
                 items[i].out16 = (cat.data_ptr() + i * C * 2) if cat_bf16 else None
             ws = workspace(4 * split_bytes, dev)
             fwd_batch = L.hupr_attn_fwd_bf16in_ld_ws_batch_qs if qscaled else L.hupr_attn_fwd_bf16in_ld_ws_batch
-            rt.check(fwd_batch(items, 4, 4 * C, 4 * C, 4 * C, B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
+            rt.check(fwd_batch(items, 4, 4 * C, 4 * C, ld16, B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
         for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
             if split_bytes:
                 break
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
             if mx8:
                 rt.check(L.hupr_attn_mx8_fwd(rt.ptr(ws8), ks, kslot, qs, qslot, vs, rt.ptr(maps[vs]) if residual else None, rt.ptr(out),
-                                             rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None, 4 * C, B, N, C, ws8.numel(),
+                                             rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None, ld16, B, N, C, ws8.numel(),
                                              rt.stream()))
             elif flash:
                 ws = _attn_ws(B, N, C, dev)
                 fwd = L.hupr_attn_fwd_bf16in_ld_ws_qs if qscaled else L.hupr_attn_fwd_bf16in_ld_ws
                 rt.check(fwd(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
                              rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
-                             4 * C, B, N, C, rt.ptr(ws) if ws is not None else None,
+                             ld16, B, N, C, rt.ptr(ws) if ws is not None else None,
                              ws.numel() if ws is not None else 0, rt.stream()))
             else:
                 # P[q][j] = Q[q] . K[j], softmax over the keys j (row softmax), out = P V (+ V)
@@ -1617,6 +1688,7 @@ class GCNLayerFn(torch.autograd.Function):
             rt.check(L.hupr_gcn_adj_fwd_f32(rt.ptr(t), rt.ptr(adj), rt.ptr(_c(bias)), rt.ptr(y), B, F, K, ld, 1 if relu else 0,
                                             rt.stream()))
         ctx.save_for_backward(x, weight, y, adj)
+        ctx.bias_ref = bias
         ctx.relu, ctx.K = relu, K
         return y
 
@@ -1628,60 +1700,98 @@ class GCNLayerFn(torch.autograd.Function):
         L = rt.lib()
         dt = torch.empty_like(x)
         gm = torch.empty_like(x)
-        dbias = torch.empty((F, K), dtype=torch.float32, device=x.device)
+        # weight / bias gradients go straight into the flat-bucket views when a gradient sink is installed (round 5: the six
+        # AccumulateGrad add kernels of the PRGCN per step are gone)
+        bias = ctx.bias_ref
+        dbias, db_direct = _pgrad(bias) if tuple(bias.shape) == (F, K) and bias.is_contiguous() else (torch.empty((F, K), dtype=torch.float32, device=x.device), False)
         rt.check(L.hupr_gcn_adj_bwd_f32(rt.ptr(_c(dy)), rt.ptr(y), rt.ptr(adj), rt.ptr(dt), rt.ptr(gm), rt.ptr(dbias), B, F, K,
                                         ld, 1 if ctx.relu else 0, rt.stream()))
         if _gcn_products_ok(x, weight) and B > 1:
             # the batch folded into the matrix pipe's column axis (dx) / reduction axis (dW) in place: csrc/gcn_products.hip
             dx = torch.empty_like(x)
             rt.check(L.hupr_gcn_wx_f32(rt.ptr(_c(weight)), rt.ptr(dt), rt.ptr(dx), B, F, ld, 1, rt.stream()))
-            dw = torch.empty((F, F), dtype=torch.float32, device=x.device)
+            dw, dw_direct = _pgrad(weight)
             rt.check(L.hupr_gcn_dw_f32(rt.ptr(dt), rt.ptr(x), rt.ptr(dw), B, F, ld, rt.stream()))
-            return dx, dw, dbias, None, None
+            return dx, _pret(weight, dw, dw_direct), _pret(bias, dbias, db_direct), None, None
         dx = gemm(1, 0, weight, dt, F, ld, F, F, ld, B, 0, F * ld, math=GCN_MATH)              # W^T dt
         # dW[f][g] = sum_{b,k} dt[b][f][k] x[b][g][k]: fold the batch into the reduction axis
         dt2 = dt.permute(1, 0, 2).reshape(F, B * ld)
         x2 = x.permute(1, 0, 2).reshape(F, B * ld)
         dw = gemm(0, 1, _c(dt2), _c(x2), F, F, B * ld, B * ld, B * ld, 1, 0, 0, math=GCN_MATH)[0]
-        return dx, dw, dbias, None, None
+        return dx, dw, _pret(bias, dbias, db_direct), None, None
+
+
+_head_cache = {}       # address of the head weight -> (zero-padded (16, 32, 1, 1) copy, pack-table entry)
+
+
+def _head_w16_cached(weight):
+    """The 14 head filters zero-padded to 16 as a PACK-TABLE entry (kind 2: a plain copy into rows 0..K-1 of a persistent buffer whose
+    other rows stay zero), refreshed by the one table launch after an optimiser step — rounds 1-4 padded with ATen in every
+    training forward (a fill, a copy, and a slice + accumulate in the backward)."""
+    K = weight.shape[0]
+    capturing = torch.cuda.is_current_stream_capturing()
+    ok = PACK_CACHE and weight.is_leaf and weight.requires_grad and weight.is_contiguous() and tuple(weight.shape[1:]) == (32, 1, 1)
+    ent = _head_cache.get(weight.data_ptr()) if ok else None
+    if ent is not None and ent[1].wref() is not weight:
+        ent = None
+    fresh = ent is not None and ent[1].stamp == (PACK_EPOCH, weight._version)
+    if not ok or (capturing and (torch.is_grad_enabled() or not fresh)):
+        return torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 0, 0, 16 - K))
+    if ent is None:
+        global _pack_table
+        for k in [k for k, v in _head_cache.items() if v[1].wref() is None]:
+            del _head_cache[k]
+        buf = torch.zeros((16,) + tuple(weight.shape[1:]), dtype=torch.float32, device=weight.device)
+        e = _PackEntry()
+        e.wref, e.ptr, e.kind, e.shape = weakref.ref(weight), weight.data_ptr(), 2, tuple(weight.shape)
+        e.wp = (buf[:K], buf[:K])
+        e.stamp = None
+        _pack_entries[(weight.data_ptr(), 2)] = e
+        ent = _head_cache[weight.data_ptr()] = (buf, e)
+        _pack_table = None
+        fresh = False
+    if not fresh:
+        _pack_refresh_all(weight.device)
+    return ent[0]
 
 
 @_math_scoped
 class Head1x1Fn(torch.autograd.Function):
-    """The 1x1 key-point head (reference models/layers.py:94) as plain fp32 FMAs: x (B,1,H,W,32) fp32, w16 (16,32,1,1) (the 14
-    filters zero-padded) -> (B,1,H,W,16).  What the "head" precision region of a bf16 run uses (PRECISION["head"] = "f32"):
-    the generic fp32 implicit-GEMM path costs 0.26 ms per training step on this 58-MFLOP product, these three kernels ~0.03."""
+    """The 1x1 key-point head (reference models/layers.py:94) as plain fp32 FMAs: x (B,1,H,W,32) fp32, weight (K,32,1,1) the parameter,
+    w16 (16,32,1,1) its zero-padded copy (``_head_w16_cached``) -> (B,1,H,W,16).  What the "head" precision region of a bf16 run uses
+    (PRECISION["head"] = "f32"): the generic fp32 implicit-GEMM path costs 0.26 ms per training step on this 58-MFLOP product, these
+    kernels ~0.03.  The weight gradient is written for the K real filters only, straight into the gradient sink."""
 
     @staticmethod
-    def forward(ctx, x, w16):
+    def forward(ctx, x, weight, w16):
         x, w16 = _c(x), _c(w16)
         B, D, H, W, Ci = _vox(x)
         assert Ci == 32 and tuple(w16.shape) == (16, 32, 1, 1) and x.dtype == torch.float32
         y = torch.empty((B, D, H, W, 16), dtype=torch.float32, device=x.device)
         rt.check(rt.lib().hupr_head1x1_fwd_f32(rt.ptr(x), rt.ptr(w16), rt.ptr(y), B * D * H * W, rt.stream()))
-        ctx.save_for_backward(x, w16)
+        ctx.save_for_backward(x, w16, weight)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w16 = ctx.saved_tensors
+        x, w16, weight = ctx.saved_tensors
         dy = _c(dy)
         M = x.numel() // 32
         L = rt.lib()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w16) if ctx.needs_input_grad[1] else None
+        dw, direct = _pgrad(weight) if ctx.needs_input_grad[1] else (None, False)
         ws = workspace(L.hupr_head1x1_ws_bytes(), x.device)
-        rt.check(L.hupr_head1x1_bwd_f32(rt.ptr(x), rt.ptr(w16), rt.ptr(dy), rt.ptr(dx) if dx is not None else None,
-                                        rt.ptr(dw) if dw is not None else None, M, rt.ptr(ws), ws.numel(), rt.stream()))
-        return dx, dw
+        rt.check(L.hupr_head1x1_bwd_rows_f32(rt.ptr(x), rt.ptr(w16), rt.ptr(dy), rt.ptr(dx) if dx is not None else None,
+                                             rt.ptr(dw) if dw is not None else None, weight.shape[0], M, rt.ptr(ws), ws.numel(), rt.stream()))
+        return dx, _pret(weight, dw, direct) if dw is not None else None, None
 
 
-def head_conv(x, w16):
+def head_conv(x, weight, num_keypoints):
     """1x1 head: the dedicated fp32 kernels inside a bf16 run whose "head" region is switched to fp32 (32 -> 16 channels),
     the generic convolution otherwise (the pure fp32 parity path keeps the arithmetic its golden fixtures were pinned with)."""
-    if _st.region_switched and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 32 and tuple(w16.shape) == (16, 32, 1, 1):
-        return Head1x1Fn.apply(x, w16)
-    return conv(x, w16, None, None, (0, 0, 0))
+    if _st.region_switched and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 32 and tuple(weight.shape) == (num_keypoints, 32, 1, 1):
+        return Head1x1Fn.apply(x, weight, _head_w16_cached(weight))
+    return conv(x, head_weight16(weight, num_keypoints), None, None, (0, 0, 0))
 
 
 @_math_scoped

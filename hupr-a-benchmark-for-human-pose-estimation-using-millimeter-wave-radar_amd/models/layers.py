@@ -174,28 +174,51 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
         # with bf16 activations (F_.act_bf16()) the BasicBlock2D stacks (3x3 convolutions, PReLU, up-sampling) read and
         # write bf16 too; the attention outputs are cast once on the way in, the 1x1 head gets fp32 back.  Every stage sits in a
         # precision region (F_.region): a region switched to fp32 takes / hands over its maps through casts at its borders.
-        maps = None
-        d1 = self.decoderLayer1
-        stages = ((0, ("dec3",), (self.decoderLayer3,), ramaps, remaps), (1, ("dec2",), (self.decoderLayer2,), ral2maps, rel2maps),
-                  (2, ("dec1a", "dec1b"), (d1[0], d1[1]), ral1maps, rel1maps))
-        for i, names, stacks, ra, re in stages:
+        d1, d2, d3 = self.decoderLayer1, self.decoderLayer2, self.decoderLayer3
+        #         level, regions of the blocks, blocks, the resampling that closes the stage, the level's two maps
+        stages = ((0, ("dec3", "dec3"), (d3[0], d3[1]), d3[2], ramaps, remaps), (1, ("dec2", "dec2"), (d2[0], d2[1]), d2[2], ral2maps, rel2maps),
+                  (2, ("dec1a", "dec1b"), (d1[0], d1[1]), None, ral1maps, rel1maps))
+        prev = None                                    # (previous stage's output before its resampling, that resampling, its region)
+        for i, names, blocks, resample, ra, re in stages:
             with F_.region(names[0]):
                 bf16_in = F_.act_bf16() and F_.ACT_BF16_DECODER
-            with F_.region("lvl%d" % i):
-                # bf16 decoder input: a fused level hands back its four maps already concatenated and cast (one tensor)
-                lv = self._level(i, ra, re, bf16_in and F_.CAT_FUSION)
+            B, _, H, W, C = ra.shape
+            if bf16_in and F_.level_cat_placement_ok(ra) and (prev is None or prev[0].dtype == torch.bfloat16):
+                # The stage's input [up-sampled previous maps | out1 | out2 | out3 | out4] (reference :166-178) is ONE buffer that its
+                # producers fill in place — the previous stage's resampling writes its channel slice, the fused level writes the
+                # other — instead of a concatenation copy per stage (F_.JoinFn: the backward hands the slices of the gradient back)
+                cprev = 0 if prev is None else prev[0].shape[-1]
+                wide = torch.empty((B, 1, H, W, cprev + 4 * C), dtype=torch.bfloat16, device=ra.device)
+                parts = []
+                if prev is not None:
+                    with F_.region(prev[2]):
+                        parts.append(F_.interp(prev[0], prev[1].size_of(prev[0]), out=wide[..., :cprev]))
+                with F_.region("lvl%d" % i):
+                    F_._level_cat_out["out"] = wide[..., cprev:]
+                    lv = self._level(i, ra, re, True)
+                assert len(lv) == 1
+                x = F_.JoinFn.apply(wide, *(parts + [lv[0]])) if parts else lv[0]
+            else:
+                maps = None
+                if prev is not None:
+                    with F_.region(prev[2]):
+                        maps = prev[1](prev[0])
+                with F_.region("lvl%d" % i):
+                    # bf16 decoder input: a fused level hands back its four maps already concatenated and cast (one tensor)
+                    lv = self._level(i, ra, re, bf16_in and F_.CAT_FUSION)
+                with F_.region(names[0]):
+                    parts = ([] if maps is None else [maps]) + list(lv)
+                    parts = [F_.to_act(t, decoder=True) for t in parts]
+                    x = torch.cat(parts, 4) if len(parts) > 1 else parts[0]
             with F_.region(names[0]):
-                parts = ([] if maps is None else [maps]) + list(lv)
-                maps = stacks[0](torch.cat([F_.to_act(t, decoder=True) for t in parts], 4))
-            for name, stack in zip(names[1:], stacks[1:]):
-                with F_.region(name):
-                    maps = stack(F_.to_act(maps, decoder=True))
+                maps = blocks[0](F_.to_act(x, decoder=True))
+            with F_.region(names[1]):
+                maps = blocks[1](F_.to_act(maps, decoder=True))
+            prev = (maps, resample, names[1]) if resample is not None else None
         x = F_.cast(maps, torch.float32)
         # 1x1 head with the 14 output channels zero-padded to 16 so later kernels stay float4-aligned
         with F_.region("head"):
-            head = self.decoderLayer1[2]
-            w16 = F_.head_weight16(head.weight, self.numKeypoints)
-            maps16 = F_.head_conv(x, w16)
+            maps16 = F_.head_conv(x, self.decoderLayer1[2].weight, self.numKeypoints)
         return maps16, self.gcn(maps16)
 
 

@@ -121,6 +121,7 @@ SIGNATURES = {
     "hupr_head1x1_ws_bytes": (c_size_t, []),
     "hupr_head1x1_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_head1x1_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_size_t, c_void_p]),
+    "hupr_head1x1_bwd_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_size_t, c_void_p]),
     "hupr_gcn_adj_fwd_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "hupr_gcn_adj_fwd_sliced_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "hupr_gcn_adj_bwd_f32": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

@@ -36,6 +36,7 @@ class TrainEngine:
         self.G = cfg.DATASET.numGroupFrames
         self.fuse_elevation_mean = os.environ.get("HUPR_NO_FUSED_MEAN", "0") != "1"
         self._fft_ws = None
+        self._seed = None
         self._graph = None
         self.keep_inference_graphs_current = True      # see _replay
         # the num_batches_tracked counters of all BatchNorms as views of one int64 vector: a training step bumps them
@@ -86,7 +87,9 @@ class TrainEngine:
                 m.num_batches_tracked.add_(1)
         loss, loss2, p2d, g2d = self.lossComputer.computeLoss(preds, joints, decode=decode)
         self.last_decode = (p2d, g2d)
-        loss.backward()
+        if self._seed is None or self._seed.device != loss.device:
+            self._seed = torch.ones((), dtype=loss.dtype, device=loss.device)      # backward()'s own ones_like is a fill launch per step
+        loss.backward(gradient=self._seed)
         if self.device.type == "cuda":
             for s in F_.side_streams_in_use(self.device):           # the side-stream branch's backward joins here
                 torch.cuda.current_stream(self.device).wait_stream(s)

@@ -376,6 +376,10 @@ size_t hupr_head1x1_ws_bytes(void);
 int hupr_head1x1_fwd_f32(const float* x, const float* w16, float* y, long M, hupr_stream_t stream);
 int hupr_head1x1_bwd_f32(const float* x, const float* w16, const float* dy, float* dx_or_null, float* dw16_or_null, long M,
                          void* ws, size_t ws_bytes, hupr_stream_t stream);
+/* ... writing only the first out_rows (<= 16) filter rows of dw: out_rows = 14 lets dw be the (14, 32, 1, 1) parameter's own gradient
+ * slot in a flat bucket (reference models/layers.py:94: nn.Conv2d(nf, numKeypoints, 1)) */
+int hupr_head1x1_bwd_rows_f32(const float* x, const float* w16, const float* dy, float* dx_or_null, float* dw_or_null, int out_rows,
+                              long M, void* ws, size_t ws_bytes, hupr_stream_t stream);
 int hupr_gcn_adj_fwd_f32(const float* t, const float* adj, const float* bias, float* y, int Bn, int F, int K,
                          int ld, int relu, hupr_stream_t stream);
 /* t as `slices` partial products [slices][Bn*F][ld] (the K slices of W x of a single-sample forward), summed here in slice order */

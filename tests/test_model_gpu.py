@@ -160,3 +160,49 @@ def test_bf16_matrix_pipe_model_gates():
             assert max(rels) < 0.1 and np.median(rels) < 0.02
     finally:
         F_.set_math("f32")
+
+
+def test_decoder_inputs_filled_in_place_match_the_concatenation_copies():
+    """Round 5: the decoder stages' inputs [up-sampled maps | four attention outputs] are buffers their producers
+    fill in place (functional.JoinFn, output placement of InterpFn / MSCSALevelFn; gradient slices read in place) instead of one
+    concatenation copy per stage and two ``contiguous`` copies per backward pass; the PRGCN and head parameters receive their gradients
+    straight in their slots.  Same kernels on the same values: a bf16 training step gives bit-identical outputs and parameter
+    gradients either way, with and without the flat gradient buckets (direct gradient sink)."""
+    from hupr_amd import functional as F_
+    from hupr_amd.misc import LossComputer
+    from hupr_amd.tools.distributed import GradientBuckets
+    g = np.load(os.path.join(G, "model_train.npz"))
+    h, v = _inputs(g)
+    gt = torch.from_numpy(synth.keypoints(2, int(g["kp_seed"])))
+    res = {}
+    try:
+        F_.set_math("bf16")
+        for sink in (False, True):
+            for inplace in (True, False):
+                F_.CAT_INPLACE = inplace
+                cfg, net = _build(g)
+                net.train()
+                F_.invalidate_packed()
+                buckets = GradientBuckets(net) if sink else None
+                if buckets is not None:
+                    buckets.prepare()
+                p1, p2 = net(h, v)
+                loss, *_ = LossComputer(cfg, "cuda").computeLoss((p1, p2), gt, decode=False)
+                loss.backward()
+                if buckets is not None:
+                    buckets.finish()
+                torch.cuda.synchronize()
+                res[(sink, inplace)] = (p1.detach().clone(), p2.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+                if buckets is not None:
+                    buckets.close()
+    finally:
+        F_.CAT_INPLACE = True
+        F_.GRAD_SINK = None
+        F_.set_math("f32")
+        F_.invalidate_packed()
+    ref = res[(False, False)]
+    for key, (p1, p2, grads) in res.items():
+        assert torch.equal(p1, ref[0]) and torch.equal(p2, ref[1]), key
+        bad = [k for k in grads if not torch.equal(grads[k], ref[2][k])]
+        assert not bad, (key, bad[:5])
+    assert all(torch.isfinite(t).all() for t in ref[2].values())

@@ -1164,10 +1164,14 @@ def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
         o2, g2 = run(True)                      # the forward keeps a deferred maximum — another rounding of the same attention
     finally:
         F_.QS_ATTN = prev
+    # Two bf16 roundings of the same level: here the query projection is rounded after the factor log2(e), there before it, and with this
+    # test's unnormalised unit-variance projections (logits up to +-30) a 2^-9 change of q moves a probability by several per cent — the
+    # outputs differ by 1-3 % of their scale (measured), the gradients by more.  The tight checks of the QS kernels are the fp64
+    # comparisons on IDENTICAL operands (test_flash_attention_qs_kernels_vs_fp64: 1e-2 / 3e-2).
     for i, (x, y) in enumerate(zip(o2, o0)):
-        close(x, y, 1e-2, "QS attention output %d" % i)
+        close(x, y, 6e-2, "QS attention output %d" % i)
     for i, (x, y) in enumerate(zip(g2, g0)):
-        close(x, y, 3e-2, "QS gradient %d (0,1: maps; 2..9: projection weights)" % i)
+        close(x, y, 2e-1, "QS gradient %d (0,1: maps; 2..9: projection weights)" % i)
 
 
 @pytest.mark.parametrize("training", [True, False])
@@ -1447,25 +1451,35 @@ def test_head1x1_fp32_kernels(B, H):
     forward, input gradient and weight gradient, incl. a voxel count that is not a multiple of the workgroup slices."""
     from hupr_amd import functional as F_
     x0 = rnd(B, 1, H, H, 32, seed=300).cuda()
-    w0 = torch.zeros(16, 32, 1, 1)
-    w0[:14] = rnd(14, 32, 1, 1, seed=301, scale=32 ** -0.5)
-    w0 = w0.cuda()
+    w0 = rnd(14, 32, 1, 1, seed=301, scale=32 ** -0.5).cuda()               # the parameter: 14 filters (reference models/layers.py:94)
     gy = rnd(B, 1, H, H, 16, seed=302).cuda()
     x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
-    y = F_.Head1x1Fn.apply(x, w)
+    w16 = F_._head_w16_cached(w)                                             # zero-padded copy, a pack-table entry (round 5)
+    assert tuple(w16.shape) == (16, 32, 1, 1) and torch.equal(w16[:14], w0) and w16[14:].abs().max().item() == 0.0
+    y = F_.Head1x1Fn.apply(x, w, w16)
     y.backward(gy)
-    xd, wd = x0.double(), w0.double().reshape(16, 32)
-    close(y, xd @ wd.t(), 2e-6, "head forward")
-    close(x.grad, gy.double() @ wd, 2e-6, "head input gradient")
-    close(w.grad.reshape(16, 32), gy.double().reshape(-1, 16).t() @ xd.reshape(-1, 32), 5e-6, "head weight gradient")
-    assert y[..., 14:].abs().max().item() == 0.0 and w.grad[14:].abs().max().item() < 1e30
+    xd, wd = x0.double(), w0.double().reshape(14, 32)
+    close(y[..., :14], xd @ wd.t(), 2e-6, "head forward")
+    wd16 = torch.cat([wd, torch.zeros(2, 32, dtype=torch.float64, device=wd.device)])
+    close(x.grad, gy.double() @ wd16, 2e-6, "head input gradient")
+    # the weight gradient is written for the 14 real filters only (the parameter's own slot in a flat gradient bucket)
+    assert tuple(w.grad.shape) == (14, 32, 1, 1)
+    close(w.grad.reshape(14, 32), (gy.double().reshape(-1, 16).t() @ xd.reshape(-1, 32))[:14], 5e-6, "head weight gradient")
+    assert y[..., 14:].abs().max().item() == 0.0
+    # a weight update behind torch's back (what FusedAdam does) reaches the padded copy with the next table refresh
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert torch.equal(F_._head_w16_cached(w)[:14], w.detach())
+    with torch.no_grad():
+        w.copy_(w0)
+    F_._head_w16_cached(w)
     # inside a bf16 run the model's head region goes through these kernels, the fp32 parity path through the generic convolution
     F_.set_math("bf16")
     try:
         with F_.region("head"):
             assert F_._REGION_SWITCHED and F_.MATH == "f32"
-            y2 = F_.head_conv(x0, w0)
-        assert torch.equal(y2, y.detach())
+            y2 = F_.head_conv(x0, w, 14)
+        assert torch.equal(y2.detach(), y.detach())
     finally:
         F_.set_math("f32")
     assert not F_._REGION_SWITCHED
