@@ -553,6 +553,317 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The LDS-DMA weight-gradient kernel on v_mfma_f32_16x16x32_bf16 (round 5).  At the chip's power limit the
+// 16 x 16 x 32 form does 15-17 % more work per joule than 32 x 32 x 16 (scripts/probes/mfma_shapes_probe.hip); the forward /
+// input-gradient convolution gained 6-7 % from the same move in round 4.  Same tile (128 voxels: 2 x 8 x 8 or 1 x 8 x 16; one
+// depth-tap plane; 64 x 64 weights), same three-image LDS-DMA ring and tile protocol, same K-half merge and partial-sum layout as
+// hupr_k_wgrad_halo_glds; what changes is who owns what:
+//   wave = K half kq (two 32-voxel K-steps of the tile) x 16-wide ci block cb; it multiplies ALL FOUR 16-wide co blocks: per
+//   (K-step, ky) three x fragments (kx) and — once per K-step — four dy fragments feed twelve MFMAs (the 32 x 32 wave tile of the old
+//   kernel read 40 transpose fragments per 32 voxels, this one 26);
+//   lane ownership inside a K-step and the two-bit row swizzle: see the comment at the address tables below.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+template <bool IS3D>
+__global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
+    constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, LOG2TW = IS3D ? 3 : 4;
+    constexpr int HH = 10, HW = TW + 2;
+    constexpr int NVOX = TD * HH * HW;               // 200 (3-D) / 180 (2-D) halo voxels of one depth-tap plane
+    constexpr int NVOXP = (NVOX + 7) / 8 * 8;        // x rows padded to whole 1 KiB DMA pieces (8 rows)
+    constexpr int ITEMS_X = NVOXP * 8, ITEMS = ITEMS_X + 128 * 8;
+    constexpr int IMG = (NVOXP + 128) * kRowB;       // one staged tile: x halo rows, then the dy rows
+    // THREE DISTINCT LDS objects with static roles in a by-3 unrolled loop: hipcc's waitcnt pass then proves that the image
+    // being read is not the target of a pending LDS-DMA and emits counted vmcnt(N) instead of vmcnt(0) in front of the
+    // first ds_read after an issue (with one array and a rotating index every tile waited for the DMA it had just issued)
+    __shared__ __attribute__((aligned(1024))) char bufA[IMG];
+    __shared__ __attribute__((aligned(1024))) char bufB[IMG];
+    __shared__ __attribute__((aligned(1024))) char bufC[IMG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = wave >> 2;                         // K half of this wave: K-steps 2 kq, 2 kq + 1 of the tile (32 voxels each)
+    const int cb = wave & 3;                          // its 16-wide ci block of the 64-wide tile (all four 16-wide co blocks)
+    const int pd = p.kd >> 1;
+    const int T = p.kd * 9;
+    // XCD-aware 1-D grid (p.xcd_map): the kd depth-tap planes and the (co, ci) tile pairs of one spatial group re-read the
+    // same x / dy tiles, so all of them are given workgroup ids that are congruent mod 8 (= one XCD, one L2): measured on
+    // the layer-1 shape the HBM fetch drops from 3.1x to 1.1x of the algorithmic bytes.  id = c + 8 n, c = group % 8,
+    // n = (group / 8) * members + member.  The launcher only chooses it when members * groups / 8 <= 32 workgroups per XCD
+    // still fill >= 90 % of the CUs; otherwise the grid is (groups, kd, tile pairs) as before.
+    int group, td, pair_;
+    if (p.xcd_map) {
+        const int members = p.kd * p.n_ci_tiles * p.n_co_tiles;
+        const int slot = (int)blockIdx.x >> 3;
+        group = (slot / members) * 8 + ((int)blockIdx.x & 7);
+        const int member = slot % members;
+        td = member % p.kd;
+        pair_ = member / p.kd;
+    } else {
+        group = blockIdx.x;
+        td = blockIdx.y;
+        pair_ = blockIdx.z;
+    }
+    const int cot = pair_ / p.n_ci_tiles, cit = pair_ % p.n_ci_tiles;
+    if (group >= p.groups) return;
+    const int co0 = cot * 64, ci0 = cit * 64;
+
+    // Lane (s = lane & 15, kq4 = lane >> 4) of a 16 x 16 x 32 operand owns column s (a co / ci of its block) and reduction elements
+    // 8 kq4 .. 8 kq4 + 7 = two transpose reads (t = 0, 1) of four image rows each; as a SUPPLIER it addresses the 8-byte segment
+    // 4 (s & 3) of row j = s >> 2 of its group's four.  Reduction element (kq4, t, j) is the voxel in row 2 (kq4 >> 1) + t, column
+    // 4 (kq4 & 1) + j of the K-step's 4-row x 8-column block, so that the two 16-lane groups of a 32-lane read touch EIGHT CONSECUTIVE
+    // image rows x one 32-byte segment; with the 32-byte granules of a row XOR-ed by (row >> 1) & 3 (swz2, source side of the fill)
+    // those are all 64 banks exactly once, at every tap offset (scripts/lds_bank_model.py: 0 conflict cycles; the 32 x 32 x 16
+    // kernel's ownership or its one-bit swizzle on this instruction shape: 100 % extra).
+    const int s = lane & 15, kq4 = lane >> 4;
+    const int colb = 8 * (s & 3);                      // byte offset of the supplier's 4-column segment inside a 16-column block
+    int dyb[2][4], xa[8][2];                           // dy: [t][co block]; x halo: [row offset mod 8][t]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int vr = 2 * (kq4 >> 1) + t, vc = 4 * (kq4 & 1) + (s >> 2);
+        const int r_dy = vr * TW + vc;                 // (K-step offsets of the dy tile are multiples of 8 rows: the key is the lane's)
+#pragma unroll
+        for (int cob = 0; cob < 4; ++cob)
+            dyb[t][cob] = (NVOXP + r_dy) * kRowB + ((32 * cob + colb) ^ (((r_dy >> 1) & 3) << 5));
+        const int r_x = vr * HW + vc;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            xa[m][t] = r_x * kRowB + ((32 * cb + colb) ^ ((((r_x + m) >> 1) & 3) << 5));
+    }
+
+    f32x4w acc[9][4];                                  // [tap][co block]: rows 4 kq4 + i of the block, column s
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4w){0.f, 0.f, 0.f, 0.f};
+
+    const long x_bytes = (long)p.Bn * p.D * p.H * p.W * p.in_ld * 2, dy_bytes = (long)p.Bn * p.D * p.H * p.W * p.dy_ld * 2;
+    constexpr int kOOB = 0x7ffffff0;                 // beyond num_records: the DMA deposits zeros
+
+    // LDS-DMA pieces of this wave: piece pc = 8 u + wave moves 64 items (8 rows x 128 B) to image offset pc KiB.  What
+    // does not depend on the tile is computed once: the byte offset of the lane's 16 bytes relative to the tile origin
+    // (rel) and which tile borders would put it outside the tensor (msk; bit 6 = always outside: row padding / channel
+    // tail).  Per tile a piece then costs an add, a mask test and a select.
+    constexpr int NP = (ITEMS / 64 + 7) / 8;          // 6 pieces for the first wave(s), 5 for the others (3-D)
+    constexpr int NLAST = ITEMS / 64 - (NP - 1) * 8;  // waves that own a piece in the last round
+    constexpr int PX = ITEMS_X / 64;                  // pieces [0, PX) are x halo rows, the rest dy rows
+    int rel[NP], msk[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int it = tid + u * 512;
+        rel[u] = 0;
+        msk[u] = 64;
+        if (it < ITEMS_X) {
+            const int vox = it >> 3, c8 = (it & 7) ^ (((vox >> 1) & 3) << 1);      // 32-byte granule (c8 >> 1) ^ ((row >> 1) & 3)
+            const int hx = vox % HW;
+            const int t2 = vox / HW;
+            const int hy = t2 % HH, hz = t2 / HH;
+            const int dzr = hz + td - pd, hyr = hy - 1, hxr = hx - 1;
+            rel[u] = (((dzr * p.H + hyr) * p.W + hxr) * p.in_ld + ci0 + c8 * 8) * 2;
+            msk[u] = (dzr < 0 ? 1 : 0) | (dzr >= TD ? 2 : 0) | (hyr < 0 ? 4 : 0) | (hyr >= 8 ? 8 : 0) | (hxr < 0 ? 16 : 0) |
+                     (hxr >= TW ? 32 : 0) | ((vox >= NVOX || ci0 + c8 * 8 >= p.Ci) ? 64 : 0);
+        } else if (it < ITEMS) {
+            const int j = it - ITEMS_X;
+            const int v = j >> 3, c8 = (j & 7) ^ (((v >> 1) & 3) << 1);
+            const int wx = v & (TW - 1), hy = (v >> LOG2TW) & 7, dz = v >> (LOG2TW + 3);
+            rel[u] = (((dz * p.H + hy) * p.W + wx) * p.dy_ld + co0 + c8 * 8) * 2;
+            msk[u] = (co0 + c8 * 8 >= p.Co) ? 64 : 0;
+        }
+    }
+    // The fill travels by LDS-DMA issued from inline asm (M0 = LDS address of the wave's 1 KiB piece, saved / restored around it):
+    // hipcc then neither counts it nor guards LDS reads with vmcnt waits of its own — the tile protocol below does its own counted
+    // waits (rounds 1-4 used the builtin and three LDS objects with static roles so that hipcc's bookkeeping came out right; that
+    // form could not carry a fill that is spread over the MFMA groups).  The fill is UNCONDITIONAL (past the last tile it
+    // re-fetches the last one), so every wave always has the same number of pieces in flight.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const u32x4 rxs = {(unsigned)(unsigned long)p.x, (unsigned)((unsigned long)p.x >> 32) & 0xffffu, (unsigned)x_bytes, 0x00020000u};
+    const u32x4 rdys = {(unsigned)(unsigned long)p.dy, (unsigned)((unsigned long)p.dy >> 32) & 0xffffu, (unsigned)dy_bytes, 0x00020000u};
+    // tile coordinates of the fill advance by carries (p.groups in mixed radix), not by divisions
+    const int last_tile = group + ((p.n_spatial - 1 - group) / p.groups) * p.groups;      // last tile of this workgroup
+    int gw_, gh_, gd_, gb_;
+    {
+        int t_ = p.groups;
+        gw_ = t_ % p.nw; t_ /= p.nw;
+        gh_ = t_ % p.nh; t_ /= p.nh;
+        gd_ = t_ % p.nd;
+        gb_ = t_ / p.nd;
+    }
+    int f_t = group, f_twi, f_thi, f_tdi, f_b;
+    {
+        int q_ = group;
+        f_twi = q_ % p.nw; q_ /= p.nw;
+        f_thi = q_ % p.nh; q_ /= p.nh;
+        f_tdi = q_ % p.nd;
+        f_b = q_ / p.nd;
+    }
+    int fl_bx = 0, fl_bdy = 0, fl_flags = 0;
+    // coordinates of the tile the NEXT fill carries (then advance to the one after)
+#define HUPR_WG_FILL_OPEN()                                                                                         \
+    {                                                                                                               \
+        const int d0_ = f_tdi * TD, h0_ = f_thi * 8, w0_ = f_twi * TW;                                              \
+        const int org_ = ((f_b * p.D + d0_) * p.H + h0_) * p.W + w0_;                                               \
+        fl_bx = org_ * p.in_ld * 2;                                                                                 \
+        fl_bdy = org_ * p.dy_ld * 2;                                                                                \
+        fl_flags = 64 | (d0_ == 0 ? 1 : 0) | (d0_ + TD == p.D ? 2 : 0) | (h0_ == 0 ? 4 : 0) |                       \
+                   (h0_ + 8 == p.H ? 8 : 0) | (w0_ == 0 ? 16 : 0) | (w0_ + TW == p.W ? 32 : 0);                     \
+        if (f_t + p.groups <= last_tile) {                                                                          \
+            f_t += p.groups;                                                                                        \
+            f_twi += gw_;                                                                                           \
+            int c_ = f_twi >= p.nw ? 1 : 0;                                                                         \
+            f_twi -= c_ ? p.nw : 0;                                                                                 \
+            f_thi += gh_ + c_;                                                                                      \
+            c_ = f_thi >= p.nh ? 1 : 0;                                                                             \
+            f_thi -= c_ ? p.nh : 0;                                                                                 \
+            f_tdi += gd_ + c_;                                                                                      \
+            c_ = f_tdi >= p.nd ? 1 : 0;                                                                             \
+            f_tdi -= c_ ? p.nd : 0;                                                                                 \
+            f_b += gb_ + c_;                                                                                        \
+        }                                                                                                           \
+    }
+    // piece U_ (compile-time) of the open fill -> image BUF_
+#define HUPR_WG_PIECE(U_, BUF_)                                                                                     \
+    if ((U_) < NP - 1 || wave_u < NLAST) {                                                                          \
+        const int pc_ = (U_) * 8 + wave_u;                       /* wave-uniform */                                 \
+        const bool isx_ = pc_ < PX;                                                                                 \
+        const int voff_ = (msk[U_] & fl_flags) ? kOOB : (isx_ ? fl_bx : fl_bdy) + rel[U_];                          \
+        const unsigned dst_ = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)(BUF_) + pc_ * 1024; \
+        unsigned keep_;                                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
+                     "s_mov_b32 m0, %0"                                                                             \
+                     : "=&s"(keep_)                                                                                 \
+                     : "s"(dst_), "v"(voff_), "s"(isx_ ? rxs : rdys)                                                \
+                     : "memory");                                                                                   \
+    }
+
+    bf16x8 a[2][4], xq[2][3];
+    // K-steps KS0_, KS0_ + 1 (32 voxels each) of the staged tile IMG_ as 6 groups (K-step, ky) of three taps, fragments one group ahead.
+    //   3-D tile 2 x 8 x 8:  K-step kst = (depth slice kst >> 1, row half kst & 1);  2-D tile 1 x 8 x 16: (row half kst >> 1, column half kst & 1)
+#define HUPR_M16_LOAD(IMG_, SET_, KS0_, J_)                                                                         \
+    {                                                                                                               \
+        constexpr int kst_ = (KS0_) + (J_) / 3, ky_ = (J_) % 3;                                                     \
+        constexpr int xoff_ = IS3D ? ((kst_ >> 1) * HH * HW + (4 * (kst_ & 1) + ky_) * HW)                          \
+                                   : ((4 * (kst_ >> 1) + ky_) * HW + 8 * (kst_ & 1));                               \
+        constexpr int dyoff_ = IS3D ? 32 * kst_ : (64 * (kst_ >> 1) + 8 * (kst_ & 1));                              \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
+            xq[SET_][kx] = tr_pair((IMG_) + (xoff_ + kx) * kRowB, xa[(xoff_ + kx) & 7][0], xa[(xoff_ + kx) & 7][1]); \
+        if (ky_ == 0) {                                                                                             \
+            _Pragma("unroll") for (int cob = 0; cob < 4; ++cob)                                                     \
+                a[kst_ & 1][cob] = tr_pair((IMG_) + dyoff_ * kRowB, dyb[0][cob], dyb[1][cob]);                      \
+        }                                                                                                           \
+    }
+    // group J_ of NJ_: its twelve MFMAs (3 kx x 4 co blocks); under them the next group's fragments — of this tile (J_ + 1 < NJ_) or
+    // group 0 of the tile in NXT_ — and, in the first groups, the pieces of the open fill -> FREE_
+#define HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, J_, NJ_)                                                             \
+    {                                                                                                               \
+        if ((J_) + 1 < (NJ_)) { HUPR_M16_LOAD(IMG_, ((J_) + 1) & 1, KS0_, ((J_) + 1 < (NJ_) ? (J_) + 1 : 0)) }      \
+        else { HUPR_M16_LOAD(NXT_, 0, KS0_, 0) }                                                                    \
+        if ((J_) + 1 < (NJ_)) {                                                                                     \
+            _Pragma("unroll") for (int u_ = 0; u_ < NP; ++u_)                                                       \
+                if (u_ % ((NJ_) - 1) == (J_)) { HUPR_WG_PIECE(u_, FREE_) }                                          \
+        }                                                                                                           \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
+            _Pragma("unroll") for (int cob = 0; cob < 4; ++cob)                                                     \
+                acc[((J_) % 3) * 3 + kx][cob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+                    a[((KS0_) + (J_) / 3) & 1][cob], xq[(J_) & 1][kx], acc[((J_) % 3) * 3 + kx][cob], 0, 0, 0);     \
+        /* the next group's fragment reads spread between this group's MFMAs */                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
+        }                                                                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }
+    // all groups but the last of a tile half (6 groups)
+#define HUPR_M16_HEAD6(IMG_, NXT_, FREE_, KS0_)                                                                     \
+    HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 0, 6) HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 1, 6) HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 2, 6) \
+    HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 3, 6) HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 4, 6)
+
+    // Tile protocol (round 5; the SQ counters of the old one — barrier, whole fill, first fragments, then the MFMAs — showed the
+    // matrix pipe busy 53 % of the cycles: profiles/r04_wgrad_sq_pmc.txt).  Three images in a ring: CUR (tile st), NXT (tile
+    // st + 1, landing or landed), FREE (tile st - 1's, released by the previous barrier).  A wave multiplies all groups of tile st
+    // but the last, issuing one piece of the fill of tile st + 2 -> FREE under each of the first groups; then it waits until its
+    // own pieces of tile st + 1 have landed (all but the youngest NP or NP - 1 operations: those of tile st + 2) and its reads of
+    // CUR have returned, and takes the tile's ONE barrier holding the last group's fragments: it leaves the barrier with three
+    // MFMAs ready and reads the first fragments of tile st + 1 under them.  The loop starts two (virtual) tiles early with the
+    // multiply switched off.
+#define HUPR_WG_ITER(CUR_, NXT_, FREE_)                                                                             \
+    {                                                                                                               \
+        if (st >= p.n_spatial) break;                                                                               \
+        HUPR_WG_FILL_OPEN()                                                                                         \
+        if (st >= 0) {                                                                                              \
+            if (kq == 0) { HUPR_M16_HEAD6(CUR_, NXT_, FREE_, 0) } else { HUPR_M16_HEAD6(CUR_, NXT_, FREE_, 2) }     \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int u_ = 0; u_ < NP; ++u_) { HUPR_WG_PIECE(u_, FREE_) }                          \
+        }                                                                                                           \
+        if (wave_u < NLAST) __builtin_amdgcn_s_waitcnt(0x0070 | NP);                                                \
+        else __builtin_amdgcn_s_waitcnt(0x0070 | (NP - 1));                                                         \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("" ::: "memory");                                                                              \
+        if (st >= 0) {                                                                                              \
+            if (kq == 0) { HUPR_M16_STEP(CUR_, NXT_, FREE_, 0, 5, 6) } else { HUPR_M16_STEP(CUR_, NXT_, FREE_, 2, 5, 6) } \
+        } else if (st + p.groups >= 0) {                        /* the first real tile's first fragments */         \
+            if (kq == 0) { HUPR_M16_LOAD(NXT_, 0, 0, 0) } else { HUPR_M16_LOAD(NXT_, 0, 2, 0) }                     \
+        }                                                                                                           \
+        st += p.groups;                                                                                             \
+    }
+    static_assert(NP < 16 && NP <= 11, "piece count exceeds the counted wait / the groups of a tile");
+    if (group >= p.n_spatial) return;
+    int st = group - 2 * p.groups;
+    for (;;) {
+        HUPR_WG_ITER(bufB, bufC, bufA)
+        HUPR_WG_ITER(bufC, bufA, bufB)
+        HUPR_WG_ITER(bufA, bufB, bufC)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // the two re-fetches past the last tile must land before the LDS is released
+#undef HUPR_WG_ITER
+#undef HUPR_WG_FILL_OPEN
+#undef HUPR_WG_PIECE
+#undef HUPR_M16_LOAD
+#undef HUPR_M16_STEP
+#undef HUPR_M16_HEAD6
+
+    // Merge the two K halves through the (now dead) images: the kq = 1 waves park their accumulators, six taps and then three, the
+    // kq = 0 waves add them (both halves hold the same (co, ci) element in the same lane and register) — one partial tensor per
+    // workgroup.
+    {
+        const int t256 = tid & 255;
+        float* const red[3] = {reinterpret_cast<float*>(bufA), reinterpret_cast<float*>(bufB), reinterpret_cast<float*>(bufC)};
+        __syncthreads();
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if (round) __syncthreads();
+            if (kq == 1) {
+#pragma unroll
+                for (int tap = round * 6; tap < (round ? 9 : 6); ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((tap - round * 6) >> 1)][(((tap & 1) * 16 + r) << 8) + t256] = acc[tap][r >> 2][r & 3];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int tap = round * 6; tap < (round ? 9 : 6); ++tap)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tap][r >> 2][r & 3] += red[((tap - round * 6) >> 1)][(((tap & 1) * 16 + r) << 8) + t256];
+            }
+        }
+    }
+    if (kq != 0) return;
+    const int ci = ci0 + 16 * cb + s;
+    float* part = p.part + (long)group * p.Co * T * p.Ci;
+    if (ci < p.Ci) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int cob = 0; cob < 4; ++cob)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + 16 * cob + 4 * kq4 + i;
+                    if (co < p.Co) part[((long)co * T + td * 9 + tap) * p.Ci + ci] = acc[tap][cob][i];
+                }
+        }
+    }
+}
+
 }  // namespace hupr
 
 using namespace hupr;
@@ -567,6 +878,8 @@ extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
 
 static int g_wgrad_groups = 0;      // A/B aid (hupr_debug_wgrad_groups): > 0 forces the workgroup count per (kz, tile pair)
 extern "C" void hupr_debug_wgrad_groups(int g) { g_wgrad_groups = g; }      // 0 auto, > 0 forced, < 0 auto without XCD affinity
+static int g_wgrad_m16 = 1;         // A/B aid (hupr_debug_wgrad_m16): 0 = the 32 x 32 x 16 kernel (rounds 2-4)
+extern "C" void hupr_debug_wgrad_m16(int on) { g_wgrad_m16 = on; }
 static int g_wgrad_ci32 = 1;        // A/B aid (hupr_debug_wgrad_ci32): 0 = Ci <= 32 through the two-quadrant kernel as before, 2 = K quarters always
 extern "C" void hupr_debug_wgrad_ci32(int on) { g_wgrad_ci32 = on; }
 
@@ -615,7 +928,10 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
             // K quarters pay once a workgroup multiplies enough tiles to amortise the extra LDS merge (measured: 222 -> 160 us on
             // the 32 -> 64 layer-1 shape at 102 tiles per workgroup; +2-3 us on shapes with one or two tiles per workgroup)
             const bool ci32 = Ci <= 32 && (g_wgrad_ci32 == 2 || (g_wgrad_ci32 == 1 && a.n_spatial >= 16 * gw));
-            if (kd == 3) {
+            if (g_wgrad_m16 && !ci32) {                                  // the 16 x 16 x 32 form (round 5)
+                if (kd == 3) HUPR_LAUNCH((hupr_k_wgrad_halo_m16<true>), grid, dim3(512), 0, s, a);
+                else HUPR_LAUNCH((hupr_k_wgrad_halo_m16<false>), grid, dim3(512), 0, s, a);
+            } else if (kd == 3) {
                 if (ci32) HUPR_LAUNCH((hupr_k_wgrad_halo_glds<true, true>), grid, dim3(512), 0, s, a);
                 else HUPR_LAUNCH((hupr_k_wgrad_halo_glds<true, false>), grid, dim3(512), 0, s, a);
             } else {

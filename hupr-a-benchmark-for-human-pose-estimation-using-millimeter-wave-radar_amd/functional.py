@@ -1113,7 +1113,7 @@ class InterpFn(torch.autograd.Function):
         else:
             assert tuple(out.shape) == (B, Do, Ho, Wo, C) and out.dtype == x.dtype and _ld_view_ok(out, C), (out.shape, out.stride())
             y, ld = out, out.stride(3)
-        rt.check(_act("interp_linear_fwd", x)(rt.ptr(x), rt.ptr(y), B, Di, Hi, Wi, Do, Ho, Wo, C, C, ld, rt.stream()))
+        rt.check(_act("interp_linear_fwd", x)(rt.ptr(x), rt.ptr_ld(y), B, Di, Hi, Wi, Do, Ho, Wo, C, C, ld, rt.stream()))
         ctx.in_shape = (B, Di, Hi, Wi, C)
         ctx.size = size
         return y
@@ -1127,7 +1127,7 @@ class InterpFn(torch.autograd.Function):
         else:
             ld = dy.stride(3)
         dx = torch.empty(ctx.in_shape, dtype=dy.dtype, device=dy.device)
-        rt.check(_act("interp_linear_bwd", dy)(rt.ptr(dy), rt.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, C, ld, rt.stream()))
+        rt.check(_act("interp_linear_bwd", dy)(rt.ptr_ld(dy), rt.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, C, ld, rt.stream()))
         return dx, None
 
 

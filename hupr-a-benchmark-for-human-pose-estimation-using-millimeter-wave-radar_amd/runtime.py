@@ -68,6 +68,7 @@ SIGNATURES = {
     "hupr_debug_halo_trace": (None, [c_void_p]),
     "hupr_debug_wgrad_groups": (None, [c_int]),
     "hupr_debug_wgrad_ci32": (None, [c_int]),
+    "hupr_debug_wgrad_m16": (None, [c_int]),
     "hupr_debug_gemm_small_tiles": (None, [c_int]),
     "hupr_conv3x3_halo_supported": (c_int, [c_int] * 10),
     "hupr_conv3x3_halo_bf16": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
@@ -242,4 +243,12 @@ def ptr(t):
         raise HuprError("tensor is on %s; the HIP path needs a GPU tensor (no CPU fallback)" % t.device)
     if not t.is_contiguous():
         raise HuprError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def ptr_ld(t):
+    """Device pointer of a GPU tensor that is a channel slice of a wider contiguous channels-last tensor (the caller passes its row
+    stride as the kernel's leading dimension and has checked the layout: functional._ld_view_ok)."""
+    if not t.is_cuda:
+        raise HuprError("tensor is on %s; the HIP path needs a GPU tensor (no CPU fallback)" % t.device)
     return t.data_ptr()

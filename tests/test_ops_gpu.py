@@ -899,6 +899,38 @@ def test_temporal_merge_bf16_activations(B, G, H, W, C, bf16_math):
     close(wg.grad, w32.grad, 2e-6, "wgrad vs generic")
 
 
+@pytest.mark.parametrize("shape", [(32, 64, 64, 8, 64, 64, 3), (3, 64, 128, 4, 16, 24, 3), (5, 128, 256, 2, 16, 16, 3), (2, 320, 64, 1, 32, 32, 1),
+                                   (7, 128, 64, 1, 16, 48, 1), (1, 64, 64, 2, 8, 8, 3), (4, 96, 72, 4, 8, 16, 3)])
+def test_wgrad_halo_on_16x16x32_matches_the_32x32x16_kernel_and_fp64(shape, bf16_math):
+    """The LDS-DMA weight gradient on v_mfma_f32_16x16x32_bf16 (round 5: new lane ownership, two-bit row swizzle, wave tile 64 co x 16
+    ci) against the rounds-2-4 kernel on the same bf16 tensors — the same bf16 products, another fp32 summation order — and against
+    fp64; level-1 shape at the bench batch, several co / ci tiles, a single tile per workgroup, ragged channel counts (96 -> 72), 2-D."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    B, Ci, Co, D, H, W, kd = shape
+    x = rnd(B, D, H, W, Ci, seed=500).cuda().bfloat16()
+    dy = rnd(B, D, H, W, Co, seed=501).cuda().bfloat16()
+    ws = torch.empty(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd), dtype=torch.uint8, device="cuda")
+    out = {}
+    try:
+        for m16 in (1, 0):
+            L.hupr_debug_wgrad_m16(m16)
+            dw = torch.full((Co, Ci, kd, 3, 3), float("nan"), device="cuda")
+            rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, kd, rt.ptr(ws), ws.numel(),
+                                                       rt.stream()))
+            out[m16] = dw
+    finally:
+        L.hupr_debug_wgrad_m16(1)
+    assert torch.isfinite(out[1]).all()
+    close(out[1], out[0], 2e-5, "16x16x32 vs 32x32x16 weight gradient")
+    if B * D * H * W <= 40000:                                   # fp64 reference on the host for the smaller cases
+        xr = x.double().cpu().permute(0, 4, 1, 2, 3)
+        wr = torch.zeros(Co, Ci, kd, 3, 3, dtype=torch.float64, requires_grad=True)
+        yr = F.conv3d(xr, wr, None, 1, (kd // 2, 1, 1))
+        yr.backward(dy.double().cpu().permute(0, 4, 1, 2, 3))
+        close(out[1], wr.grad, 1e-5, "16x16x32 weight gradient vs fp64")
+
+
 def test_pack_cache_table_refresh_matches_single_packs(bf16_math):
     """The packed-weight cache refreshes every registered weight with ONE table-driven launch (32x32xtaps LDS tiles for
     bf16 halo weights, element-wise blocks for the rest); both layouts of every entry must equal the one-weight pack
