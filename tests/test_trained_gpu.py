@@ -294,29 +294,31 @@ def test_bf16_gates_on_further_independent_fits(which):
     assert ap["f32"] >= 0.3 and ap["bf16"] >= ap["f32"] - 0.002 and abs(ap["bf16"] - ap["f32"]) <= 0.005
 
 
-def test_bf16_path_against_the_oracle_on_128_scenes():
+def test_bf16_path_against_the_oracle_on_96_scenes():
     """the 7 168-joint gates compare bf16 with the fp32 HIP path; this leg compares it with the ORACLE (the
-    reference's arithmetic on the host) on 128 held-out scenes = 1 792 joints per head, with the same tie rule; the fp32 path with
-    it on the same scenes (north_star: 1e-3 max-abs, identical arg-max up to ties).  At n = 1 792 a 99 % rate has a standard deviation
-    of 0.24 %, so the assertion is the three-sigma lower bound of the gated rate (98.3 %), as on the other sub-7 168 sets."""
+    reference's arithmetic on the host) on 96 held-out scenes = 1 344 joints per head (rounds 3-4: 128; the oracle forward is 0.9 s per
+    scene on the GPU box's host and the suite has a time budget), with the same tie rule; the fp32 path with
+    it on the same scenes (north_star: 1e-3 max-abs, identical arg-max up to ties).  At n = 1 344 a 99 % rate has a standard deviation
+    of 0.27 %, so the assertion is the three-sigma lower bound of the gated rate (98.2 %), as on the other sub-7 168 sets."""
     import time
+    NS = 96
     p = _pose_trained()
     pf = p["fit"]
-    hn, vn, _ = synth.pose_scenes(128, 3, _ZD)
+    hn, vn, _ = synth.pose_scenes(NS, 3, _ZD)
     h, v = torch.from_numpy(hn).cuda(), torch.from_numpy(vn).cuda()
     t0 = time.time()
     o1, o2 = [], []
-    for i in range(0, 128, 16):
+    for i in range(0, NS, 16):
         a, b = _oracle_eval(p["sd"], h[i:i + 16], v[i:i + 16])
         o1.append(a)
         o2.append(b)
-    o = (torch.cat(o1).reshape(128, 14, -1), torch.cat(o2).reshape(128, 14, -1))
-    print("oracle forward on 128 scenes: %.0f s on %d threads" % (time.time() - t0, torch.get_num_threads()))
+    o = (torch.cat(o1).reshape(NS, 14, -1), torch.cat(o2).reshape(NS, 14, -1))
+    print("oracle forward on %d scenes: %.0f s on %d threads" % (NS, time.time() - t0, torch.get_num_threads()))
     res = {}
     for math in ("f32", "bf16"):
-        outs = [pf.evaluate(p["sd"], p["cfg"], h[i:i + 32], v[i:i + 32], math) for i in range(0, 128, 32)]
-        res[math] = tuple(torch.cat([x[hd] for x in outs]).reshape(128, 14, -1).cpu() for hd in (0, 1))
-    n = 128 * 14
+        outs = [pf.evaluate(p["sd"], p["cfg"], h[i:i + 32], v[i:i + 32], math) for i in range(0, NS, 32)]
+        res[math] = tuple(torch.cat([x[hd] for x in outs]).reshape(NS, 14, -1).cpu() for hd in (0, 1))
+    n = NS * 14
     for math in ("f32", "bf16"):
         for hd in (0, 1):
             same, tie, near = _agree(res[math][hd], o[hd])
