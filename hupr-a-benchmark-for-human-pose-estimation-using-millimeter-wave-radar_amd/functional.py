@@ -1309,8 +1309,17 @@ def attn_fp8_ok(v):
     return ATTN_FP8 is True and _st.math == "bf16" and not torch.is_grad_enabled() and v.shape[-1] == 64 and v.shape[1] % 128 == 0
 
 
-def attn_mx8_ok(N, C):
-    return ATTN_FP8 == "mx" and C == 64 and N % 128 == 0
+# The block-scaled forward inside a TRAINING step is a second opt-in (HUPR_ATTN_FP8_TRAIN=1; bench.py --attn fp8 sets it): the bf16
+# backward kernels recompute P = exp(S_bf16 - lse) with the log-sum-exp the fp8 forward stored, so the rows of that P sum to
+# exp(lse_bf16 - lse_fp8), not 1 — a per-query scale error of the size of the fp8 quantisation noise in dS / dV (ADVICE r4 item 3;
+# bounded by tests/test_ops_gpu.py::test_mscsa_level_with_mx8_forward_trains_on_the_bf16_backward).  Without it "mx" is an
+# inference (no_grad) mode.
+ATTN_FP8_TRAIN = os.environ.get("HUPR_ATTN_FP8_TRAIN", "0") == "1"
+
+
+def attn_mx8_ok(N, C, no_grad):
+    """``no_grad``: the caller runs under torch.no_grad() (inside an autograd.Function's forward grad mode is always off)."""
+    return ATTN_FP8 == "mx" and C == 64 and N % 128 == 0 and (ATTN_FP8_TRAIN or no_grad)
 
 
 def attention_mx8(k, q, v, residual):
@@ -1482,7 +1491,7 @@ class MSCSALevelFn(torch.autograd.Function):
         infer = bool(int(cat_bf16) & 2)                  # bit 1: the caller runs under no_grad (grad mode is always off in here)
         cat_bf16 = bool(int(cat_bf16) & 1)
         # config 5, block-scaled form: quantises the plain projections itself
-        mx8 = flash and attn_mx8_ok(N, C)
+        mx8 = flash and attn_mx8_ok(N, C, infer)
         # QS: the query projections leave the GEMM as log2(e) Q (rounded to bf16 once, like every projection), the attention kernels
         # take the exponent of 2 straight from the matrix pipe (csrc/attention_bf16.hip, kDeferBits)
         qscaled = flash and QS_ATTN and not mx8      # (not `qs`: the SPEC loops below bind that name to the query source map)

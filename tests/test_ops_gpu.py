@@ -1380,9 +1380,10 @@ def test_mscsa_level_with_mx8_forward_trains_on_the_bf16_backward(bf16_math):
     re = torch.randn(B, 1, H, W, C, device="cuda") * 0.5
     ws = [(torch.randn(C, C, 1, 1, device="cuda") * C ** -0.5) for _ in range(8)]
     g = torch.randn(B, 1, H, W, 4 * C, device="cuda").bfloat16()
-    saved = F_.ATTN_FP8
+    saved = (F_.ATTN_FP8, F_.ATTN_FP8_TRAIN)
     res = {}
     try:
+        F_.ATTN_FP8_TRAIN = True              # the training forward is a second opt-in (functional.ATTN_FP8_TRAIN)
         for mode in (False, "mx"):
             F_.ATTN_FP8 = mode
             a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
@@ -1390,8 +1391,12 @@ def test_mscsa_level_with_mx8_forward_trains_on_the_bf16_backward(bf16_math):
             (cat,) = F_.MSCSALevelFn.apply(a, e, 1, *w)
             cat.backward(g)
             res[mode] = (cat.float().detach(), a.grad.clone(), e.grad.clone(), w[0].grad.clone(), w[5].grad.clone())
+        F_.ATTN_FP8_TRAIN = False             # without it a training forward stays on the bf16 kernels: bit-identical to mode False
+        a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
+        (cat,) = F_.MSCSALevelFn.apply(a, e, 1, *[t.clone().requires_grad_(True) for t in ws])
+        assert torch.equal(cat.float(), res[False][0])
     finally:
-        F_.ATTN_FP8 = saved
+        F_.ATTN_FP8, F_.ATTN_FP8_TRAIN = saved
     names = ("outputs", "d ra", "d re", "d w[0]", "d w[5]")
     for nme, x, y in zip(names, res["mx"], res[False]):
         rel = ((x - y).norm() / y.norm()).item()
