@@ -193,26 +193,28 @@ def count_device_activities(step):
         from torch.autograd import DeviceType
         step()
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
             step()
             torch.cuda.synchronize()
         ours = other = copies = 0
         names = {}
-        for e in prof.events():
+        for e in prof.key_averages():
             if e.device_type != DeviceType.CUDA:
                 continue
-            n = e.name
+            n = e.key
             if n.startswith("Memcpy") or n.startswith("Memset"):
-                copies += 1
+                copies += e.count
             elif "hupr" in n:
-                ours += 1
+                ours += e.count
             else:
-                other += 1
+                other += e.count
                 key = n.split("<")[0][:60]
-                names[key] = names.get(key, 0) + 1
+                names[key] = names.get(key, 0) + e.count
+        aten = {e.key: e.count for e in prof.key_averages() if e.key.startswith("aten::") and e.device_time_total > 0 and e.device_type != DeviceType.CUDA}
         top = sorted(names.items(), key=lambda kv: -kv[1])[:6]
         return {"library_kernels": ours, "other_kernels": other, "memcpy_memset": copies, "total": ours + other + copies,
-                "other_kernels_top": {k: v for k, v in top}, "how": "torch.profiler (kineto), one step after the timed region"}
+                "other_kernels_top": {k: v for k, v in top}, "aten_ops_with_device_time": aten,
+                "how": "torch.profiler (kineto), one step after the timed region"}
     except Exception as exc:      # noqa: BLE001 — a census, never a reason to lose the bench line
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
 
@@ -277,6 +279,9 @@ def main():
     ap.add_argument("--no-c2", action="store_true", help="skip the `c2` object (eval forward B = 1 latency, N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-launch-census", action="store_true", help="skip the one profiled step that counts the step's device activities")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="skip the FFT / attention kernel probes and the launch census after the timed region (a rocprofv3 trace of the "
+                         "command then holds the training steps only: dispatches / (warmup + steps) = launches per step)")
     ap.add_argument("--no-parity-path", action="store_true", help="skip the short fp32 parity-path measurement (N = 1 only)")
     ap.add_argument("--two-streams", action="store_true",
                     help="single-GPU runs: vertical branch on a side HIP stream (functional.TWO_STREAMS, the library default; "
@@ -496,10 +501,10 @@ def main():
         barrier()
 
     launch_census = None
-    if rank == 0 and not args.graph and not args.no_launch_census:
+    if rank == 0 and not args.graph and not args.no_launch_census and not args.no_probes:
         launch_census = count_device_activities(one_step)
     fft_roof = parity = None
-    if rank == 0:
+    if rank == 0 and not args.no_probes:
         # FFT chain on its own (HBM-bound): the step's 2 x B*G sensor-frames, HIP events on the launch stream.  Primary entry =
         # the variant the timed step ran (a1 + a2 + the elevation mean of a3 fused: 1 048 576 B algorithmic per sensor-frame);
         # `loader_variant` = the reference-shaped hand-over (a1 + a2: 2 883 584 B per sensor-frame) for comparison.
@@ -570,7 +575,7 @@ def main():
         fft_roof = dict(fused_mean if fused_step else loader)
         fft_roof["loader_variant" if fused_step else "fused_mean_variant"] = loader if fused_step else fused_mean
     attn_roof = None
-    if rank == 0 and args.dtype == "bf16":
+    if rank == 0 and args.dtype == "bf16" and not args.no_probes:
         # MSCSA level-1 attention (C = 64, N = 4096: 88 % of the attention flops) at this batch, kernels alone through the C ABI:
         # forward 4 N^2 C flops per sample, backward (prep + dQ + dK/dV) 10 N^2 C algorithmic; HIP events on the launch stream
         L_, rt_ = F_.rt.lib(), F_.rt
