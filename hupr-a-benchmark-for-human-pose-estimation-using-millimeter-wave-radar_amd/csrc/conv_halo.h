@@ -50,6 +50,7 @@ __device__ __forceinline__ void halo_store_partial(const HaloArgs& p, const f32x
 // 256-voxel persistent variant; returns false when the geometry is not supported
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf);
+bool conv_halo256_stats_ok(const HaloArgs& a, int Bn);                         // fused BatchNorm statistics available for this launch?
 void launch_conv_halo256m(const HaloArgs& a, hipStream_t s);                  // the 256-voxel kernel on v_mfma_f32_16x16x32_bf16 (conv_halo256m_bf16.hip)
 void set_halo_m16(int on);
 bool launch_conv_halo512(HaloArgs a, int Bn, bool abf, hipStream_t s);      // 512-voxel register-blocked variant (conv_halo512_bf16.hip)

@@ -508,10 +508,33 @@ bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
     return true;
 }
 
+// Would a launch with fused BatchNorm statistics (a.stats) land on a kernel that has them?  Co = 64: either 256-voxel kernel on the
+// 4 x 8 x 8 tile; Co = 128 / 256 (2 / 4 output tiles) or the 2 x 8 x 16 tile: the 16 x 16 x 32 kernel (register-resident sums, round 5).
+bool conv_halo256_stats_ok(const HaloArgs& a, int Bn) {
+    if (a.kd != 3 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
+    const int n = a.Co / 64;
+    if ((long)Bn * a.D * a.H * a.W * a.in_ld * 2 >= 0x7ffffff0L) return false;
+    const bool m16 = g_halo_m16 && a.ablate == 0 && a.trace == nullptr;
+    long tiles;
+    if (a.D % 4 == 0) {
+        if (!conv_halo256_supported(a, Bn, true)) return false;
+        if (n == 1) return true;                                   // either kernel, its one-tile form
+        if (!m16) return false;
+        tiles = (long)Bn * (a.D / 4) * (a.H / 8) * (a.W / 8) * n;
+    } else {
+        if (!(m16 && g_halo_m16_td2) || a.D % 2 != 0 || a.H % 8 != 0 || a.W % 16 != 0) return false;
+        tiles = (long)Bn * (a.D / 2) * (a.H / 8) * (a.W / 16) * n;
+        return tiles == 256;                                       // this tile: exactly one tile per workgroup (encoder level 3 at B = 32)
+    }
+    // a workgroup's run of consecutive tiles must touch at most two distinct output tiles (the register-resident sums)
+    const long per_wg = (tiles + kHalo256Grid - 1) / kHalo256Grid;
+    return n <= 2 || per_wg == 1;
+}
+
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     // measured (scripts/halo_ablation.py): faster on the 3-D encoder layers, neutral to slower on the 2-D decoder maps
     if (abf && g_halo_m16 && g_halo_m16_td2 && a.kd == 3 && a.D % 4 != 0 && a.D % 2 == 0 && a.H % 8 == 0 && a.W % 16 == 0 && a.Ci % 64 == 0 &&
-        a.Co % 64 == 0 && a.ablate == 0 && a.trace == nullptr && !a.stats) {
+        a.Co % 64 == 0 && a.ablate == 0 && a.trace == nullptr) {
         // depth not a multiple of four (encoder level 3: D = 2): the 2 x 8 x 16 tile of the 16 x 16 x 32 kernel
         a.TD = 2;
         a.log2TW = 4;

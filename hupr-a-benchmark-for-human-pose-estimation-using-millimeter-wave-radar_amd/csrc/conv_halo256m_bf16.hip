@@ -22,10 +22,15 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 
 // Tile 4 x 8 x 8 (TD = 4, TW = 8: the encoder levels with D % 4 == 0) or 2 x 8 x 16 (TD = 2, TW = 16: level 3, D = 2 — before this
 // variant those layers ran on the 128-voxel kernel at 935 TF/s); a wave owns depth slice wm (TD = 4) or (depth slice wm >> 1, column
-// half wm & 1) (TD = 2): 8 x 8 voxels either way.  The statistics slots exist for the 4 x 8 x 8 tile only (level 1, Co = 64).
+// half wm & 1) (TD = 2): 8 x 8 voxels either way.
 // 1 x 16 x 16 with KD = 1 (the decoder's 1 x 3 x 3 convolutions on 64 x 64 and 32 x 32 maps, before on the 128-voxel kernel at
 // 590-940 TF/s): three stages of three taps, a wave owns one 8 x 8 quadrant.
-template <int TD, int TH, int TW, int KD>
+// NCOT > 0: fused BatchNorm statistics; NCOT = how many DISTINCT 64-wide output-channel tiles one workgroup's run of consecutive
+// tiles touches = min(tiles per workgroup, output tiles of the layer): 1 or 2 (round 5: registers instead of the LDS slots of round 4,
+// which existed for layers of ONE output tile on the 4 x 8 x 8 kernel only — encoder level 1; levels 2 and 3, Co = 128 / 256, ran a
+// statistics pass over the stored tensor per BatchNorm: 24 launches per step).  Level 2 at the bench batch: 4 tiles per workgroup,
+// alternating between its 2 output tiles; level 3: one tile per workgroup.
+template <int TD, int TH, int TW, int KD, int NCOT = 0>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
     constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
@@ -39,11 +44,18 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     static_assert(NH <= 6 * NSTAGE - 1 && NH <= 17, "halo items must all be issued in front of the item's last barrier (and within three stages)");
     __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];
-    // fused BatchNorm statistics: per lane the running sums of its eight channels over its voxels (bf16-ROUNDED outputs):
-    // [wave][lane][cg * 4 + r sums, 8 + cg * 4 + r sums of squares]; reduced over the sixteen voxel lanes and the four depth-slice
-    // waves once, after the tile loop, in double
-    constexpr bool STATS = TD == 4 && KD == 3;                 // the statistics slots exist for the 4 x 8 x 8 tile only
-    __shared__ __attribute__((aligned(16))) float St[STATS ? 8 : 1][64][16];
+    // fused BatchNorm statistics: per lane and output-channel tile the running sums of its eight channels over its voxels (bf16-ROUNDED
+    // outputs) in REGISTERS — ssum / ssq [tile][cg][r] — reduced over the sixteen voxel lanes and the four voxel-block waves once,
+    // after the tile loop, in double (through the halo image's LDS, dead by then)
+    constexpr bool STATS = NCOT > 0 && KD == 3;
+    constexpr bool SINGLE = STATS && TD == 2;                  // the 2 x 8 x 16 tile carries statistics only for ONE tile per workgroup
+    f32x4c ssum[STATS ? NCOT : 1][2], ssq[STATS ? NCOT : 1][2];
+    if constexpr (!SINGLE) {                                   // (SINGLE: assigned once, in the tile's epilogue — not live across the tap loop)
+#pragma unroll
+        for (int ct = 0; ct < (STATS ? NCOT : 1); ++ct)
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) { ssum[ct][cg] = (f32x4c){0.f, 0.f, 0.f, 0.f}; ssq[ct][cg] = (f32x4c){0.f, 0.f, 0.f, 0.f}; }
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -107,7 +119,6 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     const int wg_rank = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // an eighth of the tile sequence per XCD
     const int t_begin = wg_rank * per_wg, t_end = min(n_tiles, t_begin + per_wg);
     if (STATS && p.stats) {
-        for (int i = tid; i < 8 * 64 * 16; i += 512) (&St[0][0][0])[i] = 0.f;      // published by the prologue barrier
         if (t_begin >= t_end) {
             for (int c = tid; c < 2 * p.Co; c += 512) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
         }
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         cur.ch = 0;
     }
     const int n_items = (t_end - t_begin) * n_chunks;
+    const int cot0 = cur.cot;                                  // first output tile of this workgroup's run (statistics)
 
     // ---- fragment addresses ----------------------------------------------------------------------------------------
     // weights: row n = 32 wn + 16 cg + idx of a tap's [64][64] image, chunk 4 kk + kq at position chunk ^ ((n >> 1) & 7)
@@ -301,20 +313,39 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
             }
             if (STATS && p.stats) {
                 // this lane's eight channels over its four voxels of the tile, rounded exactly as they are stored
-                f32x4n* slot = reinterpret_cast<f32x4n*>(&St[wave][lane][0]);
+                int li = cur.cot - cot0;                           // which of the workgroup's (at most NCOT) output tiles: workgroup-uniform
+                li += li < 0 ? p.n_co_tiles : 0;
+                if constexpr (SINGLE) {
+                    // one tile per workgroup (the launcher guarantees it): the sums START here — nothing is carried through the tap loop
 #pragma unroll
-                for (int cg = 0; cg < 2; ++cg) {
-                    f32x4n sv = {0.f, 0.f, 0.f, 0.f}, qv = sv;
+                    for (int cg = 0; cg < 2; ++cg) {
+                        f32x4c sv = {0.f, 0.f, 0.f, 0.f}, qv = sv;
 #pragma unroll
-                    for (int vg = 0; vg < 4; ++vg)
+                        for (int vg = 0; vg < 4; ++vg)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float a = (float)(__bf16)c[vg][cg][r];
-                            sv[r] += a;
-                            qv[r] = fmaf(a, a, qv[r]);
+                            for (int r = 0; r < 4; ++r) {
+                                const float a = (float)(__bf16)c[vg][cg][r];
+                                sv[r] += a;
+                                qv[r] = fmaf(a, a, qv[r]);
+                            }
+                        ssum[0][cg] = sv;
+                        ssq[0][cg] = qv;
+                    }
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < NCOT; ++ct)
+                        if (NCOT == 1 || li == ct) {
+#pragma unroll
+                            for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                                for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float a = (float)(__bf16)c[vg][cg][r];
+                                        ssum[ct][cg][r] += a;
+                                        ssq[ct][cg][r] = fmaf(a, a, ssq[ct][cg][r]);
+                                    }
                         }
-                    slot[cg] += sv;
-                    slot[2 + cg] += qv;
                 }
             }
         }
@@ -325,18 +356,34 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         cur = nxt;
     }
     if (STATS && p.stats) {
-        // channel ch = 32 wn + 16 cg + 4 kq + r collects, in a fixed order and as doubles, the sixteen voxel lanes of its (kq) row
-        // group in each of the four depth-slice waves
-        __syncthreads();
-        if (tid < 2 * BN) {
+        // channel ch = 32 wn + 16 cg + 4 kq + r of tile ct collects, in a fixed order and as doubles, the sixteen voxel lanes of its (kq)
+        // row group in each of the four voxel-block waves; tiles this workgroup never multiplied contribute their zeros
+        static_assert(NVOX * LDK * 2 >= 8 * 64 * 16 * 4, "the halo image must hold the reduction scratch");
+        float (*St)[64][16] = reinterpret_cast<float (*)[64][16]>(Hs);
+#pragma unroll
+        for (int ct = 0; ct < NCOT; ++ct) {
+            __syncthreads();
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                *reinterpret_cast<f32x4c*>(&St[wave][lane][4 * cg]) = ssum[ct][cg];
+                *reinterpret_cast<f32x4c*>(&St[wave][lane][8 + 4 * cg]) = ssq[ct][cg];
+            }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int k = tid >> 6, ch = tid & 63;
+                const int wn_ = ch >> 5, cg = (ch >> 4) & 1, kq_ = (ch >> 2) & 3, r = ch & 3;
+                double t = 0.0;
+#pragma unroll
+                for (int wm_ = 0; wm_ < 4; ++wm_)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) t += (double)St[2 * wm_ + wn_][16 * kq_ + i][8 * k + 4 * cg + r];
+                p.stats[(long)blockIdx.x * 2 * p.Co + k * p.Co + 64 * ((cot0 + ct) % p.n_co_tiles) + ch] = t;
+            }
+        }
+        if (tid < 2 * BN) {                                       // output tiles this workgroup never touched: zeros (same writer per entry)
             const int k = tid >> 6, ch = tid & 63;
-            const int wn_ = ch >> 5, cg = (ch >> 4) & 1, kq_ = (ch >> 2) & 3, r = ch & 3;
-            double t = 0.0;
-#pragma unroll
-            for (int wm_ = 0; wm_ < 4; ++wm_)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) t += (double)St[2 * wm_ + wn_][16 * kq_ + i][8 * k + 4 * cg + r];
-            p.stats[(long)blockIdx.x * 2 * p.Co + k * p.Co + ch] = t;
+            for (int ct = NCOT; ct < p.n_co_tiles; ++ct)
+                p.stats[(long)blockIdx.x * 2 * p.Co + k * p.Co + 64 * ((cot0 + ct) % p.n_co_tiles) + ch] = 0.0;
         }
     }
 #undef HUPR_W_DMA
@@ -349,9 +396,20 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 }
 
 void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
-    if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), dim3(kHalo256Grid), dim3(512), 0, s, a);
-    else if (a.TD == 4) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
-    else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<2, 8, 16, 3>), dim3(kHalo256Grid), dim3(512), 0, s, a);
+    const dim3 grid(kHalo256Grid), wg(512);
+    if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), grid, wg, 0, s, a);
+    else if (a.stats) {                       // fused BatchNorm statistics: 1 or 2 distinct output tiles per workgroup (conv_halo256_stats_ok)
+        const long tiles = (long)a.Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
+        const long per_wg = (tiles + kHalo256Grid - 1) / kHalo256Grid;
+        const bool one = per_wg == 1 || a.n_co_tiles == 1;
+        if (a.TD == 4) {
+            if (one) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 1>), grid, wg, 0, s, a);
+            else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 2>), grid, wg, 0, s, a);
+        } else {
+            HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<2, 8, 16, 3, 1>), grid, wg, 0, s, a);      // per_wg == 1 (conv_halo256_stats_ok)
+        }
+    } else if (a.TD == 4) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3>), grid, wg, 0, s, a);
+    else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<2, 8, 16, 3>), grid, wg, 0, s, a);
 }
 
 }  // namespace hupr

@@ -461,7 +461,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     a.part = nullptr;
     a.units_per_slice = 0;
     if (stats) {
-        HUPR_REQUIRE(abf && !bias && !res && Co == 64 && conv_halo256_supported(a, Bn, abf),
+        HUPR_REQUIRE(abf && !bias && !res && conv_halo256_stats_ok(a, Bn),
                      "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);
         HUPR_REQUIRE(launch_conv_halo256(a, Bn, abf, as_stream(stream)), "%s: 256-voxel kernel refused the launch", who);
         HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16<stats>");
@@ -577,7 +577,8 @@ extern "C" int hupr_conv3x3_halo_bf16act_partial(const void* x, const void* wp_b
 extern "C" int hupr_conv3x3_halo_stats_supported(int Bn, int D, int H, int W, int Ci, int Co, int kd) {
     HaloArgs a{};
     a.kd = kd; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.in_ld = Ci;
-    return (Bn > 0 && Co == 64 && conv_halo256_supported(a, Bn, true)) ? 1 : 0;      // one co tile: the lane -> channel map is fixed
+    a.ablate = g_halo_ablate; a.trace = g_halo_trace;
+    return (Bn > 0 && conv_halo256_stats_ok(a, Bn)) ? 1 : 0;
 }
 extern "C" int hupr_conv3x3_halo_stats_rows(void) { return kHalo256Grid; }
 extern "C" int hupr_conv3x3_halo_bf16act_stats(const void* x, const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci,

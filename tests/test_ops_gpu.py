@@ -984,7 +984,12 @@ def test_mscsa_level_bf16_concatenated_output(C, H, bf16_math):
         assert torch.equal(x, y), "gradient %d differs" % i
 
 
-@pytest.mark.parametrize("Ci,Co,shape", [(64, 64, (8, 8, 32, 32)), (64, 64, (6, 8, 64, 64)), (32, 64, (4, 8, 64, 64))])
+@pytest.mark.parametrize("Ci,Co,shape", [(64, 64, (8, 8, 32, 32)), (64, 64, (6, 8, 64, 64)), (32, 64, (4, 8, 64, 64)),
+                                         # round 5: several output tiles / the 2 x 8 x 16 tile (register-resident sums).  Level 2 at the bench
+                                         # batch (4 tiles per workgroup, alternating between two output tiles), with one tile per workgroup,
+                                         # with a ragged tile count; level 3 (Co = 256, one tile per workgroup), its first block (128 -> 256)
+                                         (128, 128, (32, 4, 32, 32)), (64, 128, (8, 4, 32, 32)), (128, 128, (12, 4, 32, 32)),
+                                         (256, 256, (32, 2, 16, 16)), (128, 256, (32, 2, 16, 16))])
 def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
     """The 256-voxel convolution kernel leaves the column sums of its (bf16-rounded) output for the BatchNorm that follows
     (functional.conv(..., stats=True) -> BNActFn): mean / variance / running statistics and the normalised output must
@@ -998,7 +1003,9 @@ def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
         assert not F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, Co, 3)
         return
     assert F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, Co, 3)
-    assert not F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, 128, 3)      # one co tile only (lane -> channel map)
+    # at most two distinct output tiles per workgroup: 256 output channels only with one tile per workgroup
+    assert not F_.rt.lib().hupr_conv3x3_halo_stats_supported(64, 4, 32, 32, Ci, 256, 3)
+    assert not F_.rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, 192, 3)
     res = []
     saved = F_.CONV_STATS
     F_.CONV_STATS = True                     # (the library default since round 3)
