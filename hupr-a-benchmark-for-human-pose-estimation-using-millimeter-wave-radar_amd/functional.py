@@ -1633,16 +1633,23 @@ class MSCSALevelFn(torch.autograd.Function):
         for i in range(2):
             if not any(ctx.needs_input_grad[3 + 4 * i + j] for j in range(4)):
                 continue
-            dWc = torch.empty((4 * C, C), dtype=f32, device=dev)
+            ws4 = weights[4 * i:4 * i + 4]
+            got = [_pgrad(w) if ctx.needs_input_grad[3 + 4 * i + j] else (None, False) for j, w in enumerate(ws4)]
+            # the four gradient slots adjacent in their flat bucket, in this order (HuPRNet.gradient_groups -> GradientBuckets): the
+            # GEMM writes them in place — no (4C, C) temporary, no copy launch
+            inplace = all(g is not None and d for g, d in got) and all(
+                got[j][0].is_contiguous() and got[j][0].data_ptr() == got[0][0].data_ptr() + j * C * C * 4 for j in range(4))
+            dWc = None if inplace else torch.empty((4 * C, C), dtype=f32, device=dev)
             ws = workspace(L.hupr_conv_wgrad_ws_bytes(B, 1, H, W, C, 4 * C, 1, 1, 1), dev)
-            rt.check(L.hupr_conv_wgrad_bf16(rt.ptr(maps[i]), rt.ptr(dY[i]), rt.ptr(dWc), B, 1, H, W, C, C, 1, H, W, 4 * C, 4 * C,
-                                            1, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
+            rt.check(L.hupr_conv_wgrad_bf16(rt.ptr(maps[i]), rt.ptr(dY[i]), got[0][0].data_ptr() if inplace else rt.ptr(dWc), B, 1, H, W, C, C,
+                                            1, H, W, 4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.ptr(ws), ws.numel(), rt.stream()))
             for j in range(4):
-                w = weights[4 * i + j]
+                w = ws4[j]
                 if ctx.needs_input_grad[3 + 4 * i + j]:
-                    g, direct = _pgrad(w)
-                    dsts.append(g)
-                    srcs.append(dWc[j * C:(j + 1) * C].view_as(w))
+                    g, direct = got[j]
+                    if not inplace:
+                        dsts.append(g)
+                        srcs.append(dWc[j * C:(j + 1) * C].view_as(w))
                     landed.append((4 * i + j, w, g, direct))
         if dsts:
             torch._foreach_copy_(dsts, srcs)        # the eight row blocks of the two fused gradients in one launch

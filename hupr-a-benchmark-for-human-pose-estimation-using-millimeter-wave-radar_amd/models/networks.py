@@ -36,6 +36,16 @@ class HuPRNet(nn.Module):
         # nodes, its backward) runs under that mode whatever the thread's is — two models of one process on different pipes
         self.math_mode = None
 
+    def gradient_groups(self):
+        """Parameters whose gradient slots should be adjacent in a flat bucket (tools.distributed.GradientBuckets): per MSCSA level
+        and map the four 1x1 projection weights in the order of their fused (4C, C) weight-gradient GEMM (functional.MSCSALevelFn)."""
+        d = self.radarDecoder
+        out = []
+        for i in range(len(d.phi_cross_hori)):
+            out.append([m[i].weight for m in (d.phi_cross_hori, d.theta_cross_hori, d.phi_self_hori, d.theta_self_hori)])
+            out.append([m[i].weight for m in (d.phi_cross_vert, d.theta_cross_vert, d.phi_self_vert, d.theta_self_vert)])
+        return out
+
     def forward_chirp(self, VRDAEmaps_hori, VRDAEmaps_vert):
         return self.RAchirpNet(VRDAEmaps_hori), self.REchirpNet(VRDAEmaps_vert)
 

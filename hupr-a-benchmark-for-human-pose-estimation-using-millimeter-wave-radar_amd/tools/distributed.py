@@ -217,12 +217,28 @@ class GradientBuckets:
         # reverse registration order, split by size.  The all-reduce of the LAST bucket cannot overlap with anything
         # (its final gradient is the end of backward), so the trailing parameters get a small bucket of their own
         # (<= tail_bytes): the exposed collective is then latency- instead of bandwidth-sized.
+        # parameters that ask to be ADJACENT in their bucket (module.gradient_groups(): the four 1x1 projection weights of an MSCSA
+        # level and map — their fused weight gradient is one (4C, C) GEMM output, written straight into the four slots when they are
+        # consecutive): the whole group is placed where its first member (in reverse registration order) falls
+        member = {}
+        for grp in (module.gradient_groups() if hasattr(module, "gradient_groups") else []):
+            grp = [q for q in grp if q.requires_grad]
+            for q in grp:
+                member[id(q)] = grp
+        ordered, placed = [], set()
+        for p in reversed(params):
+            if id(p) in placed:
+                continue
+            for q in member.get(id(p), [p]):
+                ordered.append(q)
+                placed.add(id(q))
         groups = []
         cur, cur_bytes = [], 0
-        for p in reversed(params):
+        for p in ordered:
             cur.append(p)
             cur_bytes += p.numel() * 4
-            if cur_bytes >= bucket_bytes:
+            # (a bucket never closes inside an adjacency group)
+            if cur_bytes >= bucket_bytes and not (id(p) in member and member[id(p)][-1] is not p):
                 groups.append(cur)
                 cur, cur_bytes = [], 0
         if cur:
@@ -235,7 +251,7 @@ class GradientBuckets:
                     break
                 acc += p.numel() * 4
                 n_tail += 1
-            if 0 < n_tail < len(last):
+            if 0 < n_tail < len(last) and not (id(last[-n_tail]) in member and member[id(last[-n_tail])][0] is not last[-n_tail]):
                 groups[-1:] = [last[:-n_tail], last[-n_tail:]]
         self.buckets = [_Bucket(g, self.device) for g in groups]
         self._owner = {}
@@ -246,6 +262,7 @@ class GradientBuckets:
                 self._by_ptr[p.data_ptr()] = (b, i)
                 p.register_post_accumulate_grad_hook(self._hook)
         self.direct = self.device.type == "cuda"
+        self.always_zero = os.environ.get("HUPR_ZERO_GRADS", "0") == "1"
         self.prepare()
 
     # -- direct gradient sink (functional.GRAD_SINK protocol) -----------------------------------
@@ -274,7 +291,16 @@ class GradientBuckets:
         from .. import functional as F_
         self.reduce_this_pass = reduce
         for b in self.buckets:
-            b.flat_grad.zero_()
+            # Every kernel that writes a parameter gradient through the sink OVERWRITES its slot, so a bucket whose parameters were
+            # all written directly in the previous pass is not zeroed again (4 fill launches, 142 MB per step).  Guarded: a slot that
+            # is not zeroed and then receives an autograd-accumulated gradient raises (``_hook``); one that receives nothing is
+            # zeroed in ``finish``.  HUPR_ZERO_GRADS=1 restores the unconditional fill.
+            skip = self.direct and not self.always_zero and getattr(b, "written", None) is not None and all(b.written) \
+                and getattr(b, "clean", False)
+            if not skip:
+                b.flat_grad.zero_()
+            b.zeroed = not skip
+            b.clean = False
             b.pending = len(b.params)
             b.written = [False] * len(b.params)
             b.work = None
@@ -287,6 +313,9 @@ class GradientBuckets:
     def _hook(self, p):
         b = self._owner[id(p)]
         v = b.views[b.index[id(p)]]
+        if not getattr(b, "zeroed", True):
+            raise RuntimeError("autograd accumulated a gradient into a flat-bucket slot that was not zeroed for this pass (the parameter "
+                               "received direct kernel writes in the previous pass but not in this one); set HUPR_ZERO_GRADS=1")
         if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
             # autograd replaced the view (accumulation into an undefined grad): copy back
             v.copy_(p.grad)
@@ -341,6 +370,12 @@ class GradientBuckets:
         if F_.GRAD_SINK is self:
             F_.GRAD_SINK = None
         for b in self.buckets:
+            if not getattr(b, "zeroed", True) and not all(b.written):
+                # slots that were left un-zeroed and received nothing in this pass hold the previous pass's gradients: clear them now
+                for i, w in enumerate(b.written):
+                    if not w:
+                        b.views[i].zero_()
+            b.clean = all(b.written)            # every slot of the bucket holds a gradient written (not accumulated) in this pass
             if self.active and self.reduce_this_pass and not b.launched:
                 # a parameter received no gradient this iteration: reduce what we have
                 b.pending = 0

@@ -383,3 +383,54 @@ def test_two_rank_step_equals_the_single_process_accumulated_step(tmp_path):
         F_.set_math("f32")
     rel = ((p0 - ref).norm() / ref.norm()).item()
     assert rel < 1e-6, rel
+
+
+def test_gradient_slots_written_in_place_and_unzeroed_buckets_are_bit_transparent(monkeypatch):
+    """Round 5: (i) the four 1x1 projection weights of an MSCSA level and map sit next to each other in their flat bucket
+    (HuPRNet.gradient_groups) and their fused (4C, C) weight gradient is written straight into the four slots; (ii) a bucket whose
+    slots were all written by kernels in the previous pass is not zero-filled again.  Four optimisation steps land on exactly the
+    parameters of the engine with HUPR_ZERO_GRADS=1 (unconditional fills); after the first pass no fill is issued any more, every
+    slot is still written in every pass; a slot that stops receiving gradients is cleared instead of keeping stale values."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    try:
+        F_.set_math("bf16")
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=77)
+        monkeypatch.setenv("HUPR_ZERO_GRADS", "1")
+        e0 = TrainEngine(cfg, device=dev, seed=0)
+        monkeypatch.delenv("HUPR_ZERO_GRADS")
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        assert e0.buckets.always_zero and not e1.buckets.always_zero
+        # adjacency: every group is consecutive inside one bucket, in the group's order
+        pos = {id(p): (bi, i) for bi, b in enumerate(e1.buckets.buckets) for i, p in enumerate(b.params)}
+        groups = e1.model.gradient_groups()
+        assert len(groups) == 6
+        for grp in groups:
+            where = [pos[id(p)] for p in grp]
+            assert all(w[0] == where[0][0] and w[1] == where[0][1] + j for j, w in enumerate(where)), where
+        for step in range(4):
+            l0, _ = e0.train_step_from_adc(adc_h, adc_v, joints)
+            l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)
+            assert all(all(b.written) and b.clean for b in e1.buckets.buckets)          # every slot written by a kernel, every pass
+            assert [b.zeroed for b in e1.buckets.buckets] == [step == 0] * len(e1.buckets.buckets)
+        torch.cuda.synchronize()
+        assert float(l0) == float(l1) and torch.equal(_flat(e0), _flat(e1))
+        for b0, b1 in zip(e0.buckets.buckets, e1.buckets.buckets):
+            assert torch.equal(b0.flat_grad, b1.flat_grad)
+        # a pass in which a slot receives nothing: it must read zero afterwards, not the previous pass's gradient
+        e1.buckets.prepare()
+        b = e1.buckets.buckets[0]
+        assert not b.zeroed and b.flat_grad.abs().max().item() > 0
+        b.written = [True] * len(b.params)
+        b.written[1] = False
+        for bb in e1.buckets.buckets[1:]:
+            bb.written = [True] * len(bb.params)
+        e1.buckets.finish()
+        assert b.views[1].abs().max().item() == 0.0 and b.views[0].abs().max().item() > 0 and not b.clean
+        e1.buckets.prepare()
+        assert e1.buckets.buckets[0].zeroed                                          # not clean -> filled again
+        e0.close(); e1.close()
+    finally:
+        F_.GRAD_SINK = None
+        F_.set_math("f32")
+        F_.invalidate_packed()
