@@ -261,6 +261,7 @@ class GradientBuckets:
                 self._owner[id(p)] = b
                 self._by_ptr[p.data_ptr()] = (b, i)
                 p.register_post_accumulate_grad_hook(self._hook)
+        self._names = {id(q): n for n, q in module.named_parameters()}
         self.direct = self.device.type == "cuda"
         self.always_zero = os.environ.get("HUPR_ZERO_GRADS", "0") == "1"
         self.prepare()
@@ -278,11 +279,22 @@ class GradientBuckets:
         b.written[i] = True
         return b.views[i]
 
-    def done(self, param):
-        b, _ = self._by_ptr[param.data_ptr()]
+    def _arrive(self, b, i):
+        """Parameter i of bucket b has its gradient for this pass: count it ONCE, launch the bucket's exchange on the last arrival.
+        (Round 5: autograd runs a parameter's accumulation node — and with it the post-accumulate hook — even when the operator's
+        backward returned None after a direct write, so rounds 1-4 counted every directly written parameter twice: ``pending``
+        reached zero half-way through a bucket and, with more than one rank, the all-reduce would have started before the bucket's
+        last gradients were written.  Never seen on hardware — every run so far had one rank, whose all-reduce is the identity.)"""
+        if b.arrived[i]:
+            return
+        b.arrived[i] = True
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
+
+    def done(self, param):
+        b, i = self._by_ptr[param.data_ptr()]
+        self._arrive(b, i)
 
     # -- per-iteration protocol ---------------------------------------------------------------
     def prepare(self, reduce=True):
@@ -303,6 +315,7 @@ class GradientBuckets:
             b.clean = False
             b.pending = len(b.params)
             b.written = [False] * len(b.params)
+            b.arrived = [False] * len(b.params)
             b.work = None
             b.launched = False
             for p, v in zip(b.params, b.views):
@@ -312,17 +325,20 @@ class GradientBuckets:
 
     def _hook(self, p):
         b = self._owner[id(p)]
-        v = b.views[b.index[id(p)]]
+        i = b.index[id(p)]
+        v = b.views[i]
+        if b.written[i]:                 # a kernel wrote this slot; the engine still visits the (empty) accumulation node
+            self._arrive(b, i)
+            return
         if not getattr(b, "zeroed", True):
-            raise RuntimeError("autograd accumulated a gradient into a flat-bucket slot that was not zeroed for this pass (the parameter "
-                               "received direct kernel writes in the previous pass but not in this one); set HUPR_ZERO_GRADS=1")
+            raise RuntimeError("autograd accumulated a gradient into the flat-bucket slot of %s, which was not zeroed for this pass (the "
+                               "parameter received direct kernel writes in the previous pass but not in this one); set HUPR_ZERO_GRADS=1"
+                               % self._names.get(id(p), "<unnamed parameter>"))
         if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
             # autograd replaced the view (accumulation into an undefined grad): copy back
             v.copy_(p.grad)
             p.grad = v
-        b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        self._arrive(b, i)
 
     def _launch(self, b):
         if not self.active or not self.reduce_this_pass:

@@ -412,6 +412,9 @@ def test_gradient_slots_written_in_place_and_unzeroed_buckets_are_bit_transparen
             l0, _ = e0.train_step_from_adc(adc_h, adc_v, joints)
             l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)
             assert all(all(b.written) and b.clean for b in e1.buckets.buckets)          # every slot written by a kernel, every pass
+            # every parameter counted exactly once (the engine visits a directly written parameter's accumulation node too: rounds 1-4
+            # ended a pass at pending == -len(params), i.e. a bucket's exchange would have started half-way through its gradients)
+            assert all(b.pending == 0 and all(b.arrived) for b in e0.buckets.buckets + e1.buckets.buckets)
             assert [b.zeroed for b in e1.buckets.buckets] == [step == 0] * len(e1.buckets.buckets)
         torch.cuda.synchronize()
         assert float(l0) == float(l1) and torch.equal(_flat(e0), _flat(e1))
@@ -430,6 +433,38 @@ def test_gradient_slots_written_in_place_and_unzeroed_buckets_are_bit_transparen
         e1.buckets.prepare()
         assert e1.buckets.buckets[0].zeroed                                          # not clean -> filled again
         e0.close(); e1.close()
+    finally:
+        F_.GRAD_SINK = None
+        F_.set_math("f32")
+        F_.invalidate_packed()
+
+
+def test_bucket_exchange_starts_after_its_last_gradient(monkeypatch):
+    """A bucket's all-reduce may be enqueued only once EVERY gradient of the bucket has been written (round 5: rounds 1-4 counted a
+    directly written parameter twice — once when its kernel was enqueued, once when the autograd engine visited its accumulation node —
+    and would have launched at the half-way point; invisible with one rank).  One rank, forced collective: at each launch all
+    parameters of the bucket have arrived, each bucket launches exactly once per pass, in bucket order."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    try:
+        F_.set_math("bf16")
+        monkeypatch.setenv("HUPR_FORCE_ALLREDUCE", "1")
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=83)
+        eng = TrainEngine(cfg, device=dev, seed=0)
+        seen = []
+        orig = eng.buckets._launch
+
+        def launch(b):
+            seen.append((eng.buckets.buckets.index(b), sum(b.arrived), len(b.params), sum(b.written)))
+            return orig(b)
+        eng.buckets._launch = launch
+        for _ in range(2):
+            seen.clear()
+            eng.train_step_from_adc(adc_h, adc_v, joints)
+            assert [s[0] for s in seen] == list(range(len(eng.buckets.buckets))), seen
+            assert all(a == n and w == n for _, a, n, w in seen), seen
+        torch.cuda.synchronize()
+        eng.close()
     finally:
         F_.GRAD_SINK = None
         F_.set_math("f32")
