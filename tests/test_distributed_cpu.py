@@ -285,3 +285,88 @@ def test_rccl_id_exchange_on_a_group_without_a_cpu_backend_world2():
     mp.spawn(_no_cpu_backend_worker, args=(world, port, out), nprocs=world, join=True)
     assert out[0][0] == out[1][0] == bytes([9] * 128)
     assert out[0][1] == out[1][1] == ["moved to the transport's device"]
+
+
+class _SinkLinear(torch.autograd.Function):
+    """y = x W^T + b whose backward writes dW / db straight into the gradient sink's views and returns None for them — the protocol
+    of hupr_amd.functional's operators (``_pgrad`` / ``_pret``), with torch arithmetic standing in for the kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w, b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        from hupr_amd import functional as F_
+        x, w, b = ctx.saved_tensors
+        dw, dw_direct = F_._pgrad(w)
+        db, db_direct = F_._pgrad(b)
+        dw.copy_(dy.t() @ x)                       # "the kernel": overwrites its slot
+        db.copy_(dy.sum(0))
+        return dy @ w, F_._pret(w, dw, dw_direct), F_._pret(b, db, db_direct)
+
+
+class _SinkNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a, self.b, self.c = torch.nn.Linear(16, 32), torch.nn.Linear(32, 8), torch.nn.Linear(8, 1)
+
+    def forward(self, x):
+        x = torch.relu(_SinkLinear.apply(x, self.a.weight, self.a.bias))
+        x = _SinkLinear.apply(x, self.b.weight, self.b.bias)
+        return self.c(x)                           # the last layer through plain autograd: both gradient paths in one bucket set
+
+
+def _sink_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.distributed import GradientBuckets
+    torch.manual_seed(99 + rank)
+    net = _SinkNet()
+    gb = GradientBuckets(net, bucket_bytes=1 << 20, tail_bytes=0)     # ONE bucket: an early launch would miss its late gradients
+    gb.direct = True                                                  # (the sink is a GPU feature; its host logic is device-agnostic)
+    gb.broadcast_parameters(0)
+    launches = []
+    orig = gb._launch
+
+    def launch(b):
+        launches.append((sum(b.arrived), len(b.params)))
+        return orig(b)
+    gb._launch = launch
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 16, generator=g), torch.randn(8, 1, generator=g)
+    shard = slice(rank * 4, rank * 4 + 4)
+    for it in range(3):
+        gb.prepare()
+        ((net(X[shard]) - Y[shard]) ** 2).sum().backward()
+        gb.finish()
+        assert F_.GRAD_SINK is None
+    flat = torch.cat([b.flat_grad for b in gb.buckets]).clone()
+    out[rank] = (flat, launches, [b.pending for b in gb.buckets], [b.zeroed for b in gb.buckets])
+    if rank == 0:
+        ref = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 1))
+        ref.load_state_dict({k.replace("a.", "0.").replace("b.", "2.").replace("c.", "3."): v for k, v in net.state_dict().items()})
+        ((ref(X) - Y) ** 2).sum().backward()
+        out["ref"] = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_gradient_sink_world2_launches_after_the_last_gradient():
+    """Round 5: operators that write parameter gradients straight into the bucket views return None for them, yet the autograd engine
+    still visits those parameters' accumulation nodes (and runs the post-accumulate hooks).  Rounds 1-4 counted such a parameter
+    twice and would have launched a bucket's all-reduce half-way through its gradients.  World size 2 over gloo, one bucket holding
+    four kernel-written and two autograd-accumulated gradients: every launch sees all six arrived, one launch per pass, the pass ends
+    at pending == 0, and the summed gradients equal the single-process full-batch gradient.  (Mixed buckets are zero-filled every
+    pass: the un-zeroed form needs every slot kernel-written.)"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sink_worker, args=(world, port, out), nprocs=world, join=True)
+    (g0, l0, p0, z0), (g1, l1, p1, z1) = out[0], out[1]
+    assert l0 == [(6, 6)] * 3 and l1 == [(6, 6)] * 3, (l0, l1)
+    assert p0 == [0] and p1 == [0] and z0 == [True] and z1 == [True]
+    assert torch.allclose(g0, g1) and torch.allclose(g0, out["ref"], atol=1e-5)
