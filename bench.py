@@ -248,7 +248,8 @@ def conv_roofline(events, B, dtype, peak):
     elif os.environ.get("HUPR_HALO_M16", "1") == "0":      # (runtime.py hands HUPR_HALO_M16 to hupr_debug_halo_m16 at load)
         kname = "hupr_k_conv_halo256_bf16 (256-voxel halo convolution on v_mfma_f32_32x32x16_bf16, bf16 activations; HUPR_HALO_M16=0)"
     else:
-        kname = "hupr_k_conv_halo256m_bf16 (256-voxel halo convolution on v_mfma_f32_16x16x32_bf16, bf16 activations)"
+        kname = ("hupr_k_conv_halo256m_bf16<4, 8, 8, 3, *> (256-voxel halo convolution on v_mfma_f32_16x16x32_bf16, bf16 activations; forward "
+                 "launches: the <..., 1> instantiation with fused BatchNorm statistics, input-gradient launches: <..., 0>)")
     # what limits the kernel: bf16 — the tap loop is issue/LDS-bound underneath the matrix pipe, graded
     # against the bf16 MFMA peak because the work is GEMM-shaped; f32 — the fp32 matrix pipe itself
     return {"bound": "mfma", "kernel": kname + " (Encoder3D.layer1 64->64 3x3x3, fwd+dgrad launches)",
