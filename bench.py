@@ -502,8 +502,15 @@ def main():
         barrier()
 
     launch_census = None
-    if rank == 0 and not args.graph and not args.no_launch_census and not args.no_probes:
-        launch_census = count_device_activities(one_step)
+    if not args.graph and not args.no_launch_census and not args.no_probes:
+        # EVERY rank runs the census' two steps (with an exchange step they contain collectives: rank 0 alone would wait for its
+        # peers forever); only rank 0 traces them
+        if rank == 0:
+            launch_census = count_device_activities(one_step)
+        else:
+            one_step()
+            one_step()
+        barrier()
     fft_roof = parity = None
     if rank == 0 and not args.no_probes:
         # FFT chain on its own (HBM-bound): the step's 2 x B*G sensor-frames, HIP events on the launch stream.  Primary entry =
