@@ -34,13 +34,6 @@ struct HaloArgs {
     // 4 us launch they save: agent-scope scalar accesses 12.7 -> 42 us per layer, L2 write-back fences 94 us.)
     float* part;
     int units_per_slice;
-    // 16 x 16 x 32 kernel only (conv_halo256m_bf16.hip), round 5: a SECOND (activation, packed weight) pair of the same shapes whose
-    // products are summed into the same output — y = conv(x, wp) + conv(x2, wp2) in ONE launch, accumulated in fp32 registers: the
-    // input gradient of a BasicBlock's two convolutions of one map (reference models/layers.py:55-65; functional.DualConvFn).
-    // n_split = Ci / 64 chunks per tensor (0: no second pair); the reduction walks chunks [0, n_split) of (x, wp), then of (x2, wp2).
-    const void* x2;
-    const __bf16* wp2;
-    int n_split;
 };
 
 // fp32 partial sums of a K slice: this lane's voxel, its four 4-channel runs (see halo_store_voxel for the lane -> channel map)
@@ -57,7 +50,6 @@ __device__ __forceinline__ void halo_store_partial(const HaloArgs& p, const f32x
 // 256-voxel persistent variant; returns false when the geometry is not supported
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf);
-bool conv_halo256m_reachable(const HaloArgs& a, int Bn);                       // would launch_conv_halo256(a, Bn, true) run the 16 x 16 x 32 kernel?
 bool conv_halo256_stats_ok(const HaloArgs& a, int Bn);                         // fused BatchNorm statistics available for this launch?
 void launch_conv_halo256m(const HaloArgs& a, hipStream_t s);                  // the 256-voxel kernel on v_mfma_f32_16x16x32_bf16 (conv_halo256m_bf16.hip)
 void set_halo_m16(int on);

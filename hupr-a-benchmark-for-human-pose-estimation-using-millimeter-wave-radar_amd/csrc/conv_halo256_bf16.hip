@@ -531,24 +531,6 @@ bool conv_halo256_stats_ok(const HaloArgs& a, int Bn) {
     return n <= 2 || per_wg == 1;
 }
 
-// Mirrors the dispatch below: which bf16-activation launches end on hupr_k_conv_halo256m_bf16 (any of its three tiles)
-bool conv_halo256m_reachable(const HaloArgs& a, int Bn) {
-    if (!g_halo_m16 || a.ablate != 0 || a.trace != nullptr || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
-    if ((long)Bn * a.D * a.H * a.W * a.in_ld * 2 >= 0x7ffffff0L) return false;
-    const int n = a.Co / 64;
-    if (a.kd == 3 && a.D % 4 != 0) {
-        if (!g_halo_m16_td2 || a.D % 2 != 0 || a.H % 8 != 0 || a.W % 16 != 0) return false;
-        const long t = (long)Bn * (a.D / 2) * (a.H / 8) * (a.W / 16) * n;
-        return t >= 256 && t < (1L << 31);
-    }
-    if (a.kd == 1) {
-        if (!g_halo_m16_2d || a.D != 1 || a.H % 16 != 0 || a.W % 16 != 0) return false;
-        const long t = (long)Bn * (a.H / 16) * (a.W / 16) * n;
-        return t >= 256 && t < (1L << 31);
-    }
-    return a.kd == 3 && conv_halo256_supported(a, Bn, true);
-}
-
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     // measured (scripts/halo_ablation.py): faster on the 3-D encoder layers, neutral to slower on the 2-D decoder maps
     if (abf && g_halo_m16 && g_halo_m16_td2 && a.kd == 3 && a.D % 4 != 0 && a.D % 2 == 0 && a.H % 8 == 0 && a.W % 16 == 0 && a.Ci % 64 == 0 &&

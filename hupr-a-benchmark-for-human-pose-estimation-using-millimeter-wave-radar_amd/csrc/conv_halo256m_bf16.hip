@@ -30,9 +30,7 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // which existed for layers of ONE output tile on the 4 x 8 x 8 kernel only — encoder level 1; levels 2 and 3, Co = 128 / 256, ran a
 // statistics pass over the stored tensor per BatchNorm: 24 launches per step).  Level 2 at the bench batch: 4 tiles per workgroup,
 // alternating between its 2 output tiles; level 3: one tile per workgroup.
-// DUAL: a second (activation, weight) pair summed into the same output (HaloArgs::x2 / wp2 / n_split) — its own instantiations, so
-// that the two extra buffer resources cost the plain kernels no scalar registers (they run at the SGPR limit).
-template <int TD, int TH, int TW, int KD, int NCOT = 0, bool DUAL = false>
+template <int TD, int TH, int TW, int KD, int NCOT = 0>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
     constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
@@ -72,24 +70,17 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     const int wsrc_lane = (wrow_ * T * p.Ci + (((lane & 7) ^ (wrow_ >> 1)) & 7) * 8) * 2;      // bytes; < 2^31
     const u32x4 wrs = {(unsigned)(unsigned long)p.wp, (unsigned)((unsigned long)p.wp >> 32) & 0xffffu,
                        (unsigned)((long)p.Co * T * p.Ci * 2), 0x00020000u};
-    // second (activation, weight) pair (p.n_split > 0): chunks >= n_split read x2 / wp2 at chunk - n_split; without one they alias the first
-    const __bf16* wp2_ = DUAL ? p.wp2 : p.wp;
-    const u32x4 wrs2 = {(unsigned)(unsigned long)wp2_, (unsigned)((unsigned long)wp2_ >> 32) & 0xffffu,
-                        (unsigned)((long)p.Co * T * p.Ci * 2), 0x00020000u};
-    const int nsplit = DUAL ? p.n_split : (1 << 20);
     const unsigned bs_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
     const unsigned wdst_wave = __builtin_amdgcn_readfirstlane(bs_lds + wave * 1024);
 #define HUPR_W_DMA(COT_, CH_, S_, PAR_)                                                                             \
     {                                                                                                               \
-        const bool w2_ = DUAL && (CH_) >= nsplit;                 /* workgroup-uniform */                           \
-        const int wbase_ = (((COT_) * BN * T + ((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + ((CH_) - (w2_ ? nsplit : 0)) * KC) * 2 + wsrc_lane; \
-        const u32x4 wr_ = (DUAL && w2_) ? wrs2 : wrs;                                                               \
+        const int wbase_ = (((COT_) * BN * T + ((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + (CH_) * KC) * 2 + wsrc_lane;   \
         _Pragma("unroll") for (int j = 0; j < TS; ++j) {                                                            \
             unsigned keep_;                                                                                         \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
                          "s_mov_b32 m0, %0"                                                                         \
                          : "=&s"(keep_)                                                                             \
-                         : "s"(wdst_wave + ((PAR_) * TS + j) * (BN * LDK * 2)), "v"(wbase_ + j * (3 * p.Ci * 2)), "s"(wr_) \
+                         : "s"(wdst_wave + ((PAR_) * TS + j) * (BN * LDK * 2)), "v"(wbase_ + j * (3 * p.Ci * 2)), "s"(wrs) \
                          : "memory");                                                                               \
         }                                                                                                           \
     }
@@ -98,12 +89,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     u32x4 vb[NH];
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.x), 0, (int)((long)p.Bn * p.D * p.H * p.W * p.in_ld * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(DUAL ? p.x2 : p.x), 0, (int)((long)p.Bn * p.D * p.H * p.W * p.in_ld * 2), 0x00020000);
-#define HUPR_HALO_ISSUE_ITEM(u, COND_, B_, D0_, H0_, W0_, CH_)                                                     \
+#define HUPR_HALO_ISSUE_ITEM(u, COND_, B_, D0_, H0_, W0_, C0_)                                                     \
     {                                                                                                               \
-        const bool x2_ = DUAL && (CH_) >= nsplit;                 /* workgroup-uniform: which tensor this chunk reads */ \
-        const int C0_ = ((CH_) - (x2_ ? nsplit : 0)) * KC;                                                          \
         const int it = tid + (u) * 512;                                                                             \
         const int vox = it >> 3, c8 = it & 7;                                                                       \
         const int hx = vox % HW;                                                                                    \
@@ -113,7 +100,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         const bool ok = (COND_) && it < NVOX * C8 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&  \
                         (unsigned)w < (unsigned)p.W;                                                                \
         const int off = (((((B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8) * 2;                  \
-        const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128((DUAL && x2_) ? xrs2 : xrs, ok ? off : 0x7ffffff0, 0, 0); \
+        const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : 0x7ffffff0, 0, 0);                  \
         vb[u] = (u32x4){ld_[0], ld_[1], ld_[2], ld_[3]};                                                            \
     }
 #define HUPR_HALO_COMMIT()                                                                                          \
@@ -127,7 +114,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     }
 
     struct Pos { int cot, twi, thi, tdi, b, ch; };
-    const int n_chunks = DUAL ? 2 * p.n_split : p.Ci / KC;
+    const int n_chunks = p.Ci / KC;
     const int per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
     const int wg_rank = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // an eighth of the tile sequence per XCD
     const int t_begin = wg_rank * per_wg, t_end = min(n_tiles, t_begin + per_wg);
@@ -197,7 +184,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     HUPR_W_DMA(cur.cot, cur.ch, 0, 0)
     HUPR_W_DMA(cur.cot, cur.ch, 1, 1)
 #pragma unroll
-    for (int u = 0; u < NH; ++u) HUPR_HALO_ISSUE_ITEM(u, true, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch)
+    for (int u = 0; u < NH; ++u) HUPR_HALO_ISSUE_ITEM(u, true, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
     HUPR_HALO_COMMIT()
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
@@ -272,7 +259,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                 }
                 // the next item's halo: one item per tap under its MFMAs (branch-free: an out-of-range offset past the last item)
                 if (NTAP * st_ + tau < NH) {
-                    HUPR_HALO_ISSUE_ITEM(NTAP * st_ + tau, has_next, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch)
+                    HUPR_HALO_ISSUE_ITEM(NTAP * st_ + tau, has_next, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
                 }
                 // a fragment read in front of the MFMAs, one at a time (six reads at most, eight MFMAs)
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -410,11 +397,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 
 void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
     const dim3 grid(kHalo256Grid), wg(512);
-    if (a.n_split) {                          // two (activation, weight) pairs summed into one output (the dual input gradient)
-        if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1, 0, true>), grid, wg, 0, s, a);
-        else if (a.TD == 4) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 0, true>), grid, wg, 0, s, a);
-        else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<2, 8, 16, 3, 0, true>), grid, wg, 0, s, a);
-    } else if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), grid, wg, 0, s, a);
+    if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), grid, wg, 0, s, a);
     else if (a.stats) {                       // fused BatchNorm statistics: 1 or 2 distinct output tiles per workgroup (conv_halo256_stats_ok)
         const long tiles = (long)a.Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
         const long per_wg = (tiles + kHalo256Grid - 1) / kHalo256Grid;

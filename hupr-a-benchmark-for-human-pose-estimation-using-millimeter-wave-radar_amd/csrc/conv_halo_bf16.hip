@@ -460,9 +460,6 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     a.stats = stats;
     a.part = nullptr;
     a.units_per_slice = 0;
-    a.x2 = nullptr;
-    a.wp2 = nullptr;
-    a.n_split = 0;
     if (stats) {
         HUPR_REQUIRE(abf && !bias && !res && conv_halo256_stats_ok(a, Bn),
                      "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);
@@ -584,42 +581,6 @@ extern "C" int hupr_conv3x3_halo_stats_supported(int Bn, int D, int H, int W, in
     return (Bn > 0 && conv_halo256_stats_ok(a, Bn)) ? 1 : 0;
 }
 extern "C" int hupr_conv3x3_halo_stats_rows(void) { return kHalo256Grid; }
-
-// y = conv(xa, wpa) + conv(xb, wpb) in ONE launch of the 16 x 16 x 32 kernel, both products accumulated in fp32 registers (bf16
-// activations of equal shape, packed bf16 weights of equal shape [Co][T][Ci]).  Replaces the pair "second convolution with the first
-// one's output as its residual" for the input gradient of a BasicBlock's two convolutions of one map (reference models/layers.py:55-65):
-// no bf16 round trip of the first sum, no residual read, the deferred epilogue stays.  hupr_conv3x3_halo_dual_supported: does the
-// dispatch reach that kernel for this shape (256-voxel tiles, >= 256 tiles, hupr_debug_halo_m16 != 0)?
-static bool dual_args(HaloArgs& a, const void* xa, const void* wpa, const void* xb, const void* wpb, void* y, int Bn, int D, int H, int W,
-                      int Ci, int in_ld, int Co, int out_ld, int kd) {
-    a = HaloArgs{};
-    a.x = xa; a.wp = reinterpret_cast<const __bf16*>(wpa); a.y = y;
-    a.x2 = xb; a.wp2 = reinterpret_cast<const __bf16*>(wpb);
-    a.Bn = Bn; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.in_ld = in_ld; a.Co = Co; a.out_ld = out_ld; a.res_ld = 0;
-    a.kd = kd;
-    a.ablate = g_halo_ablate;
-    a.trace = g_halo_trace;
-    a.n_split = Ci / 64;
-    return Ci % 64 == 0 && Co % 64 == 0 && a.ablate == 0 && a.trace == nullptr;
-}
-extern "C" int hupr_conv3x3_halo_dual_supported(int Bn, int D, int H, int W, int Ci, int Co, int kd) {
-    HaloArgs a;
-    if (Bn <= 0 || !dual_args(a, nullptr, nullptr, nullptr, nullptr, nullptr, Bn, D, H, W, Ci, Ci, Co, Co, kd)) return 0;
-    return conv_halo256m_reachable(a, Bn) ? 1 : 0;
-}
-extern "C" int hupr_conv3x3_halo_bf16act_dual(const void* xa, const void* wpa_bf16, const void* xb, const void* wpb_bf16, void* y, int Bn,
-                                              int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int kd, hupr_stream_t stream) {
-    const char* who = "hupr_conv3x3_halo_bf16act_dual";
-    HUPR_REQUIRE(xa && wpa_bf16 && xb && wpb_bf16 && y, "%s: null pointer", who);
-    HUPR_REQUIRE(hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1), "%s: unsupported geometry", who);
-    HUPR_REQUIRE(Bn > 0 && in_ld % 8 == 0 && out_ld % 4 == 0, "%s: bad leading dimensions", who);
-    HaloArgs a;
-    HUPR_REQUIRE(dual_args(a, xa, wpa_bf16, xb, wpb_bf16, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, kd) && conv_halo256m_reachable(a, Bn),
-                 "%s: this shape does not reach the 16 x 16 x 32 kernel (see hupr_conv3x3_halo_dual_supported)", who);
-    HUPR_REQUIRE(launch_conv_halo256(a, Bn, true, as_stream(stream)), "%s: the 256-voxel kernel refused the launch", who);
-    HUPR_LAUNCH_OK("hupr_k_conv_halo256m_bf16<dual>");
-    return HUPR_OK;
-}
 extern "C" int hupr_conv3x3_halo_bf16act_stats(const void* x, const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci,
                                                int in_ld, int Co, int out_ld, int kd, void* stats, hupr_stream_t stream) {
     HUPR_REQUIRE(stats, "hupr_conv3x3_halo_bf16act_stats: null pointer");

@@ -679,16 +679,8 @@ class DualConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dpad = (k[0] - 1 - pad[0], k[1] - 1 - pad[1], k[2] - 1 - pad[2])
-            if (DUAL_DGRAD and dy[0].dtype == torch.bfloat16 and CONV_PROBE is None
-                    and L.hupr_conv3x3_halo_dual_supported(B, D, H, W, Co, Ci, k[0])):
-                # both input gradients in ONE launch, summed in fp32 registers (round 5): the second launch of the pair below read the
-                # first one's bf16 output back as its residual and could not defer its epilogue (227 vs 184 us at level 1)
-                dx = torch.empty((B, D, H, W, Ci), dtype=dy[0].dtype, device=dy[0].device)
-                rt.check(L.hupr_conv3x3_halo_bf16act_dual(rt.ptr(dy[0]), rt.ptr(_packed(w_a, 1, 1)), rt.ptr(dy[1]), rt.ptr(_packed(w_b, 1, 1)),
-                                                          rt.ptr(dx), B, D, H, W, Co, Co, Ci, Ci, k[0], rt.stream()))
-            else:
-                dx = _conv_raw(dy[0], w_a, 1, None, None, Ci, k, dpad, (D, H, W))
-                dx = _conv_raw(dy[1], w_b, 1, None, dx, Ci, k, dpad, (D, H, W), out=dx)
+            dx = _conv_raw(dy[0], w_a, 1, None, None, Ci, k, dpad, (D, H, W))
+            dx = _conv_raw(dy[1], w_b, 1, None, dx, Ci, k, dpad, (D, H, W), out=dx)
         grads = []
         for i, w in enumerate((w_a, w_b)):
             if not ctx.needs_input_grad[1 + i]:
@@ -701,9 +693,6 @@ class DualConvFn(torch.autograd.Function):
                         rt.stream()))
             grads.append(_pret(w, dw, direct))
         return dx, grads[0], grads[1], None, None, None
-
-
-DUAL_DGRAD = os.environ.get("HUPR_NO_DUAL_DGRAD", "0") != "1"      # A/B aid: 0 = two launches, the second with the first's output as residual
 
 
 def dual_conv(x, w_a, w_b, pad, stats=False):

@@ -199,13 +199,6 @@ int hupr_conv3x3_halo_stats_supported(int Bn, int D, int H, int W, int Ci, int C
 int hupr_conv3x3_halo_stats_rows(void);
 int hupr_conv3x3_halo_bf16act_stats(const void* x, const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci,
                                     int in_ld, int Co, int out_ld, int kd, void* stats, hupr_stream_t stream);
-/* y = conv(xa, wa) + conv(xb, wb) in one launch, both products summed in fp32 accumulators (bf16 activations and packed bf16 weights
- * [Co][T][Ci] of equal shapes): the input gradient of the two convolutions a BasicBlock applies to one map (reference
- * models/layers.py:55-65: main[0] and downsample[0]; dx = dgrad(dy_main) + dgrad(dy_down)) without rounding the first sum to bf16 and
- * reading it back.  Applies where the dispatch reaches the v_mfma_f32_16x16x32_bf16 kernel: hupr_conv3x3_halo_dual_supported. */
-int hupr_conv3x3_halo_dual_supported(int Bn, int D, int H, int W, int Ci, int Co, int kd);
-int hupr_conv3x3_halo_bf16act_dual(const void* xa, const void* wpa_bf16, const void* xb, const void* wpb_bf16, void* y, int Bn, int D,
-                                   int H, int W, int Ci, int in_ld, int Co, int out_ld, int kd, hupr_stream_t stream);
 int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
                                 hupr_stream_t stream);
 /* Repack many weights (both layouts each) in ONE launch.  descs_dev: device array of 48-byte records

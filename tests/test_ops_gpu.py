@@ -1029,41 +1029,6 @@ def test_conv_fused_batchnorm_statistics(Ci, Co, shape, bf16_math):
     assert (o1 != o0).float().mean().item() < 2e-3           # only last-bit scale / shift differences
 
 
-@pytest.mark.parametrize("shape", [(32, 64, 64, 8, 64, 64, 3), (8, 128, 64, 4, 32, 32, 3), (32, 256, 128, 2, 16, 16, 3), (16, 128, 320, 1, 32, 32, 1),
-                                   (5, 64, 64, 4, 16, 24, 3)])
-def test_dual_input_gradient_in_one_launch(shape, bf16_math):
-    """hupr_conv3x3_halo_bf16act_dual: y = conv(xa, wa) + conv(xb, wb) in one launch of the 16 x 16 x 32 kernel, summed in fp32 registers
-    (the input gradient of a block's two convolutions of one map, reference models/layers.py:55-65) against fp64 on the same bf16
-    operands and against the pair of launches it replaces (second one with the first's bf16 output as residual: one more rounding).
-    Level-1 / level-2 / level-3 / decoder tiles, an uneven tile count, and a shape below 256 tiles that must be refused."""
-    from hupr_amd import functional as F_
-    L, rt = F_.rt.lib(), F_.rt
-    B, Cin, Cout, D, H, W, kd = shape                      # Cin: channels of the two gradient tensors, Cout: channels of dx
-    ok = bool(L.hupr_conv3x3_halo_dual_supported(B, D, H, W, Cin, Cout, kd))
-    if shape == (5, 64, 64, 4, 16, 24, 3):
-        assert not ok                                      # 30 tiles: the 128-voxel kernel's territory
-        return
-    assert ok, shape
-    k3, pad = (kd, 3, 3), (kd // 2, 1, 1)
-    xa, xb = (rnd(B, D, H, W, Cin, seed=600 + i).cuda().bfloat16() for i in range(2))
-    wa, wb = (rnd(Cout, Cin, *k3, seed=602 + i, scale=(Cin * 9 * kd * 2) ** -0.5).cuda() for i in range(2))
-    wpa, wpb = F_.pack_weights_bf16(wa, 0), F_.pack_weights_bf16(wb, 0)        # [Co][T][Ci]
-    y = torch.full((B, D, H, W, Cout), float("nan"), device="cuda").bfloat16()
-    rt.check(L.hupr_conv3x3_halo_bf16act_dual(rt.ptr(xa), rt.ptr(wpa), rt.ptr(xb), rt.ptr(wpb), rt.ptr(y), B, D, H, W, Cin, Cin, Cout, Cout, kd,
-                                              rt.stream()))
-    y1 = F_._conv_raw(xa, wa, 0, None, None, Cout, k3, pad, (D, H, W))
-    y2 = F_._conv_raw(xb, wb, 0, None, y1, Cout, k3, pad, (D, H, W))
-    d = (y.float() - y2.float()).abs()
-    assert torch.isfinite(y.float()).all()
-    assert d.max().item() <= 2.0 ** -6 * y2.float().abs().max().item()      # (the pair rounds the first sum to bf16 in between)
-    if B * D * H * W <= 40000:
-        conv = lambda x, w: F.conv3d(x.double().cpu().permute(0, 4, 1, 2, 3), w.bfloat16().double().cpu(), None, 1, pad).permute(0, 2, 3, 4, 1)
-        ref = conv(xa, wa) + conv(xb, wb)
-        e_dual, e_pair = (y.double().cpu() - ref).abs().max().item(), (y2.double().cpu() - ref).abs().max().item()
-        close(y.float(), ref, 6e-3, "dual input gradient vs fp64 (bf16 store)")
-        assert e_dual <= e_pair * 1.0001 + 1e-12            # one rounding instead of two: never worse than the pair
-
-
 @pytest.mark.parametrize("act", ["bf16", "f32"])
 def test_dual_conv_matches_two_convs(act, bf16_math):
     """DualConvFn (input gradients of the two convolutions summed in the second kernel's residual epilogue, in place)
