@@ -15,6 +15,7 @@ overlapped with backward) -> fused Adam.  One radar frame = one sample.  Prints 
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -197,7 +198,7 @@ def count_device_activities(step):
             step()
             torch.cuda.synchronize()
         ours = other = copies = 0
-        names = {}
+        names, fam = {}, {}
         for e in prof.key_averages():
             if e.device_type != DeviceType.CUDA:
                 continue
@@ -206,6 +207,9 @@ def count_device_activities(step):
                 copies += e.count
             elif "hupr" in n:
                 ours += e.count
+                m = re.search(r"hupr_k_[a-z0-9_]*[a-z0-9]", n)
+                key = m.group(0) if m else n[:40]
+                fam[key] = fam.get(key, 0) + e.count
             else:
                 other += e.count
                 key = n.split("<")[0][:60]
@@ -213,6 +217,7 @@ def count_device_activities(step):
         aten = {e.key: e.count for e in prof.key_averages() if e.key.startswith("aten::") and e.device_time_total > 0 and e.device_type != DeviceType.CUDA}
         top = sorted(names.items(), key=lambda kv: -kv[1])[:6]
         return {"library_kernels": ours, "other_kernels": other, "memcpy_memset": copies, "total": ours + other + copies,
+                "library_kernels_top": dict(sorted(fam.items(), key=lambda kv: -kv[1])[:16]),
                 "other_kernels_top": {k: v for k, v in top}, "aten_ops_with_device_time": aten,
                 "how": "torch.profiler (kineto), one step after the timed region"}
     except Exception as exc:      # noqa: BLE001 — a census, never a reason to lose the bench line
