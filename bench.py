@@ -626,12 +626,47 @@ def main():
             return ev[0].elapsed_time(ev[1]) * 1e-3 / n
         tf, tb = a_time(a_fwd), a_time(a_bwd)
         ffl, bfl = 4.0 * Na * Na * Ca * B, 10.0 * Na * Na * Ca * B
+        # ... and the same launches INSIDE the step (five steps after the timed region; HIP events around each level-1 attention of the
+        # fused MSCSA node): back-to-back copies of one matrix-heavy kernel run at the chip's power limit, in the step the kernel
+        # follows lighter ones — the in-step duration is what the frames/s above contains (rocprofv3: profiles/r05_bench_kernels.md)
+        in_step = None
+        if not args.graph and world == 1:            # (the step contains the exchange: one rank alone cannot run extra steps)
+            a_ev = {"fwd": [], "bwd": [], "bwd_level": []}
+
+            def a_probe(kind, b_, n_, c_):
+                if n_ == Na and c_ == Ca and b_ == B:
+                    pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    a_ev[kind].append(pair)
+                    return pair
+                return None
+            F_.ATTN_PROBE = a_probe
+            try:
+                for _ in range(5):
+                    one_step()
+                torch.cuda.synchronize()
+            finally:
+                F_.ATTN_PROBE = None
+            if a_ev["fwd"] and (a_ev["bwd"] or a_ev["bwd_level"]):
+                tfi = float(np.mean([s_.elapsed_time(e_) for s_, e_ in a_ev["fwd"]])) * 1e-3
+                if a_ev["bwd_level"]:          # the level's four backward passes as one call (batched row-sum and dQ launches): per attention
+                    tbi = float(np.mean([s_.elapsed_time(e_) for s_, e_ in a_ev["bwd_level"]])) * 1e-3 / 4.0
+                    a_ev["bwd"] = a_ev["bwd_level"] * 4
+                else:
+                    tbi = float(np.mean([s_.elapsed_time(e_) for s_, e_ in a_ev["bwd"]])) * 1e-3
+                in_step = {"forward": {"us": round(tfi * 1e6, 1), "achieved": round(ffl / tfi / 1e12, 1), "frac": round(ffl / tfi / 1e12 / peak, 4),
+                                       "launches": len(a_ev["fwd"])},
+                           "backward": {"us": round(tbi * 1e6, 1), "achieved": round(bfl / tbi / 1e12, 1), "frac": round(bfl / tbi / 1e12 / peak, 4),
+                                        "launches": len(a_ev["bwd"])},
+                           "frac": round((ffl + bfl) / (tfi + tbi) / 1e12 / peak, 4),
+                           "how": "HIP events around every level-1 attention of 5 steps after the timed region (forward: one launch; "
+                                  "backward: prep + dQ + dK/dV launches and the gaps between them)"}
         attn_roof = {"bound": "mfma", "kernel": "hupr_k_attn_fwd_pp64 / hupr_k_attn_bwd_dq + hupr_k_attn_bwd_dkv512%s (MSCSA level 1: C = 64, N = 4096, B = %d)" % (" <QS>" if qs_ else "", B),
                      "forward": {"us": round(tf * 1e6, 1), "achieved": round(ffl / tf / 1e12, 1), "frac": round(ffl / tf / 1e12 / peak, 4)},
                      "backward": {"us": round(tb * 1e6, 1), "achieved": round(bfl / tb / 1e12, 1), "frac": round(bfl / tb / 1e12 / peak, 4),
                                   "note": "algorithmic 10 N^2 C; the two kernels execute 14 N^2 C (S and dP recomputed in each)"},
                      "achieved": round((ffl + bfl) / (tf + tb) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round((ffl + bfl) / (tf + tb) / 1e12 / peak, 4),
+                     "how": "kernels alone, 10 back-to-back launches through the C ABI", "in_step": in_step,
                      "limiter": "non-MFMA instruction issue beside a power-paced matrix pipe: the forward's phases (MFMA 65 us, fragment reads 38, "
                                 "soft-max VALU 65-70, stores / DMA / barrier 28) add up instead of overlapping (profiles/r04_attn_ablation.txt, "
                                 "profiles/r04_valu_issue_probe.txt)"}

@@ -311,8 +311,9 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by, int xcd_map) {
 // SPLIT (few workgroups: small batches, e.g. the B = 1 inference of BASELINE config C2): blockIdx.z walks only its share of the
 // keys and leaves the un-normalised O^T tile, the running maximum and the running sum in part_o / part_ml
 // ([split][B N][D] / [split][B N][2]); hupr_k_attn_combine merges the shares (flash-decoding).
-// Up to four independent attentions of equal shape in ONE split launch (the four of an MSCSA level in single-sample inference, where
-// launches, not work, set the time): n > 0 only with SPLIT; blockIdx.z = item * splits + split.
+// Up to four independent attentions of equal shape in ONE launch (the four of an MSCSA level): n > 0; SPLIT (single-sample inference,
+// where launches, not work, set the time): blockIdx.z = item * splits + split; one-pass kernel (training batches at the levels whose
+// own grid leaves most of the chip idle — level 3: N = 256, two workgroups per sample): blockIdx.z = item.
 struct AttnBatch {
     int n, splits;
     const void* K[4];
@@ -347,6 +348,18 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
             const long rows = (long)gridDim.y * N;                               // partials: [item][split][B N]
             part_o += (long)item * nzs * rows * D;
             part_ml += (long)item * nzs * rows * 2;
+        }
+    }
+    if constexpr (!SPLIT) {
+        if (batch.n > 0) {
+            const int item = (int)blockIdx.z;
+            K = static_cast<const TI*>(batch.K[item]);
+            Q = static_cast<const TI*>(batch.Q[item]);
+            V = static_cast<const TI*>(batch.V[item]);
+            Vres = batch.Vres[item];
+            out = batch.out[item];
+            lse = batch.lse[item];
+            out16 = batch.out16[item];
         }
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
@@ -475,11 +488,39 @@ __global__ __launch_bounds__(256) void hupr_k_attn_combine(const float* __restri
     if (c == 0) lse[row] = QS ? (m + __log2f(L)) * kLn2 : m + __logf(L);
 }
 
+// Up to four attentions of one shape in one launch of a backward kernel (n > 0; the four of an MSCSA level).  Row-sum kernel: blockIdx.y
+// = item; dQ and dK / dV kernels: grid.y = n * Bn samples, item = sample / Bn.  (dK / dV: the items of ONE launch must write distinct dV.)
+struct AttnBwdBatch {
+    int n, Bn;
+    const void* K[4];
+    const void* Q[4];
+    const void* V[4];
+    const void* dO[4];
+    const float* out[4];
+    const float* V32[4];
+    const float* lse[4];
+    float* Dq[4];
+    float* dK[4];
+    float* dQ[4];
+    float* dV[4];
+    const float* add32[4];
+    const __bf16* add16[4];
+    int residual[4];
+};
+
 // D[q] = sum_c dO[q,c] * (out[q,c] - (residual ? V[q,c] : 0))
 template <int D, typename TG>
 __global__ __launch_bounds__(256) void hupr_k_attn_prep(const TG* __restrict__ dO, int lddo, const float* __restrict__ out,
                                                         const float* __restrict__ V, float* __restrict__ Dq, long rows,
-                                                        int residual) {
+                                                        int residual, const AttnBwdBatch batch = AttnBwdBatch()) {
+    if (batch.n > 0) {
+        const int item = (int)blockIdx.y;
+        dO = static_cast<const TG*>(batch.dO[item]);
+        out = batch.out[item];
+        V = batch.V32[item];
+        Dq = batch.Dq[item];
+        residual = batch.residual[item];
+    }
     // 16 lanes per row (D/16 floats each)
     const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int sub = threadIdx.x & 15;
@@ -509,12 +550,24 @@ template <int D, typename TI, bool QS = false>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
-                                                          float* __restrict__ dQ, int N, int ldk, int ldq, int lddq, int lddo, int xcd_map) {
+                                                          float* __restrict__ dQ, int N, int ldk, int ldq, int lddq, int lddo, int xcd_map,
+                                                          const AttnBwdBatch batch = AttnBwdBatch()) {
     __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     int bx, by;
     xcd_block(bx, by, xcd_map);
+    if (batch.n > 0) {
+        const int item = by / batch.Bn;
+        by -= item * batch.Bn;
+        K = static_cast<const TI*>(batch.K[item]);
+        Q = static_cast<const TI*>(batch.Q[item]);
+        V = static_cast<const TI*>(batch.V[item]);
+        dO = static_cast<const TI*>(batch.dO[item]);
+        lse = batch.lse[item];
+        Dq = batch.Dq[item];
+        dQ = batch.dQ[item];
+    }
     const long base = (long)by * N * D;
     const int q = bx * 128 + wave * 32 + lr;
     K += (long)by * N * ldk;
@@ -587,13 +640,28 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dkv(cons
                                                            const float* dVadd,
                                                            const float* __restrict__ lse, const float* __restrict__ Dq,
                                                            float* __restrict__ dK, float* dV, int N, int ldk,
-                                                           int ldq, int lddk, int lddo, const __bf16* dVadd16, int ldadd16, int xcd_map) {
+                                                           int ldq, int lddk, int lddo, const __bf16* dVadd16, int ldadd16, int xcd_map,
+                                                           const AttnBwdBatch batch = AttnBwdBatch()) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[64 * D];
     __shared__ __attribute__((aligned(16))) __bf16 Gs[64 * D];
     __shared__ __attribute__((aligned(16))) float s_lse[64], s_d[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     int bx, by;
     xcd_block(bx, by, xcd_map);
+    if (batch.n > 0) {
+        const int item = by / batch.Bn;
+        by -= item * batch.Bn;
+        K = static_cast<const TI*>(batch.K[item]);
+        Q = static_cast<const TI*>(batch.Q[item]);
+        V = static_cast<const TI*>(batch.V[item]);
+        dO = static_cast<const TI*>(batch.dO[item]);
+        lse = batch.lse[item];
+        Dq = batch.Dq[item];
+        dK = batch.dK[item];
+        dV = batch.dV[item];
+        dVadd = batch.add32[item];
+        dVadd16 = batch.add16[item];
+    }
     const long base = (long)by * N * D;
     const int key = bx * 128 + wave * 32 + lr;                // this lane's key
     bf16x8 kf[D / 16], vf[D / 16];
@@ -1232,18 +1300,28 @@ extern "C" int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, in
     return attn_fwd("hupr_attn_fwd_bf16in_ld", static_cast<const __bf16*>(K), ldk, static_cast<const __bf16*>(Q), ldq,
                     static_cast<const __bf16*>(V), Vres, out, lse, out16, ld16, Bn, N, C, stream);
 }
-// Up to four independent attentions of the same shape and strides in ONE split launch + ONE merge launch (the four attentions of an MSCSA
-// level in single-sample inference: 8 launches -> 2).  Only where the split form applies (hupr_attn_fwd_split_ws_bytes(Bn, N, C) > 0);
-// ws: n_items times that many bytes.  items: host array of hupr_attn_item (bf16 K / Q / V, fp32 Vres or null, fp32 out, lse, bf16 out16 or null).
+// Up to four independent attentions of the same shape and strides (the four of an MSCSA level) in as few launches as fill the chip:
+// single-sample inference (hupr_attn_fwd_split_ws_bytes(Bn, N, C) > 0; ws: n_items times that many bytes): ONE split launch + ONE merge
+// launch instead of 8; training batches (ws may be null): ONE launch of the one-pass kernel with blockIdx.z = item (levels 2 and 3: a
+// single attention's grid is 256 / 64 workgroups), except at the level-1 shape, whose ping-pong kernel is launched once per item.  items: host array of hupr_attn_item (bf16 K / Q / V, fp32 Vres or null, fp32 out, lse, bf16 out16 or null).
 template <bool QS>
 static int attn_fwd_batch(const char* who, const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N,
                           int C, void* ws, size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(items && n_items >= 1 && n_items <= 4 && Bn > 0 && ws, "%s: bad argument", who);
+    HUPR_REQUIRE(items && n_items >= 1 && n_items <= 4 && Bn > 0, "%s: bad argument", who);
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
     HUPR_REQUIRE(ldk >= C && ldq >= C && ldk % 8 == 0 && ldq % 8 == 0, "%s: bad row strides %d %d", who, ldk, ldq);
-    const int S = attn_splits(Bn, N);
-    HUPR_REQUIRE(S > 1, "%s: the split form does not apply to Bn=%d N=%d (use hupr_attn_fwd_bf16in_ld_ws per attention)", who, Bn, N);
-    HUPR_REQUIRE(ws_bytes >= (size_t)n_items * hupr_attn_fwd_split_ws_bytes(Bn, N, C), "%s: workspace too small", who);
+    const int S = ws ? attn_splits(Bn, N) : 1;
+    if (S == 1 && C == 64 && N % 256 == 0 && g_attn_pp && (long)N * ldk * 2 < (1L << 31)) {
+        // level-1 shape: each attention fills the chip by itself with the ping-pong kernel — one launch per item
+        for (int i = 0; i < n_items; ++i) {
+            const int rc = attn_fwd<__bf16, QS>(who, static_cast<const __bf16*>(items[i].K), ldk, static_cast<const __bf16*>(items[i].Q), ldq,
+                                               static_cast<const __bf16*>(items[i].V), items[i].Vres, items[i].out, items[i].lse,
+                                               items[i].out16, ld16, Bn, N, C, stream);
+            if (rc) return rc;
+        }
+        return HUPR_OK;
+    }
+    HUPR_REQUIRE(S == 1 || ws_bytes >= (size_t)n_items * hupr_attn_fwd_split_ws_bytes(Bn, N, C), "%s: workspace too small", who);
     AttnBatch b = AttnBatch();
     b.n = n_items;
     b.splits = S;
@@ -1255,6 +1333,18 @@ static int attn_fwd_batch(const char* who, const hupr_attn_item* items, int n_it
         any16 = any16 || items[i].out16;
     }
     HUPR_REQUIRE(!any16 || (ld16 >= C && ld16 % 4 == 0), "%s: bad bf16 output stride %d", who, ld16);
+    if (S == 1) {                                   // one-pass kernel, blockIdx.z = item
+        const dim3 g1(N / 128, Bn, n_items);
+        hipStream_t s1 = as_stream(stream);
+        const __bf16* const k0 = nullptr;
+        float* const f0 = nullptr;
+        __bf16* const h0 = nullptr;
+        if (C == 64) HUPR_LAUNCH((hupr_k_attn_fwd<64, __bf16, false, QS>), g1, dim3(256), 0, s1, k0, k0, k0, f0, f0, f0, N, ldk, ldq, h0, ld16, f0, f0, b);
+        else if (C == 128) HUPR_LAUNCH((hupr_k_attn_fwd<128, __bf16, false, QS>), g1, dim3(256), 0, s1, k0, k0, k0, f0, f0, f0, N, ldk, ldq, h0, ld16, f0, f0, b);
+        else HUPR_LAUNCH((hupr_k_attn_fwd<256, __bf16, false, QS>), g1, dim3(256), 0, s1, k0, k0, k0, f0, f0, f0, N, ldk, ldq, h0, ld16, f0, f0, b);
+        HUPR_LAUNCH_OK("hupr_k_attn_fwd (batch)");
+        return HUPR_OK;
+    }
     const long rows = (long)Bn * N;
     float* part_o = static_cast<float*>(ws);
     float* part_ml = part_o + (long)n_items * S * rows * C;
@@ -1339,6 +1429,95 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
 #undef HUPR_ATTN_BWD
     HUPR_LAUNCH_OK("hupr_k_attn_bwd");
     return HUPR_OK;
+}
+
+// The backward passes of up to four attentions of one shape (an MSCSA level; bf16 operands and a bf16-stored gradient dO): ONE row-sum
+// launch, ONE dQ launch, and dK / dV launches in as many rounds as the items' dV targets need — an item with `accumulate` adds onto
+// the dV an EARLIER item of the array writes, so it goes into a later round (SPEC order of the level: two rounds of two).  At the
+// level-1 shape the 512-thread dK / dV kernel takes one attention per launch (it fills the chip alone), in array order.
+template <bool QS>
+static int attn_bwd_batch(const char* who, const hupr_attn_bwd_item* items, int n_items, int ldk, int ldq, int lddo, int lddk, int lddq,
+                          int Bn, int N, int C, hupr_stream_t stream) {
+    HUPR_REQUIRE(items && n_items >= 1 && n_items <= 4 && Bn > 0, "%s: bad argument", who);
+    HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
+    for (int i = 0; i < n_items; ++i) {
+        const hupr_attn_bwd_item& t = items[i];
+        HUPR_REQUIRE(t.K && t.Q && t.V && t.dO && t.V32 && t.out && t.lse && t.dK && t.dQ && t.dV && t.Dq, "%s: null pointer in item %d", who, i);
+        HUPR_REQUIRE(!(t.residual && t.accumulate), "%s: accumulate is for the non-residual form (item %d)", who, i);
+    }
+    const bool level1 = C == 64 && g_attn_dkv512 && N % 256 == 0;       // its 512-thread dK / dV kernel takes one attention per launch
+    if (n_items == 1) {
+        for (int i = 0; i < n_items; ++i) {
+            const hupr_attn_bwd_item& t = items[i];
+            const int rc = attn_bwd<__bf16, QS>(who, static_cast<const __bf16*>(t.K), ldk, static_cast<const __bf16*>(t.Q), ldq,
+                                               static_cast<const __bf16*>(t.V), static_cast<const __bf16*>(t.dO), lddo, t.V32, t.out, nullptr,
+                                               t.lse, t.dK, lddk, t.dQ, lddq, t.dV, t.accumulate, t.Dq, Bn, N, C, t.residual, stream);
+            if (rc) return rc;
+        }
+        return HUPR_OK;
+    }
+    HUPR_REQUIRE(ldk >= C && ldq >= C && lddk >= C && lddq >= C && lddo >= C && ldk % 8 == 0 && ldq % 8 == 0 && lddo % 8 == 0 &&
+                     lddk % 4 == 0 && lddq % 4 == 0, "%s: bad row strides", who);
+    hipStream_t s = as_stream(stream);
+    const long rows = (long)Bn * N;
+    const int xmap = (g_attn_xcd && Bn % 8 == 0) ? 1 : 0;
+    AttnBwdBatch b = AttnBwdBatch();
+    b.n = n_items;
+    b.Bn = Bn;
+    for (int i = 0; i < n_items; ++i) {
+        const hupr_attn_bwd_item& t = items[i];
+        b.K[i] = t.K; b.Q[i] = t.Q; b.V[i] = t.V; b.dO[i] = t.dO; b.out[i] = t.out; b.V32[i] = t.V32; b.lse[i] = t.lse;
+        b.Dq[i] = t.Dq; b.dK[i] = t.dK; b.dQ[i] = t.dQ; b.dV[i] = t.dV; b.residual[i] = t.residual;
+        b.add32[i] = t.accumulate ? t.dV : nullptr;
+        b.add16[i] = t.residual ? static_cast<const __bf16*>(t.dO) : nullptr;
+    }
+    const __bf16* const k0 = nullptr;
+    const float* const c0 = nullptr;
+    float* const f0 = nullptr;
+    const dim3 pgrid((unsigned)((rows + 15) / 16), n_items), qgrid(N / 128, Bn * n_items);
+    // dK / dV rounds: an item waits for the round after the one that writes the dV it accumulates onto / shares
+    int round_of[4], n_rounds = 0;
+    for (int i = 0; i < n_items; ++i) {
+        int r = 0;
+        for (int j = 0; j < i; ++j)
+            if (items[j].dV == items[i].dV) r = round_of[j] + 1 > r ? round_of[j] + 1 : r;
+        round_of[i] = r;
+        n_rounds = r + 1 > n_rounds ? r + 1 : n_rounds;
+    }
+#define HUPR_ATTN_BWD_BATCH(D_, NH_)                                                                                             \
+    HUPR_LAUNCH((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, k0, lddo, c0, c0, f0, rows, 0, b);                      \
+    HUPR_LAUNCH((hupr_k_attn_bwd_dq<D_, __bf16, QS>), qgrid, dim3(256), 0, s, k0, k0, k0, k0, c0, c0, f0, N, ldk, ldq, lddq, lddo, xmap, b); \
+    for (int r = 0; r < n_rounds; ++r) {                                                                                         \
+        AttnBwdBatch br = AttnBwdBatch();                                                                                        \
+        br.Bn = Bn;                                                                                                              \
+        for (int i = 0; i < n_items; ++i)                                                                                        \
+            if (round_of[i] == r) {                                                                                              \
+                const int k = br.n++;                                                                                            \
+                br.K[k] = b.K[i]; br.Q[k] = b.Q[i]; br.V[k] = b.V[i]; br.dO[k] = b.dO[i]; br.lse[k] = b.lse[i]; br.Dq[k] = b.Dq[i]; \
+                br.dK[k] = b.dK[i]; br.dV[k] = b.dV[i]; br.add32[k] = b.add32[i]; br.add16[k] = b.add16[i];                      \
+            }                                                                                                                    \
+        HUPR_LAUNCH((hupr_k_attn_bwd_dkv<D_, __bf16, NH_, QS>), dim3(N / 128, Bn * br.n, NH_), dim3(256), 0, s, k0, k0, k0, k0, c0, c0, c0, \
+                    f0, f0, N, ldk, ldq, lddk, lddo, k0, lddo, xmap, br);                                                        \
+    }
+    if (level1) {
+        HUPR_LAUNCH((hupr_k_attn_prep<64, __bf16>), pgrid, dim3(256), 0, s, k0, lddo, c0, c0, f0, rows, 0, b);
+        HUPR_LAUNCH((hupr_k_attn_bwd_dq<64, __bf16, QS>), qgrid, dim3(256), 0, s, k0, k0, k0, k0, c0, c0, f0, N, ldk, ldq, lddq, lddo, xmap, b);
+        for (int i = 0; i < n_items; ++i)       // array order: an accumulating item follows the one that writes its dV
+            HUPR_LAUNCH(hupr_k_attn_bwd_dkv512<QS>, dim3(N / 256, Bn), dim3(512), 0, s, static_cast<const __bf16*>(b.K[i]),
+                        static_cast<const __bf16*>(b.Q[i]), static_cast<const __bf16*>(b.V[i]), static_cast<const __bf16*>(b.dO[i]), b.add32[i],
+                        b.lse[i], b.Dq[i], b.dK[i], b.dV[i], N, ldk, ldq, lddk, lddo, b.add16[i], lddo, xmap);
+    } else if (C == 64) { HUPR_ATTN_BWD_BATCH(64, 1) } else if (C == 128) { HUPR_ATTN_BWD_BATCH(128, 1) } else { HUPR_ATTN_BWD_BATCH(256, 2) }
+#undef HUPR_ATTN_BWD_BATCH
+    HUPR_LAUNCH_OK("hupr_k_attn_bwd (batch)");
+    return HUPR_OK;
+}
+extern "C" int hupr_attn_bwd_bf16in_ld_batch(const hupr_attn_bwd_item* items, int n_items, int ldk, int ldq, int lddo, int lddk,
+                                             int lddq, int Bn, int N, int C, hupr_stream_t stream) {
+    return attn_bwd_batch<false>("hupr_attn_bwd_bf16in_ld_batch", items, n_items, ldk, ldq, lddo, lddk, lddq, Bn, N, C, stream);
+}
+extern "C" int hupr_attn_bwd_bf16in_ld_batch_qs(const hupr_attn_bwd_item* items, int n_items, int ldk, int ldq, int lddo, int lddk,
+                                                int lddq, int Bn, int N, int C, hupr_stream_t stream) {
+    return attn_bwd_batch<true>("hupr_attn_bwd_bf16in_ld_batch_qs", items, n_items, ldk, ldq, lddo, lddk, lddq, Bn, N, C, stream);
 }
 
 extern "C" int hupr_attn_bwd_bf16(const float* K, const float* Q, const float* V, const float* out, const float* dout,

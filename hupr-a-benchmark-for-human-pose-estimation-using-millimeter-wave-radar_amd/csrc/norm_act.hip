@@ -153,6 +153,35 @@ __global__ void hupr_k_bn_finalize_fwd(const double* __restrict__ partial, int n
     }
 }
 
+// the two forward finalizes of a BasicBlock3D tail (both branches' convolutions left their column sums) in one launch: blockIdx.y = branch
+struct BnFinalizeFwd {
+    const double* partial;
+    int nblk;
+    const float *gamma, *beta;
+    float *running_mean, *running_var, *save_mean, *save_invstd, *scale, *shift;
+    float momentum, eps;
+};
+__global__ void hupr_k_bn_finalize_fwd2(BnFinalizeFwd a0, BnFinalizeFwd a1, long M, int C) {
+    const BnFinalizeFwd& a = blockIdx.y ? a1 : a0;
+    int c;
+    double s1, s2;
+    if (!reduce_partials(a.partial, a.nblk, C, c, s1, s2)) return;
+    const double mean = s1 / (double)M;
+    double var = s2 / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    a.save_mean[c] = (float)mean;
+    a.save_invstd[c] = invstd;
+    const float sc = a.gamma[c] * invstd;
+    a.scale[c] = sc;
+    a.shift[c] = a.beta[c] - (float)mean * sc;
+    if (a.running_mean) {
+        const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+}
+
 __global__ void hupr_k_bn_eval_params(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                       int C, float* __restrict__ scale, float* __restrict__ shift) {
@@ -657,6 +686,27 @@ extern "C" int hupr_bn_train_finalize_f32(const void* partial, int nblk, long M,
                        static_cast<const double*>(partial), nblk, M, C, gamma, beta, running_mean, running_var, momentum, eps,
                        save_mean, save_invstd, scale, shift);
     HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd");
+    return HUPR_OK;
+}
+
+// ... for two BatchNorms over tensors of one shape at once (the tail of a BasicBlock3D: bn_a(conv2(...)) + bn_b(residual conv(x)),
+// reference models/layers.py:66-70): one launch instead of two
+extern "C" int hupr_bn_train_finalize2_f32(const void* partial1, int nblk1, const float* gamma1, const float* beta1,
+                                           float* running_mean1, float* running_var1, float momentum1, float eps1,
+                                           float* save_mean1, float* save_invstd1, float* scale1, float* shift1,
+                                           const void* partial2, int nblk2, const float* gamma2, const float* beta2,
+                                           float* running_mean2, float* running_var2, float momentum2, float eps2,
+                                           float* save_mean2, float* save_invstd2, float* scale2, float* shift2, long M, int C,
+                                           hupr_stream_t stream) {
+    HUPR_REQUIRE(partial1 && nblk1 > 0 && gamma1 && beta1 && save_mean1 && save_invstd1 && scale1 && shift1 && partial2 && nblk2 > 0 &&
+                     gamma2 && beta2 && save_mean2 && save_invstd2 && scale2 && shift2 && M > 0 && C > 0,
+                 "hupr_bn_train_finalize2_f32: bad argument");
+    const BnFinalizeFwd a0{static_cast<const double*>(partial1), nblk1, gamma1, beta1, running_mean1, running_var1, save_mean1,
+                           save_invstd1, scale1, shift1, momentum1, eps1};
+    const BnFinalizeFwd a1{static_cast<const double*>(partial2), nblk2, gamma2, beta2, running_mean2, running_var2, save_mean2,
+                           save_invstd2, scale2, shift2, momentum2, eps2};
+    HUPR_LAUNCH(hupr_k_bn_finalize_fwd2, dim3((C + kFinalizeCh - 1) / kFinalizeCh, 2), dim3(256), 0, as_stream(stream), a0, a1, M, C);
+    HUPR_LAUNCH_OK("hupr_k_bn_finalize_fwd2");
     return HUPR_OK;
 }
 

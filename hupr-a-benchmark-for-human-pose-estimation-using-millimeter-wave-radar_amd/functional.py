@@ -452,6 +452,8 @@ def _halo_ok(x, k, pad, co=4):
 # and the immediate epilogue, -0.16 ms / +0.7 % frames/s per step measured in interleaved same-box runs -> ON by default
 # (HUPR_CONV_STATS=0 switches it off).
 CONV_STATS = os.environ.get("HUPR_CONV_STATS", "1") == "1"
+ATTN_LEVEL_BATCH = os.environ.get("HUPR_NO_ATTN_LEVEL_BATCH", "0") != "1"      # A/B aid: 1 = one launch per attention at every level
+ATTN_PROBE = None          # measurement hook (bench.py): (kind, B, N, C) -> (start, end) events around one attention's launches, or None
 _conv_stats = {}
 
 
@@ -899,6 +901,37 @@ def _bn_params(x, bn, training, need_bwd=True):
     return scale, shift, mean, invstd
 
 
+BN_FINALIZE_PAIR = os.environ.get("HUPR_NO_BN_FINALIZE_PAIR", "0") != "1"      # A/B aid
+
+
+def _bn_params_pair(x1, bn1, x2, bn2):
+    """Training-mode coefficients of the two BatchNorms of a block tail when BOTH producing convolutions left their column sums:
+    one finalize launch for the pair (hupr_bn_train_finalize2_f32).  None: not applicable — the caller takes them one by one."""
+    f1, f2 = _conv_stats.get(x1.data_ptr()), _conv_stats.get(x2.data_ptr())
+    C = x1.shape[-1]
+    M = x1.numel() // C
+    if (not BN_FINALIZE_PAIR or f1 is None or f2 is None or x1.shape != x2.shape or x1.data_ptr() == x2.data_ptr()
+            or (f1[2], f1[3]) != (M, C) or (f2[2], f2[3]) != (M, C)):
+        return None
+    _conv_stats.pop(x1.data_ptr())
+    _conv_stats.pop(x2.data_ptr())
+    dev = x1.device
+    out = [[torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4)] for _ in range(2)]      # scale, shift, mean, invstd
+    args = []
+    for f, bn, (scale, shift, mean, invstd) in ((f1, bn1, out[0]), (f2, bn2, out[1])):
+        track = bn.running_mean is not None
+        args += [rt.ptr(f[0]), f[1], rt.ptr(bn.weight), rt.ptr(bn.bias), rt.ptr(bn.running_mean) if track else None,
+                 rt.ptr(bn.running_var) if track else None, float(bn.momentum), float(bn.eps), rt.ptr(mean), rt.ptr(invstd),
+                 rt.ptr(scale), rt.ptr(shift)]
+        if track and bn.num_batches_tracked is not None:
+            if BN_COUNTER_SINK is not None:
+                BN_COUNTER_SINK.append(bn)
+            else:
+                bn.num_batches_tracked.add_(1)
+    rt.check(rt.lib().hupr_bn_train_finalize2_f32(*args, M, C, rt.stream()))
+    return tuple(out[0]), tuple(out[1])
+
+
 BN_REMASK = os.environ.get("HUPR_NO_BN_REMASK", "0") != "1"      # recompute ReLU masks in the BatchNorm backward passes
 
 
@@ -975,8 +1008,12 @@ class BNAddBNReLUFn(torch.autograd.Function):
                                              rt.ptr(bn2.bias), rt.ptr(bn2.running_mean), rt.ptr(bn2.running_var), float(bn2.eps),
                                              rt.ptr(y), x1.numel() // C, C, 1, rt.stream()))
             return y
-        s1, t1, m1, i1 = _bn_params(x1, bn1, training, not no_bwd)
-        s2, t2, m2, i2 = _bn_params(x2, bn2, training, not no_bwd)
+        pair = _bn_params_pair(x1, bn1, x2, bn2) if training else None
+        if pair is not None:
+            (s1, t1, m1, i1), (s2, t2, m2, i2) = pair
+        else:
+            s1, t1, m1, i1 = _bn_params(x1, bn1, training, not no_bwd)
+            s2, t2, m2, i2 = _bn_params(x2, bn2, training, not no_bwd)
         C = x1.shape[-1]
         y = torch.empty_like(x1)
         assert x1.dtype == x2.dtype
@@ -1525,19 +1562,24 @@ class MSCSALevelFn(torch.autograd.Function):
             rt.check(L.hupr_attn_mx8_quant_level(rt.ptr(Y[0]), rt.ptr(Y[1]), rt.ptr(vb[0]), rt.ptr(vb[1]), B, N, C, rt.ptr(ws8),
                                                  ws8.numel(), rt.stream()))
         # single-sample inference (config C2): the four attentions of the level as ONE split launch + ONE merge launch instead of eight
-        split_bytes = L.hupr_attn_fwd_split_ws_bytes(B, N, C) if (infer and flash and ATTN_BATCH and not mx8) else 0
-        if split_bytes:
+        split_ws = L.hupr_attn_fwd_split_ws_bytes(B, N, C) if (flash and not mx8) else 0       # (> 0: the key-split form applies to this batch)
+        split_bytes = split_ws if (infer and ATTN_BATCH) else 0
+        # training batches, levels 2 and 3 (C = 128 / 256: one attention's grid is 256 / 64 workgroups): the four as ONE launch of the
+        # one-pass kernel (not where the single-sample split form applies: its shares round differently)
+        level_batch = flash and ATTN_LEVEL_BATCH and not mx8 and not split_ws and C != 64
+        if split_bytes or level_batch:
             items = (rt.AttnItem * 4)()
             for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
                 items[i].K, items[i].Q = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
                 items[i].V, items[i].Vres = rt.ptr(vb[vs]), (rt.ptr(maps[vs]) if residual else None)
                 items[i].out, items[i].lse = rt.ptr(out), rt.ptr(a)
                 items[i].out16 = (cat.data_ptr() + i * C * 2) if cat_bf16 else None
-            ws = workspace(4 * split_bytes, dev)
+            ws = workspace(4 * split_bytes, dev) if split_bytes else None
             fwd_batch = L.hupr_attn_fwd_bf16in_ld_ws_batch_qs if qscaled else L.hupr_attn_fwd_bf16in_ld_ws_batch
-            rt.check(fwd_batch(items, 4, 4 * C, 4 * C, ld16, B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
+            rt.check(fwd_batch(items, 4, 4 * C, 4 * C, ld16, B, N, C, rt.ptr(ws) if ws is not None else None,
+                               ws.numel() if ws is not None else 0, rt.stream()))
         for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
-            if split_bytes:
+            if split_bytes or level_batch:
                 break
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
             if mx8:
@@ -1547,10 +1589,15 @@ class MSCSALevelFn(torch.autograd.Function):
             elif flash:
                 ws = _attn_ws(B, N, C, dev)
                 fwd = L.hupr_attn_fwd_bf16in_ld_ws_qs if qscaled else L.hupr_attn_fwd_bf16in_ld_ws
+                ev = ATTN_PROBE("fwd", B, N, C) if ATTN_PROBE is not None else None
+                if ev is not None:
+                    ev[0].record()
                 rt.check(fwd(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), rt.ptr(maps[vs]) if residual else None,
                              rt.ptr(out), rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None,
                              ld16, B, N, C, rt.ptr(ws) if ws is not None else None,
                              ws.numel() if ws is not None else 0, rt.stream()))
+                if ev is not None:
+                    ev[1].record()
             else:
                 # P[q][j] = Q[q] . K[j], softmax over the keys j (row softmax), out = P V (+ V)
                 rt.check(L.hupr_gemm_bf16(0, 1, qp, kp, rt.ptr(a), N, N, C, 4 * C, 4 * C, N, B, N * 4 * C, N * 4 * C, N * N,
@@ -1591,7 +1638,31 @@ class MSCSALevelFn(torch.autograd.Function):
                 ld = 4 * C
             douts = [None] * 4
         # SPEC order: the residual attention of a map writes its dV, the other one adds to it
+        level_batch = flash and ctx.cat_bf16 and ATTN_LEVEL_BATCH
+        if level_batch:
+            # row sums and dQ of the four attentions in one launch each; dK / dV: levels 2 and 3 in two launches of two (the residual
+            # attentions of the two maps, then the two that add onto their dV) — 4 launches instead of 12, grids four / two times as
+            # large; level 1 one launch per attention (12 -> 6 launches)
+            scr4 = torch.empty((4, B, N), dtype=f32, device=dev)
+            items = (rt.AttnBwdItem * 4)()
+            for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
+                it = items[i]
+                it.K, it.Q = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
+                it.V, it.dO = rt.ptr(vb[vs]), dcat.data_ptr() + i * C * 2
+                it.V32, it.out, it.lse = rt.ptr(maps[vs]), rt.ptr(out), rt.ptr(a)
+                it.dK, it.dQ = dY[ks].data_ptr() + kslot * C * 4, dY[qs].data_ptr() + qslot * C * 4
+                it.dV, it.Dq = rt.ptr(dV[vs]), scr4.data_ptr() + i * B * N * 4
+                it.residual, it.accumulate = (1, 0) if residual else (0, 1)
+            bwd_batch = L.hupr_attn_bwd_bf16in_ld_batch_qs if ctx.qscaled else L.hupr_attn_bwd_bf16in_ld_batch
+            ev = ATTN_PROBE("bwd_level", B, N, C) if ATTN_PROBE is not None else None
+            if ev is not None:
+                ev[0].record()
+            rt.check(bwd_batch(items, 4, 4 * C, 4 * C, ld, 4 * C, 4 * C, B, N, C, rt.stream()))
+            if ev is not None:
+                ev[1].record()
         for i, ((ks, kslot, qs, qslot, vs, residual), out, a, dout) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux, douts)):
+            if level_batch:
+                break
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
             dkp, dqp = dY[ks].data_ptr() + kslot * C * 4, dY[qs].data_ptr() + qslot * C * 4
             if flash:
@@ -1602,10 +1673,15 @@ class MSCSALevelFn(torch.autograd.Function):
                     gb = _cast(dout, torch.bfloat16)
                     gp, ldg, g32 = rt.ptr(gb), C, rt.ptr(dout)
                 bwd = L.hupr_attn_bwd_bf16in_ld_qs if ctx.qscaled else L.hupr_attn_bwd_bf16in_ld
+                ev = ATTN_PROBE("bwd", B, N, C) if ATTN_PROBE is not None else None
+                if ev is not None:
+                    ev[0].record()
                 rt.check(bwd(kp, 4 * C, qp, 4 * C, rt.ptr(vb[vs]), gp, ldg, rt.ptr(maps[vs]),
                              rt.ptr(out), g32, rt.ptr(a), dkp, 4 * C, dqp, 4 * C, rt.ptr(dV[vs]),
                              rt.ptr(scr), B, N, C, 1 if residual else 0, 0 if residual else 1,
                              rt.stream()))
+                if ev is not None:
+                    ev[1].record()
                 continue
             dout = _c(dout)
             v, P, g = maps[vs], a, rt.ptr(dout)

@@ -23,6 +23,12 @@ class AttnItem(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("lse", ctypes.c_void_p), ("out16", ctypes.c_void_p)]
 
 
+class AttnBwdItem(ctypes.Structure):
+    """hupr_attn_bwd_item (include/hupr.h): one attention of a batched backward pass."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("K", "Q", "V", "dO", "V32", "out", "lse", "dK", "dQ", "dV", "Dq")] + \
+               [("residual", ctypes.c_int), ("accumulate", ctypes.c_int)]
+
+
 SIGNATURES = {
     "hupr_version": (c_int, []),
     "hupr_last_error": (c_char_p, []),
@@ -54,6 +60,8 @@ SIGNATURES = {
     "hupr_conv3x3_halo_stats_rows": (c_int, []),
     "hupr_conv3x3_halo_bf16act_stats": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
     "hupr_bn_train_finalize_f32": (c_int, [c_void_p, c_int, c_long, c_int] + [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 5),
+    "hupr_bn_train_finalize2_f32": (c_int, ([c_void_p, c_int] + [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 4) * 2
+                                    + [c_long, c_int, c_void_p]),
     "hupr_pack_conv_weights_table": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hupr_debug_fft_range_first": (None, [c_int]),
     "hupr_debug_fft_variant": (None, [c_int]),
@@ -117,6 +125,8 @@ SIGNATURES = {
     "hupr_attn_fwd_bf16in_ld_ws_batch_qs": (c_int, [ctypes.POINTER(AttnItem)] + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     "hupr_attn_bwd_bf16in_ld_qs": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4
                                    + [c_void_p, c_int, c_void_p, c_int] + [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "hupr_attn_bwd_bf16in_ld_batch": (c_int, [ctypes.POINTER(AttnBwdItem)] + [c_int] * 9 + [c_void_p]),
+    "hupr_attn_bwd_bf16in_ld_batch_qs": (c_int, [ctypes.POINTER(AttnBwdItem)] + [c_int] * 9 + [c_void_p]),
     "hupr_softmax_rows_f32": (c_int, [c_void_p, c_long, c_int, c_void_p]),
     "hupr_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "hupr_head1x1_ws_bytes": (c_size_t, []),

@@ -258,6 +258,13 @@ int hupr_bn_eval_act_bf16act(const void* x1, const float* gamma1, const float* b
 int hupr_bn_train_finalize_f32(const void* partial, int nblk, long M, int C, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                                float* save_invstd, float* scale, float* shift, hupr_stream_t stream);
+/* ... of two BatchNorms over tensors of one shape in one launch (the tail of a BasicBlock3D, reference models/layers.py:66-70) */
+int hupr_bn_train_finalize2_f32(const void* partial1, int nblk1, const float* gamma1, const float* beta1, float* running_mean1,
+                                float* running_var1, float momentum1, float eps1, float* save_mean1, float* save_invstd1,
+                                float* scale1, float* shift1, const void* partial2, int nblk2, const float* gamma2,
+                                const float* beta2, float* running_mean2, float* running_var2, float momentum2, float eps2,
+                                float* save_mean2, float* save_invstd2, float* scale2, float* shift2, long M, int C,
+                                hupr_stream_t stream);
 int hupr_bn_bwd_f32(const float* dy, const float* y_mask, const float* x, const float* save_mean,
                     const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta, long M,
                     int C, int train, void* ws, size_t ws_bytes, hupr_stream_t stream);
@@ -339,9 +346,10 @@ int hupr_attn_fwd_bf16in_ld(const void* K, int ldk, const void* Q, int ldq, cons
  * the workspace that needs, or 0 when the one-pass kernel is used (ws may then be null): by default the split is taken for
  * single-sample calls only, so that batched runs keep the rounding their parity gates were measured with. */
 size_t hupr_attn_fwd_split_ws_bytes(int Bn, int N, int C);
-/* Up to four independent attentions of one shape (the four of an MSCSA level, reference models/layers.py:150-163) in ONE split launch and
- * ONE merge launch — single-sample inference is bound by launches, not work.  Applies where hupr_attn_fwd_split_ws_bytes() > 0; ws: n_items
- * times that size.  K / Q / V: bf16 with row strides ldk / ldq / C; Vres (fp32 V for the residual) and out16 (bf16 copy, stride ld16) may be null. */
+/* Up to four independent attentions of one shape (the four of an MSCSA level, reference models/layers.py:150-163) in as few launches as
+ * fill the chip.  Where hupr_attn_fwd_split_ws_bytes() > 0 (single-sample inference — bound by launches, not work): ONE split launch and
+ * ONE merge launch, ws: n_items times that size.  Otherwise (training batches; ws may be NULL): ONE launch of the one-pass kernel over all
+ * items (levels 2 and 3), or one ping-pong launch per item (level-1 shape).  K / Q / V: bf16 with row strides ldk / ldq / C; Vres (fp32 V for the residual) and out16 (bf16 copy, stride ld16) may be null. */
 typedef struct hupr_attn_item { const void* K; const void* Q; const void* V; const float* Vres; float* out; float* lse; void* out16; } hupr_attn_item;
 int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N, int C,
                                      void* ws, size_t ws_bytes, hupr_stream_t stream);
@@ -368,6 +376,21 @@ int hupr_attn_bwd_bf16in_ld_qs(const void* K, int ldk, const void* Qs, int ldq, 
                                const float* V32, const float* out, const float* dout32_or_null, const float* lse, float* dK,
                                int lddk, float* dQ, int lddq, float* dV, float* Dq_scratch, int Bn, int N, int C, int residual,
                                int accumulate, hupr_stream_t stream);
+/* The backward passes of up to four attentions of one shape and one set of strides (the four of an MSCSA level, reference
+ * models/layers.py:150-163 under autograd) with a bf16-stored gradient dO: one row-sum launch, one dQ launch, and dK / dV launches
+ * in as many rounds as the dV targets need (an item with `accumulate` adds onto the dV an EARLIER item writes).  Same results as n
+ * calls of hupr_attn_bwd_bf16in_ld(_qs) with dout32 == NULL in array order; the level-1 shape is launched per item as before.
+ * hupr_attn_fwd_bf16in_ld_ws_batch(_qs) is the forward counterpart (ws may be NULL for training batches). */
+typedef struct hupr_attn_bwd_item {
+    const void* K; const void* Q; const void* V; const void* dO;      /* bf16 operands (Q: Qs for the _qs form) */
+    const float* V32; const float* out; const float* lse;             /* fp32: values, forward output, log-sum-exp */
+    float* dK; float* dQ; float* dV; float* Dq;                        /* outputs (row strides lddk / lddq / C) and a (Bn, N) scratch of its own */
+    int residual, accumulate;
+} hupr_attn_bwd_item;
+int hupr_attn_bwd_bf16in_ld_batch(const hupr_attn_bwd_item* items, int n_items, int ldk, int ldq, int lddo, int lddk, int lddq,
+                                  int Bn, int N, int C, hupr_stream_t stream);
+int hupr_attn_bwd_bf16in_ld_batch_qs(const hupr_attn_bwd_item* items, int n_items, int ldk, int ldq, int lddo, int lddk, int lddq,
+                                     int Bn, int N, int C, hupr_stream_t stream);
 
 /* (a7) PRGCN: y = act(t . A + bias) with t = W . x computed by hupr_gemm_f32 (gcn_networks.py:23-29,53-58) */
 /* The 1x1 key-point head nn.Conv2d(32, 14, 1, bias=False) (reference models/layers.py:94) in plain fp32 FMAs: x [M][32],

@@ -984,6 +984,38 @@ def test_mscsa_level_bf16_concatenated_output(C, H, bf16_math):
         assert torch.equal(x, y), "gradient %d differs" % i
 
 
+@pytest.mark.parametrize("C,H,B", [(128, 32, 8), (256, 16, 8), (256, 16, 3), (64, 16, 8)])
+def test_mscsa_level_attentions_as_one_launch_per_kernel(C, H, B, bf16_math):
+    """Levels 2 and 3 of a training batch: the four attentions of the level in ONE forward launch, one row-sum launch, one dQ launch and
+    two dK / dV launches (blockIdx.z / the sample index pick the item) — the same workgroups doing the same arithmetic as twelve / sixteen
+    separate launches: identical bits, fewer launches.  (C = 64: the level-1 forward and dK / dV kernels stay one launch per attention.)"""
+    from hupr_amd import functional as F_, runtime as rt
+    ra, re = rnd(B, 1, H, H, C, seed=340).cuda(), rnd(B, 1, H, H, C, seed=341).cuda()
+    ws = [rnd(C, C, 1, 1, seed=342 + i, scale=C ** -0.5).cuda() for i in range(8)]
+    gcat = rnd(B, 1, H, H, 4 * C, seed=350).cuda().bfloat16()
+
+    def run(batch):
+        old = F_.ATTN_LEVEL_BATCH
+        F_.ATTN_LEVEL_BATCH = batch
+        try:
+            a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
+            w = [t.clone().requires_grad_(True) for t in ws]
+            n0 = rt.lib().hupr_launch_count()
+            (y,) = F_.MSCSALevelFn.apply(a, e, True, *w)
+            y.backward(gcat)
+            n = rt.lib().hupr_launch_count() - n0
+            torch.cuda.synchronize()
+            return n, [y.detach(), a.grad, e.grad] + [t.grad for t in w]
+        finally:
+            F_.ATTN_LEVEL_BATCH = old
+
+    n1, g1 = run(True)
+    n0, g0 = run(False)
+    for i, (x, y) in enumerate(zip(g1, g0)):
+        assert torch.equal(x, y), "tensor %d differs" % i
+    assert n0 - n1 == (6 if C == 64 else 3 + 8), (n0, n1)          # forward 4 -> 1, backward 12 -> 4; level-1 shape: backward 12 -> 6
+
+
 @pytest.mark.parametrize("Ci,Co,shape", [(64, 64, (8, 8, 32, 32)), (64, 64, (6, 8, 64, 64)), (32, 64, (4, 8, 64, 64)),
                                          # round 5: several output tiles / the 2 x 8 x 16 tile (register-resident sums).  Level 2 at the bench
                                          # batch (4 tiles per workgroup, alternating between two output tiles), with one tile per workgroup,
