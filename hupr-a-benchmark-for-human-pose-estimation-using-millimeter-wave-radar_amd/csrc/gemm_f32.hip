@@ -400,58 +400,68 @@ static void dispatch_tiles(const GemmArgs& a, int batch, hipStream_t s) {
     }
 }
 
-// Four outputs per thread (16-byte loads), the split axis cut into four slices per workgroup so that small outputs
-// still put enough loads in flight; fixed summation order (slice-wise, then across slices) -> deterministic.
+// Four outputs per thread (16-byte loads), the split axis cut into S slices per workgroup (256 / S columns of four outputs each) and
+// EIGHT loads of a thread in flight: the kernel is a chain of dependent memory round trips otherwise (round 5: a layer with 128
+// partial tensors and 4 slices walked 32 loads four at a time = 8 round trips, 8 us for 64 workgroups' worth of output; with 16 slices
+// — four times the workgroups, 8 loads per thread, one round trip — the small layers take what a launch takes).  Fixed summation
+// order (per thread in k order over eight accumulators, their tree, then the slices in order) -> deterministic.
+template <int S>
 __global__ __launch_bounds__(256) void hupr_k_splitk_reduce4(const float* __restrict__ part, float* __restrict__ out,
                                                              long n4, int splits, long split_stride, int taps, int ci) {
-    __shared__ float4 red[4][64];
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long i4 = (long)blockIdx.x * 64 + col;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    constexpr int COLS = 256 / S, U = 8;
+    __shared__ float4 red[S][COLS];
+    const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+    const long i4 = (long)blockIdx.x * COLS + col;
+    float4 a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 < n4) {
         const float* p = part + i4 * 4;
-        int k = sl;
-        for (; k + 12 < splits; k += 16) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p + (long)k * split_stride);
-            const float4 v1 = *reinterpret_cast<const float4*>(p + (long)(k + 4) * split_stride);
-            const float4 v2 = *reinterpret_cast<const float4*>(p + (long)(k + 8) * split_stride);
-            const float4 v3 = *reinterpret_cast<const float4*>(p + (long)(k + 12) * split_stride);
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
-        }
-        for (; k < splits; k += 4) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p + (long)k * split_stride);
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        for (int k = sl; k < splits; k += S * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                v[u] = (k + u * S < splits) ? *reinterpret_cast<const float4*>(p + (long)(k + u * S) * split_stride)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u].x += v[u].x; a[u].y += v[u].y; a[u].z += v[u].z; a[u].w += v[u].w; }
         }
     }
-    red[sl][col] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
-                               (a0.w + a1.w) + (a2.w + a3.w));
+#pragma unroll
+    for (int w = 1; w < U; w *= 2)
+#pragma unroll
+        for (int u = 0; u + w < U; u += 2 * w) { a[u].x += a[u + w].x; a[u].y += a[u + w].y; a[u].z += a[u + w].z; a[u].w += a[u + w].w; }
+    red[sl][col] = a[0];
     __syncthreads();
     if (sl != 0 || i4 >= n4) return;
-    const float4 r0 = red[0][col], r1 = red[1][col], r2 = red[2][col], r3 = red[3][col];
-    const float s[4] = {(r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
-                        (r0.w + r1.w) + (r2.w + r3.w)};
+    float4 r = red[0][col];
+#pragma unroll
+    for (int q = 1; q < S; ++q) { const float4 t = red[q][col]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    const float s4[4] = {r.x, r.y, r.z, r.w};
     const long i = i4 * 4;
     if (taps > 1) {                                  // [co][tap][ci] -> parameter layout [co][ci][tap]
         const long per = (long)taps * ci;
         const long co = i / per, rem = i - co * per;
         const int tap = rem / ci, c = rem - (long)tap * ci;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[co * per + (long)(c + j) * taps + tap] = s[j];
+        for (int j = 0; j < 4; ++j) out[co * per + (long)(c + j) * taps + tap] = s4[j];
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[i + j] = s[j];      // out may be a 4-byte aligned bucket view
+        for (int j = 0; j < 4; ++j) out[i + j] = s4[j];      // out may be a 4-byte aligned bucket view
     }
 }
+
+static int g_splitk_slices = 0;      // A/B aid (hupr_debug_splitk_slices): 0 auto, 4 / 16 forced
+extern "C" void hupr_debug_splitk_slices(int s) { g_splitk_slices = s; }
 
 void launch_splitk_reduce(const float* part, float* out, long n, int splits, long split_stride, int taps, int ci,
                           hipStream_t s) {
     if (n % 4 == 0 && ci % 4 == 0 && split_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
         const long n4 = n / 4;
-        HUPR_LAUNCH(hupr_k_splitk_reduce4, dim3((n4 + 63) / 64), dim3(256), 0, s, part, out, n4, splits, split_stride,
-                           taps, ci);
+        // many partial tensors over a small output: 16 slices (a quarter of the columns per workgroup, four times the workgroups)
+        const bool s16 = g_splitk_slices ? g_splitk_slices == 16 : (splits >= 32 && n4 <= (1L << 17));
+        if (s16) HUPR_LAUNCH(hupr_k_splitk_reduce4<16>, dim3((n4 + 15) / 16), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci);
+        else HUPR_LAUNCH(hupr_k_splitk_reduce4<4>, dim3((n4 + 63) / 64), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci);
         return;
     }
     HUPR_LAUNCH(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, out, n, splits, split_stride,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "hupr_debug_wgrad_groups": (None, [c_int]),
     "hupr_debug_wgrad_ci32": (None, [c_int]),
     "hupr_debug_wgrad_m16": (None, [c_int]),
+    "hupr_debug_splitk_slices": (None, [c_int]),
     "hupr_debug_gemm_small_tiles": (None, [c_int]),
     "hupr_conv3x3_halo_supported": (c_int, [c_int] * 10),
     "hupr_conv3x3_halo_bf16": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),

@@ -931,6 +931,38 @@ def test_wgrad_halo_on_16x16x32_matches_the_32x32x16_kernel_and_fp64(shape, bf16
         close(out[1], wr.grad, 1e-5, "16x16x32 weight gradient vs fp64")
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 64, 8, 32, 32, 3), (4, 128, 256, 2, 16, 16, 3), (8, 64, 64, 1, 32, 32, 1), (2, 96, 72, 2, 16, 16, 3)])
+def test_splitk_reduction_slices_agree(shape, bf16_math):
+    """The split-K reduction behind every weight gradient (hupr_k_splitk_reduce4<S>: S slices of the partial tensors per workgroup, eight
+    loads of a thread in flight): 4 and 16 slices add the same partial tensors in another order; both against fp64, and the same bits
+    on every run."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    B, Ci, Co, D, H, W, kd = shape
+    x = rnd(B, D, H, W, Ci, seed=510).cuda().bfloat16()
+    dy = rnd(B, D, H, W, Co, seed=511).cuda().bfloat16()
+    ws = torch.empty(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd), dtype=torch.uint8, device="cuda")
+    out = {}
+    try:
+        for sl in (4, 16, 0, 16):
+            L.hupr_debug_splitk_slices(sl)
+            dw = torch.full((Co, Ci, kd, 3, 3), float("nan"), device="cuda")
+            rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, kd, rt.ptr(ws), ws.numel(),
+                                                       rt.stream()))
+            if sl in out:
+                assert torch.equal(out[sl], dw)
+            out[sl] = dw
+    finally:
+        L.hupr_debug_splitk_slices(0)
+    close(out[16], out[4], 2e-6, "16 vs 4 slices")
+    assert torch.equal(out[0], out[4]) or torch.equal(out[0], out[16])
+    xr = x.double().cpu().permute(0, 4, 1, 2, 3)
+    wr = torch.zeros(Co, Ci, kd, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(xr, wr, None, 1, (kd // 2, 1, 1)).backward(dy.double().cpu().permute(0, 4, 1, 2, 3))
+    close(out[16], wr.grad, 1e-5, "weight gradient (16 slices) vs fp64")
+    close(out[4], wr.grad, 1e-5, "weight gradient (4 slices) vs fp64")
+
+
 def test_pack_cache_table_refresh_matches_single_packs(bf16_math):
     """The packed-weight cache refreshes every registered weight with ONE table-driven launch (32x32xtaps LDS tiles for
     bf16 halo weights, element-wise blocks for the rest); both layouts of every entry must equal the one-weight pack
