@@ -207,17 +207,20 @@ POSE_AMP, POSE_SIGMA = 3.0, 1.25
 
 
 def pose_scene_blobs(joints, G=8, R=64, A=64, img=256):
-    """joints (B,K,2) integer (x, y) image coordinates -> reflector planes (B, G, 2, R, A) fp32 (unit-height Gaussians)."""
+    """joints (B,K,2) integer (x, y) image coordinates -> reflector planes (B, G, 2, R, A) fp32 (unit-height Gaussians).
+    The exponent of a cell depends on its integer squared distance to the centre only, so the Gaussians are gathered from a table of
+    exp(-d2 / 2 sigma^2) over d2 — the very fp64 values the cell-by-cell evaluation produced (the pose fits of tests/ are chaotic: one
+    differing bit is another trained network), 25 ms -> 3 ms per batch of 32 on the host, which paced those fits."""
     joints = np.asarray(joints)
     B, K, _ = joints.shape
     mu = (joints.astype(np.int64).astype(np.float64) * (R / img) + 0.5).astype(np.int64)      # the target centres (misc/utils.py:37-38)
-    rr = np.arange(R, dtype=np.float64)[:, None]
-    aa = np.arange(A, dtype=np.float64)[None, :]
+    span = max(R, A) + int(np.abs(mu).max()) + 1
+    table = np.exp(-np.arange(2 * span * span + 1, dtype=np.float64) / (2.0 * POSE_SIGMA ** 2))
+    dy2 = (np.arange(R, dtype=np.int64)[None, None, :] - mu[:, :, 1, None]) ** 2                 # (B, K, R)
+    dx2 = (np.arange(A, dtype=np.int64)[None, None, :] - mu[:, :, 0, None]) ** 2                 # (B, K, A)
     out = np.zeros((B, G, 2, R, A), dtype=np.float64)
-    for b in range(B):
-        for k in range(K):
-            x, y = mu[b, k]
-            out[b, k % G, (k // G) % 2] += np.exp(-((rr - y) ** 2 + (aa - x) ** 2) / (2.0 * POSE_SIGMA ** 2))
+    for k in range(K):                                   # joints sharing a plane are added in joint order, as always
+        out[:, k % G, (k // G) % 2] += table[dy2[:, k, :, None] + dx2[:, k, None, :]]
     return out.astype(np.float32)
 
 

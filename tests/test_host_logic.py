@@ -377,3 +377,22 @@ def test_precision_state_is_per_thread():
         assert rec["bwd"][:2] == ("f32", True) and F_.MATH == "f32" and not F_._REGION_SWITCHED
     finally:
         F_.set_math(prev)
+
+
+def test_pose_scene_reflectors_are_the_cell_by_cell_gaussians():
+    """synth.pose_scene_blobs gathers its Gaussians from a table over the integer squared distance (the host work that paced the
+    pose fits of the GPU suite); bit for bit what evaluating exp(-((r - y)^2 + (a - x)^2) / 2 sigma^2) cell by cell gives — the fits
+    are chaotic, one differing bit is another trained network."""
+    from hupr_amd import synth
+    rng = np.random.default_rng(11)
+    cases = [synth.pose_joints(rng.random((5, 31))), rng.integers(0, 256, (3, 40, 2))]       # and: more joints than planes
+    for joints in cases:
+        B, K, _ = joints.shape
+        mu = (joints.astype(np.int64).astype(np.float64) * (64 / 256) + 0.5).astype(np.int64)
+        rr, aa = np.arange(64, dtype=np.float64)[:, None], np.arange(64, dtype=np.float64)[None, :]
+        want = np.zeros((B, 8, 2, 64, 64), dtype=np.float64)
+        for b in range(B):
+            for k in range(K):
+                x, y = mu[b, k]
+                want[b, k % 8, (k // 8) % 2] += np.exp(-((rr - y) ** 2 + (aa - x) ** 2) / (2.0 * synth.POSE_SIGMA ** 2))
+        assert np.array_equal(synth.pose_scene_blobs(joints), want.astype(np.float32))
