@@ -223,7 +223,7 @@ def _heavy_end(device):
 def refresh_packed(device):
     """Run the packed-weight table refresh now (on the current stream) if any cached entry is stale — called before
     the branches fork so that the refresh is ordered in front of both."""
-    for e in _pack_entries.values():
+    for e in _pack_candidates():
         w = e.wref()
         if w is not None and w.device == device and e.stamp != (PACK_EPOCH, w._version):
             _pack_refresh_all(device)
@@ -289,28 +289,56 @@ PACK_EPOCH = 0
 PACK_CACHE = os.environ.get("HUPR_NO_PACK_CACHE", "0") != "1"      # debugging aid: repack on every call
 _pack_entries = {}      # (storage address, kind) -> entry
 _pack_table = None      # (device uint8 tensor, n, total) or None when dirty
+# The table pass refreshes the entries that were READ during the current or the previous epoch (= optimiser step), not every weight
+# the process ever registered: a process that holds several models (the GPU test suite: a dozen live networks by the time the pose
+# fits run; an application with a training and an evaluation copy) repacked all of them after every optimiser step of one — 20 ->
+# 34 ms per fit step inside the suite, most of it this module's Python loops over thousands of entries (round 5).  An entry that
+# drops out is refreshed when it is read again (the stale path of ``_packed`` / ``_proj_cat`` / ``_head_w16_cached`` touches it first).
+_pack_recent = [{}, {}]      # id(entry) -> entry: read during the current / the previous epoch
+_pack_pinned = {}            # entries a captured inference graph reads (it baked their addresses in): refreshed after every update
+_pack_sweeps = 0
 
 
 def invalidate_packed():
     """Call after changing parameters behind torch's back (FusedAdam does)."""
     global PACK_EPOCH
     PACK_EPOCH += 1
+    _pack_recent[1] = _pack_recent[0]
+    _pack_recent[0] = {}
 
 
 class _PackEntry:
     __slots__ = ("wref", "ptr", "kind", "shape", "wp", "stamp")
 
 
+def _touch(e):
+    _pack_recent[0][id(e)] = e
+    if torch.cuda.is_current_stream_capturing():
+        _pack_pinned[id(e)] = e
+
+
+def _pack_candidates():
+    cur, prev = _pack_recent
+    return (list(cur.values()) + [e for k, e in prev.items() if k not in cur] +
+            [e for k, e in _pack_pinned.items() if k not in cur and k not in prev])
+
+
 def _pack_refresh_all(dev):
-    global _pack_table
+    global _pack_table, _pack_sweeps
     L = rt.lib()
+    _pack_sweeps += 1
+    if _pack_sweeps % 256 == 0:                      # now and then: drop the entries (and packed copies) of weights that are gone
+        for key in [k for k, e in _pack_entries.items() if e.wref() is None]:
+            del _pack_entries[key]
     live = []
-    for key in list(_pack_entries):
-        e = _pack_entries[key]
+    for e in _pack_candidates():
         w = e.wref()
         if w is None or w.data_ptr() != e.ptr or w.device != dev:
             if w is None:
-                del _pack_entries[key]
+                _pack_entries.pop((e.ptr, e.kind), None) if _pack_entries.get((e.ptr, e.kind)) is e else None
+                _pack_recent[0].pop(id(e), None)
+                _pack_recent[1].pop(id(e), None)
+                _pack_pinned.pop(id(e), None)
             continue
         live.append((e, w))
     if not live:
@@ -364,6 +392,7 @@ def _packed(weight, mode, kind):
     if capturing:
         if e is None or e.stamp != (PACK_EPOCH, weight._version):                  # nothing cached is created or refreshed mid-capture
             return pack_weights_bf16(weight, mode) if kind else pack_weights(weight, mode)
+        _touch(e)
         return e.wp[mode]
     if e is None:
         e = _PackEntry()
@@ -373,7 +402,9 @@ def _packed(weight, mode, kind):
         e.stamp = (PACK_EPOCH, weight._version)
         _pack_entries[key] = e
         _pack_table = None
+        _touch(e)
     elif e.stamp != (PACK_EPOCH, weight._version):
+        _touch(e)
         _pack_refresh_all(weight.device)
         if e.stamp != (PACK_EPOCH, weight._version):          # not covered by the table pass (should not happen)
             pk = pack_weights_bf16 if kind else pack_weights
@@ -381,6 +412,8 @@ def _packed(weight, mode, kind):
             e.wp[0].copy_(pk_into[0])                           # in place: captured inference graphs hold these addresses
             e.wp[1].copy_(pk_into[1])
             e.stamp = (PACK_EPOCH, weight._version)
+    else:
+        _touch(e)
     return e.wp[mode]
 
 
@@ -427,6 +460,8 @@ def _proj_cat(ws, C):
         ent = _proj_cache[key] = (wc, wq, entries)
         _pack_table = None
         fresh = False
+    for e in ent[2]:
+        _touch(e)
     if not fresh:
         _pack_refresh_all(ws[0].device)
     return ent[0], ent[1]
@@ -1842,6 +1877,7 @@ def _head_w16_cached(weight):
         ent = _head_cache[weight.data_ptr()] = (buf, e)
         _pack_table = None
         fresh = False
+    _touch(ent[1])
     if not fresh:
         _pack_refresh_all(weight.device)
     return ent[0]

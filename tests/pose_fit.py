@@ -56,8 +56,13 @@ def fit(steps=600, batch=32, lr=3e-4, math="bf16", model_seed=1, gain=1.0, log_e
     """-> (state_dict on the GPU, cfg, log list of (step, loss, loss2)).  Adam at ``lr``, divided by 3 at each fraction of
     ``drops`` of the run (the reference decays its rate too, tools/base.py:49-58)."""
     from hupr_amd.tools.engine import TrainEngine
+    import gc
     cfg = load_config()
     dev = torch.device("cuda")
+    # inside the whole suite a fit step took 34 ms against 20 ms in a fresh process (round 5): the process arrives here with the
+    # caching allocator's segments cut up by the tests before it and a large Python heap; start from a clean slate
+    gc.collect()
+    torch.cuda.empty_cache()
     prev = F_.MATH
     F_.set_math(math)
     try:
