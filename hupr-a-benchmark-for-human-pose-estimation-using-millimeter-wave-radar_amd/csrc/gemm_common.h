@@ -80,6 +80,6 @@ inline int wgrad_splits(long tiles, long ktiles, size_t one_bytes, size_t in_byt
     return (int)(s < 1 ? 1 : s);
 }
 void launch_splitk_reduce(const float* part, float* out, long n, int splits, long split_stride, int taps, int ci,
-                          hipStream_t s);
+                          hipStream_t s, float* out2 = nullptr, long n_first = 0);
 
 }  // namespace hupr

@@ -407,7 +407,10 @@ static void dispatch_tiles(const GemmArgs& a, int batch, hipStream_t s) {
 // order (per thread in k order over eight accumulators, their tree, then the slices in order) -> deterministic.
 template <int S>
 __global__ __launch_bounds__(256) void hupr_k_splitk_reduce4(const float* __restrict__ part, float* __restrict__ out,
-                                                             long n4, int splits, long split_stride, int taps, int ci) {
+                                                             long n4, int splits, long split_stride, int taps, int ci,
+                                                             float* __restrict__ out2, long n_first) {
+    // out2: elements [n_first, 4 n4) of the summed tensor go to out2 (a second weight gradient of the same shape: rows of the second
+    // half of the output channels), laid out like the first
     constexpr int COLS = 256 / S, U = 8;
     __shared__ float4 red[S][COLS];
     const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
@@ -438,7 +441,8 @@ __global__ __launch_bounds__(256) void hupr_k_splitk_reduce4(const float* __rest
 #pragma unroll
     for (int q = 1; q < S; ++q) { const float4 t = red[q][col]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
     const float s4[4] = {r.x, r.y, r.z, r.w};
-    const long i = i4 * 4;
+    long i = i4 * 4;
+    if (out2 != nullptr && i >= n_first) { i -= n_first; out = out2; }
     if (taps > 1) {                                  // [co][tap][ci] -> parameter layout [co][ci][tap]
         const long per = (long)taps * ci;
         const long co = i / per, rem = i - co * per;
@@ -455,13 +459,19 @@ static int g_splitk_slices = 0;      // A/B aid (hupr_debug_splitk_slices): 0 au
 extern "C" void hupr_debug_splitk_slices(int s) { g_splitk_slices = s; }
 
 void launch_splitk_reduce(const float* part, float* out, long n, int splits, long split_stride, int taps, int ci,
-                          hipStream_t s) {
+                          hipStream_t s, float* out2, long n_first) {
+    if (out2 != nullptr && !(n % 4 == 0 && ci % 4 == 0 && split_stride % 4 == 0 && n_first % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0)) {
+        launch_splitk_reduce(part, out, n_first, splits, split_stride, taps, ci, s, nullptr, 0);         // two plain reductions
+        launch_splitk_reduce(part + n_first, out2, n - n_first, splits, split_stride, taps, ci, s, nullptr, 0);
+        return;
+    }
     if (n % 4 == 0 && ci % 4 == 0 && split_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
         const long n4 = n / 4;
         // many partial tensors over a small output: 16 slices (a quarter of the columns per workgroup, four times the workgroups)
-        const bool s16 = g_splitk_slices ? g_splitk_slices == 16 : (splits >= 32 && n4 <= (1L << 17));
-        if (s16) HUPR_LAUNCH(hupr_k_splitk_reduce4<16>, dim3((n4 + 15) / 16), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci);
-        else HUPR_LAUNCH(hupr_k_splitk_reduce4<4>, dim3((n4 + 63) / 64), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci);
+        const long n4_one = out2 ? n_first / 4 : n4;          // (two gradients in one tensor: the choice each of them gets alone)
+        const bool s16 = g_splitk_slices ? g_splitk_slices == 16 : (splits >= 32 && n4_one <= (1L << 17));
+        if (s16) HUPR_LAUNCH(hupr_k_splitk_reduce4<16>, dim3((n4 + 15) / 16), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci, out2, n_first);
+        else HUPR_LAUNCH(hupr_k_splitk_reduce4<4>, dim3((n4 + 63) / 64), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci, out2, n_first);
         return;
     }
     HUPR_LAUNCH(hupr_k_splitk_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, out, n, splits, split_stride,

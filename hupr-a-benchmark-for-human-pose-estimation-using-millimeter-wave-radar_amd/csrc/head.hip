@@ -189,6 +189,56 @@ __global__ void hupr_k_bce_final(const double* __restrict__ partial, int nblk, d
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) out[0] = (float)(s * inv_n);
 }
+// The two BCE losses of a step (first head and PRGCN head against the same targets, reference misc/losses.py:24-33) and their
+// weighted sum in two launches instead of four + three torch-native ones: blockIdx.y = head in the partial pass; the final launch forms
+// both means in hupr_k_bce_final's order (one wave per head) and loss = alpha * loss1 + beta * loss2 as torch forms it (two roundings
+// of the products, one of the sum: no fma).
+__global__ __launch_bounds__(256) void hupr_k_bce_pair_fwd(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                           const float* __restrict__ t, long n, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const float* __restrict__ p = blockIdx.y ? p2 : p1;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pv = p[i], tv = t[i];
+        const float l1 = fmaxf(logf(pv), -100.f), l0 = fmaxf(logf(1.f - pv), -100.f);
+        acc -= tv * l1 + (1.f - tv) * l0;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void hupr_k_bce_pair_final(const double* __restrict__ partial, int nblk, double inv_n, float alpha, float beta,
+                                      float* __restrict__ out /* loss, loss1, loss2 */) {
+    __shared__ float l[2];
+    const int head = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int i = lane; i < nblk; i += 64) s += partial[(long)head * nblk + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) l[head] = (float)(s * inv_n);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[1] = l[0];
+        out[2] = l[1];
+        out[0] = __fadd_rn(__fmul_rn(alpha, l[0]), __fmul_rn(beta, l[1]));
+    }
+}
+// dp1 = (g alpha / n) (p1 - t) / max(p1 (1 - p1), 1e-12), dp2 likewise with (g beta [+ g2]) / n
+__global__ void hupr_k_bce_pair_bwd(const float* __restrict__ p1, const float* __restrict__ p2, const float* __restrict__ t,
+                                    const float* __restrict__ g, const float* __restrict__ g2, float alpha, float beta, float inv_n,
+                                    float* __restrict__ dp1, float* __restrict__ dp2, long n) {
+    const bool second = blockIdx.y != 0;
+    const float* __restrict__ p = second ? p2 : p1;
+    float* __restrict__ dp = second ? dp2 : dp1;
+    float go = __fmul_rn(g[0], second ? beta : alpha);
+    if (second && g2) go = __fadd_rn(go, g2[0]);
+    const float gs = go * inv_n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        dp[i] = gs * (pv - t[i]) / fmaxf(pv * (1.f - pv), 1e-12f);
+    }
+}
 // dp = gscale * (p - t) / max(p (1-p), 1e-12)     (PyTorch binary_cross_entropy_backward)
 __global__ void hupr_k_bce_bwd(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ gout,
                                float inv_n, float* __restrict__ dp, long n) {
@@ -479,6 +529,28 @@ extern "C" int hupr_bce_fwd_f32(const float* p, const float* t, long n, float* l
     HUPR_LAUNCH_OK("hupr_k_bce_fwd");
     HUPR_LAUNCH(hupr_k_bce_final, dim3(1), dim3(64), 0, s, reinterpret_cast<const double*>(ws), nblk, 1.0 / (double)n, loss);
     HUPR_LAUNCH_OK("hupr_k_bce_final");
+    return HUPR_OK;
+}
+// loss3 = {alpha * BCE(p1, t) + beta * BCE(p2, t), BCE(p1, t), BCE(p2, t)}; ws: 2 x hupr_bce_ws_bytes()
+extern "C" int hupr_bce_pair_fwd_f32(const float* p1, const float* p2, const float* t, long n, float alpha, float beta, float* loss3,
+                                     void* ws, size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(p1 && p2 && t && loss3 && ws && n > 0, "hupr_bce_pair_fwd_f32: bad argument");
+    if (ws_bytes < 2 * hupr_bce_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "hupr_bce_pair_fwd_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int nblk = grid1d(n, 256, 1024);
+    HUPR_LAUNCH(hupr_k_bce_pair_fwd, dim3(nblk, 2), dim3(256), 0, s, p1, p2, t, n, reinterpret_cast<double*>(ws));
+    HUPR_LAUNCH_OK("hupr_k_bce_pair_fwd");
+    HUPR_LAUNCH(hupr_k_bce_pair_final, dim3(1), dim3(128), 0, s, reinterpret_cast<const double*>(ws), nblk, 1.0 / (double)n, alpha, beta, loss3);
+    HUPR_LAUNCH_OK("hupr_k_bce_pair_final");
+    return HUPR_OK;
+}
+extern "C" int hupr_bce_pair_bwd_f32(const float* p1, const float* p2, const float* t, const float* grad_loss,
+                                     const float* grad_loss2_or_null, float alpha, float beta, float* dp1, float* dp2, long n,
+                                     hupr_stream_t stream) {
+    HUPR_REQUIRE(p1 && p2 && t && grad_loss && dp1 && dp2 && n > 0, "hupr_bce_pair_bwd_f32: bad argument");
+    HUPR_LAUNCH(hupr_k_bce_pair_bwd, dim3(grid1d(n), 2), dim3(256), 0, as_stream(stream), p1, p2, t, grad_loss, grad_loss2_or_null, alpha,
+                beta, 1.0f / (float)n, dp1, dp2, n);
+    HUPR_LAUNCH_OK("hupr_k_bce_pair_bwd");
     return HUPR_OK;
 }
 extern "C" int hupr_bce_bwd_f32(const float* p, const float* t, const float* grad_out, float* dp, long n, hupr_stream_t stream) {

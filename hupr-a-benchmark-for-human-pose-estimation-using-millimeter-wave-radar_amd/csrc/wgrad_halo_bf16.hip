@@ -31,6 +31,10 @@ struct WgradHaloArgs {
     int kd, TD, log2TW, nd, nh, nw;
     int n_ci_tiles, n_co_tiles, groups, n_spatial;
     int xcd_map;           // LDS-DMA kernel: 1-D XCD-aware grid (see hupr_k_wgrad_halo_glds)
+    // LDS-DMA kernels (hupr_k_wgrad_halo_glds / _m16), two gradients of ONE x in one launch (the two convolutions of a residual block read the same map):
+    // output channels [0, co_split) take dy, [co_split, Co) take dy2 (same shape and stride); co_split == 0: one tensor.
+    const void* dy2;
+    int co_split;
 };
 
 constexpr int kRowB = 128;                   // bytes per LDS row: 64 bf16 channels
@@ -267,6 +271,10 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     const int cot = pair_ / p.n_ci_tiles, cit = pair_ % p.n_ci_tiles;
     if (group >= p.groups) return;
     const int co0 = cot * 64, ci0 = cit * 64;
+    // which gradient tensor this workgroup's 64 output channels come from (see WgradHaloArgs::co_split)
+    const bool second = p.co_split != 0 && co0 >= p.co_split;
+    const void* const dyp = second ? p.dy2 : p.dy;
+    const int co0d = second ? co0 - p.co_split : co0, Cod = p.co_split ? p.co_split : p.Co;
 
     const int g = lane >> 4, s = lane & 15;
     const int kh_ = g >> 1;
@@ -320,8 +328,8 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
             const int j = it - ITEMS_X;
             const int v = j >> 3, c8 = (j & 7) ^ (((v >> 1) & 1) << 2);
             const int wx = v & (TW - 1), hy = (v >> LOG2TW) & 7, dz = v >> (LOG2TW + 3);
-            rel[u] = (((dz * p.H + hy) * p.W + wx) * p.dy_ld + co0 + c8 * 8) * 2;
-            msk[u] = (co0 + c8 * 8 >= p.Co) ? 64 : 0;
+            rel[u] = (((dz * p.H + hy) * p.W + wx) * p.dy_ld + co0d + c8 * 8) * 2;
+            msk[u] = (co0d + c8 * 8 >= Cod) ? 64 : 0;
         }
     }
     // The fill travels by LDS-DMA issued from inline asm (M0 = LDS address of the wave's 1 KiB piece, saved / restored around it):
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
     // re-fetches the last one), so every wave always has the same number of pieces in flight.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const u32x4 rxs = {(unsigned)(unsigned long)p.x, (unsigned)((unsigned long)p.x >> 32) & 0xffffu, (unsigned)x_bytes, 0x00020000u};
-    const u32x4 rdys = {(unsigned)(unsigned long)p.dy, (unsigned)((unsigned long)p.dy >> 32) & 0xffffu, (unsigned)dy_bytes, 0x00020000u};
+    const u32x4 rdys = {(unsigned)(unsigned long)dyp, (unsigned)((unsigned long)dyp >> 32) & 0xffffu, (unsigned)dy_bytes, 0x00020000u};
     // tile coordinates of the fill advance by carries (p.groups in mixed radix), not by divisions
     const int last_tile = group + ((p.n_spatial - 1 - group) / p.groups) * p.groups;      // last tile of this workgroup
     int gw_, gh_, gd_, gb_;
@@ -607,6 +615,10 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
     const int cot = pair_ / p.n_ci_tiles, cit = pair_ % p.n_ci_tiles;
     if (group >= p.groups) return;
     const int co0 = cot * 64, ci0 = cit * 64;
+    // which gradient tensor this workgroup's 64 output channels come from (see WgradHaloArgs::co_split)
+    const bool second = p.co_split != 0 && co0 >= p.co_split;
+    const void* const dyp = second ? p.dy2 : p.dy;
+    const int co0d = second ? co0 - p.co_split : co0, Cod = p.co_split ? p.co_split : p.Co;
 
     // Lane (s = lane & 15, kq4 = lane >> 4) of a 16 x 16 x 32 operand owns column s (a co / ci of its block) and reduction elements
     // 8 kq4 .. 8 kq4 + 7 = two transpose reads (t = 0, 1) of four image rows each; as a SUPPLIER it addresses the 8-byte segment
@@ -666,8 +678,8 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
             const int j = it - ITEMS_X;
             const int v = j >> 3, c8 = (j & 7) ^ (((v >> 1) & 3) << 1);
             const int wx = v & (TW - 1), hy = (v >> LOG2TW) & 7, dz = v >> (LOG2TW + 3);
-            rel[u] = (((dz * p.H + hy) * p.W + wx) * p.dy_ld + co0 + c8 * 8) * 2;
-            msk[u] = (co0 + c8 * 8 >= p.Co) ? 64 : 0;
+            rel[u] = (((dz * p.H + hy) * p.W + wx) * p.dy_ld + co0d + c8 * 8) * 2;
+            msk[u] = (co0d + c8 * 8 >= Cod) ? 64 : 0;
         }
     }
     // The fill travels by LDS-DMA issued from inline asm (M0 = LDS address of the wave's 1 KiB piece, saved / restored around it):
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
     // re-fetches the last one), so every wave always has the same number of pieces in flight.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const u32x4 rxs = {(unsigned)(unsigned long)p.x, (unsigned)((unsigned long)p.x >> 32) & 0xffffu, (unsigned)x_bytes, 0x00020000u};
-    const u32x4 rdys = {(unsigned)(unsigned long)p.dy, (unsigned)((unsigned long)p.dy >> 32) & 0xffffu, (unsigned)dy_bytes, 0x00020000u};
+    const u32x4 rdys = {(unsigned)(unsigned long)dyp, (unsigned)((unsigned long)dyp >> 32) & 0xffffu, (unsigned)dy_bytes, 0x00020000u};
     // tile coordinates of the fill advance by carries (p.groups in mixed radix), not by divisions
     const int last_tile = group + ((p.n_spatial - 1 - group) / p.groups) * p.groups;      // last tile of this workgroup
     int gw_, gh_, gd_, gb_;
@@ -883,9 +895,17 @@ extern "C" void hupr_debug_wgrad_m16(int on) { g_wgrad_m16 = on; }
 static int g_wgrad_ci32 = 1;        // A/B aid (hupr_debug_wgrad_ci32): 0 = Ci <= 32 through the two-quadrant kernel as before, 2 = K quarters always
 extern "C" void hupr_debug_wgrad_ci32(int on) { g_wgrad_ci32 = on; }
 
+// dy2 / dw2 (both or neither): a second gradient tensor of the same shape and stride over the same x — Co is then the channel count of
+// EACH; one launch of the 16 x 16 x 32 kernel over 2 Co output channels and one reduction that splits its rows between dw and dw2.
+// Same partial tensors and the same sums per element as two calls (the workgroup count per (depth tap, tile pair) is the single
+// call's).  LDS-DMA kernels (bf16 storage) only: HUPR_ERR_ARG otherwise (the caller makes two calls).
 static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci, int in_ld, int Co,
-                      int dy_ld, int kd, void* ws, size_t ws_bytes, bool abf, hupr_stream_t stream, const char* who) {
+                      int dy_ld, int kd, void* ws, size_t ws_bytes, bool abf, hupr_stream_t stream, const char* who,
+                      const void* dy2 = nullptr, float* dw2 = nullptr) {
     HUPR_REQUIRE(x && dy && dw && ws, "%s: null pointer", who);
+    HUPR_REQUIRE((dy2 == nullptr) == (dw2 == nullptr), "%s: dy2 and dw2 go together", who);
+    const bool dual = dy2 != nullptr;
+    HUPR_REQUIRE(!dual || (abf && Co % 64 == 0), "%s: the two-gradient form needs bf16 storage and Co %% 64 == 0", who);
     const int al = abf ? 8 : 4;
     HUPR_REQUIRE(Bn > 0 && Co > 0 && Ci % 8 == 0 && Co % 8 == 0 && in_ld % al == 0 && dy_ld % al == 0,
                  "%s: unsupported channels Ci=%d Co=%d", who, Ci, Co);
@@ -899,11 +919,14 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     a.kd = kd;
     if (kd == 3) { a.TD = 2; a.log2TW = 3; } else { a.TD = 1; a.log2TW = 4; }
     a.nd = D / a.TD; a.nh = H / 8; a.nw = W >> a.log2TW;
+    a.dy2 = dy2;
+    a.co_split = dual ? Co : 0;
     a.n_ci_tiles = (Ci + 63) / 64;
     a.n_co_tiles = (Co + 63) / 64;
     a.n_spatial = Bn * a.nd * a.nh * a.nw;
-    const int pairs = a.n_ci_tiles * a.n_co_tiles * kd;
-    const size_t one = (size_t)Co * kd * 9 * Ci * sizeof(float);
+    const int pairs = a.n_ci_tiles * a.n_co_tiles * kd;                 // of ONE gradient: decides the partial-tensor count below
+    const int nt = dual ? 2 : 1;
+    const size_t one = (size_t)nt * Co * kd * 9 * Ci * sizeof(float);
     int groups = max(1, min(128, 768 / pairs));      // ~3 workgroups per CU, at most 128 partial tensors
     groups = min(groups, a.n_spatial);
     while (groups > 1 && (size_t)groups * one > ws_bytes) groups >>= 1;
@@ -922,9 +945,11 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
         if (g_wgrad_groups < 0) a.xcd_map = 0;                       // A/B aid: the pre-affinity grid
         gw = min(gw, a.n_spatial);
         while (gw > 1 && (size_t)gw * one > ws_bytes) { gw >>= 1; a.xcd_map = 0; }
+        if (dual && (size_t)gw * one > ws_bytes) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small for two gradients", who);
         if ((size_t)gw * one <= ws_bytes) {
             a.groups = gw;
-            const dim3 grid = a.xcd_map ? dim3(gw * pairs) : dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles);
+            if (dual) { a.Co = 2 * Co; a.n_co_tiles *= 2; }
+            const dim3 grid = a.xcd_map ? dim3(gw * pairs * nt) : dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles);
             // K quarters pay once a workgroup multiplies enough tiles to amortise the extra LDS merge (measured: 222 -> 160 us on
             // the 32 -> 64 layer-1 shape at 102 tiles per workgroup; +2-3 us on shapes with one or two tiles per workgroup)
             const bool ci32 = Ci <= 32 && (g_wgrad_ci32 == 2 || (g_wgrad_ci32 == 1 && a.n_spatial >= 16 * gw));
@@ -939,11 +964,12 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
                 else HUPR_LAUNCH((hupr_k_wgrad_halo_glds<false, false>), grid, dim3(512), 0, s, a);
             }
             HUPR_LAUNCH_OK("hupr_k_wgrad_halo_glds");
-            launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, n, gw, n, kd * 9, Ci, s);
+            launch_splitk_reduce(reinterpret_cast<const float*>(ws), dw, nt * n, gw, nt * n, kd * 9, Ci, s, dw2, n);
             HUPR_LAUNCH_OK("hupr_k_splitk_reduce");
             return HUPR_OK;
         }
     }
+    if (dual) return fail(HUPR_ERR_ARG, "%s: the two-gradient form applies to the LDS-DMA kernel's envelope only", who);
     a.groups = groups;
     const dim3 grid(groups, kd, a.n_ci_tiles * a.n_co_tiles);
     if (kd == 3) {
@@ -967,6 +993,22 @@ extern "C" int hupr_conv3x3_wgrad_halo_bf16(const float* x, const float* dy, flo
 }
 
 // x and dy stored as bf16 (leading dimensions in elements); dw stays fp32 in parameter layout.
+// two weight gradients over the same x (the two convolutions of a residual block): see wgrad_halo.  ws: twice
+// hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd) is always enough.  hupr_conv3x3_wgrad_halo_dual_supported: 1 where this call applies.
+extern "C" int hupr_conv3x3_wgrad_halo_dual_supported(int Bn, int D, int H, int W, int Ci, int Co, int kd) {
+    if (!(Bn > 0 && Ci % 8 == 0 && Co % 64 == 0 && H % 8 == 0 &&
+          ((kd == 3 && D % 2 == 0 && W % 8 == 0) || (kd == 1 && D == 1 && W % 16 == 0))))
+        return 0;
+    return (long)Bn * D * H * W * (Ci > Co ? Ci : Co) * 2 < 0x7ffffff0L ? 1 : 0;
+}
+extern "C" int hupr_conv3x3_wgrad_halo_bf16act_dual(const void* x, const void* dy_a, const void* dy_b, float* dw_a, float* dw_b, int Bn,
+                                                    int D, int H, int W, int Ci, int in_ld, int Co, int dy_ld, int kd, void* ws,
+                                                    size_t ws_bytes, hupr_stream_t stream) {
+    HUPR_REQUIRE(dy_b && dw_b, "hupr_conv3x3_wgrad_halo_bf16act_dual: null pointer");
+    return wgrad_halo(x, dy_a, dw_a, Bn, D, H, W, Ci, in_ld, Co, dy_ld, kd, ws, ws_bytes, true, stream,
+                      "hupr_conv3x3_wgrad_halo_bf16act_dual", dy_b, dw_b);
+}
+
 extern "C" int hupr_conv3x3_wgrad_halo_bf16act(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W,
                                                int Ci, int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
                                                hupr_stream_t stream) {

@@ -719,6 +719,14 @@ class DualConvFn(torch.autograd.Function):
             dx = _conv_raw(dy[0], w_a, 1, None, None, Ci, k, dpad, (D, H, W))
             dx = _conv_raw(dy[1], w_b, 1, None, dx, Ci, k, dpad, (D, H, W), out=dx)
         grads = []
+        if (DUAL_WGRAD and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x.dtype == torch.bfloat16
+                and L.hupr_conv3x3_wgrad_halo_dual_supported(B, D, H, W, Ci, Co, k[0])):
+            # both weight gradients read the same x: one launch over 2 Co output channels, one reduction (same sums as two calls)
+            (dwa, da), (dwb, db_) = _pgrad(w_a), _pgrad(w_b)
+            ws = workspace(2 * L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, k[0]), x.device)
+            rt.check(L.hupr_conv3x3_wgrad_halo_bf16act_dual(rt.ptr(x), rt.ptr(dy[0]), rt.ptr(dy[1]), rt.ptr(dwa), rt.ptr(dwb), B, D, H, W,
+                                                            Ci, Ci, Co, Co, k[0], rt.ptr(ws), ws.numel(), rt.stream()))
+            return dx, _pret(w_a, dwa, da), _pret(w_b, dwb, db_), None, None, None
         for i, w in enumerate((w_a, w_b)):
             if not ctx.needs_input_grad[1 + i]:
                 grads.append(None)
@@ -730,6 +738,9 @@ class DualConvFn(torch.autograd.Function):
                         rt.stream()))
             grads.append(_pret(w, dw, direct))
         return dx, grads[0], grads[1], None, None, None
+
+
+DUAL_WGRAD = os.environ.get("HUPR_NO_DUAL_WGRAD", "0") != "1"      # A/B aid: 1 = one weight-gradient launch per convolution
 
 
 def dual_conv(x, w_a, w_b, pad, stats=False):
@@ -1966,6 +1977,39 @@ class BCEFn(torch.autograd.Function):
         g = _c(g.reshape(1).to(torch.float32))
         rt.check(rt.lib().hupr_bce_bwd_f32(rt.ptr(p), rt.ptr(t), rt.ptr(g), rt.ptr(dp), p.numel(), rt.stream()))
         return dp, None
+
+
+@_math_scoped
+class PairBCEFn(torch.autograd.Function):
+    """(alpha * BCE(p1, t) + beta * BCE(p2, t), BCE(p2, t)) — the two losses of a step and their weighted sum (reference
+    misc/losses.py:24-33) as two launches forward and one backward instead of four, two and three torch-native ones; the same floats
+    as two BCEFn nodes combined by torch (products and sum rounded separately)."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, t, alpha, beta):
+        p1, p2, t = _c(p1), _c(p2), _c(t)
+        assert p1.shape == p2.shape == t.shape and p1.dtype == p2.dtype == t.dtype == torch.float32
+        L = rt.lib()
+        out = torch.empty(3, dtype=torch.float32, device=p1.device)
+        ws = workspace(2 * L.hupr_bce_ws_bytes(), p1.device)
+        rt.check(L.hupr_bce_pair_fwd_f32(rt.ptr(p1), rt.ptr(p2), rt.ptr(t), p1.numel(), float(alpha), float(beta), rt.ptr(out), rt.ptr(ws),
+                                         ws.numel(), rt.stream()))
+        ctx.save_for_backward(p1, p2, t)
+        ctx.ab = (float(alpha), float(beta))
+        ctx.set_materialize_grads(False)
+        return out[0], out[2]
+
+    @staticmethod
+    def backward(ctx, g, g2):
+        p1, p2, t = ctx.saved_tensors
+        if g is None:
+            g = torch.zeros(1, dtype=torch.float32, device=p1.device)
+        dp1, dp2 = torch.empty_like(p1), torch.empty_like(p2)
+        g = _c(g.reshape(1).to(torch.float32))
+        g2 = _c(g2.reshape(1).to(torch.float32)) if g2 is not None else None
+        rt.check(rt.lib().hupr_bce_pair_bwd_f32(rt.ptr(p1), rt.ptr(p2), rt.ptr(t), rt.ptr(g), rt.ptr(g2) if g2 is not None else None,
+                                                ctx.ab[0], ctx.ab[1], rt.ptr(dp1), rt.ptr(dp2), p1.numel(), rt.stream()))
+        return dp1, dp2, None, None, None
 
 
 _PATCH_CACHE = {}

@@ -1,7 +1,13 @@
 """LossComputer (reference misc/losses.py:8-48) with device-side targets, BCE and decode."""
 
+import os
+
+import torch
+
 from .. import functional as F_
 from .metrics import get_max_preds
+
+PAIR_BCE = os.environ.get("HUPR_NO_PAIR_BCE", "0") != "1"      # A/B aid: 1 = one BCE node per head, combined by torch
 
 
 class LossComputer():
@@ -27,15 +33,21 @@ class LossComputer():
         heatmaps = self.targets(gt)
         preds1, preds2 = preds
         K, H, W = self.numKeypoints, self.height, self.width
-        loss1 = F_.BCEFn.apply(preds1.reshape(-1, K, H, W), heatmaps)
-        loss2 = F_.BCEFn.apply(preds2.reshape(-1, K, H, W), heatmaps)
+        a1, a2 = preds1.reshape(-1, K, H, W), preds2.reshape(-1, K, H, W)
         if self.alpha < 1.0:
             self.alpha += self.lossDecay
             self.beta -= self.lossDecay
-        if self.lossDecay != -1:
-            loss = self.alpha * loss1 + self.beta * loss2
+        if PAIR_BCE and a1.is_cuda and a1.dtype == a2.dtype == heatmaps.dtype == torch.float32 and a1.shape == a2.shape == heatmaps.shape:
+            # both losses and their weighted sum as one node (two launches forward, one backward; the same floats)
+            w = (self.alpha, self.beta) if self.lossDecay != -1 else (1.0, 1.0)
+            loss, loss2 = F_.PairBCEFn.apply(a1, a2, heatmaps, w[0], w[1])
         else:
-            loss = loss1 + loss2
+            loss1 = F_.BCEFn.apply(a1, heatmaps)
+            loss2 = F_.BCEFn.apply(a2, heatmaps)
+            if self.lossDecay != -1:
+                loss = self.alpha * loss1 + self.beta * loss2
+            else:
+                loss = loss1 + loss2
         if not decode:
             return loss, loss2, None, None
         if decode == "device":

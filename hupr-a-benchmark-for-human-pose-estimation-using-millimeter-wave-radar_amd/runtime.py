@@ -144,6 +144,8 @@ SIGNATURES = {
     "hupr_bce_ws_bytes": (c_size_t, []),
     "hupr_bce_fwd_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_bce_bwd_f32": (c_int, [c_void_p] * 4 + [c_long, c_void_p]),
+    "hupr_bce_pair_fwd_f32": (c_int, [c_void_p] * 3 + [c_long, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hupr_bce_pair_bwd_f32": (c_int, [c_void_p] * 5 + [c_float, c_float, c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_gaussian_targets_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_float, c_void_p]),
     "hupr_argmax_rows_f32": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p]),
     "hupr_adam_step_f32": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 5 + [c_int, c_float, c_void_p]),
@@ -164,6 +166,8 @@ SIGNATURES = {
     "hupr_tmerge_wgrad_stream_ws_bytes": (c_size_t, [c_int] * 5),
     "hupr_tmerge_wgrad_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "hupr_conv3x3_wgrad_halo_bf16act": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "hupr_conv3x3_wgrad_halo_dual_supported": (c_int, [c_int] * 7),
+    "hupr_conv3x3_wgrad_halo_bf16act_dual": (c_int, [c_void_p] * 5 + [c_int] * 9 + [c_void_p, c_size_t, c_void_p]),
     "hupr_bn_train_stats_bf16act": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_scale_shift_act_bf16act": (c_int, [c_void_p] * 7 + [c_long, c_int, c_int, c_void_p]),

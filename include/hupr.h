@@ -430,6 +430,13 @@ size_t hupr_bce_ws_bytes(void);
 int hupr_bce_fwd_f32(const float* p, const float* t, long n, float* loss, void* ws, size_t ws_bytes,
                      hupr_stream_t stream);
 int hupr_bce_bwd_f32(const float* p, const float* t, const float* grad_out, float* dp, long n, hupr_stream_t stream);
+/* Both losses of a step and their weighted sum (reference misc/losses.py:24-33: loss = alpha * BCE(heatmap, target) + beta * BCE(gcn
+ * heatmap, target)) in two launches: loss3 = {loss, loss1, loss2}, the same floats as two hupr_bce_fwd_f32 calls and torch's scalar
+ * arithmetic; the backward takes the gradient of `loss` (and optionally of loss2) and writes both dp.  ws: 2 x hupr_bce_ws_bytes(). */
+int hupr_bce_pair_fwd_f32(const float* p1, const float* p2, const float* t, long n, float alpha, float beta, float* loss3, void* ws,
+                          size_t ws_bytes, hupr_stream_t stream);
+int hupr_bce_pair_bwd_f32(const float* p1, const float* p2, const float* t, const float* grad_loss, const float* grad_loss2_or_null,
+                          float alpha, float beta, float* dp1, float* dp2, long n, hupr_stream_t stream);
 int hupr_gaussian_targets_f32(const long long* joints, const float* patch, float* t, int BK, int H, int rad,
                               float stride, hupr_stream_t stream);
 int hupr_argmax_rows_f32(const float* p, long rows, int n, int* idx, float* maxval, hupr_stream_t stream);
@@ -476,6 +483,14 @@ void hupr_debug_halo_split_k(int on);     /* A/B aid: 0 = never slice the reduct
 int hupr_conv3x3_wgrad_halo_bf16act(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci,
                                     int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
                                     hupr_stream_t stream);
+/* The weight gradients of TWO convolutions of one input (main[0] and downsample[0] of a residual block, reference models/layers.py:55-65;
+ * same weight shape, same dy stride) in one launch of the LDS-DMA kernel over 2 Co output channels and one reduction: the same partial
+ * sums, element for element, as two hupr_conv3x3_wgrad_halo_bf16act calls.  Applies where ..._dual_supported returns 1 (bf16 storage,
+ * Co % 64 == 0); ws: 2 x hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd). */
+int hupr_conv3x3_wgrad_halo_dual_supported(int Bn, int D, int H, int W, int Ci, int Co, int kd);
+int hupr_conv3x3_wgrad_halo_bf16act_dual(const void* x, const void* dy_a, const void* dy_b, float* dw_a, float* dw_b, int Bn, int D, int H,
+                                         int W, int Ci, int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
+                                         hupr_stream_t stream);
 int hupr_bn_train_stats_bf16act(const void* x, long M, int C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                                 float* save_invstd, float* scale, float* shift, void* ws, size_t ws_bytes,

@@ -164,6 +164,37 @@ def test_bn_relu_and_block_tail(training, C, vox):
     close(bn2.bias.grad, b2.grad, 5e-5, "tail dbeta2")
 
 
+@pytest.mark.parametrize("ab", [(0.3, 0.7), (1.0, 1.0), (1e-3, 0.999)])
+def test_both_losses_and_their_weighted_sum_as_one_node(ab):
+    """PairBCEFn: loss = alpha BCE(p1, t) + beta BCE(p2, t) and loss2 in two launches forward / one backward — the same floats as two
+    BCEFn nodes combined by torch's scalar arithmetic (what rounds 1-4 ran: four + two launches and three torch-native ones)."""
+    from hupr_amd import functional as F_
+    alpha, beta = ab
+    p1 = torch.sigmoid(rnd(4, 14, 64, 64, seed=610)).cuda()
+    p2 = torch.sigmoid(rnd(4, 14, 64, 64, seed=611) * 3).cuda()
+    t = torch.sigmoid(rnd(4, 14, 64, 64, seed=612) * 4).cuda()
+    a1, a2 = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+    l1, l2 = F_.BCEFn.apply(a1, t), F_.BCEFn.apply(a2, t)
+    ref = alpha * l1 + beta * l2
+    (ref * 1.7).backward()
+    b1, b2 = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+    n0 = F_.rt.lib().hupr_launch_count()
+    loss, loss2 = F_.PairBCEFn.apply(b1, b2, t, alpha, beta)
+    (loss * 1.7).backward()
+    assert F_.rt.lib().hupr_launch_count() - n0 == 3
+    assert torch.equal(loss, ref.detach()) and torch.equal(loss2, l2.detach())
+    assert torch.equal(b1.grad, a1.grad) and torch.equal(b2.grad, a2.grad)
+    # a gradient through the second output too (loss2 used on its own)
+    c1, c2 = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+    loss, loss2 = F_.PairBCEFn.apply(c1, c2, t, alpha, beta)
+    (loss + 0.5 * loss2).backward()
+    d1, d2 = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+    l1, l2 = F_.BCEFn.apply(d1, t), F_.BCEFn.apply(d2, t)
+    ((alpha * l1 + beta * l2) + 0.5 * l2).backward()
+    close(c2.grad, d2.grad, 1e-6, "gradient through both outputs")
+    assert torch.equal(c1.grad, d1.grad)
+
+
 def test_prelu():
     from hupr_amd import functional as F_
     x, a = rnd(2, 1, 16, 16, 64, seed=14), torch.tensor([0.25])
@@ -929,6 +960,37 @@ def test_wgrad_halo_on_16x16x32_matches_the_32x32x16_kernel_and_fp64(shape, bf16
         yr = F.conv3d(xr, wr, None, 1, (kd // 2, 1, 1))
         yr.backward(dy.double().cpu().permute(0, 4, 1, 2, 3))
         close(out[1], wr.grad, 1e-5, "16x16x32 weight gradient vs fp64")
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 64, 8, 32, 32, 3), (16, 128, 128, 4, 32, 32, 3), (4, 256, 256, 2, 16, 16, 3), (8, 320, 64, 1, 64, 64, 1),
+                                   (2, 64, 128, 4, 16, 16, 3), (3, 96, 64, 2, 8, 8, 3), (8, 32, 64, 8, 64, 64, 3), (2, 32, 64, 4, 16, 16, 3)])
+def test_two_weight_gradients_of_one_input_in_one_launch(shape, bf16_math):
+    """hupr_conv3x3_wgrad_halo_bf16act_dual: the weight gradients of the two convolutions of a residual block (same x, two dy) as one
+    launch over 2 Co output channels + one reduction — the same partial tensors and the same sums per element as two calls: identical
+    bits, two launches instead of four (level-1 shape with the XCD-aware grid, levels 2 / 3, a decoder block with five ci tiles,
+    small and ragged cases, the first block's 32 input channels on the K-quarter kernel)."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    B, Ci, Co, D, H, W, kd = shape
+    assert L.hupr_conv3x3_wgrad_halo_dual_supported(B, D, H, W, Ci, Co, kd)
+    x = rnd(B, D, H, W, Ci, seed=520).cuda().bfloat16()
+    dya, dyb = (rnd(B, D, H, W, Co, seed=521 + i).cuda().bfloat16() for i in range(2))
+    ws = torch.empty(2 * L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd), dtype=torch.uint8, device="cuda")
+    single = []
+    n0 = L.hupr_launch_count()
+    for dy in (dya, dyb):
+        dw = torch.full((Co, Ci, kd, 3, 3), float("nan"), device="cuda")
+        rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, kd, rt.ptr(ws), ws.numel(),
+                                                   rt.stream()))
+        single.append(dw)
+    n1 = L.hupr_launch_count()
+    da, db = (torch.full((Co, Ci, kd, 3, 3), float("nan"), device="cuda") for _ in range(2))
+    rt.check(L.hupr_conv3x3_wgrad_halo_bf16act_dual(rt.ptr(x), rt.ptr(dya), rt.ptr(dyb), rt.ptr(da), rt.ptr(db), B, D, H, W, Ci, Ci, Co, Co,
+                                                    kd, rt.ptr(ws), ws.numel(), rt.stream()))
+    n2 = L.hupr_launch_count()
+    assert torch.equal(da, single[0]) and torch.equal(db, single[1])
+    assert (n1 - n0, n2 - n1) == (4, 2)
+    assert not L.hupr_conv3x3_wgrad_halo_dual_supported(B, D, H, W, Ci, 72, kd)          # Co % 64 != 0: two calls
 
 
 @pytest.mark.parametrize("shape", [(8, 64, 64, 8, 32, 32, 3), (4, 128, 256, 2, 16, 16, 3), (8, 64, 64, 1, 32, 32, 1), (2, 96, 72, 2, 16, 16, 3)])
