@@ -34,6 +34,7 @@ struct HaloArgs {
     // 4 us launch they save: agent-scope scalar accesses 12.7 -> 42 us per layer, L2 write-back fences 94 us.)
     float* part;
     int units_per_slice;
+    int no_res_prefetch;     // A/B aid (hupr_debug_halo_res_prefetch(0)): 256-voxel 16 x 16 x 32 kernel, residual read in the immediate epilogue as in rounds 4-5a
 };
 
 // fp32 partial sums of a K slice: this lane's voxel, its four 4-channel runs (see halo_store_voxel for the lane -> channel map)

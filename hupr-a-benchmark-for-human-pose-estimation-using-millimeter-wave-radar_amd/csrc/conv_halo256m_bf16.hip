@@ -162,7 +162,15 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     unsigned accP[4][2][2];                                      // parked tile: bf16 pairs of c[vg][cg]
     __bf16* pP = nullptr;                                        // parked tile: this lane's 16-byte run of voxel group 0
     bool pend = false;
-    const bool defer = !p.bias && !p.res && (p.Co & 7) == 0 && (p.out_ld & 7) == 0;
+    // A residual no longer forces the immediate epilogue (round 5; the second input gradient of a block's convolution pair, the decoder's
+    // conv + residual: 228 us against 184 us at level 1): this lane's 32 residual elements are fetched into registers under the MFMAs
+    // of the tile's LAST stage — their loads have returned by that stage's vmcnt(0) barrier — added in fp32 before the one rounding,
+    // and the tile is parked and stored under the next tile's first stage like any other.  (Not in the instantiations that have no
+    // 16 registers to spare: fused statistics, which never carry a residual, and the 2 x 8 x 16 tile.)
+    constexpr bool RESPF = !STATS && TD != 2;
+    const bool res_pf = RESPF && p.res != nullptr && (p.res_ld & 3) == 0 && !p.no_res_prefetch;
+    const bool defer = !p.bias && (!p.res || res_pf) && (p.Co & 7) == 0 && (p.out_ld & 7) == 0;
+    bf16x4 resv[4][2];
     bf16x8 xq[2][4], x8, wq[2][2];
     // fragments of tap TAU_ (= 3 kk + ky) of stage ST_ from weight buffer BUF_ (WX_: 1 weights only, 2 activations only, 3 both)
 #define HUPR_LOAD_TAP(ST_, TAU_, BUF_, WX_)                                                                         \
@@ -257,6 +265,18 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                     const auto r1 = __builtin_amdgcn_permlane16_swap(accP[tau][0][1], accP[tau][1][1], false, false);
                     *reinterpret_cast<u32x4*>(pP + (long)(2 * tau * p.W) * p.out_ld) = (u32x4){r0[0], r1[0], r0[1], r1[1]};
                 }
+                if (RESPF && st_ == NSTAGE - 1 && tau == 0) {
+                    if (res_pf && last_chunk && defer) {
+                        const long mr = (((long)b * p.D + d0 + dzw) * p.H + h0 + yw0 + yy) * p.W + w0 + xw0 + wx;
+                        const int chr = n0 + 32 * wn + 4 * kq;
+#pragma unroll
+                        for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                            for (int cg = 0; cg < 2; ++cg)
+                                resv[vg][cg] = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.res) + (mr + 2 * vg * p.W) * p.res_ld +
+                                                                                chr + 16 * cg);
+                    }
+                }
                 // the next item's halo: one item per tap under its MFMAs (branch-free: an out-of-range offset past the last item)
                 if (NTAP * st_ + tau < NH) {
                     HUPR_HALO_ISSUE_ITEM(NTAP * st_ + tau, has_next, nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch * KC)
@@ -282,6 +302,14 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
             const int ch0 = n0 + 32 * wn + 4 * kq;
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             if (defer && has_next) {                              // park: stored during the next item's stage 0
+                if (RESPF && res_pf) {
+#pragma unroll
+                    for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                        for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) c[vg][cg][r] += (float)resv[vg][cg][r];
+                }
 #pragma unroll
                 for (int vg = 0; vg < 4; ++vg)
 #pragma unroll

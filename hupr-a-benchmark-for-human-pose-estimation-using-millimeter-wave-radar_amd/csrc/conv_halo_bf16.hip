@@ -442,6 +442,9 @@ static int halo_k_slices(int Bn, int D, int H, int W, int Ci, int Co, int kd, in
     return s;
 }
 
+static int g_halo_no_res_prefetch = 0;
+extern "C" void hupr_debug_halo_res_prefetch(int on) { g_halo_no_res_prefetch = on ? 0 : 1; }
+
 static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y, int Bn, int D,
                         int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd, bool abf,
                         hupr_stream_t stream, const char* who, double* stats = nullptr, void* ws = nullptr, size_t ws_bytes = 0,
@@ -460,6 +463,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     a.stats = stats;
     a.part = nullptr;
     a.units_per_slice = 0;
+    a.no_res_prefetch = g_halo_no_res_prefetch;
     if (stats) {
         HUPR_REQUIRE(abf && !bias && !res && conv_halo256_stats_ok(a, Bn),
                      "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "hupr_debug_wgrad_ci32": (None, [c_int]),
     "hupr_debug_wgrad_m16": (None, [c_int]),
     "hupr_debug_splitk_slices": (None, [c_int]),
+    "hupr_debug_halo_res_prefetch": (None, [c_int]),
     "hupr_debug_gemm_small_tiles": (None, [c_int]),
     "hupr_conv3x3_halo_supported": (c_int, [c_int] * 10),
     "hupr_conv3x3_halo_bf16": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
@@ -223,6 +224,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("HUPR_NO_RES_PREFETCH", "0") == "1":
+            L.hupr_debug_halo_res_prefetch(0)                            # A/B aid: residual read in the convolution's immediate epilogue
         if os.environ.get("HUPR_HALO_M16") in ("0", "1", "2", "3", "5") and hasattr(L, "hupr_debug_halo_m16"):
             L.hupr_debug_halo_m16(int(os.environ["HUPR_HALO_M16"]))      # A/B aid: the 256-voxel convolution's MFMA shape
         _lib = L

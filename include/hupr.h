@@ -217,6 +217,7 @@ void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel 
 void hupr_debug_halo_m16(int on);         /* 256-voxel halo convolution, bf16 activations: 1 (default; 3 = the same) = the v_mfma_f32_16x16x32_bf16 kernel (conv_halo256m_bf16.hip) on all three tiles: 4x8x8, 2x8x16 for D % 4 != 0, 1x16x16 for 1x3x3 taps (the decoder's convolutions; default since round 5); 5 = without the 1x16x16 tile (the round-4 default); 2 = its 4x8x8 tile only; 0 = the 32x32x16 kernels */
 void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */
 void hupr_debug_gemm_small_tiles(int off); /* A/B aid: 1 = small bf16 GEMMs keep the 64x128 tile instead of 64x64 */
+void hupr_debug_halo_res_prefetch(int on);  /* A/B aid: 0 = the 256-voxel 16 x 16 x 32 convolution reads a residual in its immediate epilogue (rounds 4-5a); default 1: prefetched, deferred epilogue */
 void hupr_debug_splitk_slices(int s);     /* A/B aid: slices per workgroup of the split-K reduction: 0 auto (round 5), 4 (rounds 1-4), 16 */
 void hupr_debug_wgrad_m16(int on);        /* A/B aid: 0 = the LDS-DMA weight gradient on v_mfma_f32_32x32x16_bf16 (rounds 2-4); default 1: v_mfma_f32_16x16x32_bf16 (round 5) */
 void hupr_debug_wgrad_ci32(int on);       /* A/B aid: 0 sends Ci <= 32 weight gradients through the two-quadrant kernel (K halves only), 2 forces the K-quarter mode at any size, 1 = default */

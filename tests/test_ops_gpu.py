@@ -733,6 +733,40 @@ def test_conv_halo256_persistent_kernel_matches_128_voxel_kernel(bf16_math):
     close(ncdhw(y256.cpu())[:1] - ncdhw(res.cpu())[:1].double(), ref, 2e-5, "halo256 vs fp64")
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 64, 8, 32, 32, 3), (5, 128, 128, 4, 32, 32, 3), (16, 64, 64, 1, 64, 64, 1), (9, 320, 64, 1, 64, 64, 1),
+                                   (32, 256, 128, 2, 16, 16, 3)])
+def test_conv_residual_prefetched_under_the_last_stage_equals_the_immediate_epilogue(shape, bf16_math):
+    """256-voxel 16 x 16 x 32 convolution with a residual (the second input gradient of a block's pair, the decoder's conv + residual):
+    the residual elements are fetched into registers under the tile's last stage and the tile is parked like any other, instead of
+    being read in an immediate epilogue — the same fp32 sum rounded once: identical bits; also with the output written over the
+    residual (``out`` is ``res``), against fp64, and on the 2 x 8 x 16 tile, which keeps the immediate epilogue."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    B, Ci, Co, D, H, W, kd = shape
+    x = rnd(B, D, H, W, Ci, seed=56).cuda().bfloat16()
+    w = rnd(Co, Ci, kd, 3, 3, seed=57, scale=(Ci * 9 * kd) ** -0.5).cuda()
+    res = rnd(B, D, H, W, Co, seed=58).cuda().bfloat16()
+    k, pad = (kd, 3, 3), (kd // 2, 1, 1)
+    out = {}
+    try:
+        for on in (1, 0):
+            L.hupr_debug_halo_res_prefetch(on)
+            y = F_._conv_raw(x, w, 0, None, res, Co, k, pad, (D, H, W))
+            inplace = res.clone()
+            y2 = F_._conv_raw(x, w, 0, None, inplace, Co, k, pad, (D, H, W), out=inplace)
+            out[on] = (y, y2)
+    finally:
+        L.hupr_debug_halo_res_prefetch(1)
+    assert torch.equal(out[1][0], out[0][0]) and torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][0], out[1][1])
+    y0 = F_._conv_raw(x, w, 0, None, None, Co, k, pad, (D, H, W))
+    if kd == 3:
+        ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
+    else:
+        ref = F.conv2d(ncdhw(x.float().cpu())[:1, :, 0].double(), _bf16_round(w.cpu())[:, :, 0], None, 1, 1).unsqueeze(2)
+    close(ncdhw(out[1][0].float().cpu())[:1], ref + ncdhw(res.float().cpu())[:1].double(), 1e-2, "conv + residual vs fp64")
+    assert not torch.equal(y0, out[1][0])
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 64, 8, 64, 64), (9, 128, 128, 4, 32, 32), (3, 64, 128, 8, 32, 64)])
 def test_conv_halo256_stage_protocols_agree_bitwise(shape, bf16_math):
     """The 256-voxel kernel's stage protocol of this round (barrier in front of a stage's last K-step, fragment pipeline across stage
