@@ -15,6 +15,14 @@ HUPR_NO_ATTN_LEVEL_BATCH=1 HUPR_NO_BN_FINALIZE_PAIR=1 python bench.py --steps 10
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-parity-path --no-c2 --sustain 0 --no-probes 2>/dev/null | pr "level-wide launches, paired finalize (default)"
 done
 } > gpurun_out/r05b_launch_merges_ab.txt
+{
+echo "python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-parity-path --no-c2 --sustain 0 --no-probes, interleaved on one box"
+echo "off = HUPR_NO_ATTN_LEVEL_BATCH HUPR_NO_BN_FINALIZE_PAIR HUPR_NO_DUAL_WGRAD HUPR_NO_PAIR_BCE HUPR_NO_RES_PREFETCH = 1 (the kernels of the round's first half)"
+for i in 1 2 3; do
+HUPR_NO_ATTN_LEVEL_BATCH=1 HUPR_NO_BN_FINALIZE_PAIR=1 HUPR_NO_DUAL_WGRAD=1 HUPR_NO_PAIR_BCE=1 HUPR_NO_RES_PREFETCH=1 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-parity-path --no-c2 --sustain 0 --no-probes 2>/dev/null | pr "second half of round 5 off"
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-parity-path --no-c2 --sustain 0 --no-probes 2>/dev/null | pr "default"
+done
+} > gpurun_out/r05b_second_half_ab.txt
 for f in gpurun_out/r05b_b_*.json; do tail -1 $f | cut -c1-160; done
-cat gpurun_out/r05b_launch_merges_ab.txt
+cat gpurun_out/r05b_launch_merges_ab.txt gpurun_out/r05b_second_half_ab.txt
 tail -3 gpurun_out/r05b_bench_kernels.md
