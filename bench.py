@@ -406,6 +406,18 @@ def main():
         enq_ranks = [None] * world
         dist.all_gather_object(enq_ranks, t_enq / args.steps * 1e3)
 
+    # What one step costs the HOST: `host_enqueue_ms_per_step` above is measured while the GPU is the bottleneck, so it contains the time the
+    # runtime blocks the host on a full queue (it approaches ms_per_step by construction).  Here: the GPU idle, ONE step enqueued, no wait
+    # — the median of five; the difference to ms_per_step is the host's slack.  Every rank runs these steps.
+    idle_enq = []
+    for _ in range(5):
+        barrier()
+        t1 = time.perf_counter()
+        one_step()
+        idle_enq.append((time.perf_counter() - t1) * 1e3)
+    barrier()
+    host_enqueue_idle_ms = float(np.median(idle_enq))
+
     # Sustained rate: a short --steps (the driver's 20 = 0.4 s) measures a burst at boost clocks.  Continue for >= 3 s more
     # of the same step (same buffers, nothing re-initialised) and report that window separately; `value` stays the --steps region.
     sustained = None
@@ -762,6 +774,7 @@ def main():
             "launch_census": launch_census,
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
             "host_enqueue_ms_per_step_by_rank": [round(float(x), 2) for x in enq_ranks],
+            "host_enqueue_ms_from_idle_gpu": round(host_enqueue_idle_ms, 2),
             "rccl_ranks": rccl_ranks,
             "scaling_check": scaling_check,
             "sustained": sustained,
