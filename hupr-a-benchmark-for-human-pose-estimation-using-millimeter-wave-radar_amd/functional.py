@@ -312,9 +312,15 @@ class _PackEntry:
 
 
 def _touch(e):
-    _pack_recent[0][id(e)] = e
+    """Mark ``e`` as read in this epoch -> was it among the table pass's candidates already?  (False: a weight that dropped out —
+    its model sat idle for two optimiser steps of another one —: the caller's refresh then sweeps EVERY stale entry of the device
+    in its one launch, so that the rest of that model does not come back one table launch per weight.)"""
+    k = id(e)
+    known = k in _pack_recent[0] or k in _pack_recent[1] or k in _pack_pinned
+    _pack_recent[0][k] = e
     if torch.cuda.is_current_stream_capturing():
-        _pack_pinned[id(e)] = e
+        _pack_pinned[k] = e
+    return known
 
 
 def _pack_candidates():
@@ -323,10 +329,15 @@ def _pack_candidates():
             [e for k, e in _pack_pinned.items() if k not in cur and k not in prev])
 
 
-def _pack_refresh_all(dev):
+def _pack_refresh_all(dev, full=False):
     global _pack_table, _pack_sweeps
     L = rt.lib()
     _pack_sweeps += 1
+    if full:                                         # a dropped-out entry came back: take every stale entry of this device along
+        for e in list(_pack_entries.values()):
+            w = e.wref()
+            if w is not None and w.device == dev and w.data_ptr() == e.ptr and e.stamp != (PACK_EPOCH, w._version):
+                _pack_recent[0].setdefault(id(e), e)
     if _pack_sweeps % 256 == 0:                      # now and then: drop the entries (and packed copies) of weights that are gone
         for key in [k for k, e in _pack_entries.items() if e.wref() is None]:
             del _pack_entries[key]
@@ -404,8 +415,7 @@ def _packed(weight, mode, kind):
         _pack_table = None
         _touch(e)
     elif e.stamp != (PACK_EPOCH, weight._version):
-        _touch(e)
-        _pack_refresh_all(weight.device)
+        _pack_refresh_all(weight.device, full=not _touch(e))
         if e.stamp != (PACK_EPOCH, weight._version):          # not covered by the table pass (should not happen)
             pk = pack_weights_bf16 if kind else pack_weights
             pk_into = (pk(weight, 0), pk(weight, 1))
@@ -460,10 +470,9 @@ def _proj_cat(ws, C):
         ent = _proj_cache[key] = (wc, wq, entries)
         _pack_table = None
         fresh = False
-    for e in ent[2]:
-        _touch(e)
+    known = all([_touch(e) for e in ent[2]])
     if not fresh:
-        _pack_refresh_all(ws[0].device)
+        _pack_refresh_all(ws[0].device, full=not known)
     return ent[0], ent[1]
 
 
@@ -1888,9 +1897,9 @@ def _head_w16_cached(weight):
         ent = _head_cache[weight.data_ptr()] = (buf, e)
         _pack_table = None
         fresh = False
-    _touch(ent[1])
+    known = _touch(ent[1])
     if not fresh:
-        _pack_refresh_all(weight.device)
+        _pack_refresh_all(weight.device, full=not known)
     return ent[0]
 
 

@@ -996,6 +996,36 @@ def test_wgrad_halo_on_16x16x32_matches_the_32x32x16_kernel_and_fp64(shape, bf16
         close(out[1], wr.grad, 1e-5, "16x16x32 weight gradient vs fp64")
 
 
+def test_pack_table_covers_recent_readers_and_brings_idle_models_back_in_one_launch(bf16_math):
+    """The table pass after an optimiser step refreshes the weights READ during the current or previous step — not every weight the
+    process holds (a second, idle model used to be repacked after every step of the first) — and a model that sat idle comes back with
+    ONE table launch at its first read, not one per weight; contents always equal the one-weight pack kernels."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    mk = lambda seed: [torch.nn.Parameter(rnd(64, 64, 3, 3, 3, seed=seed + i).cuda()) for i in range(6)]
+    wa, wb = mk(700), mk(720)
+    for w in wa + wb:
+        F_._packed(w, 0, 1)
+    for step in range(4):                                     # model A trains, model B idles
+        with torch.no_grad():
+            for w in wa:
+                w.add_(0.01)
+        F_.invalidate_packed()
+        n0 = L.hupr_launch_count()
+        F_.refresh_packed(wa[0].device)
+        for w in wa:
+            assert torch.equal(F_._packed(w, 0, 1), F_.pack_weights_bf16(w, 0))
+        n = L.hupr_launch_count() - n0 - len(wa)              # (minus the reference packs)
+        assert n == 1, n                                      # one table launch per step
+        if step >= 2:                                         # B dropped out of the table: not repacked, its entries stale
+            assert all(F_._pack_entries[(w.data_ptr(), 1)].stamp[0] != F_.PACK_EPOCH for w in wb)
+    n0 = L.hupr_launch_count()
+    got = [F_._packed(w, 1, 1) for w in wb]                   # B comes back
+    assert L.hupr_launch_count() - n0 == 1
+    for w, g in zip(wb, got):
+        assert torch.equal(g, F_.pack_weights_bf16(w, 1))
+
+
 @pytest.mark.parametrize("shape", [(8, 64, 64, 8, 32, 32, 3), (16, 128, 128, 4, 32, 32, 3), (4, 256, 256, 2, 16, 16, 3), (8, 320, 64, 1, 64, 64, 1),
                                    (2, 64, 128, 4, 16, 16, 3), (3, 96, 64, 2, 8, 8, 3), (8, 32, 64, 8, 64, 64, 3), (2, 32, 64, 4, 16, 16, 3)])
 def test_two_weight_gradients_of_one_input_in_one_launch(shape, bf16_math):
