@@ -308,13 +308,14 @@ def invalidate_packed():
 
 
 class _PackEntry:
-    __slots__ = ("wref", "ptr", "kind", "shape", "wp", "stamp")
+    __slots__ = ("wref", "ptr", "kind", "shape", "wp", "stamp", "group")      # group: the epoch the entry was created in (~ its model)
 
 
 def _touch(e):
     """Mark ``e`` as read in this epoch -> was it among the table pass's candidates already?  (False: a weight that dropped out —
-    its model sat idle for two optimiser steps of another one —: the caller's refresh then sweeps EVERY stale entry of the device
-    in its one launch, so that the rest of that model does not come back one table launch per weight.)"""
+    its model sat idle for two optimiser steps of another one —: the caller's refresh then sweeps the stale entries of that
+    model, i.e. those created in the same epoch, in its one launch, so that the rest of the model does not come back one table
+    launch per weight; sweeping EVERY stale entry of the process made the GPU suite 150 s slower again.)"""
     k = id(e)
     known = k in _pack_recent[0] or k in _pack_recent[1] or k in _pack_pinned
     _pack_recent[0][k] = e
@@ -329,14 +330,15 @@ def _pack_candidates():
             [e for k, e in _pack_pinned.items() if k not in cur and k not in prev])
 
 
-def _pack_refresh_all(dev, full=False):
+def _pack_refresh_all(dev, full=None):
     global _pack_table, _pack_sweeps
     L = rt.lib()
     _pack_sweeps += 1
-    if full:                                         # a dropped-out entry came back: take every stale entry of this device along
-        for e in list(_pack_entries.values()):
+    if full is not None:                             # a dropped-out entry came back: take the stale entries of ITS model along — those
+        for e in list(_pack_entries.values()):       # created in the same epoch (a model's first forward registers all its weights)
             w = e.wref()
-            if w is not None and w.device == dev and w.data_ptr() == e.ptr and e.stamp != (PACK_EPOCH, w._version):
+            if (getattr(e, "group", None) == full and w is not None and w.device == dev and w.data_ptr() == e.ptr
+                    and e.stamp != (PACK_EPOCH, w._version)):
                 _pack_recent[0].setdefault(id(e), e)
     if _pack_sweeps % 256 == 0:                      # now and then: drop the entries (and packed copies) of weights that are gone
         for key in [k for k, e in _pack_entries.items() if e.wref() is None]:
@@ -411,11 +413,12 @@ def _packed(weight, mode, kind):
         pk = pack_weights_bf16 if kind else pack_weights
         e.wp = (pk(weight, 0), pk(weight, 1))
         e.stamp = (PACK_EPOCH, weight._version)
+        e.group = PACK_EPOCH
         _pack_entries[key] = e
         _pack_table = None
         _touch(e)
     elif e.stamp != (PACK_EPOCH, weight._version):
-        _pack_refresh_all(weight.device, full=not _touch(e))
+        _pack_refresh_all(weight.device, full=None if _touch(e) else getattr(e, "group", None))
         if e.stamp != (PACK_EPOCH, weight._version):          # not covered by the table pass (should not happen)
             pk = pack_weights_bf16 if kind else pack_weights
             pk_into = (pk(weight, 0), pk(weight, 1))
@@ -465,14 +468,18 @@ def _proj_cat(ws, C):
             e.wref, e.ptr, e.kind, e.shape = weakref.ref(w), w.data_ptr(), 3 if j in (1, 3) else 2, tuple(w.shape)
             e.wp = (wc[j * C:(j + 1) * C], wq[j * C:(j + 1) * C])
             e.stamp = None
+            e.group = PACK_EPOCH
             _pack_entries[(w.data_ptr(), e.kind)] = e
             entries.append(e)
         ent = _proj_cache[key] = (wc, wq, entries)
         _pack_table = None
         fresh = False
+        created = True
+    else:
+        created = False
     known = all([_touch(e) for e in ent[2]])
     if not fresh:
-        _pack_refresh_all(ws[0].device, full=not known)
+        _pack_refresh_all(ws[0].device, full=None if (known or created) else ent[2][0].group)
     return ent[0], ent[1]
 
 
@@ -1893,13 +1900,17 @@ def _head_w16_cached(weight):
         e.wref, e.ptr, e.kind, e.shape = weakref.ref(weight), weight.data_ptr(), 2, tuple(weight.shape)
         e.wp = (buf[:K], buf[:K])
         e.stamp = None
+        e.group = PACK_EPOCH
         _pack_entries[(weight.data_ptr(), 2)] = e
         ent = _head_cache[weight.data_ptr()] = (buf, e)
         _pack_table = None
         fresh = False
+        created = True
+    else:
+        created = False
     known = _touch(ent[1])
     if not fresh:
-        _pack_refresh_all(weight.device, full=not known)
+        _pack_refresh_all(weight.device, full=None if (known or created) else ent[1].group)
     return ent[0]
 
 
