@@ -628,6 +628,26 @@ __global__ void hupr_k_sum_partials(const double* __restrict__ partial, int n, f
     if (threadIdx.x == 0) out[0] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
+// several sums of partials in one launch (blockIdx.x = item): the PReLU slope gradients of a backward pass, deferred until their
+// gradient bucket is complete (tools/distributed.py) — each item summed exactly as hupr_k_sum_partials sums it
+struct SumItems {
+    int n_items;
+    const double* partial[16];
+    int n[16];
+    float* out[16];
+};
+__global__ void hupr_k_sum_partials_multi(SumItems t) {
+    __shared__ double red[4];
+    const int it = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < t.n[it]; i += 256) s += t.partial[it][i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) t.out[it][0] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
 __global__ void hupr_k_colsum_final(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
     int c;
     double s, unused;
@@ -965,8 +985,10 @@ extern "C" size_t hupr_prelu_ws_bytes(void) { return 4096 * sizeof(double); }
 
 template <typename T>
 static int prelu_bwd(const char* who, const T* dy, const T* x, const float* alpha, T* dx, float* dalpha, long n, void* ws,
-                     size_t ws_bytes, hupr_stream_t stream) {
-    HUPR_REQUIRE(dy && x && alpha && dx && dalpha && ws && n > 0 && n % act_v<T>() == 0, "%s: bad argument", who);
+                     size_t ws_bytes, hupr_stream_t stream, int* n_partials = nullptr) {
+    // n_partials != null: dx only; the per-workgroup partial sums of the slope gradient stay in ws (*n_partials of them) for a later
+    // hupr_sum_partials_multi
+    HUPR_REQUIRE(dy && x && alpha && dx && (dalpha || n_partials) && ws && n > 0 && n % act_v<T>() == 0, "%s: bad argument", who);
     if (ws_bytes < hupr_prelu_ws_bytes()) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small", who);
     hipStream_t s = as_stream(stream);
     const long nv = n / act_v<T>();
@@ -974,6 +996,7 @@ static int prelu_bwd(const char* who, const T* dy, const T* x, const float* alph
     double* partial = reinterpret_cast<double*>(ws);
     HUPR_LAUNCH(hupr_k_prelu_bwd<T>, dim3(grid), dim3(256), 0, s, dy, x, alpha, dx, nv, partial);
     HUPR_LAUNCH_OK("hupr_k_prelu_bwd");
+    if (n_partials) { *n_partials = grid; return HUPR_OK; }
     HUPR_LAUNCH(hupr_k_sum_partials, dim3(1), dim3(256), 0, s, partial, grid, dalpha);
     HUPR_LAUNCH_OK("hupr_k_sum_partials");
     return HUPR_OK;
@@ -986,6 +1009,38 @@ extern "C" int hupr_prelu_bwd_bf16act(const void* dy, const void* x, const float
                                       void* ws, size_t ws_bytes, hupr_stream_t stream) {
     return prelu_bwd("hupr_prelu_bwd_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(x), alpha,
                      static_cast<__bf16*>(dx), dalpha, n, ws, ws_bytes, stream);
+}
+
+// The PReLU backward without its final sum: dx, and *n_partials partial sums of the slope gradient left in `partials` (>=
+// hupr_prelu_ws_bytes(), the caller's own buffer: it must stay untouched until hupr_sum_partials_multi has consumed it)
+extern "C" int hupr_prelu_bwd_partials_f32(const float* dy, const float* x, const float* alpha, float* dx, long n, void* partials,
+                                           size_t partials_bytes, int* n_partials, hupr_stream_t stream) {
+    HUPR_REQUIRE(n_partials, "hupr_prelu_bwd_partials_f32: null pointer");
+    return prelu_bwd("hupr_prelu_bwd_partials_f32", dy, x, alpha, dx, nullptr, n, partials, partials_bytes, stream, n_partials);
+}
+extern "C" int hupr_prelu_bwd_partials_bf16act(const void* dy, const void* x, const float* alpha, void* dx, long n, void* partials,
+                                               size_t partials_bytes, int* n_partials, hupr_stream_t stream) {
+    HUPR_REQUIRE(n_partials, "hupr_prelu_bwd_partials_bf16act: null pointer");
+    return prelu_bwd("hupr_prelu_bwd_partials_bf16act", static_cast<const __bf16*>(dy), static_cast<const __bf16*>(x), alpha,
+                     static_cast<__bf16*>(dx), nullptr, n, partials, partials_bytes, stream, n_partials);
+}
+// out[i][0] = sum of the n[i] doubles at partial[i], i < n_items, in ceil(n_items / 16) launches; each sum as hupr_prelu_bwd_* forms it
+extern "C" int hupr_sum_partials_multi(const hupr_sum_item* items, int n_items, hupr_stream_t stream) {
+    HUPR_REQUIRE(items && n_items > 0, "hupr_sum_partials_multi: bad argument");
+    for (int i0 = 0; i0 < n_items; i0 += 16) {
+        SumItems t{};
+        t.n_items = n_items - i0 < 16 ? n_items - i0 : 16;
+        for (int i = 0; i < t.n_items; ++i) {
+            const hupr_sum_item& it = items[i0 + i];
+            HUPR_REQUIRE(it.partial && it.out && it.n > 0, "hupr_sum_partials_multi: bad item %d", i0 + i);
+            t.partial[i] = static_cast<const double*>(it.partial);
+            t.n[i] = it.n;
+            t.out[i] = it.out;
+        }
+        HUPR_LAUNCH(hupr_k_sum_partials_multi, dim3(t.n_items), dim3(256), 0, as_stream(stream), t);
+        HUPR_LAUNCH_OK("hupr_k_sum_partials_multi");
+    }
+    return HUPR_OK;
 }
 
 // out[c] = sum over rows of x[row][c]   (bias gradient of a convolution)

@@ -10,6 +10,7 @@ are written straight into the flat all-reduce buckets when a gradient sink is in
 Nothing here computes with torch ops except allocation, views, concatenation of small weight matrices and gradient
 bookkeeping; every kernel is reached through ``runtime.lib()`` and fails loudly without the HIP library.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -236,6 +237,7 @@ def refresh_packed(device):
 # straight into the flat-bucket views, the autograd Functions return None for them, and the 165 per-parameter
 # AccumulateGrad add kernels of a step disappear.  Without a sink every Function returns ordinary gradient tensors.
 GRAD_SINK = None
+PRELU_DEFER = os.environ.get("HUPR_NO_PRELU_DEFER", "0") != "1"      # A/B aid: 1 = every PReLU backward sums its slope gradient at once
 BN_COUNTER_SINK = None      # list collecting the BatchNorm modules whose num_batches_tracked is due (tools.engine)
 
 
@@ -1135,9 +1137,17 @@ class PReLUFn(torch.autograd.Function):
         L = rt.lib()
         dx = torch.empty_like(x)
         da, da_direct = _pgrad(alpha)
-        ws = workspace(L.hupr_prelu_ws_bytes(), x.device)
         dy = _c(dy)
         assert dy.dtype == x.dtype
+        if da_direct and PRELU_DEFER and getattr(GRAD_SINK, "can_defer", None) is not None and GRAD_SINK.can_defer(x.device):
+            # the slope gradient's final sum waits until its gradient bucket is complete: the twelve of a step then take one launch
+            part = torch.empty(L.hupr_prelu_ws_bytes() // 8, dtype=torch.float64, device=x.device)
+            npart = ctypes.c_int(0)
+            rt.check(_act("prelu_bwd_partials", x)(rt.ptr(dy), rt.ptr(x), rt.ptr(alpha), rt.ptr(dx), x.numel(), rt.ptr(part),
+                                                   part.numel() * 8, ctypes.byref(npart), rt.stream()))
+            GRAD_SINK.defer_sum(alpha, part, npart.value, da)
+            return dx, None
+        ws = workspace(L.hupr_prelu_ws_bytes(), x.device)
         rt.check(_act("prelu_bwd", x)(rt.ptr(dy), rt.ptr(x), rt.ptr(alpha), rt.ptr(dx), rt.ptr(da), x.numel(),
                                       rt.ptr(ws), ws.numel(), rt.stream()))
         return dx, _pret(alpha, da, da_direct)

@@ -23,6 +23,11 @@ class AttnItem(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("lse", ctypes.c_void_p), ("out16", ctypes.c_void_p)]
 
 
+class SumItem(ctypes.Structure):
+    """hupr_sum_item (include/hupr.h)."""
+    _fields_ = [("partial", ctypes.c_void_p), ("n", ctypes.c_int), ("out", ctypes.c_void_p)]
+
+
 class AttnBwdItem(ctypes.Structure):
     """hupr_attn_bwd_item (include/hupr.h): one attention of a batched backward pass."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("K", "Q", "V", "dO", "V32", "out", "lse", "dK", "dQ", "dV", "Dq")] + \
@@ -176,6 +181,9 @@ SIGNATURES = {
     "hupr_colsum_bf16act": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hupr_prelu_fwd_bf16act": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_prelu_bwd_bf16act": (c_int, [c_void_p] * 5 + [c_long, c_void_p, c_size_t, c_void_p]),
+    "hupr_prelu_bwd_partials_f32": (c_int, [c_void_p] * 4 + [c_long, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
+    "hupr_prelu_bwd_partials_bf16act": (c_int, [c_void_p] * 4 + [c_long, c_void_p, c_size_t, ctypes.POINTER(c_int), c_void_p]),
+    "hupr_sum_partials_multi": (c_int, [ctypes.POINTER(SumItem), c_int, c_void_p]),
     "hupr_mnet_fwd_bf16act": (c_int, [c_void_p] * 5 + [c_long, c_int, c_void_p]),
     "hupr_mnet_bwd_bf16act": (c_int, [c_void_p] * 7 + [c_long, c_int, c_void_p, c_size_t, c_void_p]),
     "hupr_interp_linear_fwd_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),

@@ -264,6 +264,7 @@ class GradientBuckets:
         self._names = {id(q): n for n, q in module.named_parameters()}
         self.direct = self.device.type == "cuda"
         self.always_zero = os.environ.get("HUPR_ZERO_GRADS", "0") == "1"
+        self._deferred = []
         self.prepare()
 
     # -- direct gradient sink (functional.GRAD_SINK protocol) -----------------------------------
@@ -279,6 +280,28 @@ class GradientBuckets:
         b.written[i] = True
         return b.views[i]
 
+    # -- deferred final sums (functional.PReLUFn): a parameter whose gradient is a sum of partials that one launch can finish
+    # together with others'.  The parameter counts as arrived at once; the sums are launched when the first bucket completes after
+    # them (in front of its exchange), before a micro-batch is stashed, and in finish() at the latest.
+    def can_defer(self, device):
+        from .. import functional as F_
+        # (one compute stream only: with the encoder branches on two streams the completing arrival may run on the side stream)
+        return self._armed and device.type == "cuda" and not F_.TWO_STREAMS
+
+    def defer_sum(self, param, partial, n, out):
+        self._deferred.append((partial, int(n), out))
+        self.done(param)
+
+    def _flush_deferred(self):
+        if not self._deferred:
+            return
+        from .. import functional as F_
+        items = (F_.rt.SumItem * len(self._deferred))()
+        for k, (partial, n, out) in enumerate(self._deferred):
+            items[k].partial, items[k].n, items[k].out = partial.data_ptr(), n, out.data_ptr()
+        F_.rt.check(F_.rt.lib().hupr_sum_partials_multi(items, len(self._deferred), F_.rt.stream()))
+        self._deferred = []
+
     def _arrive(self, b, i):
         """Parameter i of bucket b has its gradient for this pass: count it ONCE, launch the bucket's exchange on the last arrival.
         (Round 5: autograd runs a parameter's accumulation node — and with it the post-accumulate hook — even when the operator's
@@ -290,6 +313,7 @@ class GradientBuckets:
         b.arrived[i] = True
         b.pending -= 1
         if b.pending == 0:
+            self._flush_deferred()
             self._launch(b)
 
     def done(self, param):
@@ -320,6 +344,7 @@ class GradientBuckets:
             b.launched = False
             for p, v in zip(b.params, b.views):
                 p.grad = v
+        self._deferred = []
         self._armed = self.direct
         F_.GRAD_SINK = self if self.direct else None
 
@@ -369,6 +394,7 @@ class GradientBuckets:
 
     def stash(self):
         """After the backward of a leading micro-batch (``prepare(reduce=False)``): add its gradients to the accumulator."""
+        self._flush_deferred()
         self._armed = False
         for b in self.buckets:
             if getattr(b, "accum", None) is None:
@@ -382,6 +408,7 @@ class GradientBuckets:
     def finish(self):
         """Block the compute stream on outstanding collectives (call after backward)."""
         from .. import functional as F_
+        self._flush_deferred()
         self._armed = False
         if F_.GRAD_SINK is self:
             F_.GRAD_SINK = None

@@ -519,6 +519,15 @@ int hupr_colsum_bf16act(const void* x, long M, int C, float* out, void* ws, size
 int hupr_prelu_fwd_bf16act(const void* x, const float* alpha, void* y, long n, hupr_stream_t stream);
 int hupr_prelu_bwd_bf16act(const void* dy, const void* x, const float* alpha, void* dx, float* dalpha, long n, void* ws,
                            size_t ws_bytes, hupr_stream_t stream);
+/* The PReLU backward with the final sum of its slope gradient deferred (nn.PReLU under autograd, reference models/layers.py:21-37): dx now,
+ * *n_partials partial sums left in the caller's `partials` buffer (>= hupr_prelu_ws_bytes()); hupr_sum_partials_multi finishes any number
+ * of them in one launch per 16 — the twelve slope gradients of a step when their gradient bucket is complete.  Same sums. */
+typedef struct hupr_sum_item { const void* partial; int n; float* out; } hupr_sum_item;
+int hupr_prelu_bwd_partials_f32(const float* dy, const float* x, const float* alpha, float* dx, long n, void* partials,
+                                size_t partials_bytes, int* n_partials, hupr_stream_t stream);
+int hupr_prelu_bwd_partials_bf16act(const void* dy, const void* x, const float* alpha, void* dx, long n, void* partials,
+                                    size_t partials_bytes, int* n_partials, hupr_stream_t stream);
+int hupr_sum_partials_multi(const hupr_sum_item* items, int n_items, hupr_stream_t stream);
 int hupr_mnet_fwd_bf16act(const float* x, const float* w, const float* bias, void* out, float* means_or_null, long n_bg,
                           int pixels, hupr_stream_t stream);
 /* MNet front end from the fused loader's elevation-mean planes [n_bg][16][pixels] (hupr_fft_chain_loader_means_f32); also

@@ -472,3 +472,40 @@ def test_bucket_exchange_starts_after_its_last_gradient(monkeypatch):
         F_.GRAD_SINK = None
         F_.set_math("f32")
         F_.invalidate_packed()
+
+
+@pytest.mark.gpu
+def test_deferred_slope_gradient_sums_are_bit_transparent(monkeypatch):
+    """The twelve PReLU slope gradients of a step: each backward leaves its per-workgroup partial sums, the gradient sink launches ONE
+    multi-item final sum when the first bucket completes after them (in front of that bucket's exchange) instead of twelve
+    single-workgroup launches.  Same sums: three optimisation steps — with the exchange step in the job — land on exactly the
+    parameters of the engine that sums at once; 11 launches per step less; nothing left pending after a pass."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    monkeypatch.setenv("HUPR_FORCE_ALLREDUCE", "1")
+    saved = (F_.PRELU_DEFER, F_.TWO_STREAMS)
+    try:
+        F_.set_math("bf16")
+        F_.TWO_STREAMS = False
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=78)
+        e0 = TrainEngine(cfg, device=dev, seed=0)
+        e1 = TrainEngine(cfg, device=dev, seed=0)
+        counts = []
+        for step in range(3):
+            F_.PRELU_DEFER = False
+            n0 = F_.rt.lib().hupr_launch_count()
+            l0, _ = e0.train_step_from_adc(adc_h, adc_v, joints)
+            n1 = F_.rt.lib().hupr_launch_count()
+            F_.PRELU_DEFER = True
+            l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)
+            n2 = F_.rt.lib().hupr_launch_count()
+            counts.append((n1 - n0) - (n2 - n1))
+            assert not e1.buckets._deferred and all(b.pending == 0 and all(b.arrived) for b in e1.buckets.buckets)
+        torch.cuda.synchronize()
+        assert float(l0) == float(l1) and torch.equal(_flat(e0), _flat(e1))
+        for b0, b1 in zip(e0.buckets.buckets, e1.buckets.buckets):
+            assert torch.equal(b0.flat_grad, b1.flat_grad)
+        assert counts[-1] == 11, counts
+    finally:
+        F_.PRELU_DEFER, F_.TWO_STREAMS = saved
+        F_.set_math("f32")
