@@ -221,9 +221,21 @@ def _heavy_end(device):
     _heavy_last[device.index] = ev
 
 
-def refresh_packed(device):
+def refresh_packed(device, params=None):
     """Run the packed-weight table refresh now (on the current stream) if any cached entry is stale — called before
-    the branches fork so that the refresh is ordered in front of both."""
+    the branches fork so that the refresh is ordered in front of both.
+    params: the parameters of the model about to run, passed when that model sat idle for two or more optimiser epochs of ANOTHER
+    model (its entries then dropped out of the table pass's candidates): their stale entries are taken along here, in front of the
+    fork — otherwise the first stale read inside the fork would refresh them lazily on whichever stream got there first, and the
+    sibling stream would read packed buffers with no dependency on that launch."""
+    if params is not None:
+        cur = _pack_recent[0]
+        for p in params:
+            ptr = p.data_ptr()
+            for kind in (0, 1, 2, 3):
+                e = _pack_entries.get((ptr, kind))
+                if e is not None and e.wref() is p and e.stamp != (PACK_EPOCH, p._version):
+                    cur.setdefault(id(e), e)
     for e in _pack_candidates():
         w = e.wref()
         if w is not None and w.device == device and e.stamp != (PACK_EPOCH, w._version):

@@ -183,7 +183,9 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
             with F_.region(names[0]):
                 bf16_in = F_.act_bf16() and F_.ACT_BF16_DECODER
             B, _, H, W, C = ra.shape
-            if bf16_in and F_.level_cat_placement_ok(ra) and (prev is None or prev[0].dtype == torch.bfloat16):
+            with F_.region("lvl%d" % i):               # (decided under the LEVEL's precision: a level switched to fp32 is not fused)
+                place = bf16_in and F_.level_cat_placement_ok(ra)
+            if place and (prev is None or prev[0].dtype == torch.bfloat16):
                 # The stage's input [up-sampled previous maps | out1 | out2 | out3 | out4] (reference :166-178) is ONE buffer that its
                 # producers fill in place — the previous stage's resampling writes its channel slice, the fused level writes the
                 # other — instead of a concatenation copy per stage (F_.JoinFn: the backward hands the slices of the gradient back)
@@ -196,7 +198,8 @@ class MultiScaleCrossSelfAttentionPRGCN(nn.Module):
                 with F_.region("lvl%d" % i):
                     F_._level_cat_out["out"] = wide[..., cprev:]
                     lv = self._level(i, ra, re, True)
-                assert len(lv) == 1
+                    F_._level_cat_out.clear()          # (never leaks to another level)
+                assert len(lv) == 1, "level_cat_placement_ok() promised a fused level"
                 x = F_.JoinFn.apply(wide, *(parts + [lv[0]])) if parts else lv[0]
             else:
                 maps = None

@@ -57,12 +57,17 @@ class HuPRNet(nn.Module):
 
     def _forward(self, VRDAEmaps_hori, VRDAEmaps_vert):
         F_._conv_stats.clear()                  # no fused-statistics hand-over survives a forward pass
+        # a model that sat out two or more optimiser epochs (of another model in this process) hands its parameters to the
+        # refresh in front of the fork: its packed layouts are no longer among the table pass's candidates (F_.refresh_packed)
+        seen = getattr(self, "_pack_epoch_seen", None)
+        idle_params = list(self.parameters()) if (seen is None or F_.PACK_EPOCH - seen >= 2) else None
+        self._pack_epoch_seen = F_.PACK_EPOCH
         if F_.two_streams_ok(VRDAEmaps_hori):
             # vertical branch on the side stream, horizontal branch on the current one (see functional.TWO_STREAMS)
             dev = VRDAEmaps_hori.device
             capturing = torch.cuda.is_current_stream_capturing()     # graph capture: fork / join become graph edges; the
             if not capturing:                                       # private pool is not recycled, no record_stream needed
-                F_.refresh_packed(dev)                              # (and the packed-weight cache is bypassed anyway)
+                F_.refresh_packed(dev, idle_params)                 # (and the packed-weight cache is bypassed anyway)
             main, side = torch.cuda.current_stream(dev), F_.side_stream(dev)
             side.wait_stream(main)
             if not capturing:
@@ -76,7 +81,7 @@ class HuPRNet(nn.Module):
                     t.record_stream(main)             # allocated on the side stream, consumed by the decoder
         else:
             if VRDAEmaps_hori.is_cuda and not torch.cuda.is_current_stream_capturing():
-                F_.refresh_packed(VRDAEmaps_hori.device)            # stale cached layouts / derived constants are refilled in place
+                F_.refresh_packed(VRDAEmaps_hori.device, idle_params)   # stale cached layouts / derived constants are refilled in place
             RAmaps, REmaps = self.forward_chirp(VRDAEmaps_hori, VRDAEmaps_vert)
             RAl1feat, RAl2feat, RAfeat = self.RAradarEncoder(RAmaps)
             REl1feat, REl2feat, REfeat = self.REradarEncoder(REmaps)

@@ -264,6 +264,9 @@ class GradientBuckets:
         self._names = {id(q): n for n, q in module.named_parameters()}
         self.direct = self.device.type == "cuda"
         self.always_zero = os.environ.get("HUPR_ZERO_GRADS", "0") == "1"
+        # debug mode: a bucket that is NOT zero-filled is NaN-filled instead and finish() asserts that nothing of it
+        # survived — proof that every kernel writing through the sink overwrites its whole slot (one synchronisation per step)
+        self.poison = os.environ.get("HUPR_ZERO_GRADS", "0") == "poison"
         self._deferred = []
         self.prepare()
 
@@ -335,6 +338,8 @@ class GradientBuckets:
                 and getattr(b, "clean", False)
             if not skip:
                 b.flat_grad.zero_()
+            elif self.poison:
+                b.flat_grad.fill_(float("nan"))
             b.zeroed = not skip
             b.clean = False
             b.pending = len(b.params)
@@ -412,6 +417,12 @@ class GradientBuckets:
         self._armed = False
         if F_.GRAD_SINK is self:
             F_.GRAD_SINK = None
+        if self.poison and not self._accum_live:
+            torch.cuda.synchronize(self.device)
+            bad = [i for i, b in enumerate(self.buckets) if all(b.written) and not bool(torch.isfinite(b.flat_grad).all())]
+            if bad:
+                raise RuntimeError("HUPR_ZERO_GRADS=poison: buckets %r hold NaN after a pass that wrote every slot through the sink — a "
+                                   "kernel writes its gradient slot partially or accumulates into it" % bad)
         for b in self.buckets:
             if not getattr(b, "zeroed", True) and not all(b.written):
                 # slots that were left un-zeroed and received nothing in this pass hold the previous pass's gradients: clear them now

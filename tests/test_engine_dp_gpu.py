@@ -509,3 +509,35 @@ def test_deferred_slope_gradient_sums_are_bit_transparent(monkeypatch):
     finally:
         F_.PRELU_DEFER, F_.TWO_STREAMS = saved
         F_.set_math("f32")
+
+
+def test_every_sink_writing_kernel_overwrites_its_whole_slot(monkeypatch):
+    """``GradientBuckets.prepare`` skips the zero fill of a bucket whose slots were all kernel-written in the previous pass, on
+    the assumption that every such kernel OVERWRITES its slot.  HUPR_ZERO_GRADS=poison NaN-fills those buckets instead and ``finish``
+    raises if a NaN survives: three steps at B = 4 (one compute stream: the deferred slope sums; then two) must stay finite and land
+    on the parameters of the engine that zero-fills unconditionally."""
+    from hupr_amd import functional as F_
+    from hupr_amd.tools.engine import TrainEngine
+    saved = F_.TWO_STREAMS
+    try:
+        F_.set_math("bf16")
+        cfg, dev, adc_h, adc_v, joints = _setup(seed=91)
+        for two in (False, True):
+            F_.TWO_STREAMS = two
+            monkeypatch.setenv("HUPR_ZERO_GRADS", "1")
+            e0 = TrainEngine(cfg, device=dev, seed=0)
+            monkeypatch.setenv("HUPR_ZERO_GRADS", "poison")
+            e1 = TrainEngine(cfg, device=dev, seed=0)
+            assert e1.buckets.poison and not e1.buckets.always_zero
+            for step in range(3):
+                l0, _ = e0.train_step_from_adc(adc_h, adc_v, joints)
+                l1, _ = e1.train_step_from_adc(adc_h, adc_v, joints)          # raises inside finish() if a NaN survived
+                assert [b.zeroed for b in e1.buckets.buckets] == [step == 0] * len(e1.buckets.buckets)
+            torch.cuda.synchronize()
+            assert float(l0) == float(l1) and torch.equal(_flat(e0), _flat(e1)), two
+            e0.close(); e1.close()
+    finally:
+        F_.TWO_STREAMS = saved
+        F_.GRAD_SINK = None
+        F_.set_math("f32")
+        F_.invalidate_packed()

@@ -206,3 +206,86 @@ def test_decoder_inputs_filled_in_place_match_the_concatenation_copies():
         bad = [k for k in grads if not torch.equal(grads[k], ref[2][k])]
         assert not bad, (key, bad[:5])
     assert all(torch.isfinite(t).all() for t in ref[2].values())
+
+
+def test_fp32_level_inside_a_bf16_run_takes_the_unfused_path():
+    """with an MSCSA level switched to the fp32 pipe (HUPR_F32_REGIONS=lvl1, scripts/precision_regions.py) the decoder
+    stage must not promise the fused level an output placement — the placement decision is taken under the LEVEL's precision, and no
+    placement view leaks to the next level.  Forward + backward run, outputs stay within the bf16 gate of the default configuration."""
+    from hupr_amd import functional as F_
+    from hupr_amd.misc import LossComputer
+    g = np.load(os.path.join(G, "model_train.npz"))
+    h, v = _inputs(g)
+    gt = torch.from_numpy(synth.keypoints(2, int(g["kp_seed"])))
+    saved = dict(F_.PRECISION)
+    outs = {}
+    try:
+        F_.set_math("bf16")
+        for name, prec in (("default", saved), ("lvl1_f32", dict(saved, lvl1="f32")), ("all_lvls_f32", dict(saved, lvl0="f32", lvl1="f32", lvl2="f32"))):
+            F_.PRECISION.clear()
+            F_.PRECISION.update(prec)
+            cfg, net = _build(g)
+            net.train()
+            F_.invalidate_packed()
+            p1, p2 = net(h, v)
+            assert not F_._level_cat_out
+            loss, *_ = LossComputer(cfg, "cuda").computeLoss((p1, p2), gt, decode=False)
+            loss.backward()
+            torch.cuda.synchronize()
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters()), name
+            outs[name] = p2.detach().float().cpu().numpy()
+        for name in ("lvl1_f32", "all_lvls_f32"):
+            assert np.abs(outs[name] - outs["default"]).max() <= 2e-2, name
+            assert np.abs(outs[name] - g["gcn_heatmap"]).max() <= 2e-2, name
+    finally:
+        F_.PRECISION.clear()
+        F_.PRECISION.update(saved)
+        F_.set_math("f32")
+        F_.invalidate_packed()
+
+
+def test_idle_model_repacks_in_front_of_the_two_stream_fork():
+    """a model that sat idle for two or more optimiser epochs of another model drops out of the packed-weight table's
+    candidates; its next forward must refresh its stale layouts BEFORE the encoder branches fork onto two streams (a lazy refresh
+    inside the fork runs on whichever stream gets there first, unordered against the sibling's reads).  Every table launch of that
+    forward happens on the main stream, and the outputs are those of a fresh model holding the same weights."""
+    from hupr_amd import functional as F_
+    g = np.load(os.path.join(G, "model_eval.npz"))
+    h, v = _inputs(g)
+    saved = F_.TWO_STREAMS
+    calls = []
+    orig = F_._pack_refresh_all
+    try:
+        F_.set_math("bf16")
+        F_.TWO_STREAMS = True
+        _, a = _build(g)
+        _, b = _build(g)
+        a.eval(); b.eval()
+        with torch.no_grad():
+            a(h, v)
+            for _ in range(3):                       # three optimiser epochs of the OTHER model
+                F_.invalidate_packed()
+                b(h, v)
+            sd = {k: (t * 1.03125 if t.is_floating_point() and t.dim() > 1 else t) for k, t in a.state_dict().items()}
+            a.load_state_dict(sd)                    # the idle model's weights change (e.g. copied from a training model)
+            main = torch.cuda.current_stream().cuda_stream
+
+            def logged(dev, full=None):
+                calls.append(torch.cuda.current_stream().cuda_stream)
+                return orig(dev, full=full)
+            F_._pack_refresh_all = logged
+            p1, p2 = a(h, v)
+            F_._pack_refresh_all = orig
+            torch.cuda.synchronize()
+            assert calls and all(c == main for c in calls), (calls, main)
+            _, fresh = _build(g)
+            fresh.load_state_dict(sd)
+            fresh.eval()
+            q1, q2 = fresh(h, v)
+            torch.cuda.synchronize()
+        assert torch.equal(p1, q1) and torch.equal(p2, q2)
+    finally:
+        F_._pack_refresh_all = orig
+        F_.TWO_STREAMS = saved
+        F_.set_math("f32")
+        F_.invalidate_packed()
