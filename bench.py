@@ -261,8 +261,6 @@ def conv_roofline(events, B, dtype, peak):
     ach = kflop / avg / 1e12
     if dtype != "bf16":
         kname = "hupr_k_gemm_f32<128,64,2,2,A_CONV,B_NK>"
-    elif os.environ.get("HUPR_HALO_M16", "1") == "0":      # (runtime.py hands HUPR_HALO_M16 to hupr_debug_halo_m16 at load)
-        kname = "hupr_k_conv_halo256_bf16 (256-voxel halo convolution on v_mfma_f32_32x32x16_bf16, bf16 activations; HUPR_HALO_M16=0)"
     else:
         kname = ("hupr_k_conv_halo256m_bf16<4, 8, 8, 3, *> (256-voxel halo convolution on v_mfma_f32_16x16x32_bf16, bf16 activations; forward "
                  "launches: the <..., 1> instantiation with fused BatchNorm statistics, input-gradient launches: <..., 0>)")
@@ -305,10 +303,6 @@ def main():
                          "+2-3 %% frames/s).  Off here by default: with both branches in flight the layer-1 convolutions of "
                          "the two encoders overlap, and the per-launch duration behind the roofline entry (and the matching "
                          "rocprofv3 summary) would no longer be that of one kernel owning the GPU")
-    ap.add_argument("--attn", choices=["bf16", "fp8"], default="bf16",
-                    help="fp8 = BASELINE config 5: the level-1 MSCSA attention FORWARD on the block-scaled fp8 matrix instruction "
-                         "(csrc/attention_mx8.hip: e4m3 operands, one E8M0 scale per 32 elements), backward on the bf16 kernels.  Measured, "
-                         "not the default: it misses the >= 99 %% arg-max gate on the decoded head (DESIGN.md section 7)")
     ap.add_argument("--workload", choices=["c3", "c2"], default="c3",
                     help="c3 (default, the metric's configuration): training step at 32 samples/GPU from ADC cubes; "
                          "c2: eval-mode forward latency at --batch samples (default 1) from normalised inputs")
@@ -344,16 +338,8 @@ def main():
 
     cfg = load_config()
     F_.set_math(args.dtype)
-    if args.attn == "fp8":
-        F_.ATTN_FP8, F_.ATTN_FP8_TRAIN = "mx", True
     # c2 (latency, no roofline entry): always the library default of two branches on two streams, also inside the hipGraph
     F_.TWO_STREAMS = (bool(args.two_streams) or args.workload == "c2") and os.environ.get("HUPR_ONE_STREAM", "0") != "1"
-    if os.environ.get("HUPR_HALO_ABLATE"):                           # A/B aid: conv_halo256 variants inside the real step
-        F_.rt.lib().hupr_debug_halo_ablate(int(os.environ["HUPR_HALO_ABLATE"]))
-    if os.environ.get("HUPR_HALO_SMALL_TILES_OFF", "0") == "1":      # A/B aid
-        F_.rt.lib().hupr_debug_halo_small_tiles(0)
-    if os.environ.get("HUPR_GEMM_SMALL_TILES_OFF", "0") == "1":      # A/B aid
-        F_.rt.lib().hupr_debug_gemm_small_tiles(1)
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     if args.workload == "c2":
         return bench_inference(args, cfg, dev, rank, world, peak)
@@ -693,25 +679,6 @@ def main():
                      "limiter": "non-MFMA instruction issue beside a power-paced matrix pipe: the forward's phases (MFMA 65 us, fragment reads 38, "
                                 "soft-max VALU 65-70, stores / DMA / barrier 28) add up instead of overlapping (profiles/r04_attn_ablation.txt, "
                                 "profiles/r04_valu_issue_probe.txt)"}
-        # BASELINE config 5 beside it: the same attention's forward on the block-scaled fp8 instruction (quantisation of a level's
-        # operands amortised over its four attentions), against the dense fp8 peak
-        try:
-            y4 = torch.randn(B, Na, 4 * Ca, device=dev, generator=ga).bfloat16() * 0.5
-            ws8 = torch.empty(L_.hupr_attn_mx8_ws_bytes(B, Na, Ca), dtype=torch.uint8, device=dev)
-            q8 = lambda: rt_.check(L_.hupr_attn_mx8_quant_level(rt_.ptr(y4), rt_.ptr(y4), rt_.ptr(vb_), rt_.ptr(vb_), B, Na, Ca, rt_.ptr(ws8), ws8.numel(), rt_.stream()))      # noqa: E731
-            f8 = lambda: rt_.check(L_.hupr_attn_mx8_fwd(rt_.ptr(ws8), 0, 0, 1, 1, 0, rt_.ptr(va), rt_.ptr(oa), rt_.ptr(la), None, 0, B, Na, Ca, ws8.numel(), rt_.stream()))      # noqa: E731
-            tq8, tf8 = a_time(q8), a_time(f8)
-            t8 = tf8 + tq8 / 4.0
-            attn_roof["config5_fp8_forward"] = {
-                "kernel": "hupr_k_attn_fwd_mx8 (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 + E8M0 block scales) + 1/4 of hupr_attn_mx8_quant_level",
-                "us": round(t8 * 1e6, 1), "kernel_us": round(tf8 * 1e6, 1), "quant_level_us": round(tq8 * 1e6, 1),
-                "achieved": round(ffl / t8 / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s", "frac": round(ffl / t8 / 1e12 / 5000.0, 4),
-                "vs_bf16_forward": round(t8 / tf, 3),
-                "status": "measured, not the default: decoded-head arg-max agreement 93 % (gate 99 %), step +0.3 % (DESIGN.md section 7); "
-                          "python bench.py --attn fp8 runs the step with it"}
-            del y4, ws8
-        except Exception as exc:      # noqa: BLE001
-            attn_roof["config5_fp8_forward"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         del ka, qa, va, kb_, qb_, vb_, g32, gb_, oa, la, dka, dqa, dva, sca
     if dist.is_initialized():
         dist.all_reduce(torch.zeros(1))
@@ -775,7 +742,7 @@ def main():
                        "batch_per_gpu": B, "micro_batches_per_step": micro, "global_batch": B * micro * world,
                        "parallelism": "dp%d" % world, "model_gflop_per_frame": STEP_GFLOP,
                        "collective": transport,
-                       "attention": "level-1 forward on block-scaled fp8 (config 5), backward bf16" if args.attn == "fp8" else "bf16",
+                       "attention": "bf16",
                        "launch": "hipGraph replay" if args.graph else "eager",
                        "compute_streams": 2 if (F_.TWO_STREAMS and world == 1) else 1},
             "model_tflops": round(value * STEP_GFLOP / 1e3, 2),

@@ -891,14 +891,14 @@ __device__ __forceinline__ void pp_block(int nqb, int Bn, int& b, int& qb) {
     }
 }
 
-template <int abl, bool QS = false>
+template <bool QS = false>
 __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __restrict__ K, const __bf16* __restrict__ Q,
                                                               const __bf16* __restrict__ V, const float* __restrict__ Vres,
                                                               float* __restrict__ out, float* __restrict__ lse, int N, int Bn, int ldk,
                                                               int ldq, __bf16* __restrict__ out16, int ld16,
                                                               unsigned long long* __restrict__ trace) {
-    // abl (compile-time; profiling only, wrong results): 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no exponentials, 8 no maxima,
-    // 16 no MFMAs, 32 no tile barrier, 64 no epilogue stores (scripts/attn_pp_ablate.py)
+    // (phase ablations of this kernel — no LDS-DMA / fragment reads / exponentials / maxima / MFMAs / barrier / stores — were timed in
+    // round 4: profiles/r04_attn_ablation.txt; the instantiations are gone)
     constexpr int D = 64;
     __shared__ __attribute__((aligned(1024))) __bf16 ring[kPPRing][2][64 * D];      // [slot][K image, V image]
     // profiling (scripts/attn_pp_trace.py): s_memtime stamps of waves 0 and 4 of workgroup 0, five per key tile
@@ -913,10 +913,10 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int grp = wave >> 2;
-    // static issue priority for one of the two waves of each SIMD (abl 128: none, 256: waves 4-7 instead of 0-3).  Stamps of the
+    // static issue priority for one of the two waves of each SIMD.  Stamps of the
     // equal-priority build: wave 0's tile 1 820 cycles + 860 at the barrier, wave 4's 2 470 + 220; measured 171.1 (waves 4-7) /
     // 171.5 (none) / 167.4 us (waves 0-3)
-    if (!(abl & 128) && (grp == 0) == !(abl & 256)) __builtin_amdgcn_s_setprio(1);
+    if (grp == 0) __builtin_amdgcn_s_setprio(1);
     int b, qb;
     pp_block(N / 256, Bn, b, qb);
     const long base = (long)b * N * D;
@@ -1023,12 +1023,12 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
     // work per group, groups fenced with sched_barrier(0).  FIRST_ / LAST_ (compile-time): no previous tile / no next tile.
 #define HUPR_SB() __builtin_amdgcn_sched_barrier(0)
 #define HUPR_PVM(T_, U_, CT_)                                                                                              \
-    if (!(FIRST__) && !(abl & 16)) o[CT_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[T_][U_][CT_], pb[NXT__][T_][U_], o[CT_], 0, 0, 0);
+    if (!(FIRST__)) o[CT_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[T_][U_][CT_], pb[NXT__][T_][U_], o[CT_], 0, 0, 0);
     // The MFMA of a group is pinned between two empty asm statements through its A operand: the first one "defines" the fragment
     // (after the previous group's statement), the second one "redefines" it, so the MFMA that reads it sits in between — without
     // the statements the instruction selector linearises all eight MFMAs behind the exponentials (their results are needed last).
 #define HUPR_SM(KS_, T_)                                                                                                   \
-    if (!(LAST__) && !(abl & 16)) {                                                                                        \
+    if (!(LAST__)) {                                                                                        \
         asm volatile("" : "+v"(kf[T_][KS_]));                                                                              \
         if ((KS_) == 0) st[NXT__][T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T_][0], qf[0], QS ? negm16 : zero16, 0, 0, 0); \
         else st[NXT__][T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T_][KS_], qf[KS_], st[NXT__][T_], 0, 0, 0);        \
@@ -1042,8 +1042,8 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
         v2fa s2_ = {st[CUR__][t_][8 * u_ + i_], st[CUR__][t_][8 * u_ + i_ + 1]};                                           \
         asm volatile("" : "+v"(s2_));                                                                                      \
         const v2fa e2_ = QS ? s2_ : __builtin_elementwise_fma(s2_, l2e2, nm2);                                             \
-        const float p0_ = (abl & 4) ? e2_.x : __builtin_amdgcn_exp2f(e2_.x);                                               \
-        const float p1_ = (abl & 4) ? e2_.y : __builtin_amdgcn_exp2f(e2_.y);                                               \
+        const float p0_ = __builtin_amdgcn_exp2f(e2_.x);                                                         \
+        const float p1_ = __builtin_amdgcn_exp2f(e2_.y);                                                         \
         sum2[(P_) & 1] += (v2fa){p0_, p1_};                                                                                \
         pb[CUR__][t_][u_][i_] = (__bf16)p0_;                                                                               \
         pb[CUR__][t_][u_][i_ + 1] = (__bf16)p1_;                                                                           \
@@ -1055,8 +1055,8 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
         constexpr int CUR__ = CUR_, NXT__ = NXT_;                                                                          \
         constexpr bool FIRST__ = FIRST_, LAST__ = LAST_;                                                                   \
         HUPR_PP_STAMP()                                                                                                    \
-        if (!(abl & 1)) { HUPR_PP_ISSUE(j + kPPAhead) }                                                                    \
-        if (!(abl & 2) && !LAST__) { HUPR_PP_READ_K((j + 1) & (kPPRing - 1)) }                                             \
+        { HUPR_PP_ISSUE(j + kPPAhead) }                                                                           \
+        if (!LAST__) { HUPR_PP_READ_K             ((j + 1) & (kPPRing - 1)) }                                             \
         HUPR_SB();                                                                                                         \
         /* ---- row maxima of tile j under O^T += V^T P^T of tile j - 1 (four independent chains) ---- */                  \
         const f32x16& s0_ = st[CUR__][0];                                                                                  \
@@ -1070,8 +1070,8 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
         HUPR_PVM(1, 0, 1) mc_ = HUPR_M3(mc_, s1_[5], s1_[6]); md_ = HUPR_M3(md_, s1_[13], s1_[14]); HUPR_SB();             \
         HUPR_PVM(1, 1, 0) ma_ = HUPR_M3(ma_, s0_[7], mb_); mc_ = HUPR_M3(mc_, s1_[7], md_); HUPR_SB();                     \
         HUPR_PVM(1, 1, 1) ma_ = HUPR_M3(ma_, s0_[15], s1_[15]);                                                            \
-        float mx = (abl & 8) ? ma_ : fmaxf(ma_, mc_);                                                                      \
-        if (!(abl & 8)) {                                                                                                  \
+        float mx = fmaxf(ma_, mc_);                                                                                     \
+        {                                                                                                                \
             /* the other half-wave holds the other 32 keys: v_permlane32_swap leaves the lower half-wave's maximum in every  */ \
             /* lane of its first register and the upper one's in the second.  Written as asm: through the builtin hipcc       */ \
             /* dropped the second result (max(r0, r1) compiled to r0 alone, the upper half-wave's maximum was lost — results  */ \
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
         asm volatile("" : "+v"(sum2[0]), "+v"(sum2[1]));                                                                   \
         HUPR_SB();                                                                                                         \
         /* ---- tail: the V fragments of tile j for the next iteration, the row sum, the (rare) rescale ---- */            \
-        if (!(abl & 2)) { HUPR_PP_READ_V(j & (kPPRing - 1)) }                                                              \
+        { HUPR_PP_READ_V(j & (kPPRing - 1)) }                                                                     \
         sum2[0] += sum2[1];                                                                                                \
         if constexpr (QS) l_run += sum2[0].x + sum2[0].y;                                                                  \
         else l_run = l_run * alpha + (sum2[0].x + sum2[0].y);                                                              \
@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;                                          \
         }                                                                                                                  \
         HUPR_PP_STAMP()                                                                                                    \
-        if (!(abl & 32)) {                                                                                                 \
+        {                                                                                                                \
             HUPR_PP_VMCNT(4);                                 /* this wave's pieces of tile j + 2 have landed */           \
             HUPR_PP_BARRIER();                                                                                             \
         }                                                                                                                  \
@@ -1164,12 +1164,12 @@ __global__ __launch_bounds__(512, 1) void hupr_k_attn_fwd_pp64(const __bf16* __r
 #undef HUPR_SB
     HUPR_PP_VMCNT(0);
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (!(abl & 64)) {
+    {
     store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     if (out16)
         store_ct16<D>(out16 + ((long)b * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     }
-    if (lh == 0) lse[(long)b * N + q] = (QS ? (m_run + __log2f(l_tot)) * kLn2 : m_run + __logf(l_tot)) + ((abl & 64) ? o[0][0] + o[1][5] : 0.f);
+    if (lh == 0) lse[(long)b * N + q] = (QS ? (m_run + __log2f(l_tot)) * kLn2 : m_run + __logf(l_tot));
 #undef HUPR_PP_ISSUE
 #undef HUPR_PP_READ_K
 #undef HUPR_PP_READ_V
@@ -1192,12 +1192,6 @@ extern "C" int hupr_attn_flash_supported(int N, int C) { return ((C == 64 || C =
 // widens it to every grid below 128 workgroups, -1 switches it off.
 static int g_attn_split = 0;
 extern "C" void hupr_debug_attn_split(int mode) { g_attn_split = mode; }
-static int g_attn_xcd = 1;     // A/B aid: 0 = the backward kernels keep the plain (token block, sample) -> workgroup id order
-extern "C" void hupr_debug_attn_xcd(int on) { g_attn_xcd = on; }
-static int g_attn_dkv512 = 1;      // A/B aid: 0 = the 256-thread dK / dV kernel at the level-1 shape too
-extern "C" void hupr_debug_attn_dkv512(int on) { g_attn_dkv512 = on; }
-static int g_attn_pp = 1;      // A/B aid: 0 = the rounds-1-3 kernels for the D = 64 shapes too; bits 4.. = phase ablations of the ping-pong kernels (timing only)
-extern "C" void hupr_debug_attn_pingpong(int on) { g_attn_pp = on; }
 static unsigned long long* g_attn_trace = nullptr;      // profiling: device buffer of 3 x 2 x 4096 s_memtime stamps (fwd, dQ, dK/dV) or null
 extern "C" void hupr_debug_attn_trace(void* buf) { g_attn_trace = static_cast<unsigned long long*>(buf); }
 static int attn_splits(int Bn, int N) {
@@ -1226,31 +1220,16 @@ static int attn_fwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     const int S = ws ? attn_splits(Bn, N) : 1;
     if constexpr (sizeof(TI) == 2) {
         // level-1 shape: the ping-pong kernel (256 queries per 512-thread workgroup, LDS-DMA ring)
-        if (S <= 1 && C == 64 && N % 256 == 0 && N >= 256 && g_attn_pp && (long)N * ldk * 2 < (1L << 31)) {
-#define HUPR_PP_FWD(A_) HUPR_LAUNCH(hupr_k_attn_fwd_pp64<A_>, dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, \
+        if (S <= 1 && C == 64 && N % 256 == 0 && N >= 256 && (long)N * ldk * 2 < (1L << 31)) {
+#define HUPR_PP_FWD() HUPR_LAUNCH(hupr_k_attn_fwd_pp64<false>, dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, \
                                            out, lse, N, Bn, ldk, ldq, o16, ld16, g_attn_trace)
             if constexpr (QS) {
-                HUPR_LAUNCH((hupr_k_attn_fwd_pp64<0, true>), dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, out, lse,
+                HUPR_LAUNCH((hupr_k_attn_fwd_pp64<true>), dim3((N / 256) * Bn), dim3(512), 0, as_stream(stream), K, Q, V, Vres, out, lse,
                             N, Bn, ldk, ldq, o16, ld16, g_attn_trace);
                 HUPR_LAUNCH_OK("hupr_k_attn_fwd_pp64 (QS)");
                 return HUPR_OK;
             }
-            switch (g_attn_pp >> 4) {
-                case 0: HUPR_PP_FWD(0); break;
-                case 1: HUPR_PP_FWD(1); break;
-                case 2: HUPR_PP_FWD(2); break;
-                case 4: HUPR_PP_FWD(4); break;
-                case 8: HUPR_PP_FWD(8); break;
-                case 16: HUPR_PP_FWD(16); break;
-                case 31: HUPR_PP_FWD(31); break;
-                case 27: HUPR_PP_FWD(27); break;
-                case 23: HUPR_PP_FWD(23); break;
-                case 64: HUPR_PP_FWD(64); break;
-                case 127: HUPR_PP_FWD(127); break;
-                case 128: HUPR_PP_FWD(128); break;
-                case 256: HUPR_PP_FWD(256); break;
-                default: return fail(HUPR_ERR_ARG, "hupr_k_attn_fwd_pp64: ablation %d is not instantiated", g_attn_pp >> 4);
-            }
+            HUPR_PP_FWD();
 #undef HUPR_PP_FWD
             HUPR_LAUNCH_OK("hupr_k_attn_fwd_pp64");
             return HUPR_OK;
@@ -1311,7 +1290,7 @@ static int attn_fwd_batch(const char* who, const hupr_attn_item* items, int n_it
     HUPR_REQUIRE(hupr_attn_flash_supported(N, C), "%s: unsupported shape N=%d C=%d", who, N, C);
     HUPR_REQUIRE(ldk >= C && ldq >= C && ldk % 8 == 0 && ldq % 8 == 0, "%s: bad row strides %d %d", who, ldk, ldq);
     const int S = ws ? attn_splits(Bn, N) : 1;
-    if (S == 1 && C == 64 && N % 256 == 0 && g_attn_pp && (long)N * ldk * 2 < (1L << 31)) {
+    if (S == 1 && C == 64 && N % 256 == 0 && (long)N * ldk * 2 < (1L << 31)) {
         // level-1 shape: each attention fills the chip by itself with the ping-pong kernel — one launch per item
         for (int i = 0; i < n_items; ++i) {
             const int rc = attn_fwd<__bf16, QS>(who, static_cast<const __bf16*>(items[i].K), ldk, static_cast<const __bf16*>(items[i].Q), ldq,
@@ -1413,12 +1392,12 @@ static int attn_bwd(const char* who, const TI* K, int ldk, const TI* Q, int ldq,
     const float* add32 = residual ? dout32 : (accumulate ? dV : nullptr);
     const __bf16* add16 = (residual && !dout32) ? reinterpret_cast<const __bf16*>(dO) : nullptr;
     const dim3 pgrid((unsigned)((rows + 15) / 16));
-    const int xmap = (g_attn_xcd && Bn % 8 == 0) ? 1 : 0;
+    const int xmap = (Bn % 8 == 0) ? 1 : 0;
 #define HUPR_ATTN_BWD(D_, NH_)                                                                                             \
     if (dout32) HUPR_LAUNCH((hupr_k_attn_prep<D_, float>), pgrid, dim3(256), 0, s, dout32, C, out, V32, Dq, rows, residual); \
     else HUPR_LAUNCH((hupr_k_attn_prep<D_, __bf16>), pgrid, dim3(256), 0, s, reinterpret_cast<const __bf16*>(dO), lddo, out, V32, Dq, rows, residual); \
     HUPR_LAUNCH((hupr_k_attn_bwd_dq<D_, TI, QS>), grid, dim3(256), 0, s, K, Q, V, dO, lse, Dq, dQ, N, ldk, ldq, lddq, lddo, xmap);  \
-    if (D_ == 64 && sizeof(TI) == 2 && g_attn_dkv512 && N % 256 == 0)                                                       \
+    if (D_ == 64 && sizeof(TI) == 2 && N % 256 == 0)                                                       \
         HUPR_LAUNCH(hupr_k_attn_bwd_dkv512<QS>, dim3(N / 256, Bn), dim3(512), 0, s, reinterpret_cast<const __bf16*>(K),       \
                            reinterpret_cast<const __bf16*>(Q), reinterpret_cast<const __bf16*>(V), reinterpret_cast<const __bf16*>(dO), \
                            add32, lse, Dq, dK, dV, N, ldk, ldq, lddk, lddo, add16, lddo, xmap);                                 \
@@ -1445,7 +1424,7 @@ static int attn_bwd_batch(const char* who, const hupr_attn_bwd_item* items, int 
         HUPR_REQUIRE(t.K && t.Q && t.V && t.dO && t.V32 && t.out && t.lse && t.dK && t.dQ && t.dV && t.Dq, "%s: null pointer in item %d", who, i);
         HUPR_REQUIRE(!(t.residual && t.accumulate), "%s: accumulate is for the non-residual form (item %d)", who, i);
     }
-    const bool level1 = C == 64 && g_attn_dkv512 && N % 256 == 0;       // its 512-thread dK / dV kernel takes one attention per launch
+    const bool level1 = C == 64 && N % 256 == 0;       // its 512-thread dK / dV kernel takes one attention per launch
     if (n_items == 1) {
         for (int i = 0; i < n_items; ++i) {
             const hupr_attn_bwd_item& t = items[i];
@@ -1460,7 +1439,7 @@ static int attn_bwd_batch(const char* who, const hupr_attn_bwd_item* items, int 
                      lddk % 4 == 0 && lddq % 4 == 0, "%s: bad row strides", who);
     hipStream_t s = as_stream(stream);
     const long rows = (long)Bn * N;
-    const int xmap = (g_attn_xcd && Bn % 8 == 0) ? 1 : 0;
+    const int xmap = (Bn % 8 == 0) ? 1 : 0;
     AttnBwdBatch b = AttnBwdBatch();
     b.n = n_items;
     b.Bn = Bn;

@@ -1,4 +1,4 @@
-// Shared argument block of the halo-tiled 3x3(x3) convolution kernels (conv_halo_bf16.hip, conv_halo256_bf16.hip).
+// Shared argument block of the halo-tiled 3x3(x3) convolution kernels (conv_halo_bf16.hip, conv_halo256m_bf16.hip, conv_halo512_bf16.hip).
 #pragma once
 #include "gemm_common.h"
 
@@ -52,8 +52,7 @@ __device__ __forceinline__ void halo_store_partial(const HaloArgs& p, const f32x
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf);
 bool conv_halo256_stats_ok(const HaloArgs& a, int Bn);                         // fused BatchNorm statistics available for this launch?
-void launch_conv_halo256m(const HaloArgs& a, hipStream_t s);                  // the 256-voxel kernel on v_mfma_f32_16x16x32_bf16 (conv_halo256m_bf16.hip)
-void set_halo_m16(int on);
+void set_halo_tiles(int mask);                                                // test aid: which tiles of the 256-voxel kernel are in use (conv_halo256m_bf16.hip)
 bool launch_conv_halo512(HaloArgs a, int Bn, bool abf, hipStream_t s);      // 512-voxel register-blocked variant (conv_halo512_bf16.hip)
 bool conv_halo512_supported(const HaloArgs& a, int Bn, bool abf);
 constexpr int kHalo256Grid = 256;      // persistent workgroups (= partial rows of HaloArgs::stats)

@@ -1,19 +1,28 @@
-// The 256-voxel persistent halo convolution (conv_halo256_bf16.hip, bf16 activations) on v_mfma_f32_16x16x32_bf16.
+// The 256-voxel persistent halo convolution (3 x 3 (x 3) taps, bf16-stored activations) on v_mfma_f32_16x16x32_bf16 — the kernel
+// the encoder's and decoder's convolutions and input gradients run on (conv_halo_bf16.hip holds the 128-voxel kernel for everything
+// outside this envelope, conv_halo512_bf16.hip the Co = 32 input gradient of the first layer).
 //
-// Why another instruction shape: with the chip at its power limit the 16 x 16 x 32 form does 15-17 % more work per joule than
-// the 32 x 32 x 16 form (register-fed; 5-7 % fed from LDS at this kernel's rate: scripts/probes/mfma_shapes_probe.hip), and the
-// timing-only variant 32 of the old kernel measured -5 % / -7 % on the layer-1 / layer-2 shapes (profiles/r04b_halo_ablation_m16.txt).
-// Same tile (4 x 8 x 8 voxels x 64 output channels per 512-thread workgroup), same LDS images, same LDS-DMA weight stages and the
-// same stage protocol (barrier in front of a stage's last tap, fragment pipeline across stages, next halo's register loads one
-// item per tap, its LDS commit behind the last stage's barrier) as hupr_k_conv_halo256_bf16<true, 0>; what changes is who owns what:
-//   wave = depth slice wm (4) x 32-channel half wn (2), as before; lane = (idx = lane & 15, kq = lane >> 4);
+// Design, as the measurements of rounds 2-5 shaped it (64 -> 64 channels, 3 x 3 x 3 taps, B = 32):
+//   * one persistent 512-thread workgroup per CU walks a contiguous run of 4 x 8 x 8-voxel x 64-channel tiles (an eighth of the
+//     tile sequence per XCD); the NEXT tile's halo travels global -> registers one item per tap underneath the current tile's
+//     MFMAs and is committed to LDS behind the last stage's barrier (a fill burst of all CUs otherwise saturates L2 for ~3 us per
+//     tile while the matrix pipe idles);
+//   * weights arrive by LDS-DMA (buffer_load ... lds) in stages of three taps = one (kz, kx) column, double-buffered; the stage
+//     barrier sits IN FRONT of a stage's last tap and the fragment pipeline runs across stage and tile boundaries: a wave reaches
+//     the barrier holding the fragments of the last tap and leaves it with eight MFMAs ready (matrix pipe busy 58 -> 65 % of the
+//     cycles, profiles/r04b_conv_sq_pmc.txt);
+//   * the instruction shape: at the chip's power limit the 16 x 16 x 32 form does 15-17 % more work per joule than 32 x 32 x 16
+//     (register-fed; 5-7 % fed from LDS at this kernel's rate: scripts/probes/mfma_shapes_probe.hip, profiles/r04b_halo_ablation_m16.txt);
+//   * a finished tile is parked as packed bf16 and stored under the next tile's first stage; a residual is prefetched under the
+//     tile's last stage; BatchNorm column sums of the rounded outputs are kept in registers and reduced once per launch.
+// Who owns what:
+//   wave = depth slice wm (4) x 32-channel half wn (2); lane = (idx = lane & 15, kq = lane >> 4);
 //   the wave's 64 voxels are four groups vg of 16 (rows 2 vg, 2 vg + 1; idx = 8 yy + wx), its 32 channels two groups cg of 16;
 //   D'[channel][voxel] = W X^T: lane holds voxel idx of every group and channels 16 cg + 4 kq .. + 3: c[vg][cg] (eight f32x4);
 //   a K-step is 32 input channels (lane kq reads the 16-byte chunk 4 kk + kq of a row); per tap ky: 2 weight fragments (cg) and the
 //   4 activation fragments of halo rows rho = 2 vg + ky feed 8 MFMAs; rho = 2, 4, 6 serve ky = 0 and ky = 2 (9 activation reads per
 //   K-step for 12 (vg, ky) pairs); two register banks of four activation fragments rotate (the even-rho bank of K-step kk + 1 is
-//   loaded into the odd-rho bank of kk while ky = 2 multiplies): 13 fragments live, 52 registers (the old kernel: 56).
-// The fp32 sums differ from the 32 x 32 x 16 kernel's in the order inside a 32-channel group only (checked against it and fp64).
+//   loaded into the odd-rho bank of kk while ky = 2 multiplies): 13 fragments live, 52 registers.
 #include "conv_halo.h"
 
 namespace hupr {
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     const int idx = lane & 15, kq = lane >> 4, yy = idx >> 3, wx = idx & 7;
     const int n_tiles = p.Bn * p.nd * p.nh * p.nw * p.n_co_tiles;
 
-    // ---- weight stages by LDS-DMA (as in the 32 x 32 x 16 kernel) ------------------------------------------------------
+    // ---- weight stages by LDS-DMA ---------------------------------------------------------------------------------------
     const int wrow_ = 8 * wave + (lane >> 3);
     const int wsrc_lane = (wrow_ * T * p.Ci + (((lane & 7) ^ (wrow_ >> 1)) & 7) * 8) * 2;      // bytes; < 2^31
     const u32x4 wrs = {(unsigned)(unsigned long)p.wp, (unsigned)((unsigned long)p.wp >> 32) & 0xffffu,
@@ -150,8 +159,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     // activations: halo voxel (wm + kz, rho + yy, wx + kx).  Halo row swizzle of THIS kernel: 16-byte chunk c of voxel (hy, hx) lives at
     // chunk c ^ (((hx >> 1) & 3) << 1).  A 16-lane ds_read_b128 group holds eight lanes of chunk parity 0 and eight of parity 1 such
     // that the two rows yy of a column differ in that parity; voxel pitch 128 B puts the column parity into bank bit 5; the key separates
-    // the four columns of one parity in chunk bits 1-2: all 64 banks, every tap (the 32 x 32 x 16 kernel's key gave 32 % conflict cycles
-    // with this lane map: SQ_LDS_BANK_CONFLICT)
+    // the four columns of one parity in chunk bits 1-2: all 64 banks, every tap (SQ_LDS_BANK_CONFLICT = 0, profiles/r04b_conv_sq_pmc.txt)
     const int xlane = ((dzw * HH + yw0 + yy) * HW + xw0 + wx) * LDK;
 #define HUPR_XF(ST_, RHO_, KK_)                                                                                     \
     (*reinterpret_cast<const bf16x8*>(&Hs[xlane + ((((ST_) / 3) * HH + (RHO_)) * HW + ((ST_) % 3)) * LDK +          \
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 #undef HUPR_VMCNT_LGKM0
 }
 
-void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
+static void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
     const dim3 grid(kHalo256Grid), wg(512);
     if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), grid, wg, 0, s, a);
     else if (a.stats) {                       // fused BatchNorm statistics: 1 or 2 distinct output tiles per workgroup (conv_halo256_stats_ok)
@@ -438,6 +446,64 @@ void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
         }
     } else if (a.TD == 4) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3>), grid, wg, 0, s, a);
     else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<2, 8, 16, 3>), grid, wg, 0, s, a);
+}
+
+// ---- which launches the 256-voxel kernel takes (bf16-stored activations only; everything else: the 128-voxel kernel) ----------
+// Test aid (hupr_debug_halo_tiles): bit 0 = the 4 x 8 x 8 tile, bit 1 = the 2 x 8 x 16 tile (depth not a multiple of four: encoder
+// level 3), bit 2 = the 1 x 16 x 16 tile (1 x 3 x 3 taps: the decoder).  A cleared bit sends those layers to the 128-voxel kernel —
+// the comparison the parity tests make (same products, another fp32 summation order).
+static int g_halo_tiles = 7;
+void set_halo_tiles(int mask) { g_halo_tiles = mask & 7; }
+
+static bool offsets_fit(const HaloArgs& a, int Bn) { return (long)Bn * a.D * a.H * a.W * a.in_ld * 2 < 0x7ffffff0L; }      // 32-bit buffer offsets
+
+bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf) {
+    if (!abf || !(g_halo_tiles & 1)) return false;
+    if (a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Ci % 64 != 0 || a.Co % 64 != 0) return false;
+    const long tiles = (long)Bn * (a.D / 4) * (a.H / 8) * (a.W / 8) * (a.Co / 64);
+    if (tiles >= (1L << 31) || tiles < 256) return false;      // small problems: the 128-voxel kernel fills the chip better
+    return offsets_fit(a, Bn);
+}
+
+// Would a launch with fused BatchNorm statistics (a.stats) land on an instantiation that has them?  Co = 64: the 4 x 8 x 8 tile's
+// one-tile form; Co = 128 / 256 (2 / 4 output tiles): register-resident sums of at most two distinct output tiles per workgroup;
+// the 2 x 8 x 16 tile: exactly one tile per workgroup (encoder level 3 at B = 32).
+bool conv_halo256_stats_ok(const HaloArgs& a, int Bn) {
+    if (a.kd != 3 || a.Ci % 64 != 0 || a.Co % 64 != 0 || !offsets_fit(a, Bn)) return false;
+    const int n = a.Co / 64;
+    if (a.D % 4 == 0) {
+        if (!conv_halo256_supported(a, Bn, true)) return false;
+        if (n == 1) return true;
+        const long tiles = (long)Bn * (a.D / 4) * (a.H / 8) * (a.W / 8) * n;
+        const long per_wg = (tiles + kHalo256Grid - 1) / kHalo256Grid;
+        return n <= 2 || per_wg == 1;
+    }
+    if (!(g_halo_tiles & 2) || a.D % 2 != 0 || a.H % 8 != 0 || a.W % 16 != 0) return false;
+    return (long)Bn * (a.D / 2) * (a.H / 8) * (a.W / 16) * n == 256;
+}
+
+bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
+    if (!abf || a.Ci % 64 != 0 || a.Co % 64 != 0 || !offsets_fit(a, Bn)) return false;
+    a.n_co_tiles = a.Co / 64;
+    if (a.kd == 3 && a.D % 4 == 0) {
+        if (!conv_halo256_supported(a, Bn, abf)) return false;
+        a.TD = 4; a.log2TW = 3;
+        a.nd = a.D / 4; a.nh = a.H / 8; a.nw = a.W / 8;
+    } else if (a.kd == 3) {
+        // depth not a multiple of four (encoder level 3: D = 2): the 2 x 8 x 16 tile
+        if (!(g_halo_tiles & 2) || a.D % 2 != 0 || a.H % 8 != 0 || a.W % 16 != 0) return false;
+        a.TD = 2; a.log2TW = 4;
+        a.nd = a.D / 2; a.nh = a.H / 8; a.nw = a.W / 16;
+    } else {
+        // 1 x 3 x 3 convolutions of the decoder: the 1 x 16 x 16 tile (no fused statistics)
+        if (!(g_halo_tiles & 4) || a.kd != 1 || a.D != 1 || a.H % 16 != 0 || a.W % 16 != 0 || a.stats) return false;
+        a.TD = 1; a.log2TW = 4;
+        a.nd = 1; a.nh = a.H / 16; a.nw = a.W / 16;
+    }
+    const long tiles = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
+    if (tiles < 256 || tiles >= (1L << 31)) return false;
+    launch_conv_halo256m(a, s);      // one persistent workgroup per CU
+    return true;
 }
 
 }  // namespace hupr

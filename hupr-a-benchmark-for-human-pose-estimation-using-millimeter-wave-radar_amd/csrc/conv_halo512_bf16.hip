@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo512_bf16(HaloArgs p) {
                     const int s0 = ks & 1;                        // weight-fragment set that holds (K-step ks, kz = 0)
                     // kz = 0: prefetch depth row 2 + weights of kz = 1
                     // (the prefetch reads of a group are spread in front of the MFMAs of the previous one instead of issued as a
-                    // burst, see conv_halo256_bf16.hip)
+                    // burst, see conv_halo256m_bf16.hip)
 #define HUPR_SPREAD(NR_)                                                                                            \
                     _Pragma("unroll") for (int i_ = 0; i_ < (NR_); ++i_) {                                          \
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \

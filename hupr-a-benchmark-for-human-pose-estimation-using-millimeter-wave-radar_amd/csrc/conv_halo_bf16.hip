@@ -19,7 +19,7 @@ namespace hupr {
 
 // Tile geometry (compile time): 3-D layers 2 x 8 x 8 voxels with a 4 x 10 x 10 halo and 27 taps; 2-D maps 1 x 8 x 16 with a
 // 1 x 10 x 18 halo and 9 taps.  A stage = the three ky taps of one (kz, kx) column, so that a lane whose two output rows
-// are neighbours in y reads the four halo rows hy .. hy+3 once for all six (row, ky) products (see conv_halo256_bf16.hip).
+// are neighbours in y reads the four halo rows hy .. hy+3 once for all six (row, ky) products (see conv_halo256m_bf16.hip).
 template <int BN, int KC, bool ABF, bool IS3D>
 __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {      // two workgroups per CU (LDS <= 75 KB each)
     // KC = 64: unpadded 128-byte rows whose 16-byte chunks are XOR-swizzled — halo rows by
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void hupr_k_conv_halo_bf16(HaloArgs p) {   
                     if (ks + 1 < KC / 16) {
                         if (ks & 1) { HUPR_FRAGS(0, ks + 1) } else { HUPR_FRAGS(1, ks + 1) }
                     }
-                    // (conv_halo256_bf16.hip: the reads of K-step ks + 1 are spread in front of the MFMAs of ks instead of
+                    // (as in conv_halo256m_bf16.hip: the reads of K-step ks + 1 are spread in front of the MFMAs of ks instead of
                     // issued as one burst — NA + TS reads against TS * TM MFMAs)
 #pragma unroll
                     for (int t = 0; t < TS; ++t)               // ky;  D'[channel][voxel]
@@ -409,11 +409,9 @@ static unsigned long long* g_halo_trace = nullptr;
 extern "C" void hupr_debug_halo_trace(void* buf) { g_halo_trace = reinterpret_cast<unsigned long long*>(buf); }
 extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
 extern "C" void hupr_debug_halo_variant(int v) { g_halo_variant = v; }
-extern "C" void hupr_debug_halo_m16(int on) { set_halo_m16(on); }      // 256-voxel kernel: 1 = the v_mfma_f32_16x16x32_bf16 form
+extern "C" void hupr_debug_halo_tiles(int mask) { set_halo_tiles(mask); }      // 256-voxel kernel: bit 0 / 1 / 2 = its 4 x 8 x 8 / 2 x 8 x 16 / 1 x 16 x 16 tile in use
 static int g_halo_split_k = 1;      // A/B aid: 0 = never slice the reduction of small grids
 extern "C" void hupr_debug_halo_split_k(int on) { g_halo_split_k = on; }
-static int g_halo_small_tiles = 1;  // A/B aid: 0 keeps 64-wide channel tiles on small grids
-extern "C" void hupr_debug_halo_small_tiles(int on) { g_halo_small_tiles = on; }
 
 // 1 if hupr_conv3x3_halo_bf16 supports this geometry (else use hupr_conv_fwd_bf16)
 extern "C" int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw) {
@@ -468,7 +466,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
         HUPR_REQUIRE(abf && !bias && !res && conv_halo256_stats_ok(a, Bn),
                      "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);
         HUPR_REQUIRE(launch_conv_halo256(a, Bn, abf, as_stream(stream)), "%s: 256-voxel kernel refused the launch", who);
-        HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16<stats>");
+        HUPR_LAUNCH_OK("hupr_k_conv_halo256m_bf16<stats>");
         return HUPR_OK;
     }
     // variants: 0 auto (512-voxel register-blocked kernel where its envelope holds, then 256-, then 128-voxel), 1 force the
@@ -478,7 +476,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
         return HUPR_OK;
     }
     if (!partial_only && g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {
-        HUPR_LAUNCH_OK("hupr_k_conv_halo256_bf16");
+        HUPR_LAUNCH_OK("hupr_k_conv_halo256m_bf16");
         return HUPR_OK;
     }
     if (kd == 3) { a.TD = 2; a.log2TW = 3; } else { a.TD = 1; a.log2TW = 4; }
@@ -486,7 +484,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     // 32-wide channel tiles for Co <= 32 — and for grids that would leave CUs idle or single-tiled with 64-wide ones (small
     // batches, e.g. the B = 1 inference): twice the workgroups, two of them per CU (LDS), each with half the weight traffic
     const long blocks64 = (long)Bn * a.nd * a.nh * a.nw * ((Co + 63) / 64);
-    const bool n32 = (Co <= 32) || (g_halo_small_tiles && blocks64 <= 256 && Co % 32 == 0);
+    const bool n32 = (Co <= 32) || (blocks64 <= 256 && Co % 32 == 0);
     const int bn = n32 ? 32 : 64;
     a.n_co_tiles = (Co + bn - 1) / bn;
     const long blocks = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;

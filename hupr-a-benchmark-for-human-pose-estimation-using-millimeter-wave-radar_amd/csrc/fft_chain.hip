@@ -740,10 +740,6 @@ extern "C" size_t hupr_fft_chain_ws_bytes(int n_sf) {
 // cold pass — how the training step sees it, 25 GB of other traffic since the last call — runs as fast as the Infinity-Cache-warm
 // one: 106.4 -> 68.6 us per 256 sensor-frames, 2.52 -> 3.91 TB/s on SURVEY's bytes (profiles/r04_fft_variants.txt).
 // bit 1 = the three antennas of a receiver back to back on one XCD (measured neutral, off).
-static int g_fft_variant = 0;
-extern "C" void hupr_debug_fft_variant(int v) { g_fft_variant = v; }
-static int g_fft_range_first = 0;      // A/B aid: 1 = the round-1/2 range-first kernel
-extern "C" void hupr_debug_fft_range_first(int on) { g_fft_range_first = on; }
 
 static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws, size_t ws_bytes,
                             hupr_stream_t stream, bool loader, int flags = 0, bool means = false) {
@@ -764,21 +760,17 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
     hipStream_t s = as_stream(stream);
     float2* rd = reinterpret_cast<float2*>(ws);
     const int zd = (flags & HUPR_FFT_ZERO_DOPPLER_EXACT) ? 1 : 0;
-    if (g_fft_range_first || (flags & HUPR_FFT_RANGE_FIRST)) {
+    if (flags & HUPR_FFT_RANGE_FIRST) {
         switch (flags & 3) {
             case 0: HUPR_LAUNCH(hupr_k_range_doppler<0>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
             case 1: HUPR_LAUNCH(hupr_k_range_doppler<1>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
             case 2: HUPR_LAUNCH(hupr_k_range_doppler<2>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
             default: HUPR_LAUNCH(hupr_k_range_doppler<3>, dim3(n_sf * kVant), dim3(256), 0, s, adc_iq, rd); break;
         }
-    } else if (!(g_fft_variant & 4)) {
-        // grouped order: (sensor-frame, receiver) groups x 3 antennas, one group per XCD slot; the grid is padded to a multiple of 24
-        const int n_items = n_sf * kVant, grouped = (g_fft_variant & 2) ? 1 : 0;
-        const int n_groups = n_sf * 4;
-        const dim3 g1(grouped ? ((n_groups + 7) / 8) * 24 : n_items), b1(256);
-#define HUPR_DR(W_, H_)                                                                                                      \
-        if (g_fft_variant & 1) HUPR_LAUNCH((hupr_k_doppler_range<W_, H_, 0>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped); \
-        else HUPR_LAUNCH((hupr_k_doppler_range<W_, H_, 2>), g1, b1, 0, s, adc_iq, rd, zd, n_items, grouped)
+    } else {
+        const int n_items = n_sf * kVant;
+        const dim3 g1(n_items), b1(256);
+#define HUPR_DR(W_, H_) HUPR_LAUNCH((hupr_k_doppler_range<W_, H_, 2>), g1, b1, 0, s, adc_iq, rd, zd, n_items, 0)
         switch ((flags & 3) | (loader ? 4 : 0)) {
             case 0: HUPR_DR(0, false); break;
             case 1: HUPR_DR(1, false); break;
@@ -792,7 +784,6 @@ static int fft_chain_common(const int16_t* adc_iq, int n_sf, void* out, void* ws
 #undef HUPR_DR
     }
     HUPR_LAUNCH_OK("hupr_k_range_doppler");
-    if (g_fft_variant & 8) return HUPR_OK;              // measurement only (bit 2 = no first kernel, bit 3 = no angle kernel)
     if (loader && means)
         HUPR_LAUNCH(hupr_k_angle<3>, dim3(n_sf * 8), dim3(256), 0, s, rd, out);
     else if (loader)

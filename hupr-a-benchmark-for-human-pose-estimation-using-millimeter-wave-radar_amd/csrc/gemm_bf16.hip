@@ -391,14 +391,12 @@ static void launch_h(const GemmArgs& a, int batch, hipStream_t s) {
     HUPR_LAUNCH((hupr_k_gemm_bf16<BM, BN, WM, WN, AM, BMD>), dim3(mt * nt, a.ksplit, batch), dim3(256), 0, s, a);
 }
 
-static int g_small_tiles_off = 0;      // A/B aid (hupr_debug_gemm_small_tiles)
-
 template <int AM, int BMD>
 static void dispatch_h(const GemmArgs& a, int batch, hipStream_t s) {
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
     if (a.N > 64) {
         if (a.M > 64 && blocks(128, 128) >= 512) launch_h<128, 128, 2, 2, AM, BMD>(a, batch, s);
-        else if (blocks(64, 128) >= 512 || g_small_tiles_off) launch_h<64, 128, 1, 4, AM, BMD>(a, batch, s);
+        else if (blocks(64, 128) >= 512) launch_h<64, 128, 1, 4, AM, BMD>(a, batch, s);
         else launch_h<64, 64, 2, 2, AM, BMD>(a, batch, s);      // small problems (level-0 attention GEMMs): two workgroups per CU
     } else {
         if (a.M > 64 && blocks(128, 64) >= 512) launch_h<128, 64, 2, 2, AM, BMD>(a, batch, s);
@@ -409,8 +407,6 @@ static void dispatch_h(const GemmArgs& a, int batch, hipStream_t s) {
 }  // namespace hupr
 
 using namespace hupr;
-
-extern "C" void hupr_debug_gemm_small_tiles(int off) { hupr::g_small_tiles_off = off; }
 
 extern "C" int hupr_gemm_bf16(int ta, int tb, const float* A, const float* B, float* C, int M, int N, int K, long lda,
                               long ldb, long ldc, int batch, long a_bs, long b_bs, long c_bs, const float* res,

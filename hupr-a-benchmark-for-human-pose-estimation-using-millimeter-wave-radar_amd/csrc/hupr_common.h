@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "hupr.h"
+#include "hupr_debug.h"
 
 namespace hupr {
 

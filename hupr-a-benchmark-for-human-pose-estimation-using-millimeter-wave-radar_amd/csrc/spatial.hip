@@ -481,9 +481,6 @@ static int interp_check(const char* who, int Bn, int Di, int Hi, int Wi, int Do,
     return HUPR_OK;
 }
 
-static int g_interp_packed = 0;      // probe aid (scripts/interp_race.py): 1 = the compiler-packed accumulation
-extern "C" void hupr_debug_interp_packed(int on) { g_interp_packed = on; }
-
 template <typename T>
 static int interp_fwd(const char* who, const T* x, T* y, int Bn, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C,
                       int in_ld, int out_ld, hupr_stream_t stream) {
@@ -491,12 +488,8 @@ static int interp_fwd(const char* who, const T* x, T* y, int Bn, int Di, int Hi,
     int rc = interp_check(who, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     if (rc) return rc;
     const long total = (long)Bn * Do * Ho * Wo * (C / 4);
-    if (g_interp_packed)
-        HUPR_LAUNCH((hupr_k_interp_fwd<T, true>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
-                           as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
-    else
-        HUPR_LAUNCH((hupr_k_interp_fwd<T, false>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
-                           as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
+    HUPR_LAUNCH((hupr_k_interp_fwd<T, false>), dim3((int)min((long)8192, (total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), x, y, Bn, Di, Hi, Wi, Do, Ho, Wo, C, in_ld, out_ld);
     HUPR_LAUNCH_OK("hupr_k_interp_fwd");
     return HUPR_OK;
 }

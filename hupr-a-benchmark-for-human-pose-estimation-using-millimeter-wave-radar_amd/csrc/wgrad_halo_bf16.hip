@@ -888,8 +888,6 @@ extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
     return groups * one;
 }
 
-static int g_wgrad_groups = 0;      // A/B aid (hupr_debug_wgrad_groups): > 0 forces the workgroup count per (kz, tile pair)
-extern "C" void hupr_debug_wgrad_groups(int g) { g_wgrad_groups = g; }      // 0 auto, > 0 forced, < 0 auto without XCD affinity
 static int g_wgrad_m16 = 1;         // A/B aid (hupr_debug_wgrad_m16): 0 = the 32 x 32 x 16 kernel (rounds 2-4)
 extern "C" void hupr_debug_wgrad_m16(int on) { g_wgrad_m16 = on; }
 static int g_wgrad_ci32 = 1;        // A/B aid (hupr_debug_wgrad_ci32): 0 = Ci <= 32 through the two-quadrant kernel as before, 2 = K quarters always
@@ -941,8 +939,6 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
         const int g8 = pairs <= 32 ? 8 * (32 / pairs) : 0;
         a.xcd_map = g8 > 0 && 10 * g8 >= 9 * gw && g8 <= a.n_spatial;
         if (a.xcd_map) gw = min(g8, 128);
-        if (g_wgrad_groups > 0) { gw = g_wgrad_groups; a.xcd_map = gw % 8 == 0; }
-        if (g_wgrad_groups < 0) a.xcd_map = 0;                       // A/B aid: the pre-affinity grid
         gw = min(gw, a.n_spatial);
         while (gw > 1 && (size_t)gw * one > ws_bytes) { gw >>= 1; a.xcd_map = 0; }
         if (dual && (size_t)gw * one > ws_bytes) return fail(HUPR_ERR_WORKSPACE, "%s: workspace too small for two gradients", who);

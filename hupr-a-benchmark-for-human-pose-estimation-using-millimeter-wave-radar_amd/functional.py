@@ -52,7 +52,7 @@ def __getattr__(name):             # PEP 562: F_.MATH / F_._ACT_F32_HERE / F_._R
         return _st.region_switched
     raise AttributeError("module %r has no attribute %r" % (__name__, name))
 ACT_BF16 = True        # bf16 mode only: the 3-D encoders keep their activations in HBM as bf16 ("bf16act" kernels)
-ACT_BF16_DECODER = os.environ.get("HUPR_DECODER_F32", "0") != "1"      # ... and so do the BasicBlock2D decoder stacks
+ACT_BF16_DECODER = True    # ... and so do the BasicBlock2D decoder stacks
 
 
 def set_math(mode):
@@ -196,31 +196,6 @@ def two_streams_ok(t):
     return TWO_STREAMS and t.is_cuda
 
 
-# With two compute streams the two encoders' large persistent convolutions (one workgroup per CU, all of the LDS) are
-# dispatched at the same time; they cannot co-reside, the second one's workgroups start as the first one's finish, and every
-# per-launch duration — bench.py's roofline probe, a rocprofv3 trace — measures queueing (357 instead of 212 us).  HEAVY_SERIAL
-# (opt-in, HUPR_HEAVY_SERIAL=1) orders those launches across the streams with events so that the probe stays a kernel
-# measurement; it costs 3.3 % of the two-stream throughput (1 456 -> 1 408 frames/s: the free-running version also overlaps the
-# convolutions' tails), which is why bench.py measures one stream by default instead.
-HEAVY_SERIAL = os.environ.get("HUPR_HEAVY_SERIAL", "0") == "1"
-_heavy_last = {}
-
-
-def _heavy_begin(device):
-    if not (HEAVY_SERIAL and TWO_STREAMS) or torch.cuda.is_current_stream_capturing():
-        return False
-    ev = _heavy_last.get(device.index)
-    if ev is not None:
-        torch.cuda.current_stream(device).wait_event(ev)
-    return True
-
-
-def _heavy_end(device):
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(device))
-    _heavy_last[device.index] = ev
-
-
 def refresh_packed(device, params=None):
     """Run the packed-weight table refresh now (on the current stream) if any cached entry is stale — called before
     the branches fork so that the refresh is ordered in front of both.
@@ -249,7 +224,7 @@ def refresh_packed(device, params=None):
 # straight into the flat-bucket views, the autograd Functions return None for them, and the 165 per-parameter
 # AccumulateGrad add kernels of a step disappear.  Without a sink every Function returns ordinary gradient tensors.
 GRAD_SINK = None
-PRELU_DEFER = os.environ.get("HUPR_NO_PRELU_DEFER", "0") != "1"      # A/B aid: 1 = every PReLU backward sums its slope gradient at once
+PRELU_DEFER = True         # test aid: False = every PReLU backward sums its slope gradient at once
 BN_COUNTER_SINK = None      # list collecting the BatchNorm modules whose num_batches_tracked is due (tools.engine)
 
 
@@ -300,7 +275,7 @@ def pack_weights_bf16(w, mode):
 import weakref
 
 PACK_EPOCH = 0
-PACK_CACHE = os.environ.get("HUPR_NO_PACK_CACHE", "0") != "1"      # debugging aid: repack on every call
+PACK_CACHE = True          # debugging aid: False = repack on every call
 _pack_entries = {}      # (storage address, kind) -> entry
 _pack_table = None      # (device uint8 tensor, n, total) or None when dirty
 # The table pass refreshes the entries that were READ during the current or the previous epoch (= optimiser step), not every weight
@@ -447,10 +422,10 @@ def _packed(weight, mode, kind):
 # The eight 1x1 projection weights of an MSCSA level as the two (4C, C) matrices its two GEMMs read — [phi_cross | theta_cross |
 # phi_self | theta_self] per map — kept as ENTRIES OF THE PACK TABLE (kinds 2 / 3): the one table-driven launch after an optimiser
 # step refreshes them with everything else, where rounds 1-4 concatenated them with two ATen launches per level and step.  Two
-# copies per map: the plain one (backward GEMMs, GEMM-attention fallback, fp8 forms) and the one whose query (theta) rows carry
+# copies per map: the plain one (backward GEMMs, GEMM-attention fallback) and the one whose query (theta) rows carry
 # log2(e) for the QS attention kernels (csrc/attention_bf16.hip, kDeferBits).
 _proj_cache = {}       # (addresses of the four weights) -> (Wc plain, Wc query-scaled, entries)
-QS_ATTN = os.environ.get("HUPR_NO_ATTN_QS", "0") != "1"      # A/B aid: 0 = the rounds-1-4 kernels (plain Q, fma per score)
+QS_ATTN = True             # test aid: False = the plain-Q kernels (fma per score)
 
 
 def _proj_cat(ws, C):
@@ -515,9 +490,9 @@ def _halo_ok(x, k, pad, co=4):
 # tensor next (_bn_params pops them).  Round 3: the kernel keeps running per-lane-pair sums in LDS (plain read-add-write of a
 # private slot, deferred epilogue intact) and reduces across lanes once per launch: +6 us on a 222 us launch instead of +14 us
 # and the immediate epilogue, -0.16 ms / +0.7 % frames/s per step measured in interleaved same-box runs -> ON by default
-# (HUPR_CONV_STATS=0 switches it off).
-CONV_STATS = os.environ.get("HUPR_CONV_STATS", "1") == "1"
-ATTN_LEVEL_BATCH = os.environ.get("HUPR_NO_ATTN_LEVEL_BATCH", "0") != "1"      # A/B aid: 1 = one launch per attention at every level
+# (CONV_STATS = False switches it off: the parity tests compare the two).
+CONV_STATS = True
+ATTN_LEVEL_BATCH = True    # test aid: False = one launch per attention at every level
 ATTN_PROBE = None          # measurement hook (bench.py): (kind, B, N, C) -> (start, end) events around one attention's launches, or None
 _conv_stats = {}
 
@@ -534,7 +509,6 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stat
     if _halo_ok(x, k, pad, co):
         assert res is None or res.dtype == x.dtype
         wp = _packed(weight, mode, 1)
-        heavy = k[0] == 3 and B * Do * Ho * Wo * co >= (1 << 24) and _heavy_begin(x.device)
         if ev is not None:
             ev[0].record()
         if (stats and CONV_STATS and abf and bias is None and res is None and out is None
@@ -546,8 +520,6 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stat
             _conv_stats[y.data_ptr()] = (st, rows, B * Do * Ho * Wo, co)
             if ev is not None:
                 ev[1].record()
-            if heavy:
-                _heavy_end(x.device)
             return y
         L = rt.lib()
         # inference on small grids (config C2: B = 1): the reduction is sliced over workgroups, partial sums through a workspace
@@ -563,8 +535,6 @@ def _conv_raw(x, weight, mode, bias, res, co, k, pad, out_extent, out=None, stat
                         rt.ptr(res) if res is not None else None, rt.ptr(y), B, Di, Hi, Wi, Ci, Ci, co, co, co, k[0], rt.stream()))
         if ev is not None:
             ev[1].record()
-        if heavy:
-            _heavy_end(x.device)
         return y
     if abf:
         raise rt.HuprError("bf16-stored activations are only supported by the halo-tiled 3x3 convolutions "
@@ -590,7 +560,7 @@ class ConvPartial:
         self.slices, self.n, self.shape = slices, n, shape
 
 
-INFER_TAILS = os.environ.get("HUPR_NO_INFER_TAILS", "0") != "1"      # A/B aid
+INFER_TAILS = True         # test aid
 
 
 def infer_fast_ok(x):
@@ -749,7 +719,7 @@ class DualConvFn(torch.autograd.Function):
             dx = _conv_raw(dy[0], w_a, 1, None, None, Ci, k, dpad, (D, H, W))
             dx = _conv_raw(dy[1], w_b, 1, None, dx, Ci, k, dpad, (D, H, W), out=dx)
         grads = []
-        if (DUAL_WGRAD and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x.dtype == torch.bfloat16
+        if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and x.dtype == torch.bfloat16
                 and L.hupr_conv3x3_wgrad_halo_dual_supported(B, D, H, W, Ci, Co, k[0])):
             # both weight gradients read the same x: one launch over 2 Co output channels, one reduction (same sums as two calls)
             (dwa, da), (dwb, db_) = _pgrad(w_a), _pgrad(w_b)
@@ -770,14 +740,10 @@ class DualConvFn(torch.autograd.Function):
         return dx, grads[0], grads[1], None, None, None
 
 
-DUAL_WGRAD = os.environ.get("HUPR_NO_DUAL_WGRAD", "0") != "1"      # A/B aid: 1 = one weight-gradient launch per convolution
-
-
 def dual_conv(x, w_a, w_b, pad, stats=False):
     """(conv(x, w_a), conv(x, w_b)); fused input-gradient accumulation where the halo kernels apply."""
     k = _ksize(w_a)
-    if w_a.shape == w_b.shape and _halo_ok(x, k, pad, w_a.shape[0]) and x.shape[-1] % 32 == 0 and w_a.shape[0] % 8 == 0 \
-            and os.environ.get("HUPR_NO_DUAL_CONV", "0") != "1":
+    if w_a.shape == w_b.shape and _halo_ok(x, k, pad, w_a.shape[0]) and x.shape[-1] % 32 == 0 and w_a.shape[0] % 8 == 0:
         return DualConvFn.apply(x, w_a, w_b, tuple(pad), bool(stats), not torch.is_grad_enabled())
     infer = not torch.is_grad_enabled()
     return (ConvFn.apply(x, w_a, None, None, tuple(pad), bool(stats), infer),
@@ -790,8 +756,7 @@ def conv(x, weight, bias=None, res=None, pad=(0, 0, 0), stats=False):
     return ConvFn.apply(x, weight, bias, res, tuple(pad), bool(stats), not torch.is_grad_enabled())
 
 
-TMERGE_STREAM = os.environ.get("HUPR_NO_TMERGE_STREAM", "0") != "1"      # A/B aid
-TMERGE_WIDE = os.environ.get("HUPR_NO_TMERGE_WIDE", "0") != "1"          # A/B aid: the streaming weight gradient for C = 128 / 256 too
+TMERGE_STREAM = True       # test aid: False = the generic mixed-storage convolution for the temporal merges
 
 
 def _tmerge_fwd(x, weight, y):
@@ -825,7 +790,7 @@ def _tmerge_wgrad(x, dy, weight):
     Co = weight.shape[0]
     L = rt.lib()
     dw, direct = _pgrad(weight)
-    if TMERGE_STREAM and x.dtype == torch.bfloat16 and (Ci == 64 or TMERGE_WIDE) and L.hupr_tmerge_wgrad_stream_supported(G, H * W, Ci, Co):
+    if TMERGE_STREAM and x.dtype == torch.bfloat16 and L.hupr_tmerge_wgrad_stream_supported(G, H * W, Ci, Co):
         ws = workspace(L.hupr_tmerge_wgrad_stream_ws_bytes(B, G, H * W, Ci, Co), x.device)
         rt.check(L.hupr_tmerge_wgrad_stream_bf16(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, G, H * W, Ci, Co, rt.ptr(ws), ws.numel(),
                                                  rt.stream()))
@@ -913,18 +878,13 @@ class MergeDownFn(torch.autograd.Function):
         return dx, _pret(weight, dw, direct), None
 
 
-MERGE_DOWN = os.environ.get("HUPR_NO_MERGE_DOWN", "0") != "1"
-
-
 def merge_down_ok(x):
-    return MERGE_DOWN and _st.math == "bf16" and x.dtype == torch.bfloat16 and x.is_cuda
+    return _st.math == "bf16" and x.dtype == torch.bfloat16 and x.is_cuda
 
 
 def temporal_merge(x, weight):
     """(B,G,H,W,C) -> (B,1,H,W,Co) fp32.  bf16-stored maps go through the mixed-storage kernels (bf16 math only);
     fp32 maps through the generic convolution."""
-    if x.dtype == torch.bfloat16 and os.environ.get("HUPR_TMERGE_CAST", "0") == "1":      # A/B aid: cast + generic conv
-        x = cast(x, torch.float32)
     if x.dtype == torch.bfloat16:
         if _st.math != "bf16":
             raise rt.HuprError("bf16-stored activations need the bf16 math mode")
@@ -977,16 +937,13 @@ def _bn_params(x, bn, training, need_bwd=True):
     return scale, shift, mean, invstd
 
 
-BN_FINALIZE_PAIR = os.environ.get("HUPR_NO_BN_FINALIZE_PAIR", "0") != "1"      # A/B aid
-
-
 def _bn_params_pair(x1, bn1, x2, bn2):
     """Training-mode coefficients of the two BatchNorms of a block tail when BOTH producing convolutions left their column sums:
     one finalize launch for the pair (hupr_bn_train_finalize2_f32).  None: not applicable — the caller takes them one by one."""
     f1, f2 = _conv_stats.get(x1.data_ptr()), _conv_stats.get(x2.data_ptr())
     C = x1.shape[-1]
     M = x1.numel() // C
-    if (not BN_FINALIZE_PAIR or f1 is None or f2 is None or x1.shape != x2.shape or x1.data_ptr() == x2.data_ptr()
+    if (f1 is None or f2 is None or x1.shape != x2.shape or x1.data_ptr() == x2.data_ptr()
             or (f1[2], f1[3]) != (M, C) or (f2[2], f2[3]) != (M, C)):
         return None
     _conv_stats.pop(x1.data_ptr())
@@ -1008,12 +965,10 @@ def _bn_params_pair(x1, bn1, x2, bn2):
     return tuple(out[0]), tuple(out[1])
 
 
-BN_REMASK = os.environ.get("HUPR_NO_BN_REMASK", "0") != "1"      # recompute ReLU masks in the BatchNorm backward passes
-
-
-def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training, beta=None, fwd=None):
+def _bn_bwd(dy, x, mean, invstd, gamma, training, beta=None, fwd=None):
     """-> (dx, dgamma, dbeta) as backward() return values (None for parameters written through the gradient sink).
-    fwd = (scale, shift) of the forward pass: the ReLU mask is recomputed from x instead of read from y_mask."""
+    fwd = (scale, shift) of the forward pass of a BatchNorm + ReLU: the ReLU mask is recomputed from x (the very expression the
+    forward evaluated) instead of read back as a third tensor; None: no ReLU."""
     L = rt.lib()
     C = x.shape[-1]
     M = x.numel() // C
@@ -1021,13 +976,13 @@ def _bn_bwd(dy, y_mask, x, mean, invstd, gamma, training, beta=None, fwd=None):
     dg, dg_direct = _pgrad(gamma)
     db, db_direct = _pgrad(beta) if beta is not None else (torch.empty_like(gamma), False)
     ws = workspace(L.hupr_bn_ws_bytes(C), x.device)
-    assert dy.dtype == x.dtype and (y_mask is None or y_mask.dtype == x.dtype)
+    assert dy.dtype == x.dtype
     if fwd is not None:
         rt.check(_act("bn_bwd_remask", x)(rt.ptr(dy), rt.ptr(fwd[0]), rt.ptr(fwd[1]), rt.ptr(x), rt.ptr(mean), rt.ptr(invstd),
                                           rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C, 1 if training else 0,
                                           rt.ptr(ws), ws.numel(), rt.stream()))
     else:
-        rt.check(_act("bn_bwd", x)(rt.ptr(dy), rt.ptr(y_mask) if y_mask is not None else None, rt.ptr(x), rt.ptr(mean),
+        rt.check(_act("bn_bwd", x)(rt.ptr(dy), None, rt.ptr(x), rt.ptr(mean),
                                    rt.ptr(invstd), rt.ptr(gamma), rt.ptr(dx), rt.ptr(dg), rt.ptr(db), M, C,
                                    1 if training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
     return dx, _pret(gamma, dg, dg_direct), _pret(beta, db, db_direct)
@@ -1053,17 +1008,15 @@ class BNActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         rt.check(_act("scale_shift_act", x)(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), None, None, None,
                                             rt.ptr(y), x.numel() // C, C, 1 if relu else 0, rt.stream()))
-        remask = relu and BN_REMASK
-        ctx.save_for_backward(x, y if relu and not remask else None, mean, invstd, gamma, scale if remask else None,
-                              shift if remask else None)
+        ctx.save_for_backward(x, mean, invstd, gamma, scale if relu else None, shift if relu else None)
         ctx.beta_ref = beta
         ctx.training = training
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, invstd, gamma, scale, shift = ctx.saved_tensors
-        dx, dg, db = _bn_bwd(_c(dy), y, x, mean, invstd, gamma, ctx.training, ctx.beta_ref,
+        x, mean, invstd, gamma, scale, shift = ctx.saved_tensors
+        dx, dg, db = _bn_bwd(_c(dy), x, mean, invstd, gamma, ctx.training, ctx.beta_ref,
                              fwd=(scale, shift) if scale is not None else None)
         return dx, dg, db, None, None, None, None
 
@@ -1095,23 +1048,20 @@ class BNAddBNReLUFn(torch.autograd.Function):
         assert x1.dtype == x2.dtype
         rt.check(_act("scale_shift_act", x1)(rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(x2), rt.ptr(s2),
                                              rt.ptr(t2), rt.ptr(y), x1.numel() // C, C, 1, rt.stream()))
-        if BN_REMASK:
-            ctx.save_for_backward(x1, x2, None, m1, i1, g1, m2, i2, g2, s1, t1, s2, t2)
-        else:
-            ctx.save_for_backward(x1, x2, y, m1, i1, g1, m2, i2, g2, None, None, None, None)
+        ctx.save_for_backward(x1, x2, m1, i1, g1, m2, i2, g2, s1, t1, s2, t2)
         ctx.beta_refs = (b1, b2)
         ctx.training = training
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, x2, y, m1, i1, g1, m2, i2, g2, s1, t1, s2, t2 = ctx.saved_tensors
+        x1, x2, m1, i1, g1, m2, i2, g2, s1, t1, s2, t2 = ctx.saved_tensors
         dy = _c(dy)
         # both branches share dy and the ReLU mask: one statistics pass + one apply pass for the pair
         L = rt.lib()
         C = x1.shape[-1]
         M = x1.numel() // C
-        assert dy.dtype == x1.dtype == x2.dtype and (y is None or y.dtype == dy.dtype)
+        assert dy.dtype == x1.dtype == x2.dtype
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         b1, b2 = ctx.beta_refs
         dg1, dg1_d = _pgrad(g1)
@@ -1119,16 +1069,11 @@ class BNAddBNReLUFn(torch.autograd.Function):
         dg2, dg2_d = _pgrad(g2)
         db2, db2_d = _pgrad(b2)
         ws = workspace(L.hupr_bn_ws_bytes(C), x1.device)
-        if y is None:       # ReLU mask recomputed from x1, x2 and the forward coefficients
-            rt.check(_act("bn_bwd2_remask", x1)(rt.ptr(dy), rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(m1), rt.ptr(i1), rt.ptr(g1),
-                                                rt.ptr(x2), rt.ptr(s2), rt.ptr(t2), rt.ptr(m2), rt.ptr(i2), rt.ptr(g2), rt.ptr(dx1),
-                                                rt.ptr(dx2), rt.ptr(dg1), rt.ptr(db1), rt.ptr(dg2), rt.ptr(db2), M, C,
-                                                1 if ctx.training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
-        else:
-            rt.check(_act("bn_bwd2", x1)(rt.ptr(dy), rt.ptr(y), rt.ptr(x1), rt.ptr(m1), rt.ptr(i1), rt.ptr(g1), rt.ptr(x2),
-                                         rt.ptr(m2), rt.ptr(i2), rt.ptr(g2), rt.ptr(dx1), rt.ptr(dx2), rt.ptr(dg1), rt.ptr(db1),
-                                         rt.ptr(dg2), rt.ptr(db2), M, C, 1 if ctx.training else 0, rt.ptr(ws), ws.numel(),
-                                         rt.stream()))
+        # ReLU mask recomputed from x1, x2 and the forward coefficients
+        rt.check(_act("bn_bwd2_remask", x1)(rt.ptr(dy), rt.ptr(x1), rt.ptr(s1), rt.ptr(t1), rt.ptr(m1), rt.ptr(i1), rt.ptr(g1),
+                                            rt.ptr(x2), rt.ptr(s2), rt.ptr(t2), rt.ptr(m2), rt.ptr(i2), rt.ptr(g2), rt.ptr(dx1),
+                                            rt.ptr(dx2), rt.ptr(dg1), rt.ptr(db1), rt.ptr(dg2), rt.ptr(db2), M, C,
+                                            1 if ctx.training else 0, rt.ptr(ws), ws.numel(), rt.stream()))
         return (dx1, _pret(g1, dg1, dg1_d), _pret(b1, db1, db1_d), None, dx2, _pret(g2, dg2, dg2_d), _pret(b2, db2, db2_d),
                 None, None, None)
 
@@ -1355,8 +1300,6 @@ class AttentionFn(torch.autograd.Function):
         B, N, C = v.shape
         L = rt.lib()
         ctx.flash = _st.math == "bf16" and USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
-        if attn_fp8_ok(v):                # config 5 (opt-in, no_grad only): nothing is saved for a backward pass
-            return attention_fp8(k, q, v, residual)[0]
         if ctx.flash:
             out = torch.empty_like(v)
             lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
@@ -1405,88 +1348,24 @@ class AttentionFn(torch.autograd.Function):
         return dk, dq, dv, None
 
 
-# BASELINE.json config 5: fp8 (e4m3) MFMA operands in the MSCSA attention — opt-in, forward only, the C = 64 level.  Measured
-# against the bf16 flash kernel (scripts/attn_fp8_ab.py -> profiles/r02_attn_fp8_ab.txt) it is not the default: see DESIGN.md.
-# "mx" (HUPR_ATTN_FP8=mx): the block-scaled form (csrc/attention_mx8.hip: v_mfma_scale_f32_32x32x64_f8f6f4, one E8M0 scale per 32
-# elements, probabilities as 2^8 p) — also in the TRAINING forward of a fused MSCSA level (the backward stays on the bf16 kernels,
-# which read the bf16 projections the forward quantised from); True (HUPR_ATTN_FP8=1): the round-2 per-tensor kernel, no_grad only.
-ATTN_FP8 = {"1": True, "mx": "mx"}.get(os.environ.get("HUPR_ATTN_FP8", "0"), False)
-
-
-def attention_fp8(k, q, v, residual):
-    """MSCSA attention forward on the fp8 kernels; k, q, v: fp32 (B, N, 64) token-major -> (out fp32 (B, N, 64), lse (B, N))."""
-    k, q, v = _c(k), _c(q), _c(v)
-    B, N, C = v.shape
-    L = rt.lib()
-    out = torch.empty_like(v)
-    lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
-    ws = workspace(L.hupr_attn_fp8_ws_bytes(B, N, C), v.device)
-    rt.check(L.hupr_attn_fwd_fp8(rt.ptr(k), rt.ptr(q), rt.ptr(v), 1 if residual else 0, rt.ptr(out), rt.ptr(lse), B, N, C,
-                                 rt.ptr(ws), ws.numel(), rt.stream()))
-    return out, lse
-
-
-def attn_fp8_ok(v):
-    return ATTN_FP8 is True and _st.math == "bf16" and not torch.is_grad_enabled() and v.shape[-1] == 64 and v.shape[1] % 128 == 0
-
-
-# The block-scaled forward inside a TRAINING step is a second opt-in (HUPR_ATTN_FP8_TRAIN=1; bench.py --attn fp8 sets it): the bf16
-# backward kernels recompute P = exp(S_bf16 - lse) with the log-sum-exp the fp8 forward stored, so the rows of that P sum to
-# exp(lse_bf16 - lse_fp8), not 1 — a per-query scale error of the size of the fp8 quantisation noise in dS / dV (ADVICE r4 item 3;
-# bounded by tests/test_ops_gpu.py::test_mscsa_level_with_mx8_forward_trains_on_the_bf16_backward).  Without it "mx" is an
-# inference (no_grad) mode.
-ATTN_FP8_TRAIN = os.environ.get("HUPR_ATTN_FP8_TRAIN", "0") == "1"
-
-
-def attn_mx8_ok(N, C, no_grad):
-    """``no_grad``: the caller runs under torch.no_grad() (inside an autograd.Function's forward grad mode is always off)."""
-    return ATTN_FP8 == "mx" and C == 64 and N % 128 == 0 and (ATTN_FP8_TRAIN or no_grad)
-
-
-def attention_mx8(k, q, v, residual):
-    """One MSCSA attention on the block-scaled fp8 kernels; k, q, v: fp32 or bf16 (B, N, 64) token-major -> (out fp32 (B, N, 64),
-    lse (B, N)).  (The level node quantises a level's eight projections and two value maps in one step; this wrapper packs k and q
-    into projection slots 0 and 1 of one map for tests and measurements.)"""
-    B, N, C = v.shape
-    assert C == 64 and N % 128 == 0
-    L = rt.lib()
-    y = torch.zeros((B, N, 4 * C), dtype=torch.bfloat16, device=v.device)
-    y[..., :C] = k
-    y[..., C:2 * C] = q
-    vb = _c(v.to(torch.bfloat16))
-    v32 = _c(v.float())
-    out = torch.empty((B, N, C), dtype=torch.float32, device=v.device)
-    lse = torch.empty((B, N), dtype=torch.float32, device=v.device)
-    ws = workspace(L.hupr_attn_mx8_ws_bytes(B, N, C), v.device)
-    rt.check(L.hupr_attn_mx8_quant_level(rt.ptr(y), rt.ptr(y), rt.ptr(vb), rt.ptr(vb), B, N, C, rt.ptr(ws), ws.numel(), rt.stream()))
-    rt.check(L.hupr_attn_mx8_fwd(rt.ptr(ws), 0, 0, 0, 1, 0, rt.ptr(v32) if residual else None, rt.ptr(out), rt.ptr(lse), None, 0,
-                                 B, N, C, ws.numel(), rt.stream()))
-    return out, lse
-
-
 _level_cat_out = {}      # {"out": view}: where the NEXT fused level writes its concatenated bf16 output (models/layers.py sets it)
-LEVEL_FUSION = os.environ.get("HUPR_NO_LEVEL_FUSION", "0") != "1"
-FLASH256 = os.environ.get("HUPR_NO_FLASH256", "0") != "1"      # A/B aid: level-0 (C = 256) attention on the fused kernels
-CAT_FUSION = os.environ.get("HUPR_NO_CAT_FUSION", "0") != "1"      # fused levels return their maps concatenated as bf16
+CAT_FUSION = True          # fused levels return their maps concatenated as bf16
 
 
 def mscsa_level_fused_ok(ra):
     """One MSCSA level can run as MSCSALevelFn (bf16 math; any (N, C) — shapes without a fused attention kernel keep the
     GEMM / row-softmax attention core inside the node)."""
     B, _, H, W, C = ra.shape
-    if ATTN_FP8 is True and C == 64 and not torch.is_grad_enabled():
-        return False                      # config 5, per-tensor form: this level runs as separate projections + fp8 attentions
-    return LEVEL_FUSION and _st.math == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
+    return _st.math == "bf16" and ra.dtype == torch.float32 and C % 8 == 0
 
 
-CAT_INPLACE = os.environ.get("HUPR_NO_CAT_INPLACE", "0") != "1"      # A/B aid: 0 = concatenation copies per decoder stage (rounds 1-4)
+CAT_INPLACE = True         # test aid: False = concatenation copies per decoder stage
 
 
 def level_cat_placement_ok(ra):
     """The fused level node of map ``ra`` returns ONE concatenated bf16 tensor and can write it into a slice of a wider buffer."""
     B, _, H, W, C = ra.shape
-    return (CAT_INPLACE and mscsa_level_fused_ok(ra) and USE_FLASH and CAT_FUSION and bool(rt.lib().hupr_attn_flash_supported(H * W, C))
-            and (C != 256 or FLASH256))
+    return CAT_INPLACE and mscsa_level_fused_ok(ra) and USE_FLASH and CAT_FUSION and bool(rt.lib().hupr_attn_flash_supported(H * W, C))
 
 
 # Derived inference constants (concatenated projection weights, the zero-padded head filter): one entry per set of source
@@ -1495,7 +1374,7 @@ def level_cat_placement_ok(ra):
 # update (the first version keyed entries by epoch, so an update orphaned the tensor a graph was still reading,
 # and ``clear()`` at 64 entries could free it).  Entries die with their parameters (weak references), never by count.
 _wc_cache = {}
-ATTN_BATCH = os.environ.get("HUPR_NO_ATTN_BATCH", "0") != "1"      # A/B aid: one launch pair per MSCSA level in single-sample inference
+ATTN_BATCH = True          # test aid: False = one launch pair per attention in single-sample inference
 
 
 class _WcEntry:
@@ -1605,17 +1484,15 @@ class MSCSALevelFn(torch.autograd.Function):
         N = H * W
         L = rt.lib()
         dev = ra.device
-        flash = USE_FLASH and bool(L.hupr_attn_flash_supported(N, C)) and (C != 256 or FLASH256)
+        flash = USE_FLASH and bool(L.hupr_attn_flash_supported(N, C))
         ydt = torch.bfloat16 if flash else torch.float32
         esz = 2 if flash else 4
         maps = (ra, re)
         infer = bool(int(cat_bf16) & 2)                  # bit 1: the caller runs under no_grad (grad mode is always off in here)
         cat_bf16 = bool(int(cat_bf16) & 1)
-        # config 5, block-scaled form: quantises the plain projections itself
-        mx8 = flash and attn_mx8_ok(N, C, infer)
         # QS: the query projections leave the GEMM as log2(e) Q (rounded to bf16 once, like every projection), the attention kernels
         # take the exponent of 2 straight from the matrix pipe (csrc/attention_bf16.hip, kDeferBits)
-        qscaled = flash and QS_ATTN and not mx8      # (not `qs`: the SPEC loops below bind that name to the query source map)
+        qscaled = flash and QS_ATTN                  # (not `qs`: the SPEC loops below bind that name to the query source map)
         pa, pe = _proj_cat(weights[:4], C), _proj_cat(weights[4:], C)
         Wc = (pa[0], pe[0])                              # plain: the backward GEMMs
         Wf = (pa[1], pe[1]) if qscaled else Wc                # what the forward projections multiply by
@@ -1640,17 +1517,12 @@ class MSCSALevelFn(torch.autograd.Function):
         else:
             vb = maps
             aux = [torch.empty((B, N, N), dtype=torch.float32, device=dev) for _ in range(4)]       # P[query][key]
-        # config 5, block-scaled form: the level's eight projections and two value maps -> e4m3 + E8M0 scales in one step
-        if mx8:
-            ws8 = workspace(L.hupr_attn_mx8_ws_bytes(B, N, C), dev)
-            rt.check(L.hupr_attn_mx8_quant_level(rt.ptr(Y[0]), rt.ptr(Y[1]), rt.ptr(vb[0]), rt.ptr(vb[1]), B, N, C, rt.ptr(ws8),
-                                                 ws8.numel(), rt.stream()))
         # single-sample inference (config C2): the four attentions of the level as ONE split launch + ONE merge launch instead of eight
-        split_ws = L.hupr_attn_fwd_split_ws_bytes(B, N, C) if (flash and not mx8) else 0       # (> 0: the key-split form applies to this batch)
+        split_ws = L.hupr_attn_fwd_split_ws_bytes(B, N, C) if flash else 0       # (> 0: the key-split form applies to this batch)
         split_bytes = split_ws if (infer and ATTN_BATCH) else 0
         # training batches, levels 2 and 3 (C = 128 / 256: one attention's grid is 256 / 64 workgroups): the four as ONE launch of the
         # one-pass kernel (not where the single-sample split form applies: its shares round differently)
-        level_batch = flash and ATTN_LEVEL_BATCH and not mx8 and not split_ws and C != 64
+        level_batch = flash and ATTN_LEVEL_BATCH and not split_ws and C != 64
         if split_bytes or level_batch:
             items = (rt.AttnItem * 4)()
             for i, ((ks, kslot, qs, qslot, vs, residual), out, a) in enumerate(zip(MSCSALevelFn.SPEC, outs, aux)):
@@ -1666,11 +1538,7 @@ class MSCSALevelFn(torch.autograd.Function):
             if split_bytes or level_batch:
                 break
             kp, qp = Y[ks].data_ptr() + kslot * C * esz, Y[qs].data_ptr() + qslot * C * esz
-            if mx8:
-                rt.check(L.hupr_attn_mx8_fwd(rt.ptr(ws8), ks, kslot, qs, qslot, vs, rt.ptr(maps[vs]) if residual else None, rt.ptr(out),
-                                             rt.ptr(a), cat.data_ptr() + i * C * 2 if cat_bf16 else None, ld16, B, N, C, ws8.numel(),
-                                             rt.stream()))
-            elif flash:
+            if flash:
                 ws = _attn_ws(B, N, C, dev)
                 fwd = L.hupr_attn_fwd_bf16in_ld_ws_qs if qscaled else L.hupr_attn_fwd_bf16in_ld_ws
                 ev = ATTN_PROBE("fwd", B, N, C) if ATTN_PROBE is not None else None
@@ -1821,16 +1689,13 @@ class MSCSALevelFn(torch.autograd.Function):
 # The PRGCN head stays on the fp32 matrix pipe in bf16 runs.  It is 0.07 % of the model's flops (3 x 1024 x 1024 x 14 per
 # sample) but its 1024-term dot products of un-normalised logits are where bf16 operand rounding hurt most: on trained
 # (peaky) weights the decoded head went from 94.4 % to >= 99 % arg-max agreement with the fp32 path at B = 32
-# (tests/test_trained_gpu.py), for a few tens of microseconds per step.  HUPR_GCN_BF16=1 restores the bf16 GEMMs (A/B aid).
-GCN_MATH = None if os.environ.get("HUPR_GCN_BF16", "0") == "1" else "f32"
-
-
-GCN_PRODUCTS = os.environ.get("HUPR_NO_GCN_PRODUCTS", "0") != "1"      # A/B aid: the generic fp32 engine instead of csrc/gcn_products.hip
+# (tests/test_trained_gpu.py), for a few tens of microseconds per step.
+GCN_MATH = "f32"
 
 
 def _gcn_products_ok(x, weight):
     """The dedicated PRGCN product kernels apply: fp32 pipe (the default of the head in every mode), 16-wide key-point slots."""
-    return (GCN_PRODUCTS and (GCN_MATH == "f32" or _st.math == "f32") and x.dtype == torch.float32 and x.shape[2] == 16
+    return ((GCN_MATH == "f32" or _st.math == "f32") and x.dtype == torch.float32 and x.shape[2] == 16
             and x.shape[1] % 64 == 0 and tuple(weight.shape) == (x.shape[1], x.shape[1]))
 
 

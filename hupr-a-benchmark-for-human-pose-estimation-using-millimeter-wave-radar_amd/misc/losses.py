@@ -1,13 +1,11 @@
 """LossComputer (reference misc/losses.py:8-48) with device-side targets, BCE and decode."""
 
-import os
-
 import torch
 
 from .. import functional as F_
 from .metrics import get_max_preds
 
-PAIR_BCE = os.environ.get("HUPR_NO_PAIR_BCE", "0") != "1"      # A/B aid: 1 = one BCE node per head, combined by torch
+PAIR_BCE = True      # test aid: False = one BCE node per head, combined by torch
 
 
 class LossComputer():

@@ -16,7 +16,7 @@ c_void_p, c_int, c_size_t, c_float, c_char_p = (ctypes.c_void_p, ctypes.c_int, c
                                                 ctypes.c_float, ctypes.c_char_p)
 c_long = ctypes.c_long
 
-# name -> (restype, argtypes); must list every symbol declared in include/hupr.h
+# name -> (restype, argtypes); must list every symbol declared in include/hupr.h and include/hupr_debug.h
 class AttnItem(ctypes.Structure):
     """hupr_attn_item (include/hupr.h): one attention of a batched single-sample launch."""
     _fields_ = [("K", ctypes.c_void_p), ("Q", ctypes.c_void_p), ("V", ctypes.c_void_p), ("Vres", ctypes.c_void_p),
@@ -68,23 +68,15 @@ SIGNATURES = {
     "hupr_bn_train_finalize2_f32": (c_int, ([c_void_p, c_int] + [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 4) * 2
                                     + [c_long, c_int, c_void_p]),
     "hupr_pack_conv_weights_table": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
-    "hupr_debug_fft_range_first": (None, [c_int]),
-    "hupr_debug_fft_variant": (None, [c_int]),
-    "hupr_debug_attn_pingpong": (None, [c_int]),
     "hupr_debug_attn_trace": (None, [c_void_p]),
-    "hupr_debug_attn_xcd": (None, [c_int]),
-    "hupr_debug_attn_dkv512": (None, [c_int]),
     "hupr_debug_halo_ablate": (None, [c_int]),
     "hupr_debug_halo_variant": (None, [c_int]),
-    "hupr_debug_halo_m16": (None, [c_int]),
-    "hupr_debug_halo_small_tiles": (None, [c_int]),
+    "hupr_debug_halo_tiles": (None, [c_int]),
     "hupr_debug_halo_trace": (None, [c_void_p]),
-    "hupr_debug_wgrad_groups": (None, [c_int]),
     "hupr_debug_wgrad_ci32": (None, [c_int]),
     "hupr_debug_wgrad_m16": (None, [c_int]),
     "hupr_debug_splitk_slices": (None, [c_int]),
     "hupr_debug_halo_res_prefetch": (None, [c_int]),
-    "hupr_debug_gemm_small_tiles": (None, [c_int]),
     "hupr_conv3x3_halo_supported": (c_int, [c_int] * 10),
     "hupr_conv3x3_halo_bf16": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     "hupr_conv3x3_wgrad_halo_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -164,7 +156,6 @@ SIGNATURES = {
     "hupr_infer_tail_bf16act": (c_int, [c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_float, c_void_p, c_int] + [c_void_p] * 4 +
                                 [c_float, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p]),
     "hupr_debug_halo_split_k": (None, [c_int]),
-    "hupr_debug_interp_packed": (None, [c_int]),
     "hupr_tmerge_stream_supported": (c_int, [c_int] * 4),
     "hupr_tmerge_fwd_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "hupr_tmerge_dgrad_stream_bf16": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
@@ -192,13 +183,6 @@ SIGNATURES = {
     "hupr_interp_linear_bwd_acc_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
-    "hupr_attn_fp8_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "hupr_attn_quant_fp8": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
-    "hupr_attn_fwd_fp8_quantized": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_size_t, c_void_p]),
-    "hupr_attn_fwd_fp8": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 2 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
-    "hupr_attn_mx8_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "hupr_attn_mx8_quant_level": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_size_t, c_void_p]),
-    "hupr_attn_mx8_fwd": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 4 + [c_int] * 4 + [c_size_t, c_void_p]),
     # (e) RCCL exchange step
     "hupr_comm_load": (c_int, [c_char_p]),
     "hupr_comm_unique_id": (c_int, [c_void_p]),
@@ -232,10 +216,6 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if os.environ.get("HUPR_NO_RES_PREFETCH", "0") == "1":
-            L.hupr_debug_halo_res_prefetch(0)                            # A/B aid: residual read in the convolution's immediate epilogue
-        if os.environ.get("HUPR_HALO_M16") in ("0", "1", "2", "3", "5") and hasattr(L, "hupr_debug_halo_m16"):
-            L.hupr_debug_halo_m16(int(os.environ["HUPR_HALO_M16"]))      # A/B aid: the 256-voxel convolution's MFMA shape
         _lib = L
     return _lib
 

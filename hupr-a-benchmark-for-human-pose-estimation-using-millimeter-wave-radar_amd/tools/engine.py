@@ -1,6 +1,7 @@
 """Training/inference engine shared by the Runner and bench.py: HuPRNet + LossComputer +
 flat gradient buckets (+ RCCL all-reduce when world_size > 1) + fused Adam, optionally fed by the
 on-GPU FFT loader (int16 ADC cubes -> normalised network input, config "C3" of BASELINE.json)."""
+
 import os
 
 import torch
@@ -23,12 +24,8 @@ class TrainEngine:
         self.buckets = GradientBuckets(self.model, bucket_bytes=bucket_bytes)
         self.buckets.broadcast_parameters(0)
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
-        if self.buckets.active and os.environ.get("HUPR_DP_ONE_STREAM", "0") == "1":
-            # A/B aid.  (Round 1, torch.distributed work objects: the side-stream branch cost 1 % with collectives in flight;
-            # with the stream-ordered hupr_allreduce_bucket it gains 3 % — 1 368 -> 1 412 frames/s with forced single-rank
-            # collectives — so data-parallel runs keep the library default of two compute streams.)
-            from .. import functional as F_
-            F_.TWO_STREAMS = False
+        # (data-parallel runs keep the library default of two compute streams: with the stream-ordered hupr_allreduce_bucket the
+        # side-stream branch gains 3 % with collectives in flight — 1 368 -> 1 412 frames/s with forced single-rank collectives)
         self.optimizer = FusedAdam(self.model.parameters(), lr=lr if lr is not None else cfg.TRAINING.lr,
                                    betas=(0.9, 0.999), weight_decay=1e-4)
         self.optimizer.attach_flat_buckets(self.buckets.flat_pairs(), self.buckets.layout())

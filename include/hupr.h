@@ -206,23 +206,6 @@ int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, i
  * (hupr_pack_conv_weights_f32 modes 0 and 1), 1 = bf16 layouts.  blocks_dev: one 16-byte record per workgroup
  * { int32 entry, layout; int64 start }: the workgroup writes destination elements [start, start + 2048) of that layout. */
 int hupr_pack_conv_weights_table(const void* descs_dev, const void* blocks_dev, int n_blocks, hupr_stream_t stream);
-void hupr_debug_attn_pingpong(int on);    /* A/B aid: 0 = the rounds-1-3 attention kernels for the C = 64 shapes too (default 1: ping-pong kernels) */
-void hupr_debug_attn_xcd(int on);         /* A/B aid: 0 = attention backward workgroups in plain grid order (default 1: a sample's workgroups share an XCD) */
-void hupr_debug_attn_dkv512(int on);      /* A/B aid: 0 = the 256-thread dK / dV kernel at C = 64 too (default 1: 512 threads, one barrier per query tile) */
-void hupr_debug_attn_trace(void* dev_buf); /* profiling aid: device buffer of 3 x 2 x 4096 uint64 s_memtime stamps written by workgroup 0 of the ping-pong attention kernels, or null */
-void hupr_debug_fft_variant(int bits);     /* A/B aid: bit 0 = temporal ADC loads (rounds 1-3; default: non-temporal), bit 1 = the three antennas of a receiver back to back on one XCD */
-void hupr_debug_fft_range_first(int on);  /* A/B aid: 1 = the range-first K1 of rounds 1-2 instead of the Doppler-first kernel */
-void hupr_debug_halo_small_tiles(int on); /* A/B aid: 0 keeps 64-wide channel tiles on grids of <= 256 workgroups (default 1: 32-wide there) */
-void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel, 2 skip the 512-voxel kernel */
-void hupr_debug_halo_m16(int on);         /* 256-voxel halo convolution, bf16 activations: 1 (default; 3 = the same) = the v_mfma_f32_16x16x32_bf16 kernel (conv_halo256m_bf16.hip) on all three tiles: 4x8x8, 2x8x16 for D % 4 != 0, 1x16x16 for 1x3x3 taps (the decoder's convolutions; default since round 5); 5 = without the 1x16x16 tile (the round-4 default); 2 = its 4x8x8 tile only; 0 = the 32x32x16 kernels */
-void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */
-void hupr_debug_gemm_small_tiles(int off); /* A/B aid: 1 = small bf16 GEMMs keep the 64x128 tile instead of 64x64 */
-void hupr_debug_halo_res_prefetch(int on);  /* A/B aid: 0 = the 256-voxel 16 x 16 x 32 convolution reads a residual in its immediate epilogue (rounds 4-5a); default 1: prefetched, deferred epilogue */
-void hupr_debug_splitk_slices(int s);     /* A/B aid: slices per workgroup of the split-K reduction: 0 auto (round 5), 4 (rounds 1-4), 16 */
-void hupr_debug_wgrad_m16(int on);        /* A/B aid: 0 = the LDS-DMA weight gradient on v_mfma_f32_32x32x16_bf16 (rounds 2-4); default 1: v_mfma_f32_16x16x32_bf16 (round 5) */
-void hupr_debug_wgrad_ci32(int on);       /* A/B aid: 0 sends Ci <= 32 weight gradients through the two-quadrant kernel (K halves only), 2 forces the K-quarter mode at any size, 1 = default */
-void hupr_debug_wgrad_groups(int groups); /* A/B aid: > 0 forces the LDS-DMA weight-gradient kernel's workgroups per (kz plane, tile pair) */
-void hupr_debug_halo_trace(void* device_u64_4096); /* profiling aid: per-tile s_memtime stamps of workgroup 0 (null = off) */
 int hupr_conv3x3_halo_supported(int D, int H, int W, int Ci, int kd, int kh, int kw, int pd, int ph, int pw);
 int hupr_conv3x3_halo_bf16(const float* x, const void* wp_bf16, const float* bias, const float* res, float* y,
                            int Bn, int D, int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd,
@@ -355,7 +338,6 @@ size_t hupr_attn_fwd_split_ws_bytes(int Bn, int N, int C);
 typedef struct hupr_attn_item { const void* K; const void* Q; const void* V; const float* Vres; float* out; float* lse; void* out16; } hupr_attn_item;
 int hupr_attn_fwd_bf16in_ld_ws_batch(const hupr_attn_item* items, int n_items, int ldk, int ldq, int ld16, int Bn, int N, int C,
                                      void* ws, size_t ws_bytes, hupr_stream_t stream);
-void hupr_debug_attn_split(int mode);    /* 0 (default): split for Bn == 1 only; 1: every grid below 128 workgroups; -1: never */
 int hupr_attn_fwd_bf16in_ld_ws(const void* K, int ldk, const void* Q, int ldq, const void* V, const float* Vres, float* out,
                                float* lse, void* out16_or_null, int ld16, int Bn, int N, int C, void* ws, size_t ws_bytes,
                                hupr_stream_t stream);
@@ -479,8 +461,6 @@ int hupr_infer_tail_bf16act(int mode, const void* x1, int n1, const float* gamma
                             const float* var1, float eps1, const void* x2, int n2, const float* gamma2, const float* beta2,
                             const float* mean2, const float* var2, float eps2, const float* alpha, int relu, void* y, long M,
                             int C, hupr_stream_t stream);
-void hupr_debug_interp_packed(int on);   /* probe aid: 1 = the resampling forward with hipcc's packed-fp32 accumulation (scripts/interp_race.py) */
-void hupr_debug_halo_split_k(int on);     /* A/B aid: 0 = never slice the reduction of small grids */
 int hupr_conv3x3_wgrad_halo_bf16act(const void* x, const void* dy, float* dw, int Bn, int D, int H, int W, int Ci,
                                     int in_ld, int Co, int dy_ld, int kd, void* ws, size_t ws_bytes,
                                     hupr_stream_t stream);
@@ -552,33 +532,6 @@ int hupr_interp_linear_bwd_acc_bf16act(const void* dy, void* dx, int Bn, int Di,
 /* boundary casts of the bf16-activation region (n % 4 == 0) */
 int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream);
 int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream);
-
-/* (a5, BASELINE.json config 5) MSCSA attention forward (models/layers.py:126-133) with fp8 (OCP e4m3) MFMA operands, for the
- *      level that carries 88 % of the attention flops (C = 64, N % 128 == 0).  K, Q, V, out: fp32 (Bn, N, C) token-major;
- *      per-tensor scales 448 / amax; probabilities rounded to e4m3; fp32 accumulate / softmax statistics; residual != 0 adds V
- *      (cross attention :146,148).  hupr_attn_fwd_fp8 = hupr_attn_quant_fp8 (amax + convert, V transposed) followed by
- *      hupr_attn_fwd_fp8_quantized; ws holds the three e4m3 copies.  Opt-in (functional.ATTN_FP8 / HUPR_ATTN_FP8=1, forward
- *      under no_grad only): measured against the bf16 kernel in profiles/r02_attn_fp8_ab.txt. */
-size_t hupr_attn_fp8_ws_bytes(int Bn, int N, int C);
-int hupr_attn_quant_fp8(const float* K, const float* Q, const float* V, int Bn, int N, int C, void* ws, size_t ws_bytes,
-                        hupr_stream_t stream);
-int hupr_attn_fwd_fp8_quantized(const void* ws, const float* Vres, float* out, float* lse, int Bn, int N, int C, size_t ws_bytes,
-                                hupr_stream_t stream);
-int hupr_attn_fwd_fp8(const float* K, const float* Q, const float* V, int residual, float* out, float* lse, int Bn, int N, int C,
-                      void* ws, size_t ws_bytes, hupr_stream_t stream);
-/* The same attention on the block-scaled fp8 matrix instruction of gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4: one E8M0 power-of-two
- *      scale per 32 elements of the reduction axis, applied in the matrix pipe): the operands of ONE MSCSA level (layers.py:150-163)
- *      are quantised in one step — Ya / Ye: bf16 (Bn, N, 4 C), the four 1x1 projections of map 0 / map 1 side by side; va / ve:
- *      bf16 (Bn, N, C) value maps (written transposed, keys in the accumulator order of a probability tile pair) — and each of the
- *      level's attentions then names its operands: keys = projection kslot (0..3) of map kmap (0 / 1), queries likewise, values =
- *      map vmap.  Vres: fp32 value map added to the output (cross attention :146,148) or null; out fp32 (Bn, N, C); lse (Bn, N);
- *      out16 (optional): bf16 copy of out, ld16 elements between tokens.  C = 64, N % 128 == 0.  functional.ATTN_FP8 = "mx"
- *      (HUPR_ATTN_FP8=mx): inference and the training forward (the backward stays on the bf16 kernels). */
-size_t hupr_attn_mx8_ws_bytes(int Bn, int N, int C);
-int hupr_attn_mx8_quant_level(const void* Ya, const void* Ye, const void* va, const void* ve, int Bn, int N, int C, void* ws,
-                              size_t ws_bytes, hupr_stream_t stream);
-int hupr_attn_mx8_fwd(const void* ws, int kmap, int kslot, int qmap, int qslot, int vmap, const float* Vres, float* out, float* lse,
-                      void* out16, int ld16, int Bn, int N, int C, size_t ws_bytes, hupr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * (e) Data-parallel exchange over RCCL / xGMI.  Nothing in the reference to mirror: it trains on one

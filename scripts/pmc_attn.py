@@ -6,7 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hupr_amd import functional as F_
 F_.set_math("bf16")
 L, rt = F_.rt.lib(), F_.rt
-L.hupr_debug_attn_pingpong(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 B, N, C = 32, 4096, 64
 k, q, v = (torch.randn(B, N, C, device="cuda") for _ in range(3))
 kb, qb, vb = (k * 0.5).bfloat16(), (q * 0.5).bfloat16(), v.bfloat16()

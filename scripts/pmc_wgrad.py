@@ -6,7 +6,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hupr_amd import functional as F_
 F_.set_math("bf16")
 L = F_.rt.lib()
-L.hupr_debug_wgrad_groups(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 B, C, D, H, W = 32, 64, 8, 64, 64
 x = torch.randn(B, D, H, W, C, device="cuda").bfloat16(); dy = torch.randn(B, D, H, W, C, device="cuda").bfloat16()
 dw = torch.empty(C, C, 3, 3, 3, device="cuda")

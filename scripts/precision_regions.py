@@ -34,7 +34,6 @@ ap.add_argument("--sets", default="")
 ap.add_argument("--brief", action="store_true", help="only the all-bf16 row")
 ap.add_argument("--full", action="store_true", help="with --sets: also the leave-one-out / leave-one-in rows")
 ap.add_argument("--lrs", default="", help="comma list: fit once per learning rate (brief tables), instead of --lr")
-ap.add_argument("--fp8", action="store_true", help="also: the default switches with fp8 level-1 attention (config 5)")
 args = ap.parse_args()
 DEFAULT = dict(F_.PRECISION)
 
@@ -67,12 +66,6 @@ def table(tag, sd, cfg, h, v, joints=None):
               ((name,) + a1 + a2 + (extra,)), flush=True)
     row("all bf16", {})
     row("library default (%s)" % ",".join("%s=%s" % kv for kv in DEFAULT.items()), dict(DEFAULT))
-    if args.fp8:                       # BASELINE config 5: level-1 attention forward on the fp8 matrix pipe (eval only)
-        F_.ATTN_FP8 = True
-        try:
-            row("default + fp8 level-1 attention", dict(DEFAULT))
-        finally:
-            F_.ATTN_FP8 = False
     if args.brief:
         return
     if args.sets:

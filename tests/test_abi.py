@@ -17,10 +17,20 @@ def built():
     return runtime
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "hupr.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(hupr_[a-z0-9_]+)\s*\(", txt)))
+def _declared(headers=("hupr.h", "hupr_debug.h")):
+    names = set()
+    for h in headers:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(hupr_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_operator_header_holds_no_debug_entry_points():
+    """include/hupr.h is the operator contract only; test / profiling switches live in include/hupr_debug.h."""
+    assert not [n for n in _declared(("hupr.h",)) if n.startswith("hupr_debug_")]
+    dbg = _declared(("hupr_debug.h",))
+    assert dbg and all(n.startswith("hupr_debug_") for n in dbg) and len(dbg) <= 12
 
 
 def test_every_declared_symbol_is_exported(built):
@@ -92,7 +102,7 @@ def test_hot_kernels_keep_their_register_and_lds_budgets():
             get = lambda key: re.search(r"\.%s:\s+(\S+)" % key, blk).group(1)
             meta[get("name")] = dict(vgpr=int(get("vgpr_count")), spill=int(get("vgpr_spill_count")),
                                      scratch=int(get("private_segment_fixed_size")), lds=int(get("group_segment_fixed_size")))
-    assert len(meta) >= 200
+    assert len(meta) >= 150
     # (substring of the mangled name, max unified VGPRs as the code object states them, max static LDS bytes).  512-thread kernels
     # with one workgroup per CU run two waves per SIMD: 256 registers each; the FFT kernels are sized for >= 3-4 waves per SIMD
     budgets = [("hupr_k_conv_halo256m_bf16ILi4ELi8ELi8ELi3ELi0E", 256, 160 * 1024),
@@ -100,10 +110,10 @@ def test_hot_kernels_keep_their_register_and_lds_budgets():
                ("hupr_k_conv_halo256m_bf16ILi1ELi16ELi16ELi1E", 256, 160 * 1024),
                ("hupr_k_conv_halo256m_bf16ILi4ELi8ELi8ELi3ELi1E", 256, 160 * 1024),      # fused BatchNorm statistics, one output tile (level 1)
                ("hupr_k_wgrad_halo_m16ILb1E", 256, 160 * 1024), ("hupr_k_wgrad_halo_m16ILb0E", 256, 160 * 1024),
-               ("hupr_k_attn_fwd_pp64ILi0ELb1E", 256, 160 * 1024), ("hupr_k_attn_bwd_dkvILi256EDF16bLi2ELb1E", 512, 160 * 1024),
+               ("hupr_k_attn_fwd_pp64ILb1E", 256, 160 * 1024), ("hupr_k_attn_bwd_dkvILi256EDF16bLi2ELb1E", 512, 160 * 1024),
                ("hupr_k_attn_fwdILi256EDF16bLb0ELb1E", 512, 160 * 1024), ("hupr_k_attn_bwd_dqILi256EDF16bLb1E", 512, 160 * 1024),
                ("hupr_k_wgrad_halo_gldsILb1ELb0E", 256, 160 * 1024),
-               ("hupr_k_attn_fwd_pp64ILi0E", 256, 160 * 1024),
+               ("hupr_k_attn_fwd_pp64ILb0E", 256, 160 * 1024),
                ("hupr_k_attn_bwd_dkv512", 256, 64 * 1024),
                ("hupr_k_attn_bwd_dqILi64EDF16bLb", 256, 64 * 1024),      # both forms: plain and QS (round 5)
                ("hupr_k_gcn_wxILb0E", 168, 64 * 1024), ("hupr_k_gcn_wxILb1E", 168, 64 * 1024), ("hupr_k_gcn_dw", 168, 64 * 1024),

@@ -294,13 +294,13 @@ def test_single_sample_attentions_of_a_level_in_one_launch(H, C, cat, bf16_math)
 @pytest.fixture(params=["hupr_k_conv_halo_bf16<64, 64>", "hupr_k_conv_halo256m_bf16<2, 16>"])
 def level3_aggressor(request):
     """The level-3 convolution at B = 32 that shares the chip with a victim: round 3's aggressor (the 128-voxel kernel, which these
-    layers ran on until the end of round 4 and smaller batches still do: hupr_debug_halo_m16(2) keeps depth-2 layers on it) and the
+    layers ran on until the end of round 4 and smaller batches still do: hupr_debug_halo_tiles(1) keeps depth-2 layers on it) and the
     kernel they run on now (the 16 x 16 x 32 kernel's 2 x 8 x 16 tile)."""
     from hupr_amd import functional as F_
     L = F_.rt.lib()
-    L.hupr_debug_halo_m16(2 if request.param.startswith("hupr_k_conv_halo_bf16") else 1)
+    L.hupr_debug_halo_tiles(1 if request.param.startswith("hupr_k_conv_halo_bf16") else 7)
     yield request.param
-    L.hupr_debug_halo_m16(1)
+    L.hupr_debug_halo_tiles(7)
 
 
 def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(level3_aggressor, bf16_math):
@@ -768,43 +768,36 @@ def test_conv_residual_prefetched_under_the_last_stage_equals_the_immediate_epil
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 64, 8, 64, 64), (9, 128, 128, 4, 32, 32), (3, 64, 128, 8, 32, 64)])
-def test_conv_halo256_stage_protocols_agree_bitwise(shape, bf16_math):
-    """The 256-voxel kernel's stage protocol of this round (barrier in front of a stage's last K-step, fragment pipeline across stage
-    and item boundaries) against the rounds-1-4 protocol kept as template variant 16: same MFMA order, so the same bits — one and
-    two channel chunks, one and two output-channel tiles, a tile count that does not divide evenly over the 256 workgroups."""
+def test_conv_halo256m_4x8x8_tile_matches_the_128_voxel_kernel(shape, bf16_math):
+    """The 256-voxel kernel's 4 x 8 x 8 tile (v_mfma_f32_16x16x32_bf16, persistent workgroups, fragment pipeline across stage and item
+    boundaries) against the 128-voxel kernel (hupr_debug_halo_tiles(0): 32 x 32 x 16, another fp32 order inside a 32-channel group —
+    a handful of outputs one bf16 step apart) and against fp64: one and two channel chunks, one and two output-channel tiles, a tile
+    count that does not divide evenly over the 256 workgroups; deterministic from launch to launch."""
     from hupr_amd import functional as F_
     L = F_.rt.lib()
     B, Ci, Co, D, H, W = shape
     x = rnd(B, D, H, W, Ci, seed=54).cuda().bfloat16()
     w = rnd(Co, Ci, 3, 3, 3, seed=55, scale=(Ci * 27) ** -0.5).cuda()
     try:
-        L.hupr_debug_halo_m16(0)
-        L.hupr_debug_halo_ablate(16 << 4)
-        y_old = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
-        L.hupr_debug_halo_ablate(0)
-        y_new = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
-        y_new2 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
-        L.hupr_debug_halo_m16(1)
+        L.hupr_debug_halo_tiles(0)
+        y_128 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        L.hupr_debug_halo_tiles(7)
         y_m16 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
         y_m16b = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
     finally:
-        L.hupr_debug_halo_ablate(0)
-        L.hupr_debug_halo_m16(1)
-    assert y_new.dtype == torch.bfloat16 and torch.equal(y_new, y_old) and torch.equal(y_new, y_new2)
+        L.hupr_debug_halo_tiles(7)
     ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
-    close(ncdhw(y_new.float().cpu())[:1], ref, 1e-2, "halo256 (bf16 store) vs fp64")
-    # the default kernel (v_mfma_f32_16x16x32_bf16: another fp32 order inside a 32-channel group): deterministic, the same products,
-    # a handful of outputs one bf16 step away from the 32 x 32 x 16 kernel's
-    assert torch.equal(y_m16, y_m16b)
-    d = (y_m16.float() - y_new.float()).abs()
-    assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(y_new.float().abs(), y_m16.float().abs()) * 2 ** -7 + 1e-5).all()
+    close(ncdhw(y_128.float().cpu())[:1], ref, 1e-2, "128-voxel kernel (bf16 store) vs fp64")
+    assert y_m16.dtype == torch.bfloat16 and torch.equal(y_m16, y_m16b)
+    d = (y_m16.float() - y_128.float()).abs()
+    assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(y_128.float().abs(), y_m16.float().abs()) * 2 ** -7 + 1e-5).all()
     close(ncdhw(y_m16.float().cpu())[:1], ref, 1e-2, "halo256m (bf16 store) vs fp64")
 
 
 @pytest.mark.parametrize("shape", [(32, 64, 256, 2, 16, 16), (17, 128, 128, 2, 16, 32), (8, 320, 64, 1, 64, 64), (9, 64, 192, 1, 32, 48)])
 def test_conv_halo256m_two_slice_tile_matches_the_128_voxel_kernel(shape, bf16_math):
     """Depth 2 (encoder level 3) and depth 1 with 1 x 3 x 3 taps (decoder): the 16 x 16 x 32 kernel's 2 x 8 x 16 / 1 x 16 x 16 tiles against the 128-voxel kernel these layers ran on before
-    (hupr_debug_halo_m16(2)) — same products, another fp32 order: a few outputs one bf16 step apart — and against fp64; with and
+    (hupr_debug_halo_tiles(1)) — same products, another fp32 order: a few outputs one bf16 step apart — and against fp64; with and
     without the residual epilogue; even and uneven tile counts over the 256 workgroups."""
     from hupr_amd import functional as F_
     L = F_.rt.lib()
@@ -815,17 +808,17 @@ def test_conv_halo256m_two_slice_tile_matches_the_128_voxel_kernel(shape, bf16_m
     res = rnd(B, D, H, W, Co, seed=58).cuda().bfloat16()
     out = {}
     try:
-        for mode in (2, 3):                 # 3: all tiles (the 1 x 16 x 16 one is opt-in), 2: the 4 x 8 x 8 tile only
-            L.hupr_debug_halo_m16(mode)
+        for mode in (1, 7):                 # 7: all tiles, 1: the 4 x 8 x 8 tile only
+            L.hupr_debug_halo_tiles(mode)
             out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, k3, pad, (D, H, W)),
                          F_._conv_raw(x, w, 0, None, res, Co, k3, pad, (D, H, W)))
     finally:
-        L.hupr_debug_halo_m16(1)
-    for a, b in zip(out[3], out[2]):
+        L.hupr_debug_halo_tiles(7)
+    for a, b in zip(out[7], out[1]):
         d = (a.float() - b.float()).abs()
         assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + 1e-5).all()
     ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, pad)
-    close(ncdhw(out[3][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 / 1x16x16 (bf16 store) vs fp64")
+    close(ncdhw(out[7][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 / 1x16x16 (bf16 store) vs fp64")
 
 
 # ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
@@ -858,15 +851,15 @@ def test_conv_halo_bf16_activations(case, bf16_math):
     assert y16.dtype == torch.bfloat16
     d16 = (y16.float() - _q(y32)).abs()
     if not torch.equal(y16.float(), _q(y32)):
-        # only where the 256-voxel kernel engages: its bf16-activation form multiplies on v_mfma_f32_16x16x32_bf16 (another fp32 order
-        # inside a 32-channel group than the fp32-activation form's 32 x 32 x 16): a few outputs land one bf16 step away
+        # only where the 256-voxel kernel engages (bf16-stored activations only): it multiplies on v_mfma_f32_16x16x32_bf16 (another fp32
+        # order inside a 32-channel group than the 128-voxel kernel's 32 x 32 x 16): a few outputs land one bf16 step away
         assert (d16 > 0).float().mean().item() < 2e-3 and (d16 <= torch.maximum(_q(y32).abs(), y16.float().abs()) * 2 ** -7 + 1e-5).all(), d16.max().item()      # (+ the fp32 order noise where residual and sum cancel)
         L_ = F_.rt.lib()
         try:
-            L_.hupr_debug_halo_m16(0)
+            L_.hupr_debug_halo_tiles(0)
             y16b = F_._conv_raw(x.bfloat16(), w, 0, bias, res.bfloat16() if has_res else None, Co, k, pad, (D, H, W))
         finally:
-            L_.hupr_debug_halo_m16(1)
+            L_.hupr_debug_halo_tiles(7)
         assert torch.equal(y16b.float(), _q(y32))              # the 32 x 32 x 16 form: store rounding only
     # weight gradient: fp32 output, identical products; only the fp32 summation order over voxel slices differs
     # (LDS-DMA kernel: two K halves per workgroup, other slice count)
@@ -1466,165 +1459,6 @@ def test_interp_mnet_cast_bf16_activations():
         m[dt] = (o.detach().float(), wi.grad, bi.grad)
     assert torch.equal(m[torch.bfloat16][0], _q(m[torch.float32][0]))
     assert torch.equal(m[torch.bfloat16][1], m[torch.float32][1]) and torch.equal(m[torch.bfloat16][2], m[torch.float32][2])
-
-
-@pytest.mark.parametrize("residual", [True, False])
-def test_attention_fp8_forward_vs_fp64(residual):
-    """BASELINE.json config 5: e4m3 MFMA operands for QK^T and PV (per-tensor scales, probabilities rounded to e4m3) against
-    the fp64 statement of models/layers.py:126-133.  fp8 has 3 mantissa bits: the gate is on the attention term relative to its
-    own norm (measured 8e-2 at logit std 3 — e4m3 K and Q perturb every un-normalised logit by a few percent of its size; the
-    bf16 kernel sits at 5e-3, profiles/r02_attn_fp8_ab.txt), and on the log-sum-exp."""
-    from hupr_amd import functional as F_
-    torch.manual_seed(3)
-    B, N, C = 2, 1024, 64
-    k = torch.randn(B, N, C, device="cuda") * 0.6
-    q = torch.randn(B, N, C, device="cuda") * 0.6
-    v = torch.randn(B, N, C, device="cuda")
-    out, lse = F_.attention_fp8(k, q, v, residual)
-    S = torch.einsum("bjc,bqc->bjq", k.double(), q.double())
-    att = torch.einsum("bjq,bjc->bqc", torch.softmax(S, dim=1), v.double())
-    ref = att + (v.double() if residual else 0)
-    rel = ((out.double() - ref).norm() / att.norm()).item()
-    print("fp8 attention (residual=%s): rel-L2 of the attention term %.3e, lse max-abs %.3e" %
-          (residual, rel, (lse.double() - torch.logsumexp(S, dim=1)).abs().max().item()))
-    assert rel <= 1.5e-1
-    assert (lse.double() - torch.logsumexp(S, dim=1)).abs().max().item() <= 1.5
-    # shapes outside the kernel's envelope are refused by the C ABI
-    L = F_.rt.lib()
-    assert L.hupr_attn_fwd_fp8(F_.rt.ptr(k), F_.rt.ptr(q), F_.rt.ptr(v), 0, F_.rt.ptr(out), F_.rt.ptr(lse), B, 1000, C, F_.rt.ptr(k), 1 << 30, None) == -1
-
-
-def test_model_eval_with_fp8_attention_stays_inside_the_bf16_envelope():
-    """HuPRNet eval forward with config 5 switched on (level-1 attentions on the fp8 kernels): finite, close to the bf16 run."""
-    import numpy as np
-    from hupr_amd import functional as F_, synth
-    from hupr_amd.config_tree import load_config
-    from hupr_amd.models import HuPRNet
-    saved = F_.ATTN_FP8
-    try:
-        F_.set_math("bf16")
-        net = HuPRNet(load_config()).cuda().eval()
-        net.load_state_dict({k_: torch.from_numpy(np.array(v_)) for k_, v_ in synth.hupr_state(1, gain=1.4).items()})
-        h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(2, 5))
-        with torch.no_grad():
-            F_.ATTN_FP8 = False
-            a1, a2 = net(h, v)
-            F_.ATTN_FP8 = True
-            b1, b2 = net(h, v)
-        d1, d2 = (a1 - b1).abs().max().item(), (a2 - b2).abs().max().item()
-        print("fp8 vs bf16 attention inside the model: heat-map max-abs %.3e / %.3e" % (d1, d2))
-        assert torch.isfinite(b1).all() and torch.isfinite(b2).all() and 0 < d1 <= 2e-2 and d2 <= 2e-2
-    finally:
-        F_.ATTN_FP8 = saved
-        F_.set_math("f32")
-
-
-def _mx_e4m3(x, dim):
-    """OCP MX restated with torch casts: blocks of 32 along ``dim`` share the power-of-two scale 2^ceil(log2(amax / 448)); values
-    rounded to e4m3 (round to nearest even, nothing saturates) and scaled back, fp64."""
-    x = x.double().movedim(dim, -1)
-    sh = x.shape
-    b = x.reshape(sh[:-1] + (sh[-1] // 32, 32))
-    amax = b.abs().amax(-1, keepdim=True)
-    sc = torch.exp2(torch.ceil(torch.log2(amax.clamp_min(1e-300) / 448.0)))
-    sc = torch.where(amax > 0, sc, torch.ones_like(sc))
-    return ((b / sc).float().to(torch.float8_e4m3fn).double() * sc).reshape(sh).movedim(-1, dim)
-
-
-@pytest.mark.parametrize("residual", [True, False])
-def test_attention_mx8_forward_vs_restatement_and_fp64(residual):
-    """BASELINE.json config 5, block-scaled form (csrc/attention_mx8.hip): v_mfma_scale_f32_32x32x64_f8f6f4 with one E8M0 scale per
-    (token, 32 channels) of K and Q and per (channel, 32 consecutive keys) of V, probabilities as e4m3(2^8 p).
-    Against (a) a torch restatement of exactly that quantisation evaluated in fp64 — pins the operand layout of the instruction, the
-    scale bytes and the key permutation of the transposed values — and (b) the fp64 statement of models/layers.py:126-133."""
-    from hupr_amd import functional as F_
-    torch.manual_seed(5)
-    B, N, C = 2, 1024, 64
-    k = (torch.randn(B, N, C, device="cuda") * 0.6 * torch.rand(B, N, 1, device="cuda")).bfloat16().float()
-    q = (torch.randn(B, N, C, device="cuda") * 0.6).bfloat16().float()
-    v = (torch.randn(B, N, C, device="cuda") * (0.2 + torch.rand(1, 1, C, device="cuda"))).bfloat16().float()
-    out, lse = F_.attention_mx8(k, q, v, residual)
-    # (a) the restatement: K, Q blocks of 32 channels; V blocks of 32 consecutive keys per channel
-    kq, qq, vq = _mx_e4m3(k, 2), _mx_e4m3(q, 2), _mx_e4m3(v, 1)
-    S = torch.einsum("bjc,bqc->bjq", kq, qq)
-    P = torch.softmax(S, dim=1)
-    m = S.amax(1, keepdim=True)
-    p8 = (256.0 * torch.exp(S - m)).float().to(torch.float8_e4m3fn).double()      # relative to the FINAL maximum (the kernel: the running one)
-    att_q = torch.einsum("bjq,bjc->bqc", p8, vq) / (256.0 * torch.exp(S - m)).sum(1).unsqueeze(-1)
-    S0 = torch.einsum("bjc,bqc->bjq", k.double(), q.double())
-    att = torch.einsum("bjq,bjc->bqc", torch.softmax(S0, dim=1), v.double())
-    add = v.double() if residual else 0
-    rel_q = ((out.double() - (att_q + add)).norm() / att.norm()).item()
-    rel = ((out.double() - (att + add)).norm() / att.norm()).item()
-    lse_q = (lse.double() - torch.logsumexp(S, dim=1)).abs().max().item()
-    lse_0 = (lse.double() - torch.logsumexp(S0, dim=1)).abs().max().item()
-    print("mx8 attention (residual=%s): rel-L2 of the attention term vs the restatement %.3e, vs fp64 %.3e; lse max-abs %.3e / %.3e" %
-          (residual, rel_q, rel, lse_q, lse_0))
-    assert rel_q <= 2e-2 and lse_q <= 1e-3          # the same quantised operands: only the running-maximum rounding of P differs
-    assert rel <= 1.2e-1 and lse_0 <= 0.5
-    L = F_.rt.lib()
-    assert L.hupr_attn_mx8_fwd(None, 0, 0, 0, 1, 0, None, F_.rt.ptr(out), F_.rt.ptr(lse), None, 0, B, 1000, C, 1 << 30, None) == -1
-
-
-def test_mscsa_level_with_mx8_forward_trains_on_the_bf16_backward(bf16_math):
-    """A fused MSCSA level with config 5's block-scaled forward (functional.ATTN_FP8 = "mx") against the bf16 level on the same
-    inputs: outputs within the fp8 envelope, and the backward — the bf16 kernels on the bf16 projections, with the forward's fp8
-    log-sum-exp — gives gradients close to the bf16 level's."""
-    from hupr_amd import functional as F_
-    torch.manual_seed(6)
-    B, H, W, C = 2, 32, 32, 64
-    ra = torch.randn(B, 1, H, W, C, device="cuda") * 0.5
-    re = torch.randn(B, 1, H, W, C, device="cuda") * 0.5
-    ws = [(torch.randn(C, C, 1, 1, device="cuda") * C ** -0.5) for _ in range(8)]
-    g = torch.randn(B, 1, H, W, 4 * C, device="cuda").bfloat16()
-    saved = (F_.ATTN_FP8, F_.ATTN_FP8_TRAIN)
-    res = {}
-    try:
-        F_.ATTN_FP8_TRAIN = True              # the training forward is a second opt-in (functional.ATTN_FP8_TRAIN, ADVICE r4 item 3)
-        for mode in (False, "mx"):
-            F_.ATTN_FP8 = mode
-            a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
-            w = [t.clone().requires_grad_(True) for t in ws]
-            (cat,) = F_.MSCSALevelFn.apply(a, e, 1, *w)
-            cat.backward(g)
-            res[mode] = (cat.float().detach(), a.grad.clone(), e.grad.clone(), w[0].grad.clone(), w[5].grad.clone())
-        F_.ATTN_FP8_TRAIN = False             # without it a training forward stays on the bf16 kernels: bit-identical to mode False
-        a, e = ra.clone().requires_grad_(True), re.clone().requires_grad_(True)
-        (cat,) = F_.MSCSALevelFn.apply(a, e, 1, *[t.clone().requires_grad_(True) for t in ws])
-        assert torch.equal(cat.float(), res[False][0])
-    finally:
-        F_.ATTN_FP8, F_.ATTN_FP8_TRAIN = saved
-    names = ("outputs", "d ra", "d re", "d w[0]", "d w[5]")
-    for nme, x, y in zip(names, res["mx"], res[False]):
-        rel = ((x - y).norm() / y.norm()).item()
-        print("mx8 level vs bf16 level, %s: rel-L2 %.3e" % (nme, rel))
-        assert torch.isfinite(x).all() and rel <= (5e-2 if nme == "outputs" else 1.5e-1), nme
-    assert not torch.equal(res["mx"][0], res[False][0])
-
-
-def test_model_eval_with_mx8_attention_stays_inside_the_bf16_envelope():
-    """HuPRNet eval forward with config 5's block-scaled form switched on: finite, close to the bf16 run."""
-    import numpy as np
-    from hupr_amd import functional as F_, synth
-    from hupr_amd.config_tree import load_config
-    from hupr_amd.models import HuPRNet
-    saved = F_.ATTN_FP8
-    try:
-        F_.set_math("bf16")
-        net = HuPRNet(load_config()).cuda().eval()
-        net.load_state_dict({k_: torch.from_numpy(np.array(v_)) for k_, v_ in synth.hupr_state(1, gain=1.4).items()})
-        h, v = (torch.from_numpy(t).cuda() for t in synth.model_inputs(2, 5))
-        with torch.no_grad():
-            F_.ATTN_FP8 = False
-            a1, a2 = net(h, v)
-            F_.ATTN_FP8 = "mx"
-            b1, b2 = net(h, v)
-        d1, d2 = (a1 - b1).abs().max().item(), (a2 - b2).abs().max().item()
-        print("mx8 vs bf16 attention inside the model: heat-map max-abs %.3e / %.3e" % (d1, d2))
-        assert torch.isfinite(b1).all() and torch.isfinite(b2).all() and 0 < d1 <= 2e-2 and d2 <= 2e-2
-    finally:
-        F_.ATTN_FP8 = saved
-        F_.set_math("f32")
 
 
 def test_conv_halo512_first_layer_shape_matches_the_128_voxel_kernel(bf16_math):
