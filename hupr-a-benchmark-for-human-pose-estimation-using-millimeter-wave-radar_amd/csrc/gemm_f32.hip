@@ -455,7 +455,67 @@ __global__ __launch_bounds__(256) void hupr_k_splitk_reduce4(const float* __rest
     }
 }
 
-static int g_splitk_slices = 0;      // A/B aid (hupr_debug_splitk_slices): 0 auto, 4 / 16 forced
+// The same sums with the parameter-layout write made contiguous (round 6).  hupr_k_splitk_reduce4 stores the four
+// sums of a thread 4 bytes each, taps * 4 bytes apart ([co][tap][ci] -> [co][ci][tap]): a wave's store instruction touches 64 cache
+// lines, and the level-3 / decoder gradients (1.8-4.7 M elements, 5-13 partial tensors) ran at 2 TB/s of reads.  Here a workgroup
+// owns ONE output row segment — output channel co, CB4 * 4 consecutive input channels, all taps: taps runs of CB4 float4 in the
+// partial layout (64- or 128-byte runs, coalesced), ONE contiguous run of CB4 * 4 * taps floats in the parameter layout — sums every
+// (element, slice) pair with exactly the arithmetic of hupr_k_splitk_reduce4<S> (eight accumulators in k order, their tree, the slices in
+// order: bit-identical results), transposes the sums through LDS and writes the run with consecutive 4-byte stores of consecutive
+// lanes.  S / CB4: 4 / 8 or 16 / 4 (the slice rule of launch_splitk_reduce is unchanged).
+template <int S, int CB4>
+__global__ __launch_bounds__(256) void hupr_k_splitk_reduce_t(const float* __restrict__ part, float* __restrict__ out, int splits,
+                                                              long split_stride, int taps, int ci, int n_ci_blocks,
+                                                              float* __restrict__ out2, long n_first) {
+    constexpr int U = 8, CB = CB4 * 4, MAXT = 27;
+    __shared__ float4 red[S][MAXT * CB4];
+    __shared__ float tr[CB * MAXT + 1];
+    const int row = blockIdx.x / n_ci_blocks, cblk = blockIdx.x - row * n_ci_blocks;       // row = output channel (of both gradients)
+    const int items = taps * CB4;                              // float4 sums of this workgroup: (tap, column c4)
+    const long per = (long)taps * ci;
+    const float* prow = part + row * per + cblk * CB;
+    for (int p = threadIdx.x; p < items * S; p += 256) {
+        const int sl = p / items, it = p - sl * items;
+        const int tap = it / CB4, c4 = it - tap * CB4;
+        const float* q = prow + (long)tap * ci + c4 * 4;
+        float4 a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = sl; k < splits; k += S * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                v[u] = (k + u * S < splits) ? *reinterpret_cast<const float4*>(q + (long)(k + u * S) * split_stride)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a[u].x += v[u].x; a[u].y += v[u].y; a[u].z += v[u].z; a[u].w += v[u].w; }
+        }
+#pragma unroll
+        for (int w = 1; w < U; w *= 2)
+#pragma unroll
+            for (int u = 0; u + w < U; u += 2 * w) { a[u].x += a[u + w].x; a[u].y += a[u + w].y; a[u].z += a[u + w].z; a[u].w += a[u + w].w; }
+        red[sl][it] = a[0];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < items; it += 256) {
+        float4 r = red[0][it];
+#pragma unroll
+        for (int q = 1; q < S; ++q) { const float4 t = red[q][it]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+        const int tap = it / CB4, c = (it - tap * CB4) * 4;
+        tr[(c + 0) * taps + tap] = r.x;                        // [channel of the block][tap]: the parameter layout of the run
+        tr[(c + 1) * taps + tap] = r.y;
+        tr[(c + 2) * taps + tap] = r.z;
+        tr[(c + 3) * taps + tap] = r.w;
+    }
+    __syncthreads();
+    long i = row * per;                                        // first element of this row in the summed tensor
+    float* o = out;
+    if (out2 != nullptr && i >= n_first) { i -= n_first; o = out2; }
+    o += i + (long)cblk * CB * taps;
+    for (int e = threadIdx.x; e < CB * taps; e += 256) o[e] = tr[e];      // out may be a 4-byte aligned bucket view
+}
+
+static int g_splitk_slices = 0;      // test aid (hupr_debug_splitk_slices): 0 auto, 4 / 16 forced; + 256: the scattered-store kernel of rounds 1-5
 extern "C" void hupr_debug_splitk_slices(int s) { g_splitk_slices = s; }
 
 void launch_splitk_reduce(const float* part, float* out, long n, int splits, long split_stride, int taps, int ci,
@@ -469,7 +529,17 @@ void launch_splitk_reduce(const float* part, float* out, long n, int splits, lon
         const long n4 = n / 4;
         // many partial tensors over a small output: 16 slices (a quarter of the columns per workgroup, four times the workgroups)
         const long n4_one = out2 ? n_first / 4 : n4;          // (two gradients in one tensor: the choice each of them gets alone)
-        const bool s16 = g_splitk_slices ? g_splitk_slices == 16 : (splits >= 32 && n4_one <= (1L << 17));
+        const int forced = g_splitk_slices & 255;
+        const bool s16 = forced ? forced == 16 : (splits >= 32 && n4_one <= (1L << 17));
+        // convolution weight gradients ([co][tap][ci] partials): the contiguous-store kernel where its row segments tile the tensor
+        const int cb = s16 ? 16 : 32;
+        if (taps > 1 && taps <= 27 && ci % cb == 0 && !(g_splitk_slices & 256) && (n / ((long)taps * ci)) * ((long)taps * ci) == n &&
+            (out2 == nullptr || n_first % ((long)taps * ci) == 0)) {
+            const int rows = (int)(n / ((long)taps * ci)), nb = ci / cb;
+            if (s16) HUPR_LAUNCH((hupr_k_splitk_reduce_t<16, 4>), dim3(rows * nb), dim3(256), 0, s, part, out, splits, split_stride, taps, ci, nb, out2, n_first);
+            else HUPR_LAUNCH((hupr_k_splitk_reduce_t<4, 8>), dim3(rows * nb), dim3(256), 0, s, part, out, splits, split_stride, taps, ci, nb, out2, n_first);
+            return;
+        }
         if (s16) HUPR_LAUNCH(hupr_k_splitk_reduce4<16>, dim3((n4 + 15) / 16), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci, out2, n_first);
         else HUPR_LAUNCH(hupr_k_splitk_reduce4<4>, dim3((n4 + 63) / 64), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci, out2, n_first);
         return;

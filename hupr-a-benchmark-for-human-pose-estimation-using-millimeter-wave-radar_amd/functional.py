@@ -1691,11 +1691,12 @@ class MSCSALevelFn(torch.autograd.Function):
 # (peaky) weights the decoded head went from 94.4 % to >= 99 % arg-max agreement with the fp32 path at B = 32
 # (tests/test_trained_gpu.py), for a few tens of microseconds per step.
 GCN_MATH = "f32"
+GCN_PRODUCTS = True        # test aid: False = the generic fp32 engine instead of csrc/gcn_products.hip
 
 
 def _gcn_products_ok(x, weight):
     """The dedicated PRGCN product kernels apply: fp32 pipe (the default of the head in every mode), 16-wide key-point slots."""
-    return ((GCN_MATH == "f32" or _st.math == "f32") and x.dtype == torch.float32 and x.shape[2] == 16
+    return (GCN_PRODUCTS and (GCN_MATH == "f32" or _st.math == "f32") and x.dtype == torch.float32 and x.shape[2] == 16
             and x.shape[1] % 64 == 0 and tuple(weight.shape) == (x.shape[1], x.shape[1]))
 
 

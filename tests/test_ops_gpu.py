@@ -1052,9 +1052,11 @@ def test_two_weight_gradients_of_one_input_in_one_launch(shape, bf16_math):
 
 @pytest.mark.parametrize("shape", [(8, 64, 64, 8, 32, 32, 3), (4, 128, 256, 2, 16, 16, 3), (8, 64, 64, 1, 32, 32, 1), (2, 96, 72, 2, 16, 16, 3)])
 def test_splitk_reduction_slices_agree(shape, bf16_math):
-    """The split-K reduction behind every weight gradient (hupr_k_splitk_reduce4<S>: S slices of the partial tensors per workgroup, eight
-    loads of a thread in flight): 4 and 16 slices add the same partial tensors in another order; both against fp64, and the same bits
-    on every run."""
+    """The split-K reduction behind every weight gradient (S slices of the partial tensors per workgroup, eight loads of a thread in
+    flight): 4 and 16 slices add the same partial tensors in another order; both against fp64, and the same bits on every run.  Round 6:
+    the convolution gradients' parameter-layout write goes through LDS (hupr_k_splitk_reduce_t: one contiguous run per output channel and
+    channel block instead of 4-byte stores 108 bytes apart) — the same sums bit for bit as the scattered-store kernel (+ 256), for one
+    gradient and for the two of a dual launch, written into views that are only 4-byte aligned (gradient-bucket slots)."""
     from hupr_amd import functional as F_
     L, rt = F_.rt.lib(), F_.rt
     B, Ci, Co, D, H, W, kd = shape
@@ -1075,6 +1077,30 @@ def test_splitk_reduction_slices_agree(shape, bf16_math):
         L.hupr_debug_splitk_slices(0)
     close(out[16], out[4], 2e-6, "16 vs 4 slices")
     assert torch.equal(out[0], out[4]) or torch.equal(out[0], out[16])
+    n0 = L.hupr_launch_count()
+    try:
+        for sl in (4, 16):
+            L.hupr_debug_splitk_slices(sl + 256)              # the scattered-store kernel of rounds 1-5
+            flat = torch.full((Co * Ci * kd * 9 + 3,), float("nan"), device="cuda")
+            dw = flat[3:].view(Co, Ci, kd, 3, 3)              # a 4-byte aligned destination (offset 12 bytes)
+            rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(rt.ptr(x), rt.ptr(dy), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, kd, rt.ptr(ws), ws.numel(),
+                                                       rt.stream()))
+            assert torch.equal(dw, out[sl]), sl
+            assert torch.isnan(flat[:3]).all()
+            if Co % 64 == 0 and Ci % 8 == 0:                  # the two gradients of a residual block in one reduction (rows split between dw / dw2)
+                ws2 = torch.empty(2 * ws.numel(), dtype=torch.uint8, device="cuda")
+                dy2 = rnd(B, D, H, W, Co, seed=512).cuda().bfloat16()
+                pair = {}
+                for legacy in (256, 0):
+                    L.hupr_debug_splitk_slices(sl + legacy)
+                    da, db = (torch.full((Co, Ci, kd, 3, 3), float("nan"), device="cuda") for _ in range(2))
+                    rt.check(L.hupr_conv3x3_wgrad_halo_bf16act_dual(rt.ptr(x), rt.ptr(dy), rt.ptr(dy2), rt.ptr(da), rt.ptr(db), B, D, H, W, Ci, Ci,
+                                                                    Co, Co, kd, rt.ptr(ws2), ws2.numel(), rt.stream()))
+                    pair[legacy] = (da, db)
+                assert torch.equal(pair[0][0], pair[256][0]) and torch.equal(pair[0][1], pair[256][1]) and torch.equal(pair[0][0], out[sl])
+    finally:
+        L.hupr_debug_splitk_slices(0)
+    assert L.hupr_launch_count() > n0
     xr = x.double().cpu().permute(0, 4, 1, 2, 3)
     wr = torch.zeros(Co, Ci, kd, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv3d(xr, wr, None, 1, (kd // 2, 1, 1)).backward(dy.double().cpu().permute(0, 4, 1, 2, 3))
