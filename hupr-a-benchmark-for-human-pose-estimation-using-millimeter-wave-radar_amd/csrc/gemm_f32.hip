@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void hupr_k_splitk_reduce4(const float* __rest
 // partial layout (64- or 128-byte runs, coalesced), ONE contiguous run of CB4 * 4 * taps floats in the parameter layout — sums every
 // (element, slice) pair with exactly the arithmetic of hupr_k_splitk_reduce4<S> (eight accumulators in k order, their tree, the slices in
 // order: bit-identical results), transposes the sums through LDS and writes the run with consecutive 4-byte stores of consecutive
-// lanes.  S / CB4: 4 / 8 or 16 / 4 (the slice rule of launch_splitk_reduce is unchanged).
+// lanes.  S / CB4 = 4 / 8: the 4-slice class of launch_splitk_reduce (its slice rule is unchanged).
 template <int S, int CB4>
 __global__ __launch_bounds__(256) void hupr_k_splitk_reduce_t(const float* __restrict__ part, float* __restrict__ out, int splits,
                                                               long split_stride, int taps, int ci, int n_ci_blocks,
@@ -531,13 +531,15 @@ void launch_splitk_reduce(const float* part, float* out, long n, int splits, lon
         const long n4_one = out2 ? n_first / 4 : n4;          // (two gradients in one tensor: the choice each of them gets alone)
         const int forced = g_splitk_slices & 255;
         const bool s16 = forced ? forced == 16 : (splits >= 32 && n4_one <= (1L << 17));
-        // convolution weight gradients ([co][tap][ci] partials): the contiguous-store kernel where its row segments tile the tensor
-        const int cb = s16 ? 16 : 32;
-        if (taps > 1 && taps <= 27 && ci % cb == 0 && !(g_splitk_slices & 256) && (n / ((long)taps * ci)) * ((long)taps * ci) == n &&
+        // convolution weight gradients ([co][tap][ci] partials) of the 4-slice class — the large gradients with few partial tensors
+        // (levels 2-3, the decoder) —: the contiguous-store kernel where its row segments tile the tensor.  (The 16-slice class —
+        // many partials over a small output — stays on hupr_k_splitk_reduce4<16>: a workgroup of the row kernel would walk 7
+        // sequential rounds of (element, slice) pairs there; measured 274 vs 208 us per step, profiles/r06_splitk_ab.txt.)
+        constexpr int cb = 32;
+        if (!s16 && taps > 1 && taps <= 27 && ci % cb == 0 && !(g_splitk_slices & 256) && (n / ((long)taps * ci)) * ((long)taps * ci) == n &&
             (out2 == nullptr || n_first % ((long)taps * ci) == 0)) {
             const int rows = (int)(n / ((long)taps * ci)), nb = ci / cb;
-            if (s16) HUPR_LAUNCH((hupr_k_splitk_reduce_t<16, 4>), dim3(rows * nb), dim3(256), 0, s, part, out, splits, split_stride, taps, ci, nb, out2, n_first);
-            else HUPR_LAUNCH((hupr_k_splitk_reduce_t<4, 8>), dim3(rows * nb), dim3(256), 0, s, part, out, splits, split_stride, taps, ci, nb, out2, n_first);
+            HUPR_LAUNCH((hupr_k_splitk_reduce_t<4, 8>), dim3(rows * nb), dim3(256), 0, s, part, out, splits, split_stride, taps, ci, nb, out2, n_first);
             return;
         }
         if (s16) HUPR_LAUNCH(hupr_k_splitk_reduce4<16>, dim3((n4 + 15) / 16), dim3(256), 0, s, part, out, n4, splits, split_stride, taps, ci, out2, n_first);
