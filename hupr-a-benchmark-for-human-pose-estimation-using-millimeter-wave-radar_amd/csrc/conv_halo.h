@@ -35,13 +35,6 @@ struct HaloArgs {
     float* part;
     int units_per_slice;
     int no_res_prefetch;     // A/B aid (hupr_debug_halo_res_prefetch(0)): 256-voxel 16 x 16 x 32 kernel, residual read in the immediate epilogue as in rounds 4-5a
-    // 256-voxel kernel with fused statistics only (hupr_conv3x3_halo_bf16act_stats_bnrelu): x is the previous convolution's raw output,
-    // the kernel applies relu(in_scale[c] * x + in_shift[c]) per input channel while committing the halo to LDS and writes the
-    // activated tensor (leading dimension act_ld) to act_out; null = plain input
-    const float* in_scale;
-    const float* in_shift;
-    void* act_out;
-    int act_ld;
 };
 
 // fp32 partial sums of a K slice: this lane's voxel, its four 4-channel runs (see halo_store_voxel for the lane -> channel map)

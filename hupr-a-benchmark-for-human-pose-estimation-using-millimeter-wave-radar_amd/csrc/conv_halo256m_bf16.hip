@@ -39,13 +39,7 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // which existed for layers of ONE output tile on the 4 x 8 x 8 kernel only — encoder level 1; levels 2 and 3, Co = 128 / 256, ran a
 // statistics pass over the stored tensor per BatchNorm: 24 launches per step).  Level 2 at the bench batch: 4 tiles per workgroup,
 // alternating between its 2 output tiles; level 3: one tile per workgroup.
-// INACT (round 6): the input x is the RAW output of the previous convolution and this kernel applies that
-// layer's BatchNorm + ReLU, relu(in_scale[c] * x + in_shift[c]), to every halo item on its way from the load registers to LDS —
-// the arithmetic of hupr_k_scale_shift_act (one fma, one max, one rounding to bf16: the same bits) — so that the separate
-// scale-shift-activation pass over the tensor disappears; voxels outside the tensor stay zero (the padding applies AFTER the
-// activation).  The workgroup that multiplies output tile 0 of a spatial tile also writes the activated interior voxels to act_out
-// (the tensor the weight gradient of this convolution reads, and what the unfused pass used to write).
-template <int TD, int TH, int TW, int KD, int NCOT = 0, bool INACT = false>
+template <int TD, int TH, int TW, int KD, int NCOT = 0>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
     constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
@@ -59,8 +53,6 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     static_assert(NH <= 6 * NSTAGE - 1 && NH <= 17, "halo items must all be issued in front of the item's last barrier (and within three stages)");
     __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];
-    __shared__ __attribute__((aligned(16))) float Cf[INACT ? 2 * 256 : 4];      // INACT: in_scale[Ci] | in_shift[Ci] (Ci <= 256)
-    unsigned okm = 0;                                                             // INACT: bit u = halo item u of the pending fill lies inside the tensor
     // fused BatchNorm statistics: per lane and output-channel tile the running sums of its eight channels over its voxels (bf16-ROUNDED
     // outputs) in REGISTERS — ssum / ssq [tile][cg][r] — reduced over the sixteen voxel lanes and the four voxel-block waves once,
     // after the tile loop, in double (through the halo image's LDS, dead by then)
@@ -119,47 +111,14 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         const int off = (((((B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8) * 2;                  \
         const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : 0x7ffffff0, 0, 0);                  \
         vb[u] = (u32x4){ld_[0], ld_[1], ld_[2], ld_[3]};                                                            \
-        if constexpr (INACT) okm = (okm & ~(1u << (u))) | ((ok ? 1u : 0u) << (u));                                  \
     }
-    // (B_, D0_, H0_, W0_, CH_, COT_: the item the committed halo belongs to — only the INACT form uses them)
-    // INACT: every item of a thread holds the same eight channels (chunk c8 = tid & 7), so the coefficient pairs are read from LDS
-    // once per dword position j and applied to that dword of all items (four coefficient registers live instead of sixteen)
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
-        INACT ? p.act_out : nullptr, 0, INACT && p.act_out ? (int)((long)p.Bn * p.D * p.H * p.W * p.act_ld * 2) : 0, 0x00020000);
-#define HUPR_HALO_COMMIT(B_, D0_, H0_, W0_, CH_, COT_)                                                              \
-    {                                                                                                               \
-        if constexpr (INACT) {                                                                                      \
-            const int cc_ = (CH_) * KC + (tid & 7) * 8;                                                             \
-            typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));                                             \
-            typedef float f32x2_ __attribute__((ext_vector_type(2)));                                               \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
-                const f32x2_ sc_ = *reinterpret_cast<const f32x2_*>(&Cf[cc_ + 2 * j]);                              \
-                const f32x2_ sh_ = *reinterpret_cast<const f32x2_*>(&Cf[256 + cc_ + 2 * j]);                        \
-                _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                    \
-                    if ((okm >> u) & 1u) {                        /* outside the tensor: stays zero (padding AFTER the activation) */ \
-                        const float lo_ = __uint_as_float(vb[u][j] << 16), hi_ = __uint_as_float(vb[u][j] & 0xffff0000u); \
-                        const bf16x2_ pk_ = {(__bf16)fmaxf(fmaf(lo_, sc_[0], sh_[0]), 0.f), (__bf16)fmaxf(fmaf(hi_, sc_[1], sh_[1]), 0.f)}; \
-                        vb[u][j] = __builtin_bit_cast(unsigned, pk_);                                               \
-                    }                                                                                               \
-                }                                                                                                   \
-            }                                                                                                       \
-        }                                                                                                           \
-        _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                            \
-            const int it = tid + u * 512;                                                                           \
-            if (it < NVOX * C8) {                                                                                   \
-                const int vox = it >> 3, c8 = it & 7;                                                               \
-                const int hx = vox % HW;                                                                            \
-                if constexpr (INACT) {                                                                              \
-                    const int t2_ = vox / HW;                                                                       \
-                    const int hy_ = t2_ % HH, hz_ = t2_ / HH;                                                       \
-                    const bool in_ = p.act_out && (COT_) == 0 && (unsigned)(hx - 1) < (unsigned)TW &&               \
-                                     (unsigned)(hy_ - 1) < (unsigned)TH && (unsigned)(hz_ - KD / 2) < (unsigned)TD; \
-                    const int ao_ = ((((((B_) * p.D + (D0_) + hz_ - KD / 2) * p.H + (H0_) + hy_ - 1) * p.W + (W0_) + hx - 1) * p.act_ld + \
-                                      (CH_) * KC + c8 * 8) * 2);                                                    \
-                    __builtin_amdgcn_raw_buffer_store_b128(vb[u], ars, in_ ? ao_ : 0x7ffffff0, 0, 0);              \
-                }                                                                                                   \
-                *reinterpret_cast<u32x4*>(&Hs[vox * LDK + ((c8 ^ (((hx >> 1) & 3) << 1)) << 3)]) = vb[u];          \
-            }                                                                                                       \
+#define HUPR_HALO_COMMIT()                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
+        const int it = tid + u * 512;                                                                               \
+        if (it < NVOX * C8) {                                                                                       \
+            const int vox = it >> 3, c8 = it & 7;                                                                   \
+            const int hx = vox % HW;                                                                                \
+            *reinterpret_cast<u32x4*>(&Hs[vox * LDK + ((c8 ^ (((hx >> 1) & 3) << 1)) << 3)]) = vb[u];              \
         }                                                                                                           \
     }
 
@@ -242,11 +201,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     HUPR_W_DMA(cur.cot, cur.ch, 1, 1)
 #pragma unroll
     for (int u = 0; u < NH; ++u) HUPR_HALO_ISSUE_ITEM(u, true, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
-    if constexpr (INACT) {
-        for (int i = tid; i < p.Ci; i += 512) { Cf[i] = p.in_scale[i]; Cf[256 + i] = p.in_shift[i]; }
-        __syncthreads();
-    }
-    HUPR_HALO_COMMIT(cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch, cur.cot)
+    HUPR_HALO_COMMIT()
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     HUPR_LOAD_TAP(0, 0, 0, 3)
@@ -293,7 +248,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                     __syncthreads();
                     if (st_ + 2 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 2, par) }
                     else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, st_ + 2 - NSTAGE, par) }
-                    if (st_ == NSTAGE - 1 && has_next) { HUPR_HALO_COMMIT(nxt.b, nxt.tdi * TD, nxt.thi * TH, nxt.twi * TW, nxt.ch, nxt.cot) }
+                    if (st_ == NSTAGE - 1 && has_next) { HUPR_HALO_COMMIT() }
                 }
                 // the next tap's fragments: of this stage, or tap 0 of the next one (across an item boundary only its weights)
                 if (tau == 0) { HUPR_LOAD_TAP(st_, 1, par, 3) }
@@ -483,14 +438,7 @@ static void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
         const long tiles = (long)a.Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
         const long per_wg = (tiles + kHalo256Grid - 1) / kHalo256Grid;
         const bool one = per_wg == 1 || a.n_co_tiles == 1;
-        if (a.in_scale) {                     // ... with the previous layer's BatchNorm + ReLU applied to the input on its way into LDS
-            if (a.TD == 4) {
-                if (one) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 1, true>), grid, wg, 0, s, a);
-                else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 2, true>), grid, wg, 0, s, a);
-            } else {
-                HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<2, 8, 16, 3, 1, true>), grid, wg, 0, s, a);
-            }
-        } else if (a.TD == 4) {
+        if (a.TD == 4) {
             if (one) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 1>), grid, wg, 0, s, a);
             else HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 2>), grid, wg, 0, s, a);
         } else {

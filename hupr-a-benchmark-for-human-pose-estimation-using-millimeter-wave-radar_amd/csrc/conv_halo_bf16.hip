@@ -446,8 +446,7 @@ extern "C" void hupr_debug_halo_res_prefetch(int on) { g_halo_no_res_prefetch = 
 static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, const void* res, void* y, int Bn, int D,
                         int H, int W, int Ci, int in_ld, int Co, int out_ld, int res_ld, int kd, bool abf,
                         hupr_stream_t stream, const char* who, double* stats = nullptr, void* ws = nullptr, size_t ws_bytes = 0,
-                        bool partial_only = false, const float* in_scale = nullptr, const float* in_shift = nullptr,
-                        void* act_out = nullptr) {
+                        bool partial_only = false) {
     HUPR_REQUIRE(x && wp_bf16 && y, "%s: null pointer", who);
     HUPR_REQUIRE(hupr_conv3x3_halo_supported(D, H, W, Ci, kd, 3, 3, kd / 2, 1, 1), "%s: unsupported geometry", who);
     const int al = abf ? 8 : 4;                      // 16-byte halo loads, 4-channel output vectors
@@ -463,9 +462,6 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     a.part = nullptr;
     a.units_per_slice = 0;
     a.no_res_prefetch = g_halo_no_res_prefetch;
-    a.in_scale = in_scale; a.in_shift = in_shift; a.act_out = act_out; a.act_ld = Ci;
-    HUPR_REQUIRE(!in_scale || (stats && in_shift && Ci <= 256 && Ci % 64 == 0),
-                 "%s: the fused input activation needs the statistics form and Ci %% 64 == 0, Ci <= 256", who);
     if (stats) {
         HUPR_REQUIRE(abf && !bias && !res && conv_halo256_stats_ok(a, Bn),
                      "%s: fused statistics need the 256-voxel kernel (see hupr_conv3x3_halo_stats_supported), no bias / residual", who);
@@ -587,18 +583,6 @@ extern "C" int hupr_conv3x3_halo_stats_supported(int Bn, int D, int H, int W, in
     return (Bn > 0 && conv_halo256_stats_ok(a, Bn)) ? 1 : 0;
 }
 extern "C" int hupr_conv3x3_halo_stats_rows(void) { return kHalo256Grid; }
-// The same with the PREVIOUS layer's BatchNorm + ReLU fused into the input path (models/layers.py:55-60: conv -> bn -> relu -> conv):
-// x is the raw output of the previous convolution, the kernel multiplies relu(in_scale[c] * x + in_shift[c]) (rounded to bf16 like the
-// stored activation) and writes that activated tensor to act_out (same shape as x; may be null when nothing else reads it).  Replaces
-// one hupr_scale_shift_act_bf16act pass; bit-identical to it followed by hupr_conv3x3_halo_bf16act_stats.
-extern "C" int hupr_conv3x3_halo_bf16act_stats_bnrelu(const void* x, const float* in_scale, const float* in_shift, void* act_out,
-                                                      const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci, int in_ld, int Co,
-                                                      int out_ld, int kd, void* stats, hupr_stream_t stream) {
-    HUPR_REQUIRE(stats && in_scale && in_shift, "hupr_conv3x3_halo_bf16act_stats_bnrelu: null pointer");
-    HUPR_REQUIRE(in_ld == Ci, "hupr_conv3x3_halo_bf16act_stats_bnrelu: x must be dense (in_ld == Ci)");
-    return conv3x3_halo(x, wp_bf16, nullptr, nullptr, y, Bn, D, H, W, Ci, in_ld, Co, out_ld, 0, kd, true, stream,
-                        "hupr_conv3x3_halo_bf16act_stats_bnrelu", static_cast<double*>(stats), nullptr, 0, false, in_scale, in_shift, act_out);
-}
 extern "C" int hupr_conv3x3_halo_bf16act_stats(const void* x, const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci,
                                                int in_ld, int Co, int out_ld, int kd, void* stats, hupr_stream_t stream) {
     HUPR_REQUIRE(stats, "hupr_conv3x3_halo_bf16act_stats: null pointer");

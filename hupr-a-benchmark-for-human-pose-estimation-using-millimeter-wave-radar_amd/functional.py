@@ -1021,77 +1021,6 @@ class BNActFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None
 
 
-BN_CONV_FUSION = True      # test aid: False = BatchNorm + ReLU as its own pass in front of the block's second convolution
-
-
-def bn_relu_conv_ok(x, weight, pad, training):
-    """BasicBlock3D's main[1..3] (BatchNorm -> ReLU -> convolution, reference models/layers.py:55-60) as ONE node: the convolution
-    kernel applies scale / shift / ReLU to its halo on the way into LDS (hupr_conv3x3_halo_bf16act_stats_bnrelu).  Training mode,
-    bf16-stored activations, the envelope of the fused-statistics convolution."""
-    if not (BN_CONV_FUSION and CONV_STATS and training and _st.math == "bf16" and x.is_cuda and x.dtype == torch.bfloat16):
-        return False
-    B, D, H, W, Ci = _vox(x)
-    k = _ksize(weight)
-    co = weight.shape[0]
-    return (weight.shape[1] == Ci and Ci % 64 == 0 and Ci <= 256 and tuple(pad) == (k[0] // 2, 1, 1) and _halo_ok(x, k, pad, co)
-            and bool(rt.lib().hupr_conv3x3_halo_stats_supported(B, D, H, W, Ci, co, k[0])))
-
-
-@_math_scoped
-class BNReLUConvFn(torch.autograd.Function):
-    """y = conv(relu(batch_norm(x)), weight) with the convolution leaving the column sums of y for the BatchNorm that follows.
-    x: the raw bf16 output of the block's first convolution.  Saves x and the activated tensor a (written by the convolution kernel:
-    the weight gradient reads it); the backward is ConvFn's followed by BNActFn's on the same kernels."""
-
-    @staticmethod
-    def forward(ctx, x, gamma, beta, bn, weight, pad, no_bwd=False):
-        x = _c(x)
-        B, D, H, W, Ci = _vox(x)
-        k = _ksize(weight)
-        co = weight.shape[0]
-        L = rt.lib()
-        scale, shift, mean, invstd = _bn_params(x, bn, True, not no_bwd)
-        a = None if no_bwd else torch.empty_like(x)
-        y = torch.empty((B, D, H, W, co), dtype=x.dtype, device=x.device)
-        rows = L.hupr_conv3x3_halo_stats_rows()
-        st = torch.empty((rows, 2, co), dtype=torch.float64, device=x.device)
-        wp = _packed(weight, 0, 1)
-        ev = CONV_PROBE(x, co, k) if CONV_PROBE is not None else None
-        if ev is not None:
-            ev[0].record()
-        rt.check(L.hupr_conv3x3_halo_bf16act_stats_bnrelu(rt.ptr(x), rt.ptr(scale), rt.ptr(shift), rt.ptr(a) if a is not None else None,
-                                                          rt.ptr(wp), rt.ptr(y), B, D, H, W, Ci, Ci, co, co, k[0], rt.ptr(st), rt.stream()))
-        if ev is not None:
-            ev[1].record()
-        _conv_stats[y.data_ptr()] = (st, rows, B * D * H * W, co)
-        ctx.save_for_backward(x, a, mean, invstd, gamma, scale, shift, weight)
-        ctx.beta_ref = beta
-        ctx.k, ctx.pad = k, pad
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, a, mean, invstd, gamma, scale, shift, weight = ctx.saved_tensors
-        dy = _c(dy)
-        k, pad = ctx.k, ctx.pad
-        B, D, H, W, Ci = _vox(x)
-        Co = weight.shape[0]
-        L = rt.lib()
-        # the convolution's backward on the activated tensor: input gradient (flipped / transposed packed weights), weight gradient
-        dpad = (k[0] - 1 - pad[0], k[1] - 1 - pad[1], k[2] - 1 - pad[2])
-        da = _conv_raw(dy, weight, 1, None, None, Ci, k, dpad, (D, H, W))
-        dw = None
-        dw_direct = False
-        if ctx.needs_input_grad[4]:
-            dw, dw_direct = _pgrad(weight)
-            ws = workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, k[0]), x.device)
-            rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(rt.ptr(a), rt.ptr(dy), rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, k[0], rt.ptr(ws), ws.numel(),
-                                                       rt.stream()))
-        # BatchNorm + ReLU backward (mask recomputed from x with the forward's scale / shift)
-        dx, dg, db = _bn_bwd(da, x, mean, invstd, gamma, True, ctx.beta_ref, fwd=(scale, shift))
-        return dx, dg, db, None, _pret(weight, dw, dw_direct) if dw is not None else None, None, None
-
-
 @_math_scoped
 class BNAddBNReLUFn(torch.autograd.Function):
     """y = relu(bn_a(x1) + bn_b(x2)) — the tail of BasicBlock3D.forward (models/layers.py:66-70)."""

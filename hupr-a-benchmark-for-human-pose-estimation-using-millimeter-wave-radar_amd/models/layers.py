@@ -88,13 +88,8 @@ class BasicBlock3D(nn.Module):
                                 stats=self.training)
         bn1 = self.main[1]
         no_bwd = not torch.is_grad_enabled()
-        pad3 = tuple(self.main[3].padding)
-        if F_.bn_relu_conv_ok(out, self.main[3].weight, pad3, self.training):
-            # BatchNorm + ReLU applied by the second convolution on its input's way into LDS: no pass of its own over the tensor
-            out = F_.BNReLUConvFn.apply(out, bn1.weight, bn1.bias, bn1, self.main[3].weight, pad3, no_bwd)
-        else:
-            out = F_.BNActFn.apply(out, bn1.weight, bn1.bias, bn1, self.training, True, no_bwd)
-            out = F_.conv(out, self.main[3].weight, None, None, pad3, stats=self.training)
+        out = F_.BNActFn.apply(out, bn1.weight, bn1.bias, bn1, self.training, True, no_bwd)
+        out = F_.conv(out, self.main[3].weight, None, None, tuple(self.main[3].padding), stats=self.training)
         bn2, bnd = self.main[4], self.downsample[1]
         return F_.BNAddBNReLUFn.apply(out, bn2.weight, bn2.bias, bn2, res, bnd.weight, bnd.bias, bnd, self.training, no_bwd)
 

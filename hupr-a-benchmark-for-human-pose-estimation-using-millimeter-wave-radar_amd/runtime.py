@@ -64,7 +64,6 @@ SIGNATURES = {
     "hupr_conv3x3_halo_stats_supported": (c_int, [c_int] * 7),
     "hupr_conv3x3_halo_stats_rows": (c_int, []),
     "hupr_conv3x3_halo_bf16act_stats": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p]),
-    "hupr_conv3x3_halo_bf16act_stats_bnrelu": (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
     "hupr_bn_train_finalize_f32": (c_int, [c_void_p, c_int, c_long, c_int] + [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 5),
     "hupr_bn_train_finalize2_f32": (c_int, ([c_void_p, c_int] + [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 4) * 2
                                     + [c_long, c_int, c_void_p]),

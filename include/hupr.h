@@ -199,15 +199,6 @@ int hupr_conv3x3_halo_stats_supported(int Bn, int D, int H, int W, int Ci, int C
 int hupr_conv3x3_halo_stats_rows(void);
 int hupr_conv3x3_halo_bf16act_stats(const void* x, const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci,
                                     int in_ld, int Co, int out_ld, int kd, void* stats, hupr_stream_t stream);
-/* The same with the PREVIOUS layer's BatchNorm + ReLU fused into the input path — BasicBlock3D.forward, models/layers.py:55-60:
- * conv -> bn -> relu -> conv.  x: the raw bf16 output of the previous convolution (dense, Ci channels); in_scale / in_shift: that
- * BatchNorm's per-channel coefficients (hupr_bn_train_finalize_f32); the kernel multiplies relu(in_scale[c] * x + in_shift[c]),
- * rounded to bf16 exactly like hupr_scale_shift_act_bf16act stores it, and writes that activated tensor to act_out (shape of x; the
- * weight gradient of this convolution reads it; null: not written).  Bit-identical to the two separate calls; same envelope as
- * hupr_conv3x3_halo_stats_supported with Ci % 64 == 0, Ci <= 256. */
-int hupr_conv3x3_halo_bf16act_stats_bnrelu(const void* x, const float* in_scale, const float* in_shift, void* act_out,
-                                           const void* wp_bf16, void* y, int Bn, int D, int H, int W, int Ci, int in_ld, int Co,
-                                           int out_ld, int kd, void* stats, hupr_stream_t stream);
 int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co, int Ci, int taps, int mode,
                                 hupr_stream_t stream);
 /* Repack many weights (both layouts each) in ONE launch.  descs_dev: device array of 48-byte records

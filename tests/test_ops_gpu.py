@@ -1657,46 +1657,3 @@ def test_streaming_temporal_merge_matches_the_generic_kernel(B, H, bf16_math):
     close(dw1, dw0, 5e-5, "streaming vs generic wgrad")
     dx2, dw2 = grads()
     assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2), "the streaming backward is deterministic"
-
-
-@pytest.mark.parametrize("shape", [(4, 64, 64, 8, 64, 64), (9, 128, 128, 4, 32, 32), (5, 64, 128, 8, 32, 64), (32, 256, 256, 2, 16, 16)])
-def test_batchnorm_relu_fused_into_the_next_convolution_is_bit_identical(shape, bf16_math):
-    """Round 6: BasicBlock3D's bn -> relu -> conv (reference models/layers.py:55-60) as ONE node — the convolution
-    applies scale / shift / ReLU to its halo on the way into LDS and writes the activated tensor for its own weight gradient
-    (hupr_conv3x3_halo_bf16act_stats_bnrelu) — against the separate scale-shift-activation pass + convolution: outputs, the fused
-    BatchNorm column sums of the output, running statistics and all four gradients (input, gamma, beta, weight) bit for bit; one and
-    two channel chunks, one / two / four output tiles, the 4 x 8 x 8 and the 2 x 8 x 16 tile; padding applied AFTER the activation
-    (a border voxel sees zeros, not relu(shift))."""
-    import torch.nn as nn
-    from hupr_amd import functional as F_
-    B, Ci, Co, D, H, W = shape
-    x = (rnd(B, D, H, W, Ci, seed=700) * 1.5 + 0.25).cuda().bfloat16()
-    w = rnd(Co, Ci, 3, 3, 3, seed=701, scale=(Ci * 27) ** -0.5).cuda().requires_grad_(True)
-    g0, b0 = (1.0 + 0.2 * rnd(Ci, seed=702)).cuda(), (0.3 * rnd(Ci, seed=703)).cuda()       # negative shifts included: relu(shift) != 0 somewhere
-    dy = rnd(B, D, H, W, Co, seed=704).cuda().bfloat16()
-    res = {}
-    assert F_.bn_relu_conv_ok(x, w, (1, 1, 1), True)
-    for fused in (False, True):
-        bn = nn.BatchNorm3d(Ci).cuda().train()
-        with torch.no_grad():
-            bn.weight.copy_(g0); bn.bias.copy_(b0)
-        xi = x.clone().requires_grad_(True)
-        w.grad = None
-        F_._conv_stats.clear()
-        if fused:
-            y = F_.BNReLUConvFn.apply(xi, bn.weight, bn.bias, bn, w, (1, 1, 1), False)
-        else:
-            a = F_.BNActFn.apply(xi, bn.weight, bn.bias, bn, True, True, False)
-            y = F_.conv(a, w, None, None, (1, 1, 1), stats=True)
-        st = F_._conv_stats.pop(y.data_ptr())[0].clone()
-        y.backward(dy)
-        torch.cuda.synchronize()
-        res[fused] = (y.detach().clone(), st, xi.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), w.grad.clone(),
-                      bn.running_mean.clone(), bn.running_var.clone())
-    names = ("y", "column sums of y", "dx", "dgamma", "dbeta", "dw", "running_mean", "running_var")
-    for n, a, b in zip(names, res[True], res[False]):
-        assert torch.equal(a, b), n
-    assert all(torch.isfinite(t.float()).all() for t in res[True])
-    # the activation really was applied (the output differs from the convolution of the raw input)
-    y_raw = F_._conv_raw(x, w.detach(), 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
-    assert not torch.equal(y_raw, res[True][0])
