@@ -749,6 +749,9 @@ def main():
             "model_frac_of_mfma_peak": round(value * STEP_GFLOP / 1e3 / world / peak, 4),
             "loss": round(loss_value, 5),
             "launches_per_step": round(launches_native, 1),
+            "launches_per_step_note": "library launches counted by the C ABI over the timed region, in THIS run's stream mode (%s): with one compute "
+                                      "stream the twelve PReLU slope-gradient sums are one deferred launch (functional.PRELU_DEFER), with two "
+                                      "streams they are twelve" % ("two compute streams" if F_.TWO_STREAMS else "one compute stream"),
             "launch_census": launch_census,
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
             "host_enqueue_ms_per_step_by_rank": [round(float(x), 2) for x in enq_ranks],
