@@ -1350,6 +1350,7 @@ class AttentionFn(torch.autograd.Function):
 
 _level_cat_out = {}      # {"out": view}: where the NEXT fused level writes its concatenated bf16 output (models/layers.py sets it)
 CAT_FUSION = True          # fused levels return their maps concatenated as bf16
+PROJ_STREAM = True         # test aid: False = the level's projections through the generic implicit-GEMM engine
 
 
 def mscsa_level_fused_ok(ra):
@@ -1498,6 +1499,10 @@ class MSCSALevelFn(torch.autograd.Function):
         Wf = (pa[1], pe[1]) if qscaled else Wc                # what the forward projections multiply by
         Y = (torch.empty((B, N, 4 * C), dtype=ydt, device=dev), torch.empty((B, N, 4 * C), dtype=ydt, device=dev))
         for x, wc, y in zip(maps, Wf, Y):          # a 1x1 kernel's packed layout IS the parameter layout (Co, Ci)
+            if flash and PROJ_STREAM and L.hupr_mscsa_proj_supported(B * N, C):
+                # the four projections of the map as one HBM-bound streaming product (csrc/projection.hip)
+                rt.check(L.hupr_mscsa_proj_fwd_bf16(rt.ptr(x), rt.ptr(wc), rt.ptr(y), B * N, C, rt.stream()))
+                continue
             rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(y), 1 if flash else 0, B, 1, H, W, C, C,
                                                 1, H, W, 4 * C, 4 * C, 1, 1, 1, 0, 0, 0, rt.stream()))
         outs = [torch.empty((B, 1, H, W, C), dtype=torch.float32, device=dev) for _ in range(4)]
@@ -1653,8 +1658,11 @@ class MSCSALevelFn(torch.autograd.Function):
         for i in range(2):
             if ctx.needs_input_grad[i]:
                 dx = torch.empty_like(maps[i])
-                rt.check(L.hupr_gemm_bf16(0, 0, rt.ptr(dY[i]), rt.ptr(Wc[i]), rt.ptr(dx), B * N, C, 4 * C, 4 * C, C, C, 1, 0, 0,
-                                          0, rt.ptr(dV[i]), C, 0, 0, rt.stream()))
+                if PROJ_STREAM and L.hupr_mscsa_proj_dgrad_supported(B * N, C):
+                    rt.check(L.hupr_mscsa_proj_dgrad_f32(rt.ptr(dY[i]), rt.ptr(Wc[i]), rt.ptr(dV[i]), rt.ptr(dx), B * N, C, rt.stream()))
+                else:
+                    rt.check(L.hupr_gemm_bf16(0, 0, rt.ptr(dY[i]), rt.ptr(Wc[i]), rt.ptr(dx), B * N, C, 4 * C, 4 * C, C, C, 1, 0, 0,
+                                              0, rt.ptr(dV[i]), C, 0, 0, rt.stream()))
                 grads[i] = dx
         wgrads = [None] * 8
         dsts, srcs, landed = [], [], []

@@ -183,6 +183,10 @@ SIGNATURES = {
     "hupr_interp_linear_bwd_acc_bf16act": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "hupr_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
     "hupr_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p]),
+    "hupr_mscsa_proj_supported": (c_int, [c_long, c_int]),
+    "hupr_mscsa_proj_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "hupr_mscsa_proj_dgrad_supported": (c_int, [c_long, c_int]),
+    "hupr_mscsa_proj_dgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     # (e) RCCL exchange step
     "hupr_comm_load": (c_int, [c_char_p]),
     "hupr_comm_unique_id": (c_int, [c_void_p]),

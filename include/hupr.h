@@ -533,6 +533,17 @@ int hupr_interp_linear_bwd_acc_bf16act(const void* dy, void* dx, int Bn, int Di,
 int hupr_cast_f32_to_bf16(const float* x, void* y, long n, hupr_stream_t stream);
 int hupr_cast_bf16_to_f32(const void* x, float* y, long n, hupr_stream_t stream);
 
+/* (a5) The four 1 x 1 projections of one map of an MSCSA level (models/layers.py:150-157: phi / theta, cross / self — bias-free
+ *      nn.Conv2d(C, C, 1)) as ONE streaming product: Y (M, 4 C) bf16 = X (M, C) fp32 . Wc^T with Wc (4 C, C) fp32 the four weight
+ *      matrices stacked in the order the caller reads their column blocks (functional.MSCSALevelFn: [phi_cross | theta_cross | phi_self |
+ *      theta_self], query rows pre-scaled by log2 e for the QS attention kernels); M = B H W channels-last rows.  Same operand roundings
+ *      as hupr_conv_fwd_bf16_mixed with a bf16 epilogue (which it replaces for C in {64, 128}: levels 1 and 2); HBM-bound. */
+int hupr_mscsa_proj_supported(long M, int C);
+int hupr_mscsa_proj_fwd_bf16(const float* X, const float* Wc, void* Y, long M, int C, hupr_stream_t stream);
+/* its input gradient: dX (M, C) fp32 = dY (M, 4 C) fp32 . Wc (+ res (M, C) fp32 or null — the map's value gradient dV) */
+int hupr_mscsa_proj_dgrad_supported(long M, int C);      /* C == 64 (level 1) */
+int hupr_mscsa_proj_dgrad_f32(const float* dY, const float* Wc, const float* res, float* dX, long M, int C, hupr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * (e) Data-parallel exchange over RCCL / xGMI.  Nothing in the reference to mirror: it trains on one
  *     device (tools/base.py:14 `self.device = 'cuda'`, tools/run.py:76-79 forward / backward / step with no

@@ -1657,3 +1657,59 @@ def test_streaming_temporal_merge_matches_the_generic_kernel(B, H, bf16_math):
     close(dw1, dw0, 5e-5, "streaming vs generic wgrad")
     dx2, dw2 = grads()
     assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2), "the streaming backward is deterministic"
+
+
+@pytest.mark.parametrize("shape", [(32, 4096, 64), (32, 1024, 128), (1, 4096, 64), (3, 1008, 128), (2, 72, 64)])
+def test_mscsa_projection_stream_kernel(shape, bf16_math):
+    """Round 6: the four 1 x 1 projections of an MSCSA map (reference models/layers.py:150-157) as one streaming product
+    (csrc/projection.hip: weights resident in LDS, rows straight from global memory into MFMA fragments) against the implicit-GEMM engine
+    it replaces — same operand roundings, another fp32 order inside a row: a few outputs one bf16 step apart — and against fp64 on the
+    bf16-rounded operands; a row count that is not a multiple of the 64-row workgroup step; deterministic."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    B, N, C = shape
+    M = B * N
+    x = rnd(M, C, seed=800).cuda()
+    wc = rnd(4 * C, C, seed=801, scale=C ** -0.5).cuda()
+    assert L.hupr_mscsa_proj_supported(M, C)
+    y = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    y2 = torch.full_like(y, float("nan"))
+    rt.check(L.hupr_mscsa_proj_fwd_bf16(rt.ptr(x), rt.ptr(wc), rt.ptr(y), M, C, rt.stream()))
+    rt.check(L.hupr_mscsa_proj_fwd_bf16(rt.ptr(x), rt.ptr(wc), rt.ptr(y2), M, C, rt.stream()))
+    assert torch.equal(y, y2) and torch.isfinite(y.float()).all()
+    ref = _bf16_round(x.cpu()).double() @ _bf16_round(wc.cpu()).double().t()
+    close(y.float().cpu(), ref, 1e-2, "projection (bf16 store) vs fp64")
+    if N % 64 == 0:
+        H = int(round(N ** 0.5))
+        ye = torch.empty_like(y)
+        rt.check(L.hupr_conv_fwd_bf16_mixed(rt.ptr(x), 0, rt.ptr(wc), None, rt.ptr(ye), 1, B, 1, H, N // H, C, C, 1, H, N // H, 4 * C, 4 * C,
+                                            1, 1, 1, 0, 0, 0, rt.stream()))
+        d = (y.float() - ye.float()).abs()
+        assert (d > 0).float().mean().item() < 5e-3 and (d <= torch.maximum(y.float().abs(), ye.float().abs()) * 2 ** -7 + 1e-6).all()
+
+
+@pytest.mark.parametrize("shape", [(32, 4096, 64), (1, 4096, 64), (3, 1008, 64), (2, 72, 64)])
+def test_mscsa_projection_input_gradient_stream_kernel(shape, bf16_math):
+    """The input gradient of the fused projections, dX = dY . Wc + dV (functional.MSCSALevelFn.backward), as a streaming kernel against
+    the GEMM engine call it replaces (same operand roundings, fp32 accumulate; another K order: 1e-6-relative differences) and against
+    fp64 on the bf16-rounded operands; with and without the residual term; deterministic."""
+    from hupr_amd import functional as F_
+    L, rt = F_.rt.lib(), F_.rt
+    B, N, C = shape
+    M = B * N
+    dy = rnd(M, 4 * C, seed=810).cuda()
+    wc = rnd(4 * C, C, seed=811, scale=C ** -0.5).cuda()
+    dv = rnd(M, C, seed=812).cuda()
+    ref = _bf16_round(dy.cpu()).double() @ _bf16_round(wc.cpu()).double()
+    for res in (dv, None):
+        dx = torch.full((M, C), float("nan"), device="cuda")
+        dx2 = torch.full_like(dx, float("nan"))
+        rt.check(L.hupr_mscsa_proj_dgrad_f32(rt.ptr(dy), rt.ptr(wc), rt.ptr(res) if res is not None else None, rt.ptr(dx), M, C, rt.stream()))
+        rt.check(L.hupr_mscsa_proj_dgrad_f32(rt.ptr(dy), rt.ptr(wc), rt.ptr(res) if res is not None else None, rt.ptr(dx2), M, C, rt.stream()))
+        assert torch.equal(dx, dx2) and torch.isfinite(dx).all()
+        want = ref + (dv.cpu().double() if res is not None else 0.0)
+        close(dx.cpu(), want, 2e-5, "projection input gradient vs fp64")
+        de = torch.empty_like(dx)
+        rt.check(L.hupr_gemm_bf16(0, 0, rt.ptr(dy), rt.ptr(wc), rt.ptr(de), M, C, 4 * C, 4 * C, C, C, 1, 0, 0, 0,
+                                  rt.ptr(res) if res is not None else None, C, 0, 0, rt.stream()))
+        close(dx, de, 2e-5, "projection input gradient vs the GEMM engine")
