@@ -1,6 +1,6 @@
 // The 256-voxel persistent halo convolution (3 x 3 (x 3) taps, bf16-stored activations) on v_mfma_f32_16x16x32_bf16 — the kernel
 // the encoder's and decoder's convolutions and input gradients run on (conv_halo_bf16.hip holds the 128-voxel kernel for everything
-// outside this envelope, conv_halo512_bf16.hip the Co = 32 input gradient of the first layer).
+// outside this envelope — the first layer's 64 -> 32 input gradient among them —, conv_halo512_bf16.hip the first layer's Ci = 32 forward).
 //
 // Design, as the measurements of rounds 2-5 shaped it (64 -> 64 channels, 3 x 3 x 3 taps, B = 32):
 //   * one persistent 512-thread workgroup per CU walks a contiguous run of 4 x 8 x 8-voxel x 64-channel tiles (an eighth of the

@@ -20,9 +20,7 @@
 // barriers — the matrix pipe fed from LDS is power-limited well below its nominal rate (scripts/probes/mfma_peak_probe.hip:
 // 1 850 TF/s register-only, 1 475 / 1 573 TF/s with 7 / 4 fragment reads per 6 MFMAs), and the bigger tile pays more for
 // fill and epilogue.  It wins only where the 256-voxel kernel does not apply: Ci = 32 (the encoder's first layer, one chunk:
-// 130 vs 150 us).  The dispatcher therefore selects it for Ci == 32 only; HUPR_HALO512_ALL=1 widens it to its envelope.
-#include <stdlib.h>
-
+// 130 vs 150 us).  The dispatcher therefore selects it for Ci == 32 only.
 #include "conv_halo.h"
 
 namespace hupr {
@@ -263,8 +261,7 @@ bool conv_halo512_supported(const HaloArgs& a, int Bn, bool abf) {
 
 bool launch_conv_halo512(HaloArgs a, int Bn, bool abf, hipStream_t s) {
     if (!conv_halo512_supported(a, Bn, abf)) return false;
-    static const bool all = getenv("HUPR_HALO512_ALL") && getenv("HUPR_HALO512_ALL")[0] == '1';
-    if (a.Ci != 32 && !all) return false;                       // see the measurement note at the top of this file
+    if (a.Ci != 32) return false;                               // see the measurement note at the top of this file
     a.TD = 4;
     a.log2TW = 4;
     a.nd = a.D / 4;
