@@ -159,7 +159,7 @@ __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img,
     // all A fragments of the 64 x D image rows are read before the first MFMA (hipcc otherwise issues each read right in
     // front of its MFMA and every MFMA waits out the LDS latency)
     // (D = 256: in chunks of four K-steps — sixteen would hold 128 registers of fragments)
-    constexpr int KS = D / 16, CHK = KS > 8 ? 4 : KS;
+    constexpr int KS = D / 16, CHK = KS >= 8 ? 4 : KS;      // (D = 128: chunks of four since round 6 — 32 fragment registers instead of 64; same MFMA order)
     if constexpr (ZERO) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -325,8 +325,10 @@ struct AttnBatch {
     __bf16* out16[4];
 };
 
+// Two workgroups per CU (<= 256 unified registers) at D = 128 as well (round 6): the level-2 forward had compiled to 316 registers = ONE
+// wave per SIMD, every MFMA result shuttled through AGPRs, nothing to overlap a wave's own latencies with (150 us for 69 GF).
 template <int D, typename TI, bool SPLIT = false, bool QS = false>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
+__global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void hupr_k_attn_fwd(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                        const TI* __restrict__ V, const float* __restrict__ Vres,
                                                        float* __restrict__ out, float* __restrict__ lse, int N, int ldk,
                                                        int ldq, __bf16* __restrict__ out16, int ld16,
@@ -363,11 +365,18 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
         }
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
-    const long base = (long)blockIdx.y * N * D;
-    const int q = blockIdx.x * 128 + wave * 32 + lr;         // this lane's query
-    K += (long)blockIdx.y * N * ldk;
+    // (query block bx, sample by): with Bn % 8 == 0 the query blocks of one sample are given workgroup ids that are congruent mod 8 =
+    // one XCD, whose L2 then fetches the sample's K / V once (round 6: in plain grid order the eight query blocks of a level-2 sample
+    // sat on eight different XCDs — every workgroup streams ALL keys and values of its sample and lives only ~9 us: the SQ counters
+    // showed one resident wave per CU on average in a 150 us launch, profiles/r06_attn_l2_sq_pmc.txt; the backward kernels and the
+    // ping-pong forward have mapped their grids this way since round 4)
+    int bx, by;
+    xcd_block(bx, by, (!SPLIT && gridDim.y % 8 == 0) ? 1 : 0);
+    const long base = (long)by * N * D;
+    const int q = bx * 128 + wave * 32 + lr;                 // this lane's query
+    K += (long)by * N * ldk;
     bf16x8 qf[D / 16];
-    load_frags<D, TI>(qf, Q + ((long)blockIdx.y * N + q) * ldq, lh);
+    load_frags<D, TI>(qf, Q + ((long)by * N + q) * ldq, lh);
     f32x16 o[D / 32];
 #pragma unroll
     for (int ct = 0; ct < D / 32; ++ct)
@@ -404,7 +413,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the other half-wave holds the other 32 keys
-        const float m_new = fmaxf(m_run, mx);               // (QS: scores, maxima and the share statistics are in binary orders)
+        // (QS: scores, maxima and the share statistics are in binary orders.)  QS keeps the running maximum a query started with unless a
+        // tile exceeds it by more than kDeferBits orders (round 6; the ping-pong kernel has done so since round 5): P then lies in
+        // (0, 2^kDeferBits] at the same relative bf16 precision, row sum and O scale with it — the same soft-max.  With 16 (level 2) or 4
+        // (level 3) key tiles per query SOME lane of the wave met a new maximum in nearly every tile, and the rescale of O — accumulators
+        // the compiler keeps in AGPRs: 64 reads + 64 multiplies + 64 writes at D = 128 — ran nearly every tile: 13.7 VALU
+        // instructions per MFMA (profiles/r06_attn_l2_sq_pmc.txt).
+        const float m_new = QS ? ((mx > m_run + kDeferBits) ? mx : m_run) : fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * (QS ? 1.f : kLog2e));
         const float nm = -m_new * (QS ? 1.f : kLog2e);      // exp(s - m) = 2^(s log2e - m log2e): one fma + v_exp_f32 per score
         float sum = 0.f;
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (SPLIT) {
-        const long row = ((long)zs * gridDim.y + blockIdx.y) * N + q;
+        const long row = ((long)zs * gridDim.y + by) * N + q;
         store_ct<D>(part_o + row * D, o, 1.f, nullptr, lh);
         if (lh == 0) {
             part_ml[2 * row] = m_run;
@@ -438,8 +453,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_fwd(const TI
     }
     store_ct<D>(out + base + (long)q * D, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
     if (out16)
-        store_ct16<D>(out16 + ((long)blockIdx.y * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
-    if (lh == 0) lse[(long)blockIdx.y * N + q] = QS ? (m_run + __log2f(l_tot)) * kLn2 : m_run + __logf(l_tot);
+        store_ct16<D>(out16 + ((long)by * N + q) * ld16, o, 1.f / l_tot, Vres ? Vres + base + (long)q * D : nullptr, lh);
+    if (lh == 0) lse[(long)by * N + q] = QS ? (m_run + __log2f(l_tot)) * kLn2 : m_run + __logf(l_tot);
 }
 
 // merge the key shares of the SPLIT forward: out = sum_s w_s O_s / sum_s w_s l_s with w_s = exp(m_s - max_s m_s) (+ V), the bf16
