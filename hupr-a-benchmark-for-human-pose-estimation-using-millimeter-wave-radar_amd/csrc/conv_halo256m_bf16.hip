@@ -39,14 +39,23 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // which existed for layers of ONE output tile on the 4 x 8 x 8 kernel only — encoder level 1; levels 2 and 3, Co = 128 / 256, ran a
 // statistics pass over the stored tensor per BatchNorm: 24 launches per step).  Level 2 at the bench batch: 4 tiles per workgroup,
 // alternating between its 2 output tiles; level 3: one tile per workgroup.
-template <int TD, int TH, int TW, int KD, int NCOT = 0>
+// NWN = 1 (round 6; Co = 32: the input gradient of the encoders' first convolution, 64 -> 32 channels, before on the 128-voxel kernel
+// at 702 TF/s): the eight waves are eight 8 x 8 voxel blocks of an 8 x 8 x 8 tile (512 voxels), each with all 32 output channels —
+// per wave the same 8 MFMAs per tap from the same fragment reads as the 64-channel form; a weight stage is 3 x 4 KB (two DMA
+// instructions, the second by waves 0-3 only); sixteen halo items per thread ride under the first sixteen taps.
+template <int TD, int TH, int TW, int KD, int NCOT = 0, int NWN = 2>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
-    constexpr int KC = 64, LDK = 64, BN = 64, TS = 3, C8 = 8;
+    constexpr int KC = 64, LDK = 64, BN = 32 * NWN, TS = 3, C8 = 8;
     constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
-    static_assert(TD * TH * TW == 256 && TH % 8 == 0 && TW % 8 == 0 && (KD == 1 || KD == 3), "256 voxels per tile, 8 x 8 per wave");
+    static_assert(TD * TH * TW == 64 * (8 / NWN) && TH % 8 == 0 && TW % 8 == 0 && (KD == 1 || KD == 3) && (NWN == 2 || NCOT == 0),
+                  "256 (512) voxels per tile, 8 x 8 per wave");
     constexpr int NVOX = HD * HH * HW;                         // 600 (4 x 8 x 8) / 720 (2 x 8 x 16) halo voxels
     constexpr int T = 9 * KD, NSTAGE = 3 * KD, NTAP = 6;       // stage = (kz, kx); its taps: K-step kk (2) x ky (3)
-    constexpr int NH = (NVOX * C8 + 511) / 512;                // 10 / 12 halo items (8 channels of a voxel) per thread
+    // NWN = 1: the tile spans the whole depth (launcher: D == TD), so the halo's first and last planes are the zero padding — never
+    // loaded, zeroed once in the prologue; the items cover planes 1 .. TD only (13 per thread instead of 16: the register file is full)
+    constexpr bool FULLD = NWN == 1;
+    constexpr int NVOXL = FULLD ? TD * HH * HW : NVOX, VOX0 = FULLD ? HH * HW : 0;
+    constexpr int NH = (NVOXL * C8 + 511) / 512;               // 10 / 12 / 13 halo items (8 channels of a voxel) per thread
     // items are issued one per tap from the item's first tap on; in front of the barriers of stages 0, 1, 2 (each in front of the stage's
     // sixth tap) the items of taps 6 s - 1 .. 6 s + 4 are younger than the weight pieces the barrier waits for
     constexpr int Y0 = NH < 5 ? NH : 5, Y1 = NH - 5 < 0 ? 0 : (NH - 5 > 6 ? 6 : NH - 5), Y2 = NH - 11 < 0 ? 0 : (NH - 11 > 6 ? 6 : NH - 11);
@@ -68,15 +77,18 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NWN == 2 ? wave >> 1 : wave, wn = NWN == 2 ? wave & 1 : 0;
     constexpr int NBX = TW / 8, NBY = TH / 8;
     const int xw0 = 8 * (wm % NBX), yw0 = 8 * ((wm / NBX) % NBY), dzw = wm / (NBX * NBY);      // the wave's 8 x 8 block: first column, first row, depth slice
     const int idx = lane & 15, kq = lane >> 4, yy = idx >> 3, wx = idx & 7;
     const int n_tiles = p.Bn * p.nd * p.nh * p.nw * p.n_co_tiles;
 
     // ---- weight stages by LDS-DMA ---------------------------------------------------------------------------------------
-    const int wrow_ = 8 * wave + (lane >> 3);
-    const int wsrc_lane = (wrow_ * T * p.Ci + (((lane & 7) ^ (wrow_ >> 1)) & 7) * 8) * 2;      // bytes; < 2^31
+    // (NWN = 1: a DMA instruction moves TWO taps of 32 rows — waves 0-3 the first, waves 4-7 the second)
+    const int wrow_ = NWN == 2 ? 8 * wave + (lane >> 3) : ((8 * wave + (lane >> 3)) & 31);
+    const int wsrc_lane = (wrow_ * T * p.Ci + (((lane & 7) ^ (wrow_ >> 1)) & 7) * 8) * 2 +
+                          (NWN == 2 ? 0 : (wave >> 2) * (3 * p.Ci * 2));                       // bytes; < 2^31
+    constexpr int NDMA = NWN == 2 ? TS : 2, DMA_TAPS = NWN == 2 ? 1 : 2;
     const u32x4 wrs = {(unsigned)(unsigned long)p.wp, (unsigned)((unsigned long)p.wp >> 32) & 0xffffu,
                        (unsigned)((long)p.Co * T * p.Ci * 2), 0x00020000u};
     const unsigned bs_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
@@ -84,13 +96,17 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 #define HUPR_W_DMA(COT_, CH_, S_, PAR_)                                                                             \
     {                                                                                                               \
         const int wbase_ = (((COT_) * BN * T + ((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + (CH_) * KC) * 2 + wsrc_lane;   \
-        _Pragma("unroll") for (int j = 0; j < TS; ++j) {                                                            \
-            unsigned keep_;                                                                                         \
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
-                         "s_mov_b32 m0, %0"                                                                         \
-                         : "=&s"(keep_)                                                                             \
-                         : "s"(wdst_wave + ((PAR_) * TS + j) * (BN * LDK * 2)), "v"(wbase_ + j * (3 * p.Ci * 2)), "s"(wrs) \
-                         : "memory");                                                                               \
+        _Pragma("unroll") for (int j = 0; j < NDMA; ++j) {                                                          \
+            if (NWN == 2 || j == 0 || wave < 4) {                                                                   \
+                unsigned keep_;                                                                                     \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
+                             "s_mov_b32 m0, %0"                                                                     \
+                             : "=&s"(keep_)                                                                         \
+                             : "s"(NWN == 2 ? wdst_wave + ((PAR_) * TS + j) * (BN * LDK * 2)                        \
+                                            : wdst_wave + (PAR_) * TS * (BN * LDK * 2) + j * 8192),                 \
+                               "v"(NWN == 2 ? wbase_ + j * (3 * p.Ci * 2) : wbase_ + j * DMA_TAPS * (3 * p.Ci * 2)), "s"(wrs) \
+                             : "memory");                                                                           \
+            }                                                                                                       \
         }                                                                                                           \
     }
 
@@ -105,8 +121,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         const int hx = vox % HW;                                                                                    \
         const int t_ = vox / HW;                                                                                    \
         const int hy = t_ % HH, hz = t_ / HH;                                                                       \
-        const int d = (D0_) + hz - KD / 2, h = (H0_) + hy - 1, w = (W0_) + hx - 1;                                  \
-        const bool ok = (COND_) && it < NVOX * C8 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H &&  \
+        const int d = (D0_) + hz - (FULLD ? 0 : KD / 2), h = (H0_) + hy - 1, w = (W0_) + hx - 1;                    \
+        const bool ok = (COND_) && it < NVOXL * C8 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && \
                         (unsigned)w < (unsigned)p.W;                                                                \
         const int off = (((((B_) * p.D + d) * p.H + h) * p.W + w) * p.in_ld + (C0_) + c8 * 8) * 2;                  \
         const auto ld_ = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : 0x7ffffff0, 0, 0);                  \
@@ -115,10 +131,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 #define HUPR_HALO_COMMIT()                                                                                          \
     _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
         const int it = tid + u * 512;                                                                               \
-        if (it < NVOX * C8) {                                                                                       \
+        if (it < NVOXL * C8) {                                                                                      \
             const int vox = it >> 3, c8 = it & 7;                                                                   \
             const int hx = vox % HW;                                                                                \
-            *reinterpret_cast<u32x4*>(&Hs[vox * LDK + ((c8 ^ (((hx >> 1) & 3) << 1)) << 3)]) = vb[u];              \
+            *reinterpret_cast<u32x4*>(&Hs[(vox + VOX0) * LDK + ((c8 ^ (((hx >> 1) & 3) << 1)) << 3)]) = vb[u];     \
         }                                                                                                           \
     }
 
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     // of the tile's LAST stage — their loads have returned by that stage's vmcnt(0) barrier — added in fp32 before the one rounding,
     // and the tile is parked and stored under the next tile's first stage like any other.  (Not in the instantiations that have no
     // 16 registers to spare: fused statistics, which never carry a residual, and the 2 x 8 x 16 tile.)
-    constexpr bool RESPF = !STATS && TD != 2;
+    constexpr bool RESPF = !STATS && TD != 2 && NWN == 2;
     const bool res_pf = RESPF && p.res != nullptr && (p.res_ld & 3) == 0 && !p.no_res_prefetch;
     const bool defer = !p.bias && (!p.res || res_pf) && (p.Co & 7) == 0 && (p.out_ld & 7) == 0;
     bf16x4 resv[4][2];
@@ -197,6 +213,12 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 #define HUPR_VMCNT_LGKM0(N_) __builtin_amdgcn_s_waitcnt(0x0070 | ((N_) & 15) | (((N_) >> 4) << 14))
 
     // prologue: first item's halo, weight stages 0 and 1
+    if constexpr (FULLD) {
+        for (int i = tid; i < 2 * HH * HW * C8; i += 512) {
+            const int pl = i / (HH * HW * C8), r = i - pl * (HH * HW * C8);
+            *reinterpret_cast<u32x4*>(&Hs[pl * (HD - 1) * HH * HW * LDK + r * 8]) = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
     HUPR_W_DMA(cur.cot, cur.ch, 0, 0)
     HUPR_W_DMA(cur.cot, cur.ch, 1, 1)
 #pragma unroll
@@ -433,7 +455,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 
 static void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
     const dim3 grid(kHalo256Grid), wg(512);
-    if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), grid, wg, 0, s, a);
+    if (a.TD == 8) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<8, 8, 8, 3, 0, 1>), grid, wg, 0, s, a);
+    else if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), grid, wg, 0, s, a);
     else if (a.stats) {                       // fused BatchNorm statistics: 1 or 2 distinct output tiles per workgroup (conv_halo256_stats_ok)
         const long tiles = (long)a.Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
         const long per_wg = (tiles + kHalo256Grid - 1) / kHalo256Grid;
@@ -451,9 +474,10 @@ static void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
 // ---- which launches the 256-voxel kernel takes (bf16-stored activations only; everything else: the 128-voxel kernel) ----------
 // Test aid (hupr_debug_halo_tiles): bit 0 = the 4 x 8 x 8 tile, bit 1 = the 2 x 8 x 16 tile (depth not a multiple of four: encoder
 // level 3), bit 2 = the 1 x 16 x 16 tile (1 x 3 x 3 taps: the decoder).  A cleared bit sends those layers to the 128-voxel kernel —
-// the comparison the parity tests make (same products, another fp32 summation order).
-static int g_halo_tiles = 7;
-void set_halo_tiles(int mask) { g_halo_tiles = mask & 7; }
+// the comparison the parity tests make (same products, another fp32 summation order).  Bit 3 = the 8 x 8 x 8 tile of the 32-output-
+// channel form.
+static int g_halo_tiles = 15;
+void set_halo_tiles(int mask) { g_halo_tiles = mask & 15; }
 
 static bool offsets_fit(const HaloArgs& a, int Bn) { return (long)Bn * a.D * a.H * a.W * a.in_ld * 2 < 0x7ffffff0L; }      // 32-bit buffer offsets
 
@@ -483,7 +507,19 @@ bool conv_halo256_stats_ok(const HaloArgs& a, int Bn) {
 }
 
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
-    if (!abf || a.Ci % 64 != 0 || a.Co % 64 != 0 || !offsets_fit(a, Bn)) return false;
+    if (!abf || a.Ci % 64 != 0 || !offsets_fit(a, Bn)) return false;
+    if (a.Co == 32) {
+        // 32 output channels (the first layer's input gradient): the 8 x 8 x 8 tile, every wave with all the channels
+        if (!(g_halo_tiles & 8) || a.kd != 3 || a.D != 8 || a.H % 8 != 0 || a.W % 8 != 0 || a.stats || (a.out_ld & 7)) return false;
+        a.n_co_tiles = 1;
+        a.TD = 8; a.log2TW = 3;
+        a.nd = a.D / 8; a.nh = a.H / 8; a.nw = a.W / 8;
+        const long tiles32 = (long)Bn * a.nd * a.nh * a.nw;
+        if (tiles32 < 256 || tiles32 >= (1L << 31)) return false;
+        launch_conv_halo256m(a, s);
+        return true;
+    }
+    if (a.Co % 64 != 0) return false;
     a.n_co_tiles = a.Co / 64;
     if (a.kd == 3 && a.D % 4 == 0) {
         if (!conv_halo256_supported(a, Bn, abf)) return false;

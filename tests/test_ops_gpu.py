@@ -298,9 +298,9 @@ def level3_aggressor(request):
     kernel they run on now (the 16 x 16 x 32 kernel's 2 x 8 x 16 tile)."""
     from hupr_amd import functional as F_
     L = F_.rt.lib()
-    L.hupr_debug_halo_tiles(1 if request.param.startswith("hupr_k_conv_halo_bf16") else 7)
+    L.hupr_debug_halo_tiles(1 if request.param.startswith("hupr_k_conv_halo_bf16") else 15)
     yield request.param
-    L.hupr_debug_halo_tiles(7)
+    L.hupr_debug_halo_tiles(15)
 
 
 def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(level3_aggressor, bf16_math):
@@ -781,17 +781,49 @@ def test_conv_halo256m_4x8x8_tile_matches_the_128_voxel_kernel(shape, bf16_math)
     try:
         L.hupr_debug_halo_tiles(0)
         y_128 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
-        L.hupr_debug_halo_tiles(7)
+        L.hupr_debug_halo_tiles(15)
         y_m16 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
         y_m16b = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
     finally:
-        L.hupr_debug_halo_tiles(7)
+        L.hupr_debug_halo_tiles(15)
     ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
     close(ncdhw(y_128.float().cpu())[:1], ref, 1e-2, "128-voxel kernel (bf16 store) vs fp64")
     assert y_m16.dtype == torch.bfloat16 and torch.equal(y_m16, y_m16b)
     d = (y_m16.float() - y_128.float()).abs()
     assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(y_128.float().abs(), y_m16.float().abs()) * 2 ** -7 + 1e-5).all()
     close(ncdhw(y_m16.float().cpu())[:1], ref, 1e-2, "halo256m (bf16 store) vs fp64")
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 8, 64, 64), (5, 128, 8, 32, 64), (7, 64, 8, 64, 40)])
+def test_conv_halo256m_32_output_channels_match_the_128_voxel_kernel(shape, bf16_math):
+    """32 output channels (the input gradient of the encoders' first convolution, `layers.py:194` Conv3d(32 -> 64) seen from its output):
+    the 16 x 16 x 32 kernel's 8 x 8 x 8 tile — eight waves = eight depth slices, every wave with all the channels, the halo's padding
+    planes zeroed once — against the 128-voxel kernel these launches ran on before (hupr_debug_halo_tiles(7)) and against fp64; one and two
+    channel chunks, with and without the residual epilogue, an uneven tile count over the 256 workgroups; deterministic."""
+    from hupr_amd import functional as F_
+    L = F_.rt.lib()
+    B, Ci, D, H, W = shape
+    Co = 32
+    x = rnd(B, D, H, W, Ci, seed=154).cuda().bfloat16()
+    w = rnd(Co, Ci, 3, 3, 3, seed=155, scale=(Ci * 27) ** -0.5).cuda()
+    res = rnd(B, D, H, W, Co, seed=156).cuda().bfloat16()
+    out = {}
+    try:
+        for mode in (7, 15):
+            L.hupr_debug_halo_tiles(mode)
+            out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W)),
+                         F_._conv_raw(x, w, 0, None, res, Co, (3, 3, 3), (1, 1, 1), (D, H, W)))
+        again = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+    finally:
+        L.hupr_debug_halo_tiles(15)
+    assert torch.equal(again, out[15][0])
+    for a, b in zip(out[15], out[7]):
+        d = (a.float() - b.float()).abs()
+        assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + 1e-5).all()
+    assert not torch.equal(out[15][0], out[15][1])
+    ref = F.conv3d(ncdhw(x.float().cpu())[:2].double(), _bf16_round(w.cpu()), None, 1, 1)
+    close(ncdhw(out[15][0].float().cpu())[:2], ref, 1e-2, "halo256m 8x8x8, Co = 32 (bf16 store) vs fp64")
+    close(ncdhw(out[15][1].float().cpu())[:2], ref + ncdhw(res.float().cpu())[:2].double(), 1e-2, "halo256m 8x8x8, Co = 32 + residual vs fp64")
 
 
 @pytest.mark.parametrize("shape", [(32, 64, 256, 2, 16, 16), (17, 128, 128, 2, 16, 32), (8, 320, 64, 1, 64, 64), (9, 64, 192, 1, 32, 48)])
@@ -808,17 +840,17 @@ def test_conv_halo256m_two_slice_tile_matches_the_128_voxel_kernel(shape, bf16_m
     res = rnd(B, D, H, W, Co, seed=58).cuda().bfloat16()
     out = {}
     try:
-        for mode in (1, 7):                 # 7: all tiles, 1: the 4 x 8 x 8 tile only
+        for mode in (1, 15):                # 7: all tiles, 1: the 4 x 8 x 8 tile only
             L.hupr_debug_halo_tiles(mode)
             out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, k3, pad, (D, H, W)),
                          F_._conv_raw(x, w, 0, None, res, Co, k3, pad, (D, H, W)))
     finally:
-        L.hupr_debug_halo_tiles(7)
-    for a, b in zip(out[7], out[1]):
+        L.hupr_debug_halo_tiles(15)
+    for a, b in zip(out[15], out[1]):
         d = (a.float() - b.float()).abs()
         assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + 1e-5).all()
     ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, pad)
-    close(ncdhw(out[7][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 / 1x16x16 (bf16 store) vs fp64")
+    close(ncdhw(out[15][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 / 1x16x16 (bf16 store) vs fp64")
 
 
 # ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
@@ -859,7 +891,7 @@ def test_conv_halo_bf16_activations(case, bf16_math):
             L_.hupr_debug_halo_tiles(0)
             y16b = F_._conv_raw(x.bfloat16(), w, 0, bias, res.bfloat16() if has_res else None, Co, k, pad, (D, H, W))
         finally:
-            L_.hupr_debug_halo_tiles(7)
+            L_.hupr_debug_halo_tiles(15)
         assert torch.equal(y16b.float(), _q(y32))              # the 32 x 32 x 16 form: store rounding only
     # weight gradient: fp32 output, identical products; only the fp32 summation order over voxel slices differs
     # (LDS-DMA kernel: two K halves per workgroup, other slice count)
