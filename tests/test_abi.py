@@ -108,6 +108,7 @@ def test_hot_kernels_keep_their_register_and_lds_budgets():
     budgets = [("hupr_k_conv_halo256m_bf16ILi4ELi8ELi8ELi3ELi0E", 256, 160 * 1024),
                ("hupr_k_conv_halo256m_bf16ILi2ELi8ELi16ELi3ELi0E", 256, 160 * 1024),
                ("hupr_k_conv_halo256m_bf16ILi1ELi16ELi16ELi1E", 256, 160 * 1024),
+               ("hupr_k_conv_halo256m_bf16ILi8ELi8ELi8ELi3ELi0ELi1E", 256, 160 * 1024),   # 32 output channels: the 8 x 8 x 8 tile (first-layer input gradient)
                ("hupr_k_conv_halo256m_bf16ILi4ELi8ELi8ELi3ELi1E", 256, 160 * 1024),      # fused BatchNorm statistics, one output tile (level 1)
                ("hupr_k_wgrad_halo_m16ILb1E", 256, 160 * 1024), ("hupr_k_wgrad_halo_m16ILb0E", 256, 160 * 1024),
                ("hupr_k_attn_fwd_pp64ILb1E", 256, 160 * 1024), ("hupr_k_attn_bwd_dkvILi256EDF16bLi2ELb1E", 512, 160 * 1024),
