@@ -574,7 +574,10 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_glds(WgradHaloArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
-template <bool IS3D>
+// CI32 (round 6; Ci <= 32: the 32-channel input of Encoder3D.layer1's first convolution, before on hupr_k_wgrad_halo_glds<.., true> at
+// 806 TF/s): only two of the four 16-wide ci blocks exist, so a wave is a K QUARTER (one 32-voxel K-step of the tile: three groups
+// of twelve MFMAs) x ci block 0 / 1, and the four quarters are merged through the dead images at the end (fixed order).
+template <bool IS3D, bool CI32 = false>
 __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
     constexpr int TD = IS3D ? 2 : 1, TW = IS3D ? 8 : 16, LOG2TW = IS3D ? 3 : 4;
     constexpr int HH = 10, HW = TW + 2;
@@ -590,8 +593,8 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
     __shared__ __attribute__((aligned(1024))) char bufC[IMG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kq = wave >> 2;                         // K half of this wave: K-steps 2 kq, 2 kq + 1 of the tile (32 voxels each)
-    const int cb = wave & 3;                          // its 16-wide ci block of the 64-wide tile (all four 16-wide co blocks)
+    const int kq = CI32 ? wave >> 1 : wave >> 2;      // K half of this wave: K-steps 2 kq, 2 kq + 1 of the tile (32 voxels each); CI32: K quarter = K-step kq
+    const int cb = CI32 ? wave & 1 : wave & 3;        // its 16-wide ci block of the 64-wide tile (all four 16-wide co blocks)
     const int pd = p.kd >> 1;
     const int T = p.kd * 9;
     // XCD-aware 1-D grid (p.xcd_map): the kd depth-tap planes and the (co, ci) tile pairs of one spatial group re-read the
@@ -634,10 +637,14 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
     for (int t = 0; t < 2; ++t) {
         const int vr = 2 * (kq4 >> 1) + t, vc = 4 * (kq4 & 1) + (s >> 2);
         const int r_dy = vr * TW + vc;                 // (K-step offsets of the dy tile are multiples of 8 rows: the key is the lane's)
+        // CI32: the wave's K-step kq (depth slice kq >> 1, row half kq & 1) is part of its tables — one code path for the four quarters
+        // (a branch per quarter made hipcc keep a second set of accumulators)
+        static_assert(!CI32 || IS3D, "K quarters: 3-D tiles only");
+        const int q_dy = CI32 ? 32 * kq : 0, q_x = CI32 ? (kq >> 1) * HH * HW + 4 * (kq & 1) * HW : 0;
 #pragma unroll
         for (int cob = 0; cob < 4; ++cob)
-            dyb[t][cob] = (NVOXP + r_dy) * kRowB + ((32 * cob + colb) ^ (((r_dy >> 1) & 3) << 5));
-        const int r_x = vr * HW + vc;
+            dyb[t][cob] = (NVOXP + r_dy + q_dy) * kRowB + ((32 * cob + colb) ^ (((r_dy >> 1) & 3) << 5));
+        const int r_x = vr * HW + vc + q_x;
 #pragma unroll
         for (int m = 0; m < 8; ++m)
             xa[m][t] = r_x * kRowB + ((32 * cb + colb) ^ ((((r_x + m) >> 1) & 3) << 5));
@@ -789,6 +796,42 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
 #define HUPR_M16_HEAD6(IMG_, NXT_, FREE_, KS0_)                                                                     \
     HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 0, 6) HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 1, 6) HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 2, 6) \
     HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 3, 6) HUPR_M16_STEP(IMG_, NXT_, FREE_, KS0_, 4, 6)
+    // CI32: a K quarter = K-step KS_ = 3 groups per tile.  With an odd group count the fragment sets cannot have static roles per group: tile
+    // parity TP_ (compile-time; the loop is unrolled by six) picks them — group J_ multiplies xq[(TP_ + J_) & 1] and the tile's dy
+    // fragments a[TP_]; under the last group the next tile's first fragments land in the OTHER sets.
+#define HUPR_M16Q_LOAD(IMG_, XSET_, ASET_, KS_, KY_)                                                                \
+    {                                                                                                               \
+        constexpr int xoff_ = IS3D ? (((KS_) >> 1) * HH * HW + (4 * ((KS_) & 1) + (KY_)) * HW)                      \
+                                   : ((4 * ((KS_) >> 1) + (KY_)) * HW + 8 * ((KS_) & 1));                           \
+        constexpr int dyoff_ = IS3D ? 32 * (KS_) : (64 * ((KS_) >> 1) + 8 * ((KS_) & 1));                           \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
+            xq[XSET_][kx] = tr_pair((IMG_) + (xoff_ + kx) * kRowB, xa[(xoff_ + kx) & 7][0], xa[(xoff_ + kx) & 7][1]); \
+        if ((KY_) == 0) {                                                                                           \
+            _Pragma("unroll") for (int cob = 0; cob < 4; ++cob)                                                     \
+                a[ASET_][cob] = tr_pair((IMG_) + dyoff_ * kRowB, dyb[0][cob], dyb[1][cob]);                         \
+        }                                                                                                           \
+    }
+#define HUPR_M16Q_STEP(IMG_, NXT_, FREE_, KS_, J_, TP_)                                                             \
+    {                                                                                                               \
+        if ((J_) < 2) { HUPR_M16Q_LOAD(IMG_, ((TP_) + (J_) + 1) & 1, TP_, KS_, ((J_) < 2 ? (J_) + 1 : 1)) }         \
+        else { HUPR_M16Q_LOAD(NXT_, ((TP_) + 1) & 1, (TP_) ^ 1, KS_, 0) }                                           \
+        if ((J_) < 2) {                                                                                             \
+            _Pragma("unroll") for (int u_ = 0; u_ < NP; ++u_)                                                       \
+                if (u_ % 2 == (J_)) { HUPR_WG_PIECE(u_, FREE_) }                                                    \
+        }                                                                                                           \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                            \
+            _Pragma("unroll") for (int cob = 0; cob < 4; ++cob)                                                     \
+                acc[(J_) * 3 + kx][cob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                  \
+                    a[TP_][cob], xq[((TP_) + (J_)) & 1][kx], acc[(J_) * 3 + kx][cob], 0, 0, 0);                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
+        }                                                                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }
+#define HUPR_M16_HEAD3(IMG_, NXT_, FREE_, KS_, TP_)                                                                 \
+    HUPR_M16Q_STEP(IMG_, NXT_, FREE_, KS_, 0, TP_) HUPR_M16Q_STEP(IMG_, NXT_, FREE_, KS_, 1, TP_)
 
     // Tile protocol (round 5; the SQ counters of the old one — barrier, whole fill, first fragments, then the MFMAs — showed the
     // matrix pipe busy 53 % of the cycles: profiles/r04_wgrad_sq_pmc.txt).  Three images in a ring: CUR (tile st), NXT (tile
@@ -798,12 +841,16 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
     // CUR have returned, and takes the tile's ONE barrier holding the last group's fragments: it leaves the barrier with three
     // MFMAs ready and reads the first fragments of tile st + 1 under them.  The loop starts two (virtual) tiles early with the
     // multiply switched off.
-#define HUPR_WG_ITER(CUR_, NXT_, FREE_)                                                                             \
+#define HUPR_WG_ITER(CUR_, NXT_, FREE_, TP_)                                                                        \
     {                                                                                                               \
         if (st >= p.n_spatial) break;                                                                               \
         HUPR_WG_FILL_OPEN()                                                                                         \
         if (st >= 0) {                                                                                              \
-            if (kq == 0) { HUPR_M16_HEAD6(CUR_, NXT_, FREE_, 0) } else { HUPR_M16_HEAD6(CUR_, NXT_, FREE_, 2) }     \
+            if constexpr (CI32) {                                                                                   \
+                HUPR_M16_HEAD3(CUR_, NXT_, FREE_, 0, TP_)       /* (the K quarter's offset sits in the address tables) */ \
+            } else {                                                                                                \
+                if (kq == 0) { HUPR_M16_HEAD6(CUR_, NXT_, FREE_, 0) } else { HUPR_M16_HEAD6(CUR_, NXT_, FREE_, 2) } \
+            }                                                                                                       \
         } else {                                                                                                    \
             _Pragma("unroll") for (int u_ = 0; u_ < NP; ++u_) { HUPR_WG_PIECE(u_, FREE_) }                          \
         }                                                                                                           \
@@ -811,7 +858,13 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
         else __builtin_amdgcn_s_waitcnt(0x0070 | (NP - 1));                                                         \
         __builtin_amdgcn_s_barrier();                                                                               \
         asm volatile("" ::: "memory");                                                                              \
-        if (st >= 0) {                                                                                              \
+        if constexpr (CI32) {                                                                                       \
+            if (st >= 0) {                                                                                          \
+                HUPR_M16Q_STEP(CUR_, NXT_, FREE_, 0, 2, TP_)                                                        \
+            } else if (st + p.groups >= 0) {                                                                        \
+                HUPR_M16Q_LOAD(NXT_, ((TP_) + 1) & 1, (TP_) ^ 1, 0, 0)                                              \
+            }                                                                                                       \
+        } else if (st >= 0) {                                                                                       \
             if (kq == 0) { HUPR_M16_STEP(CUR_, NXT_, FREE_, 0, 5, 6) } else { HUPR_M16_STEP(CUR_, NXT_, FREE_, 2, 5, 6) } \
         } else if (st + p.groups >= 0) {                        /* the first real tile's first fragments */         \
             if (kq == 0) { HUPR_M16_LOAD(NXT_, 0, 0, 0) } else { HUPR_M16_LOAD(NXT_, 0, 2, 0) }                     \
@@ -822,22 +875,55 @@ __global__ __launch_bounds__(512) void hupr_k_wgrad_halo_m16(WgradHaloArgs p) {
     if (group >= p.n_spatial) return;
     int st = group - 2 * p.groups;
     for (;;) {
-        HUPR_WG_ITER(bufB, bufC, bufA)
-        HUPR_WG_ITER(bufC, bufA, bufB)
-        HUPR_WG_ITER(bufA, bufB, bufC)
+        HUPR_WG_ITER(bufB, bufC, bufA, 0)
+        HUPR_WG_ITER(bufC, bufA, bufB, 1)
+        HUPR_WG_ITER(bufA, bufB, bufC, 0)
+        if constexpr (CI32) {                        // (tile parity: see HUPR_M16Q_STEP; the other form ignores it)
+            HUPR_WG_ITER(bufB, bufC, bufA, 1)
+            HUPR_WG_ITER(bufC, bufA, bufB, 0)
+            HUPR_WG_ITER(bufA, bufB, bufC, 1)
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);              // the two re-fetches past the last tile must land before the LDS is released
 #undef HUPR_WG_ITER
 #undef HUPR_WG_FILL_OPEN
 #undef HUPR_WG_PIECE
+#undef HUPR_M16Q_LOAD
+#undef HUPR_M16Q_STEP
 #undef HUPR_M16_LOAD
 #undef HUPR_M16_STEP
 #undef HUPR_M16_HEAD6
+#undef HUPR_M16_HEAD3
 
     // Merge the two K halves through the (now dead) images: the kq = 1 waves park their accumulators, six taps and then three, the
     // kq = 0 waves add them (both halves hold the same (co, ci) element in the same lane and register) — one partial tensor per
     // workgroup.
-    {
+    if constexpr (CI32) {
+        // four K quarters: quarters 1-3 park three taps at a time (one image per tap), quarter 0 adds them in the order 1, 2, 3
+        const int t128 = tid & 127;
+        float* const red[3] = {reinterpret_cast<float*>(bufA), reinterpret_cast<float*>(bufB), reinterpret_cast<float*>(bufC)};
+        static_assert(3 * 16 * 128 * 4 <= IMG, "an image must hold one tap of three quarters");
+        __syncthreads();
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            if (round) __syncthreads();
+            if (kq != 0) {
+#pragma unroll
+                for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[tl][(((kq - 1) * 16 + r) << 7) + t128] = acc[3 * round + tl][r >> 2][r & 3];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc[3 * round + tl][r >> 2][r & 3] += red[tl][((q * 16 + r) << 7) + t128];
+            }
+        }
+    } else {
         const int t256 = tid & 255;
         float* const red[3] = {reinterpret_cast<float*>(bufA), reinterpret_cast<float*>(bufB), reinterpret_cast<float*>(bufC)};
         __syncthreads();
@@ -948,10 +1034,12 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
             const dim3 grid = a.xcd_map ? dim3(gw * pairs * nt) : dim3(gw, kd, a.n_ci_tiles * a.n_co_tiles);
             // K quarters pay once a workgroup multiplies enough tiles to amortise the extra LDS merge (measured: 222 -> 160 us on
             // the 32 -> 64 layer-1 shape at 102 tiles per workgroup; +2-3 us on shapes with one or two tiles per workgroup)
-            const bool ci32 = Ci <= 32 && (g_wgrad_ci32 == 2 || (g_wgrad_ci32 == 1 && a.n_spatial >= 16 * gw));
+            const bool ci32 = Ci <= 32 && (g_wgrad_ci32 >= 2 || (g_wgrad_ci32 == 1 && a.n_spatial >= 16 * gw));
             if (g_wgrad_m16 && !ci32) {                                  // the 16 x 16 x 32 form (round 5)
                 if (kd == 3) HUPR_LAUNCH((hupr_k_wgrad_halo_m16<true>), grid, dim3(512), 0, s, a);
                 else HUPR_LAUNCH((hupr_k_wgrad_halo_m16<false>), grid, dim3(512), 0, s, a);
+            } else if (g_wgrad_m16 && kd == 3 && g_wgrad_ci32 != 3) {    // ... and its K-quarter form for Ci <= 32 (round 6; hupr_debug_wgrad_ci32(3): the 32 x 32 x 16 one)
+                HUPR_LAUNCH((hupr_k_wgrad_halo_m16<true, true>), grid, dim3(512), 0, s, a);
             } else if (kd == 3) {
                 if (ci32) HUPR_LAUNCH((hupr_k_wgrad_halo_glds<true, true>), grid, dim3(512), 0, s, a);
                 else HUPR_LAUNCH((hupr_k_wgrad_halo_glds<true, false>), grid, dim3(512), 0, s, a);

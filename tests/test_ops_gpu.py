@@ -910,7 +910,8 @@ def test_conv_halo_bf16_activations(case, bf16_math):
 
 @pytest.mark.parametrize("shape", [(3, 32, 64, 2, 16, 16, 3), (2, 24, 40, 1, 16, 32, 1), (2, 32, 72, 4, 8, 24, 3)])
 def test_wgrad_k_quarter_mode_for_narrow_inputs(shape, bf16_math):
-    """Ci <= 32: the LDS-DMA weight-gradient kernel splits K four ways instead of leaving the second ci quadrant's waves idle.
+    """Ci <= 32: the LDS-DMA weight-gradient kernels split K four ways instead of leaving the waves of the missing ci blocks idle
+    (3-D taps: hupr_k_wgrad_halo_m16<true, true> since round 6 — a wave = one K-step x one 16-wide ci block).
     Both modes against fp64 autograd on the same bf16 operands, and against each other (summation order only)."""
     from hupr_amd import functional as F_
     B, Ci, Co, D, H, W, kd = shape
@@ -922,7 +923,7 @@ def test_wgrad_k_quarter_mode_for_narrow_inputs(shape, bf16_math):
     ws = F_.workspace(L.hupr_conv3x3_wgrad_halo_ws_bytes(Ci, Co, kd), x.device)
     got = {}
     try:
-        for mode in (0, 2):
+        for mode in (0, 2, 3):                 # 2: K quarters on the 16 x 16 x 32 kernel (3-D; round 6), 3: on the 32 x 32 x 16 kernel
             L.hupr_debug_wgrad_ci32(mode)
             dw = torch.full((Co, Ci, kd, 3, 3), float("nan"), device="cuda")
             F_.rt.check(L.hupr_conv3x3_wgrad_halo_bf16act(F_.rt.ptr(x), F_.rt.ptr(dy), F_.rt.ptr(dw), B, D, H, W, Ci, Ci, Co, Co, kd,
@@ -932,6 +933,7 @@ def test_wgrad_k_quarter_mode_for_narrow_inputs(shape, bf16_math):
     finally:
         L.hupr_debug_wgrad_ci32(1)
     close(got[2], got[0], 2e-6, "K quarters vs K halves")
+    close(got[3], got[0], 2e-6, "K quarters (32 x 32 x 16 kernel) vs K halves")
 
 
 def test_conv_autograd_bf16_activations(bf16_math):
