@@ -154,7 +154,8 @@ __device__ __forceinline__ void load_frags(bf16x8* frag, const TI* __restrict__ 
 // acc[t] (t = 0,1: image rows 32t..32t+31) = img(64 rows x D) . frags  ->  tile [image row][lane token]
 constexpr int g_attn_sched = 0;      // 1: the round-1 order (all fragment reads of a chunk, then its MFMAs)
 // ZERO = false: acc arrives initialised (the QS kernels start the chain from -max / -log-sum-exp)
-template <int D, bool ZERO = true>
+// NT = image rows / 32 (2; 1: the 32-key tiles of the level-2 dQ kernel)
+template <int D, bool ZERO = true, int NT = 2>
 __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img, const bf16x8* frag, int lr, int lh) {
     // all A fragments of the 64 x D image rows are read before the first MFMA (hipcc otherwise issues each read right in
     // front of its MFMA and every MFMA waits out the LDS latency)
@@ -162,38 +163,38 @@ __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img,
     constexpr int KS = D / 16, CHK = KS >= 8 ? 4 : KS;      // (D = 128: chunks of four since round 6 — 32 fragment registers instead of 64; same MFMA order)
     if constexpr (ZERO) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         }
     }
 #pragma unroll
     for (int k0 = 0; k0 < KS; k0 += CHK) {
-        bf16x8 a[2][CHK];
+        bf16x8 a[NT][CHK];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < CHK; ++ks)                   // in the order the MFMAs consume them
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
                 a[t][ks] = *reinterpret_cast<const bf16x8*>(&img[Img<D>::off(32 * t + lr, (k0 + ks) * 2 + lh)]);
 #pragma unroll
         for (int ks = 0; ks < CHK; ++ks)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][ks], frag[k0 + ks], acc[t], 0, 0, 0);
         if (g_attn_sched == 0) {
             // four reads ahead, then one read behind every MFMA (a burst of all 2 CHK reads first delays the first MFMA by the
             // whole burst; a read right in front of its MFMA exposes the LDS latency every time)
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int i_ = 0; i_ < 2 * CHK - 4; ++i_) {
+            for (int i_ = 0; i_ < NT * CHK - 4; ++i_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * CHK, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * CHK, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT * CHK, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT * CHK, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -203,13 +204,13 @@ __device__ __forceinline__ void mma_rows_x_frags(f32x16* acc, const __bf16* img,
 // held in accumulator layout w[2][16] (as produced by mma_rows_x_frags).  K slot 8h+i of K-step (t,u) <-> image row
 // 32t + 16u + 8(i>>2) + 4h + (i&3); the A operand rows are fetched with transpose-reads.
 // NCT channel tiles starting at tile ct0 (a channel half of the dK / dV kernel at D = 256; everything otherwise).
-template <int D, int NCT = D / 32>
+template <int D, int NCT = D / 32, int NT = 2>
 __device__ __forceinline__ void mma_tr_x_tile(f32x16* out, const __bf16* img, const f32x16* w, int lane, int ct0 = 0) {
     const int g = lane >> 4, s = lane & 15, h = g >> 1;
     const int col = 16 * (g & 1) + 4 * (s & 3);            // first of the 4 channels this supplier lane addresses
     const int rsub = s >> 2;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             bf16x8 b;
@@ -562,13 +563,19 @@ __global__ __launch_bounds__(256) void hupr_k_attn_prep(const TG* __restrict__ d
 // backward, dQ: same walk as the forward
 // ------------------------------------------------------------------------------------------------------
 template <int D, typename TI, bool QS = false>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
+__global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void hupr_k_attn_bwd_dq(const TI* __restrict__ K, const TI* __restrict__ Q,
                                                           const TI* __restrict__ V, const TI* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ Dq,
                                                           float* __restrict__ dQ, int N, int ldk, int ldq, int lddq, int lddo, int xcd_map,
                                                           const AttnBwdBatch batch = AttnBwdBatch()) {
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * D];
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * D];
+    // D = 128 (level 2): key tiles of 32 since round 6 — two S^T / dP^T accumulator tiles instead of four, half the staging registers:
+    // <= 256 unified registers = two workgroups per CU (358 = one wave per SIMD before: 156 us for the level's four attentions); the same
+    // MFMA sequence per query (the 16-key blocks arrive in the same order): the same bits
+    // (The dK / dV kernel at D = 128 — 446 registers — does not follow: with 32-query tiles, the V rows in LDS and the dO rows staged
+    // synchronously it still spills 19-41 registers at 256 and ran 131 us instead of 116, profiles/r06_attn_dq128_ab.txt.)
+    constexpr int KT = D == 128 ? 32 : 64, NT = KT / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[KT * D];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[KT * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     int bx, by;
     xcd_block(bx, by, xcd_map);
@@ -599,38 +606,38 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[ct][r] = 0.f;
     constexpr bool PF = (D <= 128);
-    StageRegs<PF ? D : 64, 64, TI> kr, vr;
+    StageRegs<PF ? D : 64, KT, TI> kr, vr;
     if (PF) {
         kr.load(K, ldk, tid);
         vr.load(V + base, D, tid);
     }
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = 0; j0 < N; j0 += KT) {
         __syncthreads();
         if (PF) {
             kr.store(Ks, tid);
             vr.store(Vs, tid);
         } else {
-            stage_rows<D, 64, TI>(Ks, K + (long)j0 * ldk, ldk, tid);
-            stage_rows<D, 64, TI>(Vs, V + base + (long)j0 * D, D, tid);
+            stage_rows<D, KT, TI>(Ks, K + (long)j0 * ldk, ldk, tid);
+            stage_rows<D, KT, TI>(Vs, V + base + (long)j0 * D, D, tid);
         }
         __syncthreads();
-        if (PF && j0 + 64 < N) {
-            kr.load(K + (long)(j0 + 64) * ldk, ldk, tid);
-            vr.load(V + base + (long)(j0 + 64) * D, D, tid);
+        if (PF && j0 + KT < N) {
+            kr.load(K + (long)(j0 + KT) * ldk, ldk, tid);
+            vr.load(V + base + (long)(j0 + KT) * D, D, tid);
         }
-        f32x16 st[2], dp[2];
+        f32x16 st[NT], dp[NT];
         if constexpr (QS) {                                   // the chain starts from -log-sum-exp (binary orders): S^T leaves as the exponent
-            st[0] = nlse16;
-            st[1] = nlse16;
-            mma_rows_x_frags<D, false>(st, Ks, qf, lr, lh);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) st[t] = nlse16;
+            mma_rows_x_frags<D, false, NT>(st, Ks, qf, lr, lh);
         } else {
-            mma_rows_x_frags<D>(st, Ks, qf, lr, lh);          // S^T
+            mma_rows_x_frags<D, true, NT>(st, Ks, qf, lr, lh);          // S^T
         }
-        mma_rows_x_frags<D>(dp, Vs, gf, lr, lh);              // dP^T = V dO^T
+        mma_rows_x_frags<D, true, NT>(dp, Vs, gf, lr, lh);    // dP^T = V dO^T
         {      // dS^T on accumulator pairs (packed fma / add / mul: same roundings, half the VALU instructions)
             typedef float f32x2a __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const f32x2a arg = QS ? (f32x2a){st[t][r], st[t][r + 1]}
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void hupr_k_attn_bwd_dq(const
                     st[t][r + 1] = ds[1];
                 }
         }
-        mma_tr_x_tile<D>(dq, Ks, st, lane);                   // dQ^T += K^T dS^T
+        mma_tr_x_tile<D, D / 32, NT>(dq, Ks, st, lane);       // dQ^T += K^T dS^T
     }
     store_ct<D>(dQ + ((long)by * N + q) * lddq, dq, 1.f, nullptr, lh);
 }

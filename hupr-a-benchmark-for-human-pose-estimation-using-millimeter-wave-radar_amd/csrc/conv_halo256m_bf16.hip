@@ -43,14 +43,18 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // at 702 TF/s): the eight waves are eight 8 x 8 voxel blocks of an 8 x 8 x 8 tile (512 voxels), each with all 32 output channels —
 // per wave the same 8 MFMAs per tap from the same fragment reads as the 64-channel form; a weight stage is 3 x 4 KB (two DMA
 // instructions, the second by waves 0-3 only); sixteen halo items per thread ride under the first sixteen taps.
-template <int TD, int TH, int TW, int KD, int NCOT = 0, int NWN = 2>
+// KC = 32 (round 6; Ci = 32: the encoders' first convolution, before on the 512-voxel kernel at 1.0 PF/s): a halo / weight row is 64 bytes,
+// a tap is ONE K-step, a stage is a kz plane with its nine (kx, ky) taps (nine 4 KB weight images by 36 LDS-DMA pieces); the
+// 64-byte rows have their own bank keys (see the fragment addresses).
+template <int TD, int TH, int TW, int KD, int NCOT = 0, int NWN = 2, int KC = 64>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
-    constexpr int KC = 64, LDK = 64, BN = 32 * NWN, TS = 3, C8 = 8;
+    constexpr int LDK = KC, BN = 32 * NWN, TS = KC == 64 ? 3 : 9, C8 = KC / 8, L2C8 = KC == 64 ? 3 : 2;
+    static_assert(KC == 64 || (KC == 32 && KD == 3 && NWN == 2 && NCOT == 0), "32-channel rows: 3 x 3 x 3 taps, 64 output channels per tile");
     constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
     static_assert(TD * TH * TW == 64 * (8 / NWN) && TH % 8 == 0 && TW % 8 == 0 && (KD == 1 || KD == 3) && (NWN == 2 || NCOT == 0),
                   "256 (512) voxels per tile, 8 x 8 per wave");
     constexpr int NVOX = HD * HH * HW;                         // 600 (4 x 8 x 8) / 720 (2 x 8 x 16) halo voxels
-    constexpr int T = 9 * KD, NSTAGE = 3 * KD, NTAP = 6;       // stage = (kz, kx); its taps: K-step kk (2) x ky (3)
+    constexpr int T = 9 * KD, NSTAGE = KC == 64 ? 3 * KD : KD, NTAP = KC == 64 ? 6 : 9;      // stage = (kz, kx); its taps: K-step kk (2) x ky (3)  [KC = 32: stage = kz; taps: kx (3) x ky (3)]
     // NWN = 1: the tile spans the whole depth (launcher: D == TD), so the halo's first and last planes are the zero padding — never
     // loaded, zeroed once in the prologue; the items cover planes 1 .. TD only (13 per thread instead of 16: the register file is full)
     constexpr bool FULLD = NWN == 1;
@@ -58,8 +62,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int NH = (NVOXL * C8 + 511) / 512;               // 10 / 12 / 13 halo items (8 channels of a voxel) per thread
     // items are issued one per tap from the item's first tap on; in front of the barriers of stages 0, 1, 2 (each in front of the stage's
     // sixth tap) the items of taps 6 s - 1 .. 6 s + 4 are younger than the weight pieces the barrier waits for
-    constexpr int Y0 = NH < 5 ? NH : 5, Y1 = NH - 5 < 0 ? 0 : (NH - 5 > 6 ? 6 : NH - 5), Y2 = NH - 11 < 0 ? 0 : (NH - 11 > 6 ? 6 : NH - 11);
-    static_assert(NH <= 6 * NSTAGE - 1 && NH <= 17, "halo items must all be issued in front of the item's last barrier (and within three stages)");
+    // (stage s: the items NTAP s - 1 .. NTAP s + NTAP - 2)
+    constexpr int Y0 = NH < NTAP - 1 ? NH : NTAP - 1, Y1 = NH - (NTAP - 1) < 0 ? 0 : (NH - (NTAP - 1) > NTAP ? NTAP : NH - (NTAP - 1)),
+                  Y2 = NH - (2 * NTAP - 1) < 0 ? 0 : (NH - (2 * NTAP - 1) > NTAP ? NTAP : NH - (2 * NTAP - 1));
+    static_assert(NH <= NTAP * NSTAGE - 1 && NH <= 3 * NTAP - 1, "halo items must all be issued in front of the item's last barrier (and within three stages)");
     __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];
     // fused BatchNorm statistics: per lane and output-channel tile the running sums of its eight channels over its voxels (bf16-ROUNDED
@@ -89,12 +95,30 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     const int wsrc_lane = (wrow_ * T * p.Ci + (((lane & 7) ^ (wrow_ >> 1)) & 7) * 8) * 2 +
                           (NWN == 2 ? 0 : (wave >> 2) * (3 * p.Ci * 2));                       // bytes; < 2^31
     constexpr int NDMA = NWN == 2 ? TS : 2, DMA_TAPS = NWN == 2 ? 1 : 2;
+    // KC = 32: piece pc = 8 j + wave (1 KB = 16 rows of 64 B) of a stage's 36: tap slot pc >> 2 = kx * 3 + ky, rows 16 (pc & 3) + (lane >> 2);
+    // chunk c of weight row n lives at position c ^ (((n >> 3) & 1) << 1) (the four rows n = v mod 4 of a ds_read_b128 lane group then
+    // hold four different positions)
+    const int wrow32_ = 16 * (wave & 3) + (lane >> 2);
+    const int wsrc32_lane = (wrow32_ * T * p.Ci + (((lane & 3) ^ (((wrow32_ >> 3) & 1) << 1)) & 3) * 8) * 2;
     const u32x4 wrs = {(unsigned)(unsigned long)p.wp, (unsigned)((unsigned long)p.wp >> 32) & 0xffffu,
                        (unsigned)((long)p.Co * T * p.Ci * 2), 0x00020000u};
     const unsigned bs_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&Bs[0][0][0];
     const unsigned wdst_wave = __builtin_amdgcn_readfirstlane(bs_lds + wave * 1024);
 #define HUPR_W_DMA(COT_, CH_, S_, PAR_)                                                                             \
-    {                                                                                                               \
+    if constexpr (KC == 32) {                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                             \
+            if (j < 4 || wave < 4) {                                                                                \
+                const int t9_ = 2 * j + (wave >> 2);             /* wave-uniform: kx * 3 + ky */                     \
+                const int wb32_ = (((COT_) * BN * T + (S_) * 9 + (t9_ % 3) * 3 + t9_ / 3) * p.Ci) * 2 + wsrc32_lane; \
+                unsigned keep_;                                                                                     \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
+                             "s_mov_b32 m0, %0"                                                                     \
+                             : "=&s"(keep_)                                                                         \
+                             : "s"(wdst_wave + (PAR_) * TS * (BN * LDK * 2) + j * 8192), "v"(wb32_), "s"(wrs)       \
+                             : "memory");                                                                           \
+            }                                                                                                       \
+        }                                                                                                           \
+    } else {                                                                                                        \
         const int wbase_ = (((COT_) * BN * T + ((S_) / 3) * 9 + ((S_) % 3)) * p.Ci + (CH_) * KC) * 2 + wsrc_lane;   \
         _Pragma("unroll") for (int j = 0; j < NDMA; ++j) {                                                          \
             if (NWN == 2 || j == 0 || wave < 4) {                                                                   \
@@ -117,7 +141,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 #define HUPR_HALO_ISSUE_ITEM(u, COND_, B_, D0_, H0_, W0_, C0_)                                                     \
     {                                                                                                               \
         const int it = tid + (u) * 512;                                                                             \
-        const int vox = it >> 3, c8 = it & 7;                                                                       \
+        const int vox = it >> L2C8, c8 = it & (C8 - 1);                                                             \
         const int hx = vox % HW;                                                                                    \
         const int t_ = vox / HW;                                                                                    \
         const int hy = t_ % HH, hz = t_ / HH;                                                                       \
@@ -132,9 +156,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     _Pragma("unroll") for (int u = 0; u < NH; ++u) {                                                                \
         const int it = tid + u * 512;                                                                               \
         if (it < NVOXL * C8) {                                                                                      \
-            const int vox = it >> 3, c8 = it & 7;                                                                   \
+            const int vox = it >> L2C8, c8 = it & (C8 - 1);                                                         \
             const int hx = vox % HW;                                                                                \
-            *reinterpret_cast<u32x4*>(&Hs[(vox + VOX0) * LDK + ((c8 ^ (((hx >> 1) & 3) << 1)) << 3)]) = vb[u];     \
+            const int key_ = KC == 64 ? (((hx >> 1) & 3) << 1) : ((((vox / HW) % HH) & 1) << 1);                    \
+            *reinterpret_cast<u32x4*>(&Hs[(vox + VOX0) * LDK + ((c8 ^ key_) << 3)]) = vb[u];                        \
         }                                                                                                           \
     }
 
@@ -170,17 +195,24 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int n = 32 * wn + 16 * cg + idx;
-            woff[cg][kk] = n * LDK + (((4 * kk + kq) ^ ((n >> 1) & 7)) << 3);
+            woff[cg][kk] = KC == 64 ? n * LDK + (((4 * kk + kq) ^ ((n >> 1) & 7)) << 3) : n * LDK + ((kq ^ (((n >> 3) & 1) << 1)) << 3);
         }
     // activations: halo voxel (wm + kz, rho + yy, wx + kx).  Halo row swizzle of THIS kernel: 16-byte chunk c of voxel (hy, hx) lives at
     // chunk c ^ (((hx >> 1) & 3) << 1).  A 16-lane ds_read_b128 group holds eight lanes of chunk parity 0 and eight of parity 1 such
     // that the two rows yy of a column differ in that parity; voxel pitch 128 B puts the column parity into bank bit 5; the key separates
     // the four columns of one parity in chunk bits 1-2: all 64 banks, every tap (SQ_LDS_BANK_CONFLICT = 0, profiles/r04b_conv_sq_pmc.txt)
     const int xlane = ((dzw * HH + yw0 + yy) * HW + xw0 + wx) * LDK;
+    // KC = 32 (64-byte rows): a voxel's four chunks sit at chunk ^ ((halo row & 1) << 1).  A ds_read_b128 lane group holds, for each
+    // voxel class (index mod 4 = a 64-byte bank quarter), the four lanes (kq, row), (kq, row + 1), (kq + 1, row), (kq + 1, row + 1): positions
+    // kq ^ {0, 2} and (kq + 1) ^ {0, 2} — all four.  KK_ there = kx (the stage is the kz plane ST_).
 #define HUPR_XF(ST_, RHO_, KK_)                                                                                     \
-    (*reinterpret_cast<const bf16x8*>(&Hs[xlane + ((((ST_) / 3) * HH + (RHO_)) * HW + ((ST_) % 3)) * LDK +          \
-        (((4 * (KK_) + kq) ^ ((((xw0 + wx + ((ST_) % 3)) >> 1) & 3) << 1)) << 3)]))
-#define HUPR_WF(BUF_, KY_, CG_, KK_) (*reinterpret_cast<const bf16x8*>(&Bs[BUF_][KY_][woff[CG_][KK_]]))
+    (KC == 64 ? *reinterpret_cast<const bf16x8*>(&Hs[xlane + ((((ST_) / 3) * HH + (RHO_)) * HW + ((ST_) % 3)) * LDK + \
+                    (((4 * (KK_) + kq) ^ ((((xw0 + wx + ((ST_) % 3)) >> 1) & 3) << 1)) << 3)])                      \
+              : *reinterpret_cast<const bf16x8*>(&Hs[xlane + (((ST_) * HH + (RHO_)) * HW + (KK_)) * LDK +           \
+                    ((kq ^ (((yy + (RHO_)) & 1) << 1)) << 3)]))
+#define HUPR_WF(BUF_, KY_, CG_, KK_)                                                                                \
+    (KC == 64 ? *reinterpret_cast<const bf16x8*>(&Bs[BUF_][KY_][woff[CG_][KK_]])                                    \
+              : *reinterpret_cast<const bf16x8*>(&Bs[BUF_][3 * (KK_) + (KY_)][woff[CG_][0]]))
 
     f32x4c c[4][2];
     unsigned accP[4][2][2];                                      // parked tile: bf16 pairs of c[vg][cg]
@@ -193,20 +225,28 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     // 16 registers to spare: fused statistics, which never carry a residual, and the 2 x 8 x 16 tile.)
     constexpr bool RESPF = !STATS && TD != 2 && NWN == 2;
     const bool res_pf = RESPF && p.res != nullptr && (p.res_ld & 3) == 0 && !p.no_res_prefetch;
-    const bool defer = !p.bias && (!p.res || res_pf) && (p.Co & 7) == 0 && (p.out_ld & 7) == 0;
+    // (KC = 32 — the encoders' first convolution carries a bias —: the lane's eight bias values are fetched at the top of a tile and added in
+    // front of the one rounding; the other instantiations have no registers for them and their layers no bias)
+    constexpr bool BIASPF = KC == 32;
+    const bool defer = (!p.bias || BIASPF) && (!p.res || res_pf) && (p.Co & 7) == 0 && (p.out_ld & 7) == 0;
+    float biasv[BIASPF ? 2 : 1][4];
     bf16x4 resv[4][2];
-    bf16x8 xq[2][4], x8, wq[2][2];
+    // (KC = 32: THREE fragment banks — a stage has an odd number of tap groups (kx = 0, 1, 2) and of taps (9), so with two banks the first
+    // fragments of the next stage would land in the bank the stage's last tap is still multiplying: even rows of group kx in bank kx, odd
+    // rows in bank (kx + 1) % 3, weights of tap tau in set tau % 3.  KC = 64: two K-steps, six taps: banks kk & 1, sets tau & 1 as always.)
+    constexpr int NB = KC == 64 ? 2 : 3;
+    bf16x8 xq[NB][4], x8, wq[NB][2];
     // fragments of tap TAU_ (= 3 kk + ky) of stage ST_ from weight buffer BUF_ (WX_: 1 weights only, 2 activations only, 3 both)
 #define HUPR_LOAD_TAP(ST_, TAU_, BUF_, WX_)                                                                         \
     {                                                                                                               \
         constexpr int kk_ = (TAU_) / 3, ky_ = (TAU_) % 3;                                                           \
         if ((WX_) & 1) {                                                                                            \
-            wq[(TAU_) & 1][0] = HUPR_WF(BUF_, ky_, 0, kk_);                                                         \
-            wq[(TAU_) & 1][1] = HUPR_WF(BUF_, ky_, 1, kk_);                                                         \
+            wq[(TAU_) % NB][0] = HUPR_WF(BUF_, ky_, 0, kk_);                                                        \
+            wq[(TAU_) % NB][1] = HUPR_WF(BUF_, ky_, 1, kk_);                                                        \
         }                                                                                                           \
         if ((WX_) & 2) {                                                                                            \
-            if (ky_ == 0) { _Pragma("unroll") for (int vg = 0; vg < 4; ++vg) xq[kk_ & 1][vg] = HUPR_XF(ST_, 2 * vg, kk_); } \
-            else if (ky_ == 1) { _Pragma("unroll") for (int vg = 0; vg < 4; ++vg) xq[(kk_ & 1) ^ 1][vg] = HUPR_XF(ST_, 2 * vg + 1, kk_); } \
+            if (ky_ == 0) { _Pragma("unroll") for (int vg = 0; vg < 4; ++vg) xq[kk_ % NB][vg] = HUPR_XF(ST_, 2 * vg, kk_); } \
+            else if (ky_ == 1) { _Pragma("unroll") for (int vg = 0; vg < 4; ++vg) xq[(kk_ + 1) % NB][vg] = HUPR_XF(ST_, 2 * vg + 1, kk_); } \
             else { x8 = HUPR_XF(ST_, 8, kk_); }                                                                     \
         }                                                                                                           \
     }
@@ -252,6 +292,14 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
             for (int vg = 0; vg < 4; ++vg)
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg) c[vg][cg] = (f32x4c){0.f, 0.f, 0.f, 0.f};
+            if constexpr (BIASPF) {
+                if (p.bias && defer) {
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) biasv[cg][r] = p.bias[n0 + 32 * wn + 16 * cg + 4 * kq + r];
+                }
+            }
         }
 #pragma unroll
         for (int st_ = 0; st_ < NSTAGE; ++st_) {
@@ -278,14 +326,17 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                 else if (tau == 2) { HUPR_LOAD_TAP(st_, 3, par, 3) }
                 else if (tau == 3) { HUPR_LOAD_TAP(st_, 4, par, 3) }
                 else if (tau == 4) { HUPR_LOAD_TAP(st_, 5, par, 3) }
+                else if (NTAP == 9 && tau == 5) { if constexpr (NTAP == 9) { HUPR_LOAD_TAP(st_, 6, par, 3) } }
+                else if (NTAP == 9 && tau == 6) { if constexpr (NTAP == 9) { HUPR_LOAD_TAP(st_, 7, par, 3) } }
+                else if (NTAP == 9 && tau == 7) { if constexpr (NTAP == 9) { HUPR_LOAD_TAP(st_, 8, par, 3) } }
                 else if (st_ + 1 < NSTAGE) { HUPR_LOAD_TAP((st_ + 1) % NSTAGE, 0, par ^ 1, 3) }
                 else if (has_next) { HUPR_LOAD_TAP(0, 0, par ^ 1, 1) }
                 // eight MFMAs: activation rows rho = 2 vg + ky
 #pragma unroll
                 for (int vg = 0; vg < 4; ++vg) {
-                    const bf16x8 xf = ky == 0 ? xq[kk & 1][vg] : (ky == 1 ? xq[(kk & 1) ^ 1][vg] : (vg < 3 ? xq[kk & 1][vg + 1] : x8));
-                    c[vg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[tau & 1][0], xf, c[vg][0], 0, 0, 0);
-                    c[vg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[tau & 1][1], xf, c[vg][1], 0, 0, 0);
+                    const bf16x8 xf = ky == 0 ? xq[kk % NB][vg] : (ky == 1 ? xq[(kk + 1) % NB][vg] : (vg < 3 ? xq[kk % NB][vg + 1] : x8));
+                    c[vg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[tau % NB][0], xf, c[vg][0], 0, 0, 0);
+                    c[vg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[tau % NB][1], xf, c[vg][1], 0, 0, 0);
                 }
                 if (st_ == 0 && pend && tau < 4) {
                     // one voxel group of the parked tile per tap.  v_permlane16_swap trades the odd 16-lane rows of the cg = 0 dwords for the
@@ -332,6 +383,16 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
             const int ch0 = n0 + 32 * wn + 4 * kq;
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             if (defer && has_next) {                              // park: stored during the next item's stage 0
+                if constexpr (BIASPF) {
+                    if (p.bias) {
+#pragma unroll
+                        for (int vg = 0; vg < 4; ++vg)
+#pragma unroll
+                            for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) c[vg][cg][r] += biasv[cg][r];
+                    }
+                }
                 if (RESPF && res_pf) {
 #pragma unroll
                     for (int vg = 0; vg < 4; ++vg)
@@ -455,7 +516,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 
 static void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
     const dim3 grid(kHalo256Grid), wg(512);
-    if (a.TD == 8) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<8, 8, 8, 3, 0, 1>), grid, wg, 0, s, a);
+    if (a.Ci == 32) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<4, 8, 8, 3, 0, 2, 32>), grid, wg, 0, s, a);
+    else if (a.TD == 8) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<8, 8, 8, 3, 0, 1>), grid, wg, 0, s, a);
     else if (a.kd == 1) HUPR_LAUNCH((hupr_k_conv_halo256m_bf16<1, 16, 16, 1>), grid, wg, 0, s, a);
     else if (a.stats) {                       // fused BatchNorm statistics: 1 or 2 distinct output tiles per workgroup (conv_halo256_stats_ok)
         const long tiles = (long)a.Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
@@ -475,9 +537,9 @@ static void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
 // Test aid (hupr_debug_halo_tiles): bit 0 = the 4 x 8 x 8 tile, bit 1 = the 2 x 8 x 16 tile (depth not a multiple of four: encoder
 // level 3), bit 2 = the 1 x 16 x 16 tile (1 x 3 x 3 taps: the decoder).  A cleared bit sends those layers to the 128-voxel kernel —
 // the comparison the parity tests make (same products, another fp32 summation order).  Bit 3 = the 8 x 8 x 8 tile of the 32-output-
-// channel form.
-static int g_halo_tiles = 15;
-void set_halo_tiles(int mask) { g_halo_tiles = mask & 15; }
+// channel form, bit 4 = the 32-input-channel form (cleared: the 512-voxel kernel takes those launches).
+static int g_halo_tiles = 31;
+void set_halo_tiles(int mask) { g_halo_tiles = mask & 31; }
 
 static bool offsets_fit(const HaloArgs& a, int Bn) { return (long)Bn * a.D * a.H * a.W * a.in_ld * 2 < 0x7ffffff0L; }      // 32-bit buffer offsets
 
@@ -507,7 +569,21 @@ bool conv_halo256_stats_ok(const HaloArgs& a, int Bn) {
 }
 
 bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s) {
-    if (!abf || a.Ci % 64 != 0 || !offsets_fit(a, Bn)) return false;
+    if (!abf || !offsets_fit(a, Bn)) return false;
+    if (a.Ci == 32) {
+        // 32 input channels (the encoders' first convolution): the 4 x 8 x 8 tile on 64-byte rows, one K-step per tap
+        if (!(g_halo_tiles & 16) || a.kd != 3 || a.D % 4 != 0 || a.H % 8 != 0 || a.W % 8 != 0 || a.Co % 64 != 0 || a.stats ||
+            (a.in_ld & 7) || (long)a.Co * 27 * a.Ci * 2 >= 0x7ffffff0L)
+            return false;
+        a.n_co_tiles = a.Co / 64;
+        a.TD = 4; a.log2TW = 3;
+        a.nd = a.D / 4; a.nh = a.H / 8; a.nw = a.W / 8;
+        const long tiles_ = (long)Bn * a.nd * a.nh * a.nw * a.n_co_tiles;
+        if (tiles_ < 256 || tiles_ >= (1L << 31)) return false;
+        launch_conv_halo256m(a, s);
+        return true;
+    }
+    if (a.Ci % 64 != 0) return false;
     if (a.Co == 32) {
         // 32 output channels (the first layer's input gradient): the 8 x 8 x 8 tile, every wave with all the channels
         if (!(g_halo_tiles & 8) || a.kd != 3 || a.D != 8 || a.H % 8 != 0 || a.W % 8 != 0 || a.stats || (a.out_ld & 7)) return false;

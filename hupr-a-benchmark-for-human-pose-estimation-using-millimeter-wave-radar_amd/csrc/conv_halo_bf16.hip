@@ -471,6 +471,10 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
     }
     // variants: 0 auto (512-voxel register-blocked kernel where its envelope holds, then 256-, then 128-voxel), 1 force the
     // 128-voxel kernel, 2 skip the 512-voxel kernel (A/B comparisons)
+    if (!partial_only && g_halo_variant != 1 && Ci == 32 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {      // 32 input channels: its 64-byte-row form (round 6)
+        HUPR_LAUNCH_OK("hupr_k_conv_halo256m_bf16<KC = 32>");
+        return HUPR_OK;
+    }
     if (!partial_only && g_halo_variant == 0 && launch_conv_halo512(a, Bn, abf, as_stream(stream))) {
         HUPR_LAUNCH_OK("hupr_k_conv_halo512_bf16");
         return HUPR_OK;

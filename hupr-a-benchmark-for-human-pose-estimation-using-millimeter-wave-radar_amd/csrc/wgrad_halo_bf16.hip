@@ -976,8 +976,9 @@ extern "C" size_t hupr_conv3x3_wgrad_halo_ws_bytes(int Ci, int Co, int kd) {
 
 static int g_wgrad_m16 = 1;         // A/B aid (hupr_debug_wgrad_m16): 0 = the 32 x 32 x 16 kernel (rounds 2-4)
 extern "C" void hupr_debug_wgrad_m16(int on) { g_wgrad_m16 = on; }
+static int g_wgrad_groups256 = 1;   // (hupr_debug_wgrad_ci32(16 + mode): 128 partial tensors at most, as before)
 static int g_wgrad_ci32 = 1;        // A/B aid (hupr_debug_wgrad_ci32): 0 = Ci <= 32 through the two-quadrant kernel as before, 2 = K quarters always
-extern "C" void hupr_debug_wgrad_ci32(int on) { g_wgrad_ci32 = on; }
+extern "C" void hupr_debug_wgrad_ci32(int on) { g_wgrad_ci32 = on & 15; g_wgrad_groups256 = !(on & 16); }
 
 // dy2 / dw2 (both or neither): a second gradient tensor of the same shape and stride over the same x — Co is then the channel count of
 // EACH; one launch of the 16 x 16 x 32 kernel over 2 Co output channels and one reduction that splits its rows between dw and dw2.
@@ -1011,7 +1012,9 @@ static int wgrad_halo(const void* x, const void* dy, float* dw, int Bn, int D, i
     const int pairs = a.n_ci_tiles * a.n_co_tiles * kd;                 // of ONE gradient: decides the partial-tensor count below
     const int nt = dual ? 2 : 1;
     const size_t one = (size_t)nt * Co * kd * 9 * Ci * sizeof(float);
-    int groups = max(1, min(128, 768 / pairs));      // ~3 workgroups per CU, at most 128 partial tensors
+    // ~3 workgroups per CU, at most 128 partial tensors — 256 for the register-staged kernel on 2-D maps (round 6: the fp32-stored last
+    // decoder block, one (co, ci) tile pair: 128 workgroups of synchronous fills left half the chip idle, 56 us for 50 MB)
+    int groups = max(1, min(kd == 1 && g_wgrad_groups256 ? 256 : 128, 768 / pairs));
     groups = min(groups, a.n_spatial);
     while (groups > 1 && (size_t)groups * one > ws_bytes) groups >>= 1;
     if ((size_t)groups * one > ws_bytes) return fail(HUPR_ERR_WORKSPACE, "hupr_conv3x3_wgrad_halo_bf16: workspace too small");

@@ -18,7 +18,7 @@ void hupr_debug_wgrad_ci32(int on);       /* A/B aid: 0 sends Ci <= 32 weight gr
 void hupr_debug_halo_trace(void* device_u64_4096); /* profiling aid: per-tile s_memtime stamps of workgroup 0 (null = off) */
 void hupr_debug_attn_split(int mode);    /* 0 (default): split for Bn == 1 only; 1: every grid below 128 workgroups; -1: never */
 void hupr_debug_halo_split_k(int on);     /* A/B aid: 0 = never slice the reduction of small grids */
-void hupr_debug_halo_tiles(int mask);     /* test aid: which tiles of the 256-voxel convolution kernel (conv_halo256m_bf16.hip) are in use — bit 0: 4 x 8 x 8, bit 1: 2 x 8 x 16 (D % 4 != 0), bit 2: 1 x 16 x 16 (1 x 3 x 3 taps), bit 3: 8 x 8 x 8 (32 output channels, D = 8); default 15.  A cleared bit sends those layers to the 128-voxel kernel (the comparison the parity tests make) */
+void hupr_debug_halo_tiles(int mask);     /* test aid: which tiles of the 256-voxel convolution kernel (conv_halo256m_bf16.hip) are in use — bit 0: 4 x 8 x 8, bit 1: 2 x 8 x 16 (D % 4 != 0), bit 2: 1 x 16 x 16 (1 x 3 x 3 taps), bit 3: 8 x 8 x 8 (32 output channels, D = 8), bit 4: 4 x 8 x 8 on 64-byte rows (32 input channels; cleared: the 512-voxel kernel); default 31.  A cleared bit sends those layers to the 128-voxel kernel (the comparison the parity tests make) */
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,7 @@ def test_hot_kernels_keep_their_register_and_lds_budgets():
                ("hupr_k_attn_bwd_dkv512", 256, 64 * 1024),
                ("hupr_k_attn_fwdILi128EDF16bLb0ELb1E", 256, 80 * 1024),      # level-2 forward: two workgroups per CU since round 6 (316 registers = one wave per SIMD before)
                ("hupr_k_attn_bwd_dqILi64EDF16bLb", 256, 64 * 1024),      # both forms: plain and QS (round 5)
+               ("hupr_k_attn_bwd_dqILi128E", 256, 64 * 1024),           # level-2 dQ on 32-key tiles: two workgroups per CU (358 registers before round 6)
                ("hupr_k_gcn_wxILb0E", 168, 64 * 1024), ("hupr_k_gcn_wxILb1E", 168, 64 * 1024), ("hupr_k_gcn_dw", 168, 64 * 1024),
                ("hupr_k_doppler_rangeILi0ELb1E", 128, 40 * 1024), ("hupr_k_angle", 64, 16 * 1024)]
     for pat, max_vgpr, max_lds in budgets:

@@ -298,9 +298,9 @@ def level3_aggressor(request):
     kernel they run on now (the 16 x 16 x 32 kernel's 2 x 8 x 16 tile)."""
     from hupr_amd import functional as F_
     L = F_.rt.lib()
-    L.hupr_debug_halo_tiles(1 if request.param.startswith("hupr_k_conv_halo_bf16") else 15)
+    L.hupr_debug_halo_tiles(1 if request.param.startswith("hupr_k_conv_halo_bf16") else 31)
     yield request.param
-    L.hupr_debug_halo_tiles(15)
+    L.hupr_debug_halo_tiles(31)
 
 
 def test_resampling_forward_is_unaffected_by_a_convolution_on_another_stream(level3_aggressor, bf16_math):
@@ -781,11 +781,11 @@ def test_conv_halo256m_4x8x8_tile_matches_the_128_voxel_kernel(shape, bf16_math)
     try:
         L.hupr_debug_halo_tiles(0)
         y_128 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
-        L.hupr_debug_halo_tiles(15)
+        L.hupr_debug_halo_tiles(31)
         y_m16 = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
         y_m16b = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
     finally:
-        L.hupr_debug_halo_tiles(15)
+        L.hupr_debug_halo_tiles(31)
     ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, 1)
     close(ncdhw(y_128.float().cpu())[:1], ref, 1e-2, "128-voxel kernel (bf16 store) vs fp64")
     assert y_m16.dtype == torch.bfloat16 and torch.equal(y_m16, y_m16b)
@@ -809,21 +809,21 @@ def test_conv_halo256m_32_output_channels_match_the_128_voxel_kernel(shape, bf16
     res = rnd(B, D, H, W, Co, seed=156).cuda().bfloat16()
     out = {}
     try:
-        for mode in (7, 15):
+        for mode in (7, 31):
             L.hupr_debug_halo_tiles(mode)
             out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W)),
                          F_._conv_raw(x, w, 0, None, res, Co, (3, 3, 3), (1, 1, 1), (D, H, W)))
         again = F_._conv_raw(x, w, 0, None, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
     finally:
-        L.hupr_debug_halo_tiles(15)
-    assert torch.equal(again, out[15][0])
-    for a, b in zip(out[15], out[7]):
+        L.hupr_debug_halo_tiles(31)
+    assert torch.equal(again, out[31][0])
+    for a, b in zip(out[31], out[7]):
         d = (a.float() - b.float()).abs()
         assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + 1e-5).all()
-    assert not torch.equal(out[15][0], out[15][1])
+    assert not torch.equal(out[31][0], out[31][1])
     ref = F.conv3d(ncdhw(x.float().cpu())[:2].double(), _bf16_round(w.cpu()), None, 1, 1)
-    close(ncdhw(out[15][0].float().cpu())[:2], ref, 1e-2, "halo256m 8x8x8, Co = 32 (bf16 store) vs fp64")
-    close(ncdhw(out[15][1].float().cpu())[:2], ref + ncdhw(res.float().cpu())[:2].double(), 1e-2, "halo256m 8x8x8, Co = 32 + residual vs fp64")
+    close(ncdhw(out[31][0].float().cpu())[:2], ref, 1e-2, "halo256m 8x8x8, Co = 32 (bf16 store) vs fp64")
+    close(ncdhw(out[31][1].float().cpu())[:2], ref + ncdhw(res.float().cpu())[:2].double(), 1e-2, "halo256m 8x8x8, Co = 32 + residual vs fp64")
 
 
 @pytest.mark.parametrize("shape", [(32, 64, 256, 2, 16, 16), (17, 128, 128, 2, 16, 32), (8, 320, 64, 1, 64, 64), (9, 64, 192, 1, 32, 48)])
@@ -840,17 +840,17 @@ def test_conv_halo256m_two_slice_tile_matches_the_128_voxel_kernel(shape, bf16_m
     res = rnd(B, D, H, W, Co, seed=58).cuda().bfloat16()
     out = {}
     try:
-        for mode in (1, 15):                # 7: all tiles, 1: the 4 x 8 x 8 tile only
+        for mode in (1, 31):                # 7: all tiles, 1: the 4 x 8 x 8 tile only
             L.hupr_debug_halo_tiles(mode)
             out[mode] = (F_._conv_raw(x, w, 0, None, None, Co, k3, pad, (D, H, W)),
                          F_._conv_raw(x, w, 0, None, res, Co, k3, pad, (D, H, W)))
     finally:
-        L.hupr_debug_halo_tiles(15)
-    for a, b in zip(out[15], out[1]):
+        L.hupr_debug_halo_tiles(31)
+    for a, b in zip(out[31], out[1]):
         d = (a.float() - b.float()).abs()
         assert (d > 0).float().mean().item() < 2e-3 and (d <= torch.maximum(a.float().abs(), b.float().abs()) * 2 ** -7 + 1e-5).all()
     ref = F.conv3d(ncdhw(x.float().cpu())[:1].double(), _bf16_round(w.cpu()), None, 1, pad)
-    close(ncdhw(out[15][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 / 1x16x16 (bf16 store) vs fp64")
+    close(ncdhw(out[31][0].float().cpu())[:1], ref, 1e-2, "halo256m 2x8x16 / 1x16x16 (bf16 store) vs fp64")
 
 
 # ---- bf16-stored activations ("bf16act" kernels of the encoder island) ------------------------------------------------
@@ -891,7 +891,7 @@ def test_conv_halo_bf16_activations(case, bf16_math):
             L_.hupr_debug_halo_tiles(0)
             y16b = F_._conv_raw(x.bfloat16(), w, 0, bias, res.bfloat16() if has_res else None, Co, k, pad, (D, H, W))
         finally:
-            L_.hupr_debug_halo_tiles(15)
+            L_.hupr_debug_halo_tiles(31)
         assert torch.equal(y16b.float(), _q(y32))              # the 32 x 32 x 16 form: store rounding only
     # weight gradient: fp32 output, identical products; only the fp32 summation order over voxel slices differs
     # (LDS-DMA kernel: two K halves per workgroup, other slice count)
@@ -1521,28 +1521,39 @@ def test_interp_mnet_cast_bf16_activations():
     assert torch.equal(m[torch.bfloat16][1], m[torch.float32][1]) and torch.equal(m[torch.bfloat16][2], m[torch.float32][2])
 
 
-def test_conv_halo512_first_layer_shape_matches_the_128_voxel_kernel(bf16_math):
-    """The 512-voxel register-blocked kernel (Ci = 32: the encoder's first layer at the bench batch) against the 128-voxel
-    kernel on the same bf16 operands — same products, another fp32 summation order (K chunks of 32, kz-major taps): equal up to
-    one rounding of the bf16 store — and against fp64 on one sample."""
+@pytest.mark.parametrize("shape", [(32, 64, 8, 64, 64, True), (7, 128, 4, 32, 48, False)])
+def test_conv_first_layer_shape_32_input_channels(shape, bf16_math):
+    """Ci = 32 (the encoders' first convolution, `layers.py:236`): the 256-voxel kernel's 64-byte-row form (one K-step per tap, a stage = one kz
+    plane of nine taps, three fragment banks; round 6) and the 512-voxel register-blocked kernel it replaced (hupr_debug_halo_tiles(15)) against the
+    128-voxel kernel on the same bf16 operands — same products, another fp32 summation order: equal up to one rounding of the bf16 store —
+    and against fp64; the bench shape with bias, and two output tiles over an uneven tile count without; deterministic."""
     from hupr_amd import functional as F_
     L = F_.rt.lib()
-    B, Ci, Co, D, H, W = 32, 32, 64, 8, 64, 64
+    B, Co, D, H, W, with_bias = shape
+    Ci = 32
     x = _q(rnd(B, D, H, W, Ci, seed=90)).cuda().bfloat16()
     w = rnd(Co, Ci, 3, 3, 3, seed=91, scale=(Ci * 27) ** -0.5).cuda()
-    bias = rnd(Co, seed=92).cuda()
+    bias = rnd(Co, seed=92).cuda() if with_bias else None
+    run = lambda: F_._conv_raw(x, w, 0, bias, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
     try:
-        L.hupr_debug_halo_variant(0)
-        y512 = F_._conv_raw(x, w, 0, bias, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        y256 = run()
+        y256b = run()
+        L.hupr_debug_halo_tiles(15)
+        y512 = run()
         L.hupr_debug_halo_variant(1)
-        y128 = F_._conv_raw(x, w, 0, bias, None, Co, (3, 3, 3), (1, 1, 1), (D, H, W))
+        y128 = run()
     finally:
         L.hupr_debug_halo_variant(0)
-    d = (y512.float() - y128.float()).abs()
+        L.hupr_debug_halo_tiles(31)
+    assert torch.equal(y256, y256b)
     ulp = y128.float().abs().clamp_min(2.0 ** -6) * 2.0 ** -7           # one bf16 step of the stored value
-    assert bool((d <= ulp).all()), (d / ulp).max().item()
-    assert (d > 0).float().mean().item() < 0.05                           # and almost all of them identical
-    ref = F.conv3d(_bf16_round(ncdhw(x.float().cpu()))[:1], _bf16_round(w.cpu()), bias.cpu().double(), 1, 1)
+    for name, y in (("halo256m<KC = 32>", y256), ("halo512", y512)):
+        d = (y.float() - y128.float()).abs()
+        assert bool((d <= ulp).all()), (name, (d / ulp).max().item())
+        assert (d > 0).float().mean().item() < 0.05, name                 # and almost all of them identical
+    assert not torch.equal(y256, y512) or B < 32                          # (two kernels, two summation orders)
+    ref = F.conv3d(_bf16_round(ncdhw(x.float().cpu()))[:1], _bf16_round(w.cpu()), bias.cpu().double() if with_bias else None, 1, 1)
+    close(ncdhw(y256.float().cpu())[:1], ref, 6e-3, "halo256m<KC = 32> vs fp64 (one bf16 store rounding)")
     close(ncdhw(y512.float().cpu())[:1], ref, 6e-3, "halo512 vs fp64 (one bf16 store rounding)")
 
 
