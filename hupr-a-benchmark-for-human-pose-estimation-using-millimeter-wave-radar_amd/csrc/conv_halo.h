@@ -1,4 +1,4 @@
-// Shared argument block of the halo-tiled 3x3(x3) convolution kernels (conv_halo_bf16.hip, conv_halo256m_bf16.hip, conv_halo512_bf16.hip).
+// Shared argument block of the halo-tiled 3x3(x3) convolution kernels (conv_halo_bf16.hip, conv_halo256m_bf16.hip).
 #pragma once
 #include "gemm_common.h"
 
@@ -53,8 +53,6 @@ bool launch_conv_halo256(HaloArgs a, int Bn, bool abf, hipStream_t s);
 bool conv_halo256_supported(const HaloArgs& a, int Bn, bool abf);
 bool conv_halo256_stats_ok(const HaloArgs& a, int Bn);                         // fused BatchNorm statistics available for this launch?
 void set_halo_tiles(int mask);                                                // test aid: which tiles of the 256-voxel kernel are in use (conv_halo256m_bf16.hip)
-bool launch_conv_halo512(HaloArgs a, int Bn, bool abf, hipStream_t s);      // 512-voxel register-blocked variant (conv_halo512_bf16.hip)
-bool conv_halo512_supported(const HaloArgs& a, int Bn, bool abf);
 constexpr int kHalo256Grid = 256;      // persistent workgroups (= partial rows of HaloArgs::stats)
 
 // Epilogue of both kernels.  The MFMAs are issued as D' = W * X^T, so a lane holds ONE voxel (column lane & 31 of the

@@ -1,6 +1,7 @@
 // The 256-voxel persistent halo convolution (3 x 3 (x 3) taps, bf16-stored activations) on v_mfma_f32_16x16x32_bf16 — the kernel
 // the encoder's and decoder's convolutions and input gradients run on (conv_halo_bf16.hip holds the 128-voxel kernel for everything
-// outside this envelope — the first layer's 64 -> 32 input gradient among them —, conv_halo512_bf16.hip the first layer's Ci = 32 forward).
+// outside this envelope: fp32-stored activations, small grids).  Since round 6 the first layer's two odd shapes run here as well: Ci = 32
+// forward (KC = 32) and the 64 -> 32 input gradient (NWN = 1).
 //
 // Design, as the measurements of rounds 2-5 shaped it (64 -> 64 channels, 3 x 3 x 3 taps, B = 32):
 //   * one persistent 512-thread workgroup per CU walks a contiguous run of 4 x 8 x 8-voxel x 64-channel tiles (an eighth of the
@@ -43,7 +44,8 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // at 702 TF/s): the eight waves are eight 8 x 8 voxel blocks of an 8 x 8 x 8 tile (512 voxels), each with all 32 output channels —
 // per wave the same 8 MFMAs per tap from the same fragment reads as the 64-channel form; a weight stage is 3 x 4 KB (two DMA
 // instructions, the second by waves 0-3 only); sixteen halo items per thread ride under the first sixteen taps.
-// KC = 32 (round 6; Ci = 32: the encoders' first convolution, before on the 512-voxel kernel at 1.0 PF/s): a halo / weight row is 64 bytes,
+// KC = 32 (round 6; Ci = 32: the encoders' first convolution, in rounds 2-5 on a 512-voxel register-blocked kernel of its own — 118-127 us
+// against 115 here, profiles/r06_conv_ci32_ab.txt; removed): a halo / weight row is 64 bytes,
 // a tap is ONE K-step, a stage is a kz plane with its nine (kx, ky) taps (nine 4 KB weight images by 36 LDS-DMA pieces); the
 // 64-byte rows have their own bank keys (see the fragment addresses).
 template <int TD, int TH, int TW, int KD, int NCOT = 0, int NWN = 2, int KC = 64>
@@ -537,7 +539,7 @@ static void launch_conv_halo256m(const HaloArgs& a, hipStream_t s) {
 // Test aid (hupr_debug_halo_tiles): bit 0 = the 4 x 8 x 8 tile, bit 1 = the 2 x 8 x 16 tile (depth not a multiple of four: encoder
 // level 3), bit 2 = the 1 x 16 x 16 tile (1 x 3 x 3 taps: the decoder).  A cleared bit sends those layers to the 128-voxel kernel —
 // the comparison the parity tests make (same products, another fp32 summation order).  Bit 3 = the 8 x 8 x 8 tile of the 32-output-
-// channel form, bit 4 = the 32-input-channel form (cleared: the 512-voxel kernel takes those launches).
+// channel form, bit 4 = the 32-input-channel form.
 static int g_halo_tiles = 31;
 void set_halo_tiles(int mask) { g_halo_tiles = mask & 31; }
 

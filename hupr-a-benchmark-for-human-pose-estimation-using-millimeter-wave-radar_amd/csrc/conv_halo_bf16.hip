@@ -404,7 +404,7 @@ extern "C" int hupr_pack_conv_weights_bf16(const float* w, void* wp_bf16, int Co
 }
 
 static int g_halo_ablate = 0;
-static int g_halo_variant = 0;      // 0 auto, 1 force the 128-voxel kernel, 2 skip the 512-voxel kernel (A/B comparisons)
+static int g_halo_variant = 0;      // 0 auto, 1 force the 128-voxel kernel (A/B comparisons)
 static unsigned long long* g_halo_trace = nullptr;
 extern "C" void hupr_debug_halo_trace(void* buf) { g_halo_trace = reinterpret_cast<unsigned long long*>(buf); }
 extern "C" void hupr_debug_halo_ablate(int bits) { g_halo_ablate = bits; }   // profiling aids (scripts/halo_ablation.py)
@@ -469,16 +469,7 @@ static int conv3x3_halo(const void* x, const void* wp_bf16, const float* bias, c
         HUPR_LAUNCH_OK("hupr_k_conv_halo256m_bf16<stats>");
         return HUPR_OK;
     }
-    // variants: 0 auto (512-voxel register-blocked kernel where its envelope holds, then 256-, then 128-voxel), 1 force the
-    // 128-voxel kernel, 2 skip the 512-voxel kernel (A/B comparisons)
-    if (!partial_only && g_halo_variant != 1 && Ci == 32 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {      // 32 input channels: its 64-byte-row form (round 6)
-        HUPR_LAUNCH_OK("hupr_k_conv_halo256m_bf16<KC = 32>");
-        return HUPR_OK;
-    }
-    if (!partial_only && g_halo_variant == 0 && launch_conv_halo512(a, Bn, abf, as_stream(stream))) {
-        HUPR_LAUNCH_OK("hupr_k_conv_halo512_bf16");
-        return HUPR_OK;
-    }
+    // variants: 0 auto (the 256-voxel kernel where one of its forms applies, else the 128-voxel kernel), 1 force the 128-voxel kernel (A/B comparisons)
     if (!partial_only && g_halo_variant != 1 && launch_conv_halo256(a, Bn, abf, as_stream(stream))) {
         HUPR_LAUNCH_OK("hupr_k_conv_halo256m_bf16");
         return HUPR_OK;

@@ -9,7 +9,7 @@ extern "C" {
 #endif
 
 void hupr_debug_attn_trace(void* dev_buf); /* profiling aid: device buffer of 3 x 2 x 4096 uint64 s_memtime stamps written by workgroup 0 of the ping-pong attention kernels, or null */
-void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel, 2 skip the 512-voxel kernel */
+void hupr_debug_halo_variant(int v);  /* A/B aid: 0 auto, 1 force the 128-voxel kernel */
 void hupr_debug_halo_ablate(int bits); /* profiling aid: bit0 skip halo fill, bit1 skip MFMA, bit2 skip stores */
 void hupr_debug_halo_res_prefetch(int on);  /* A/B aid: 0 = the 256-voxel 16 x 16 x 32 convolution reads a residual in its immediate epilogue (rounds 4-5a); default 1: prefetched, deferred epilogue */
 void hupr_debug_splitk_slices(int s);     /* test aid: slices per workgroup of the split-K reduction: 0 auto, 4, 16; + 256: the scattered-store kernel (hupr_k_splitk_reduce4) for convolution weight gradients too — same sums, the comparison the parity test makes */
@@ -18,7 +18,7 @@ void hupr_debug_wgrad_ci32(int on);       /* A/B aid: 0 sends Ci <= 32 weight gr
 void hupr_debug_halo_trace(void* device_u64_4096); /* profiling aid: per-tile s_memtime stamps of workgroup 0 (null = off) */
 void hupr_debug_attn_split(int mode);    /* 0 (default): split for Bn == 1 only; 1: every grid below 128 workgroups; -1: never */
 void hupr_debug_halo_split_k(int on);     /* A/B aid: 0 = never slice the reduction of small grids */
-void hupr_debug_halo_tiles(int mask);     /* test aid: which tiles of the 256-voxel convolution kernel (conv_halo256m_bf16.hip) are in use — bit 0: 4 x 8 x 8, bit 1: 2 x 8 x 16 (D % 4 != 0), bit 2: 1 x 16 x 16 (1 x 3 x 3 taps), bit 3: 8 x 8 x 8 (32 output channels, D = 8), bit 4: 4 x 8 x 8 on 64-byte rows (32 input channels; cleared: the 512-voxel kernel); default 31.  A cleared bit sends those layers to the 128-voxel kernel (the comparison the parity tests make) */
+void hupr_debug_halo_tiles(int mask);     /* test aid: which tiles of the 256-voxel convolution kernel (conv_halo256m_bf16.hip) are in use — bit 0: 4 x 8 x 8, bit 1: 2 x 8 x 16 (D % 4 != 0), bit 2: 1 x 16 x 16 (1 x 3 x 3 taps), bit 3: 8 x 8 x 8 (32 output channels, D = 8), bit 4: 4 x 8 x 8 on 64-byte rows (32 input channels); default 31.  A cleared bit sends those layers to the 128-voxel kernel (the comparison the parity tests make) */
 
 #ifdef __cplusplus
 }
