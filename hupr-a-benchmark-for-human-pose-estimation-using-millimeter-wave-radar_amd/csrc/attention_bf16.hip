@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256, D <= 128 ? 2 : 1) void hupr_k_attn_bwd_dq(cons
     // MFMA sequence per query (the 16-key blocks arrive in the same order): the same bits
     // (The dK / dV kernel at D = 128 — 446 registers — does not follow: with 32-query tiles, the V rows in LDS and the dO rows staged
     // synchronously it still spills 19-41 registers at 256 and ran 131 us instead of 116, profiles/r06_attn_dq128_ab.txt.)
-    constexpr int KT = D == 128 ? 32 : 64, NT = KT / 32;
+    constexpr int KT = D == 128 ? 32 : 64, NT = KT / 32;      // (D = 64 on 32-key tiles — 156 registers, three workgroups per CU: 789 vs 781 us, no gain)
     __shared__ __attribute__((aligned(16))) __bf16 Ks[KT * D];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[KT * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
