@@ -47,7 +47,9 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // KC = 32 (round 6; Ci = 32: the encoders' first convolution, in rounds 2-5 on a 512-voxel register-blocked kernel of its own — 118-127 us
 // against 115 here, profiles/r06_conv_ci32_ab.txt; removed): a halo / weight row is 64 bytes,
 // a tap is ONE K-step, a stage is a kz plane with its nine (kx, ky) taps (nine 4 KB weight images by 36 LDS-DMA pieces); the
-// 64-byte rows have their own bank keys (see the fragment addresses).
+// 64-byte rows have their own bank keys (see the fragment addresses).  The kernel walks Ci / 32 chunks per tile, so it also takes 64-channel
+// layers (two chunks: the two halo images then replace the one 64-channel image); measured on layer 1 (64 -> 64, B = 32): 192 us against
+// 182 us of the KC = 64 form (207 us with one image and a commit burst per chunk) — not dispatched (profiles/r06_conv_ci32_ab.txt).
 template <int TD, int TH, int TW, int KD, int NCOT = 0, int NWN = 2, int KC = 64>
 __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int LDK = KC, BN = 32 * NWN, TS = KC == 64 ? 3 : 9, C8 = KC / 8, L2C8 = KC == 64 ? 3 : 2;
@@ -68,7 +70,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     constexpr int Y0 = NH < NTAP - 1 ? NH : NTAP - 1, Y1 = NH - (NTAP - 1) < 0 ? 0 : (NH - (NTAP - 1) > NTAP ? NTAP : NH - (NTAP - 1)),
                   Y2 = NH - (2 * NTAP - 1) < 0 ? 0 : (NH - (2 * NTAP - 1) > NTAP ? NTAP : NH - (2 * NTAP - 1));
     static_assert(NH <= NTAP * NSTAGE - 1 && NH <= 3 * NTAP - 1, "halo items must all be issued in front of the item's last barrier (and within three stages)");
-    __shared__ __attribute__((aligned(16))) __bf16 Hs[NVOX * LDK];
+    // KC = 32: TWO halo images (2 x 38 KB — what the one 64-channel image takes): item q multiplies image q & 1 while the halo of item q + 1
+    // is committed to the other one, one ds_write_b128 per tap under the MFMAs of the item's last stage — no commit burst and no barrier
+    // at the item boundary (the last stage's barrier already stands between those writes and the first reads of the next item)
+    __shared__ __attribute__((aligned(16))) __bf16 Hs[(KC == 32 ? 2 : 1) * NVOX * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[2][TS][BN * LDK];
     // fused BatchNorm statistics: per lane and output-channel tile the running sums of its eight channels over its voxels (bf16-ROUNDED
     // outputs) in REGISTERS — ssum / ssq [tile][cg][r] — reduced over the sixteen voxel lanes and the four voxel-block waves once,
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
         _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                             \
             if (j < 4 || wave < 4) {                                                                                \
                 const int t9_ = 2 * j + (wave >> 2);             /* wave-uniform: kx * 3 + ky */                     \
-                const int wb32_ = (((COT_) * BN * T + (S_) * 9 + (t9_ % 3) * 3 + t9_ / 3) * p.Ci) * 2 + wsrc32_lane; \
+                const int wb32_ = (((COT_) * BN * T + (S_) * 9 + (t9_ % 3) * 3 + t9_ / 3) * p.Ci + (CH_) * KC) * 2 + wsrc32_lane; \
                 unsigned keep_;                                                                                     \
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\t" \
                              "s_mov_b32 m0, %0"                                                                     \
@@ -207,10 +212,19 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     // KC = 32 (64-byte rows): a voxel's four chunks sit at chunk ^ ((halo row & 1) << 1).  A ds_read_b128 lane group holds, for each
     // voxel class (index mod 4 = a 64-byte bank quarter), the four lanes (kq, row), (kq, row + 1), (kq + 1, row), (kq + 1, row + 1): positions
     // kq ^ {0, 2} and (kq + 1) ^ {0, 2} — all four.  KK_ there = kx (the stage is the kz plane ST_).
+#define HUPR_HALO_COMMIT1(u, HW_)                                                                                   \
+    {                                                                                                               \
+        const int it = tid + (u) * 512;                                                                             \
+        if (it < NVOXL * C8) {                                                                                      \
+            const int vox = it >> L2C8, c8 = it & (C8 - 1);                                                         \
+            const int key_ = (((vox / HW) % HH) & 1) << 1;                                                          \
+            *reinterpret_cast<u32x4*>(&Hs[(HW_) + (vox + VOX0) * LDK + ((c8 ^ key_) << 3)]) = vb[u];                \
+        }                                                                                                           \
+    }
 #define HUPR_XF(ST_, RHO_, KK_)                                                                                     \
     (KC == 64 ? *reinterpret_cast<const bf16x8*>(&Hs[xlane + ((((ST_) / 3) * HH + (RHO_)) * HW + ((ST_) % 3)) * LDK + \
                     (((4 * (KK_) + kq) ^ ((((xw0 + wx + ((ST_) % 3)) >> 1) & 3) << 1)) << 3)])                      \
-              : *reinterpret_cast<const bf16x8*>(&Hs[xlane + (((ST_) * HH + (RHO_)) * HW + (KK_)) * LDK +           \
+              : *reinterpret_cast<const bf16x8*>(&Hs[hrd + xlane + (((ST_) * HH + (RHO_)) * HW + (KK_)) * LDK +     \
                     ((kq ^ (((yy + (RHO_)) & 1) << 1)) << 3)]))
 #define HUPR_WF(BUF_, KY_, CG_, KK_)                                                                                \
     (KC == 64 ? *reinterpret_cast<const bf16x8*>(&Bs[BUF_][KY_][woff[CG_][KK_]])                                    \
@@ -265,7 +279,13 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
     HUPR_W_DMA(cur.cot, cur.ch, 1, 1)
 #pragma unroll
     for (int u = 0; u < NH; ++u) HUPR_HALO_ISSUE_ITEM(u, true, cur.b, cur.tdi * TD, cur.thi * TH, cur.twi * TW, cur.ch * KC)
-    HUPR_HALO_COMMIT()
+    [[maybe_unused]] int hrd = 0;                                 // (KC = 32) element offset of the halo image this item reads
+    if constexpr (KC == 32) {
+#pragma unroll
+        for (int u = 0; u < NH; ++u) HUPR_HALO_COMMIT1(u, 0)
+    } else {
+        HUPR_HALO_COMMIT()
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     HUPR_LOAD_TAP(0, 0, 0, 3)
@@ -289,6 +309,8 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
             }
         }
         const bool has_next = q + 1 < n_items;
+        if constexpr (KC == 32) hrd = (q & 1) * (NVOX * LDK);
+        [[maybe_unused]] const int hwr = NVOX * LDK - hrd;            // (KC = 32) ... and the one the next item's halo is written to
         if (first_chunk) {
 #pragma unroll
             for (int vg = 0; vg < 4; ++vg)
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                     __syncthreads();
                     if (st_ + 2 < NSTAGE) { HUPR_W_DMA(cur.cot, cur.ch, st_ + 2, par) }
                     else if (has_next) { HUPR_W_DMA(nxt.cot, nxt.ch, st_ + 2 - NSTAGE, par) }
-                    if (st_ == NSTAGE - 1 && has_next) { HUPR_HALO_COMMIT() }
+                    if (KC == 64 && st_ == NSTAGE - 1 && has_next) { HUPR_HALO_COMMIT() }
                 }
                 // the next tap's fragments: of this stage, or tap 0 of the next one (across an item boundary only its weights)
                 if (tau == 0) { HUPR_LOAD_TAP(st_, 1, par, 3) }
@@ -332,7 +354,10 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                 else if (NTAP == 9 && tau == 6) { if constexpr (NTAP == 9) { HUPR_LOAD_TAP(st_, 7, par, 3) } }
                 else if (NTAP == 9 && tau == 7) { if constexpr (NTAP == 9) { HUPR_LOAD_TAP(st_, 8, par, 3) } }
                 else if (st_ + 1 < NSTAGE) { HUPR_LOAD_TAP((st_ + 1) % NSTAGE, 0, par ^ 1, 3) }
-                else if (has_next) { HUPR_LOAD_TAP(0, 0, par ^ 1, 1) }
+                else if (has_next) {
+                    if constexpr (KC == 32) { const int hrd = hwr; HUPR_LOAD_TAP(0, 0, par ^ 1, 3) }      // (the next image is complete: this stage's barrier)
+                    else { HUPR_LOAD_TAP(0, 0, par ^ 1, 1) }
+                }
                 // eight MFMAs: activation rows rho = 2 vg + ky
 #pragma unroll
                 for (int vg = 0; vg < 4; ++vg) {
@@ -359,6 +384,9 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                                 resv[vg][cg] = *reinterpret_cast<const bf16x4*>(static_cast<const __bf16*>(p.res) + (mr + 2 * vg * p.W) * p.res_ld +
                                                                                 chr + 16 * cg);
                     }
+                }
+                if constexpr (KC == 32) {                         // the next item's halo -> the idle image, one item per tap of the last stage
+                    if (st_ == NSTAGE - 1 && tau < NH && has_next) { HUPR_HALO_COMMIT1(tau, hwr) }
                 }
                 // the next item's halo: one item per tap under its MFMAs (branch-free: an out-of-range offset past the last item)
                 if (NTAP * st_ + tau < NH) {
@@ -470,7 +498,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
                 }
             }
         }
-        if (has_next) {
+        if (KC == 64 && has_next) {
             __syncthreads();                                      // the halo committed behind the last stage's barrier is complete
             HUPR_LOAD_TAP(0, 0, g & 1, 2)                         // its weight fragments were read under the last MFMAs above
         }
@@ -510,6 +538,7 @@ __global__ __launch_bounds__(512) void hupr_k_conv_halo256m_bf16(HaloArgs p) {
 #undef HUPR_W_DMA
 #undef HUPR_HALO_ISSUE_ITEM
 #undef HUPR_HALO_COMMIT
+#undef HUPR_HALO_COMMIT1
 #undef HUPR_XF
 #undef HUPR_WF
 #undef HUPR_LOAD_TAP
